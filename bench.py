@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py — denoising-steps/sec of the ChronoEdit-14B hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of ChronoEditPipeline.__call__'s loop
+(/root/reference/chronoedit_diffusers/pipeline_chronoedit.py:695-756) at BASELINE.json configs[1]:
+ChronoEdit-14B bf16, 1280x720, 5 pixel frames -> latents [1,16,2,90,160] -> N = 7200 tokens,
+guidance 5.0 -> TWO DiT forwards + CFG + flow-UniPC update.  Synthetic (seeded) weights of the real
+architecture and synthetic inputs — there are no checkpoints offline.  Inputs are resident in HBM
+before the timed region; nothing is cached across steps unless --cache-context is given (then the
+step-invariant text/image K/V are reused, and the JSON says so).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): each rank denoises its own
+edit (independent replicas, no data-path collective; "scaling": "weak").  Timing: barrier +
+synchronize on both sides, MAX over ranks.
+
+The JSON line carries:
+  roofline      dominant kernel (FFN-up GEMM) algorithmic FLOPs / mean launch duration measured with HIP events
+                on the launch stream in one extra profiled step after the timed region, vs 2.5 PFLOP/s dense bf16;
+  cpu_baseline  the CPU oracle (oracle/dit_oracle.py, "port") timed on this host's cores on ONE transformer block
+                at the same N (rank 0, N=1 only), extrapolated to steps/sec.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--layers", type=int, default=40, help="(debug only) fewer blocks => result marked invalid")
+    ap.add_argument("--frames", type=int, default=2, help="latent frames: 2 (edit) or 8 (temporal reasoning)")
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--guidance", type=float, default=5.0)
+    ap.add_argument("--cache-context", action="store_true", help="reuse step-invariant text/image K/V across steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(layers: int, dev):
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    m = ChronoEditTransformer3DModel(num_attention_heads=40, attention_head_dim=128, in_channels=36, out_channels=16,
+                                     text_dim=4096, freq_dim=256, ffn_dim=13824, num_layers=layers, image_dim=1280,
+                                     added_kv_proj_dim=5120, device=dev, dtype=torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    D = 5120
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("scale_shift_table"):
+                p.copy_(torch.randn(p.shape, generator=g, device=dev) / D**0.5)
+            elif "norm" in name and name.endswith(".weight"):
+                p.fill_(1.0)
+            elif name.endswith(".bias"):
+                p.zero_()
+            else:
+                p.normal_(0.0, 0.02, generator=g)
+    return m
+
+
+def cpu_baseline(N: int, steps_fwd: int):
+    """Oracle ("port") on the host cores: one full-width transformer block at N tokens, fp32."""
+    from oracle import dit_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.DiTConfig(num_layers=1)
+    g = torch.Generator().manual_seed(1)
+    p = {k: v for k, v in O.make_synthetic_params(cfg, seed=1).items() if k.startswith("blocks.0.")}
+    x = torch.randn(1, N, cfg.inner_dim, generator=g)
+    enc = torch.randn(1, 769, cfg.inner_dim, generator=g)
+    temb6 = torch.randn(1, 6, cfg.inner_dim, generator=g) * 0.1
+    T, hp, wp = 2, 45, N // 90
+    rot = O.rope_table(cfg, T, 2 * hp, 2 * wp) if T * hp * wp == N else None
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.block_forward(p, 0, cfg, x, enc, temb6, rot)
+        dt = time.perf_counter() - t0
+    per_step = dt * 40 * steps_fwd
+    return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, {dt:.2f} s measured; x40 blocks x{steps_fwd} forwards/step"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from chronoedit_amd import ops
+    from chronoedit_amd.pipeline import denoise_step
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from oracle.dit_oracle import DiTConfig, flops_per_forward
+
+    ops.lib()  # fail loudly if the HIP library is missing
+    model = build_model(a.layers, dev)
+    model.cache_context = a.cache_context
+    T, h, w = a.frames, a.height // 8, a.width // 8
+    N = T * (h // 2) * (w // 2)
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    latents = torch.randn((1, 16, T, h, w), generator=g, device=dev, dtype=torch.float32)
+    condition = torch.randn((1, 20, T, h, w), generator=g, device=dev).to(torch.bfloat16)
+    prompt = torch.randn((1, 512, 4096), generator=g, device=dev)
+    prompt[:, 64:] = 0
+    negative = torch.randn((1, 512, 4096), generator=g, device=dev)
+    negative[:, 64:] = 0
+    prompt, negative = prompt.to(torch.bfloat16), negative.to(torch.bfloat16)
+    image = torch.randn((1, 257, 1280), generator=g, device=dev).to(torch.bfloat16)
+    sched = FlowUniPCMultistepScheduler(flow_shift=5.0)
+    total = a.warmup + a.steps + (0 if a.no_profile else 1)
+    sched.set_timesteps(max(50, total), device=dev)
+    fwd_per_step = 2 if a.guidance > 1.0 else 1
+
+    def one_step(i):
+        denoise_step(model, sched, latents, condition, sched.timesteps[i], prompt, negative, image, a.guidance)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(a.warmup + i)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    finite = bool(torch.isfinite(latents).all().item())
+
+    # ---- per-kernel HIP-event profile of ONE more step (outside the timed region) -> roofline of the dominant kernel
+    roofline = None
+    breakdown = None
+    if not a.no_profile and rank == 0:
+        with ops.profile() as prof:
+            one_step(a.warmup + a.steps)
+        summ = prof.summary()
+        tot = sum(d["total_ms"] for d in summ.values())
+        breakdown = {k: {"n": d["n"], "avg_ms": round(d["avg_ms"], 4), "share": round(d["total_ms"] / tot, 4),
+                         "tflops": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e12, 1) if k.startswith(("gemm", "attention")) else None,
+                         "GBps": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e9, 1) if k.startswith(("ln_", "rmsnorm")) else None}
+                     for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
+        dom = max((k for k in summ if k.startswith(("gemm", "attention"))), key=lambda k: summ[k]["total_ms"])
+        ach = summ[dom]["work"] / (summ[dom]["avg_ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": summ[dom]["n"], "avg_ms": round(summ[dom]["avg_ms"], 4)}
+
+    if rank == 0:
+        steps_per_s = a.steps / dt * world
+        fl = flops_per_forward(DiTConfig(num_layers=a.layers), N) * fwd_per_step
+        out = {
+            "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": "denoising-steps/sec (ChronoEdit-14B, 720p)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
+                                   f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
+                                   "BASELINE.json configs[1]",
+                       "tokens": N, "forwards_per_step": fwd_per_step, "parallelism": f"replica x{world}",
+                       "context_cache": bool(a.cache_context)},
+            "model_tflops_per_step": round(fl / 1e12, 2),
+            "achieved_tflops_per_gpu": round(fl * a.steps / dt / 1e12, 1),
+            "mfma_roofline_frac_whole_step": round(fl * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "finite": finite,
+            "roofline": roofline,
+            "kernel_breakdown": breakdown,
+        }
+        if a.layers != 40:
+            out["invalid"] = "reduced depth (debug run)"
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, fwd_per_step)
+            except Exception as e:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

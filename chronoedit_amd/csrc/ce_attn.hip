@@ -1,0 +1,298 @@
+// Fused (flash-style) attention forward for the DiT blocks, head_dim = 128, bf16, non-causal:
+//     O = softmax(Q K^T / sqrt(128)) V                      (K9, self-attention over N tokens)
+//     O = bf16(softmax(Q Kt^T) Vt) + bf16(softmax(Q Ki^T) Vi)  (K14, text + image cross-attn)
+// Reference: F.scaled_dot_product_attention calls at transformer_chronoedit.py:91-104.
+//
+// Bound: bf16 MFMA; algorithmic flops = 4 * Nq * Nkv * 128 per head.
+//
+// Structure (CDNA4 wave64, v_mfma_f32_32x32x16_bf16):
+//  * 512-thread workgroup = 8 waves x 32 query rows = 256 query rows of one head; KV tile = 64.
+//  * "Swapped" products so the softmax row lives in ONE lane:  S^T = K.Q^T  puts column q = lane&31
+//    of the 32x32 accumulator in each lane (16 kv values per 32-kv fragment per lane; the two
+//    half-waves hold disjoint kv subsets) -> row max / row sum are in-register + one lane^32 exchange.
+//  * O^T = V^T . P^T: the P^T B-operand is taken straight from the S^T accumulator registers
+//    (no cross-lane movement): MFMA contracts over "k slots", and we are free to assign slot
+//    (half h, j) <-> kv = base + 4h + (j&3) + 8*(j>>2) as long as the V^T A-operand uses the same
+//    assignment - it does, via two 8-byte LDS reads per fragment.
+//  * K tile row-major in LDS, 16-B chunks XOR-swizzled by row (conflict-free ds_read_b128);
+//    V tile transposed in registers (4x4 bf16 blocks) on its way into LDS as V^T[dv][kv] with an
+//    8-B-chunk XOR swizzle that is conflict-free for both the ds_write_b64 and the ds_read_b64 side.
+//  * K/V tile t+1 is fetched global->VGPR under the MFMAs of tile t and written to the other LDS
+//    buffer afterwards (one barrier per tile).
+//  * Output rows are staged through LDS and stored as whole 256-B rows (16 B per lane).
+//  * blockIdx -> (head, q-block) keeps all q-blocks of a head on one XCD (K/V stay in that L2).
+#include "ce_common.h"
+
+namespace {
+
+constexpr int HD = 128;            // head dim
+constexpr int QW = 32;             // query rows per wave
+constexpr int NWAVE = 8;
+constexpr int QB = QW * NWAVE;     // 256 query rows per workgroup
+constexpr int KVB = 64;            // kv rows per tile
+constexpr int K_TILE_BYTES = KVB * HD * 2;   // 16 KiB, row = 256 B
+constexpr int VT_TILE_BYTES = HD * KVB * 2;  // 16 KiB, row (one dv) = 128 B
+constexpr int BUF_BYTES = K_TILE_BYTES + VT_TILE_BYTES;
+constexpr int OST_ROW = HD * 2 + 16;         // 272-B padded output staging row
+constexpr int SMEM_BYTES = QB * OST_ROW;     // 69632 B >= 2 * BUF_BYTES (65536): staging overlays the tile buffers
+constexpr int SMEM_BYTES_2SEG = 2 * BUF_BYTES + QB * OST_ROW;  // 2-segment form: staging kept beside the tiles
+constexpr float NEG_BIG = -1.0e30f;
+
+__device__ __forceinline__ int vt_swz(int dv) { return (((dv >> 2) & 7) << 1) | (((dv >> 1) ^ (dv >> 5)) & 1); }
+
+struct KVSeg {
+  const bf16* k;
+  const bf16* v;
+  int len;
+  int ldk;
+  int ldv;
+};
+
+template <bool TWO_SEG>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
+                                                       KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
+                                                       float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * QB + wave * QW;
+  const int hoff = head * HD;
+
+  // Q^T B-operand fragments: lane (q = l31, half hh) holds Q[q][16*ks + 8*hh .. +8]
+  bf16x8 qf[8];
+  {
+    const bf16* qrow = Q + (size_t)min(q0 + l31, Nq - 1) * ldq + hoff + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+  }
+
+  // staging maps
+  // K: 64 rows x 16 chunks(16 B); thread handles chunks tid and tid + 512
+  const int k_ck = tid & 15, k_row0 = tid >> 4;  // rows k_row0, k_row0 + 32
+  // V: thread handles a 4(kv) x 4(dv) patch: dv = 4*dvq.., kv = 4*kvq..
+  const int v_dvq = tid & 31, v_kvq = tid >> 5;
+
+  // output staging rows; in the 2-segment form they live beside the tile buffers so that the
+  // segment-0 result can wait there (as bf16) while segment 1 streams through the tiles
+  unsigned char* ost = smem + (TWO_SEG ? 2 * BUF_BYTES : 0) + (size_t)(wave * QW + l31) * OST_ROW;
+
+#pragma unroll
+  for (int sidx = 0; sidx < (TWO_SEG ? 2 : 1); ++sidx) {
+    const KVSeg sg = sidx == 0 ? seg0 : seg1;
+    const int ntiles = (sg.len + KVB - 1) / KVB;
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    u32x4 kreg[2];
+    u32x2 vreg[4];
+    auto load_tile = [&](int t) {
+      const int kv0 = t * KVB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = min(kv0 + k_row0 + 32 * i, sg.len - 1);
+        kreg[i] = *reinterpret_cast<const u32x4*>(sg.k + (size_t)r * sg.ldk + hoff + k_ck * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = min(kv0 + 4 * v_kvq + i, sg.len - 1);
+        vreg[i] = *reinterpret_cast<const u32x2*>(sg.v + (size_t)r * sg.ldv + hoff + v_dvq * 4);
+      }
+    };
+    auto store_tile = [&](int buf) {
+      unsigned char* sK = smem + buf * BUF_BYTES;
+      unsigned char* sV = sK + K_TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = k_row0 + 32 * i;
+        *reinterpret_cast<u32x4*>(sK + r * (HD * 2) + ((k_ck ^ (r & 15)) << 4)) = kreg[i];
+      }
+      // 4x4 transpose of 16-bit elements: vreg[i] = {dv0,dv1 | dv2,dv3} of kv row i
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = j >> 1;
+        uint32_t lo, hi;
+        if ((j & 1) == 0) {
+          lo = (vreg[0][w] & 0xffffu) | (vreg[1][w] << 16);
+          hi = (vreg[2][w] & 0xffffu) | (vreg[3][w] << 16);
+        } else {
+          lo = (vreg[0][w] >> 16) | (vreg[1][w] & 0xffff0000u);
+          hi = (vreg[2][w] >> 16) | (vreg[3][w] & 0xffff0000u);
+        }
+        const int dv = 4 * v_dvq + j;
+        u32x2 val = {lo, hi};
+        *reinterpret_cast<u32x2*>(sV + dv * (KVB * 2) + ((v_kvq ^ vt_swz(dv)) << 3)) = val;
+      }
+    };
+
+    load_tile(0);
+    __syncthreads();  // previous segment / nothing: LDS free
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+      const int cur = t & 1;
+      if (t + 1 < ntiles) load_tile(t + 1);
+      const unsigned char* sK = smem + cur * BUF_BYTES;
+      const unsigned char* sV = sK + K_TILE_BYTES;
+
+      // ---- S^T = K . Q^T  (two 32-kv fragments)
+      f32x16 st[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[f][r] = 0.f;
+        const int r = 32 * f + l31;
+        const unsigned char* krow = sK + r * (HD * 2);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * ks + hh) ^ (r & 15)) << 4));
+          st[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[f], 0, 0, 0);
+        }
+      }
+      // ---- mask the kv tail of the last tile: kv = 64 t + 32 f + (r&3) + 8 (r>>2) + 4 hh
+      if ((t + 1) * KVB > sg.len) {
+        const int base = t * KVB + 4 * hh;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
+            if (kv >= sg.len) st[f][r] = NEG_BIG;
+          }
+      }
+      // ---- online softmax (row = this lane's q; partner lane^32 holds the other kv half)
+      float mx = st[0][0];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[f][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      const float mc = m_new * scale_log2e;
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[f][r], scale_log2e, -mc));
+          st[f][r] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha;
+
+      // ---- O^T += V^T . P^T : 4 k-steps of 16 kv; step s uses st[s>>1] regs 8*(s&1) .. +8
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int f = s >> 1, rb = 8 * (s & 1);
+        f32x2 t0 = {st[f][rb + 0], st[f][rb + 1]}, t1 = {st[f][rb + 2], st[f][rb + 3]};
+        f32x2 t2 = {st[f][rb + 4], st[f][rb + 5]}, t3 = {st[f][rb + 6], st[f][rb + 7]};
+        const bf16x2 p0 = __builtin_convertvector(t0, bf16x2), p1 = __builtin_convertvector(t1, bf16x2);
+        const bf16x2 p2 = __builtin_convertvector(t2, bf16x2), p3 = __builtin_convertvector(t3, bf16x2);
+        const bf16x8 pf = {p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+        const int c0 = 4 * s + hh;  // 8-B chunk index of kv = 16 s + 4 hh
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int dv = 32 * m + l31;
+          const unsigned char* vrow = sV + dv * (KVB * 2);
+          const int sw = vt_swz(dv);
+          const bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow + ((c0 ^ sw) << 3));
+          const bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + (((c0 + 2) ^ sw) << 3));
+          const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+          oacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[m], 0, 0, 0);
+        }
+      }
+      if (t + 1 < ntiles) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+
+    // ---- finalize this segment: normalise, round to bf16 (SDPA output dtype)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    // stage this wave's 32 x 128 tile: lane (q = l31, half hh) owns dv = 32 m + 8 a + 4 hh + b
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        uint32_t w0 = pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv);
+        uint32_t w1 = pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv);
+        u32x2* slot = reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2);
+        if (TWO_SEG && sidx == 1) {  // bf16 add of the two SDPA outputs (transformer_chronoedit.py:104)
+          const u32x2 pv = *slot;    // this lane's own segment-0 value
+          w0 = pack_bf16(bf16lo(pv[0]) + bf16lo(w0), bf16hi(pv[0]) + bf16hi(w0));
+          w1 = pack_bf16(bf16lo(pv[1]) + bf16lo(w1), bf16hi(pv[1]) + bf16hi(w1));
+        }
+        u32x2 val = {w0, w1};
+        *slot = val;
+      }
+  }
+
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = q0 + rl;
+    if (q < Nq) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? 2 * BUF_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    }
+  }
+}
+
+}  // namespace
+
+// Q [Nq][ldq], K*/V* [len][ld*], O [Nq][ldo]; all bf16, head h occupies columns [128 h, 128 h + 128).
+// Second kv segment optional (k2 == nullptr or len2 == 0): O = bf16(attn(seg1)) + bf16(attn(seg2)).
+extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
+                                 const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq,
+                                 int ldo, float softmax_scale, hipStream_t stream) {
+  if (!Q || !K1 || !V1 || !O) return CE_ERR_ARG;
+  if (head_dim != HD || Nq <= 0 || H <= 0 || len1 <= 0) return CE_ERR_SHAPE;
+  if ((ldq & 7) || (ldo & 7) || (ldk1 & 7) || (ldv1 & 3)) return CE_ERR_ALIGN;
+  const bool two = (K2 != nullptr && V2 != nullptr && len2 > 0);
+  if (two && ((ldk2 & 7) || (ldv2 & 3))) return CE_ERR_ALIGN;
+  const int nqb = (Nq + QB - 1) / QB;
+  KVSeg s0{(const bf16*)K1, (const bf16*)V1, len1, ldk1, ldv1};
+  KVSeg s1{(const bf16*)K2, (const bf16*)V2, two ? len2 : 0, ldk2, ldv2};
+  const float sl2 = softmax_scale * 1.4426950408889634f;
+  dim3 grid(nqb * H), block(512);
+  if (two) {
+    static bool attr_done2 = false;
+    if (!attr_done2) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES_2SEG);
+      attr_done2 = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, SMEM_BYTES_2SEG, stream, (const bf16*)Q, (bf16*)O, s0, s1, Nq, H, ldq,
+                       ldo, nqb, sl2);
+  } else {
+    static bool attr_done1 = false;
+    if (!attr_done1) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+      attr_done1 = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, SMEM_BYTES, stream, (const bf16*)Q, (bf16*)O, s0, s1, Nq, H, ldq,
+                       ldo, nqb, sl2);
+  }
+  return (int)hipGetLastError();
+}

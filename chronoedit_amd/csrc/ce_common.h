@@ -1,0 +1,68 @@
+// Shared device helpers for the ChronoEdit gfx950 (CDNA4) kernels.
+// Wave = 64 lanes everywhere; MFMA fragment typedefs follow the gfx950 bf16 forms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define CE_WAVE 64
+
+// error codes returned by every extern "C" launcher (include/chronoedit_hip.h)
+#define CE_OK 0
+#define CE_ERR_ARG (-1)
+#define CE_ERR_SHAPE (-2)
+#define CE_ERR_ALIGN (-3)
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
+__device__ __forceinline__ float bf16lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+
+// round-to-nearest-even fp32 -> bf16 (v_cvt_pk_bf16_f32 on gfx950), packed pair
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  bf16x2 r = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ float round_bf16(float x) {
+  bf16 b = (bf16)x;
+  return (float)b;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh-approximated GELU exactly as torch's F.gelu(x, approximate="tanh") evaluates it in fp32
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
+  const float kKappa = 0.044715f;
+  float inner = kBeta * (x + kKappa * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// Bijective XCD-aware remap of a 1-D block id (cdna guide T1): block b runs on XCD b % 8,
+// so give every XCD one contiguous chunk of the logical tile sequence.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}

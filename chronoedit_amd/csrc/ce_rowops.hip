@@ -1,0 +1,275 @@
+// HBM-bound row kernels of the ChronoEdit DiT block (one wave64 per token row, 16-B loads):
+//   ce_ln_affine      K5/K11/K18  LN(fp32 stats, eps) * a[d] + b[d] -> bf16
+//                                 (reference: transformer_chronoedit.py:279,284,289,460)
+//   ce_rmsnorm_rope   K7+K8       RMSNorm across ALL heads' channels, then 3-D RoPE on
+//                                 (even,odd) pairs (reference: transformer_chronoedit.py:62-79)
+// plus the once-per-forward small kernels (timestep embed K2, modulation tables, patchify,
+// unpatchify).  Algorithmic bytes per row pass: 2 * D * 2 B (read bf16 + write bf16).
+#include "ce_common.h"
+
+#define ROW_MAXC 10  // 16-B chunks per lane: D <= 64 * 8 * 10 = 5120
+
+// ------------------------------------------------------------------------------------
+// LN * a + b
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                        const float* __restrict__ a, const float* __restrict__ b,
+                                                        int M, int D, int ldx, int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = D >> 3;
+  const bf16* xr = x + (size_t)row * ldx;
+  u32x4 raw[ROW_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      raw[i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += bf16lo(raw[i][j]) + bf16hi(raw[i][j]);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = bf16lo(raw[i][j]) - mean, d1 = bf16hi(raw[i][j]) - mean;
+        v += d0 * d0 + d1 * d1;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
+  bf16* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + c * 8), a1 = *reinterpret_cast<const f32x4*>(a + c * 8 + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + c * 8), b1 = *reinterpret_cast<const f32x4*>(b + c * 8 + 4);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float aa0 = j < 2 ? a0[2 * j] : a1[2 * j - 4], aa1 = j < 2 ? a0[2 * j + 1] : a1[2 * j - 3];
+        const float bb0 = j < 2 ? b0[2 * j] : b1[2 * j - 4], bb1 = j < 2 ? b0[2 * j + 1] : b1[2 * j - 3];
+        const float n0 = (bf16lo(raw[i][j]) - mean) * rstd, n1 = (bf16hi(raw[i][j]) - mean) * rstd;
+        o[j] = pack_bf16(n0 * aa0 + bb0, n1 * aa1 + bb1);
+      }
+      *reinterpret_cast<u32x4*>(yr + c * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// RMSNorm(across heads) [+ RoPE], in place.  cs = [ntok][head_dim/2][2] fp32 (cos, sin)
+// Rounding points follow diffusers RMSNorm under bf16: bf16(x * rstd) then bf16(. * w).
+// RoPE is evaluated in fp32 on the bf16-rounded values (reference uses fp64: the two
+// agree to ~1e-7 relative before the final bf16 rounding).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ cs, int M, int D, int ld,
+                                                           int head_dim, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = D >> 3;
+  bf16* xr = x + (size_t)row * ld;
+  u32x4 raw[ROW_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      raw[i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = bf16lo(raw[i][j]), v1 = bf16hi(raw[i][j]);
+        s += v0 * v0 + v1 * v1;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(s) / (float)D + eps);
+  const int half = head_dim >> 1;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c * 8), w1 = *reinterpret_cast<const f32x4*>(w + c * 8 + 4);
+      u32x4 o;
+      f32x4 cs0, cs1;
+      if (cs != nullptr) {
+        const int pair0 = ((c * 8) % head_dim) >> 1;  // first of the 4 (even,odd) pairs of this chunk
+        const float* p = cs + ((size_t)row * half + pair0) * 2;
+        cs0 = *reinterpret_cast<const f32x4*>(p);
+        cs1 = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ww0 = j < 2 ? w0[2 * j] : w1[2 * j - 4], ww1 = j < 2 ? w0[2 * j + 1] : w1[2 * j - 3];
+        float v0 = round_bf16(round_bf16(bf16lo(raw[i][j]) * rstd) * ww0);
+        float v1 = round_bf16(round_bf16(bf16hi(raw[i][j]) * rstd) * ww1);
+        if (cs != nullptr) {
+          const float co = j < 2 ? cs0[2 * j] : cs1[2 * j - 4], si = j < 2 ? cs0[2 * j + 1] : cs1[2 * j - 3];
+          const float r0 = v0 * co - v1 * si, r1 = v0 * si + v1 * co;
+          v0 = r0;
+          v1 = r1;
+        }
+        o[j] = pack_bf16(v0, v1);
+      }
+      *reinterpret_cast<u32x4*>(xr + c * 8) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K2: timestep sinusoid + small GEMV chain (one wave per output feature)
+// ------------------------------------------------------------------------------------
+// out[i] = cos(t * f_i) for i < half, sin(t * f_i) otherwise;  f_i = exp(-ln(1e4) * i / half)
+__global__ void timestep_sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim >> 1;
+  if (i >= dim) return;
+  const int k = i < half ? i : i - half;
+  const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+  const float arg = (float)t[0] * freq;
+  out[i] = i < half ? cosf(arg) : sinf(arg);
+}
+
+// y[n] = post( W[n,:] . pre(x) + bias[n] );  WT = float or bf16.
+// flags: bit0 pre: x <- bf16(silu(x));  bit1 post: silu;  bit2 post: round to bf16 (stored as fp32)
+template <typename WT>
+__global__ __launch_bounds__(256) void gemv_kernel(const WT* __restrict__ W, const float* __restrict__ x,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int N, int K,
+                                                   int flags) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const WT* wr = W + (size_t)n * K;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    float xv = x[k];
+    if (flags & 1) xv = round_bf16(silu(xv));
+    acc += (float)wr[k] * xv;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float r = acc + (bias ? bias[n] : 0.f);
+    if (flags & 4) r = round_bf16(r);
+    if (flags & 2) r = silu(r);
+    y[n] = r;
+  }
+}
+
+// mod[l][j][d] = table[l][j][d] + v[j][d]  (+1 on the rows flagged in one_mask), fp32.
+// Reference: (scale_shift_table + temb.float()).chunk(6) then (1 + scale), transformer_chronoedit.py:274-279,451.
+__global__ void modulation_kernel(const float* __restrict__ table, const float* __restrict__ v, float* __restrict__ mod,
+                                  int L, int J, int D, int v_rows, int one_mask) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)L * J * D;
+  if (idx >= total) return;
+  const int d = idx % D;
+  const int j = (idx / D) % J;
+  const float add = v[(size_t)(v_rows == 1 ? 0 : j) * D + d];
+  float r = table[idx] + add;
+  if ((one_mask >> j) & 1) r = 1.0f + r;
+  mod[idx] = r;
+}
+
+// ------------------------------------------------------------------------------------
+// K1 patchify (im2col of the k=s=(1,2,2) Conv3d) and K18 unpatchify
+// x [C][T][H][W] bf16 -> cols [N = T*(H/2)*(W/2)][Kpad], k = c*4 + dh*2 + dw, zero padded
+// ------------------------------------------------------------------------------------
+__global__ void patchify_kernel(const bf16* __restrict__ x, bf16* __restrict__ cols, int C, int T, int H, int W, int Kpad) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int h2 = H >> 1, w2 = W >> 1;
+  const size_t total = (size_t)T * h2 * w2 * Kpad;
+  if (idx >= total) return;
+  const int k = idx % Kpad;
+  const size_t tok = idx / Kpad;
+  bf16 v = (bf16)0.f;
+  if (k < C * 4) {
+    const int c = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
+    const int wq = tok % w2, hq = (tok / w2) % h2, t = tok / ((size_t)w2 * h2);
+    v = x[(((size_t)c * T + t) * H + (hq * 2 + dh)) * W + wq * 2 + dw];
+  }
+  cols[idx] = v;
+}
+
+// y [N][ldy >= 4*Cout], col = (dh*2+dw)*Cout + c  ->  out [Cout][T][H][W]
+// (reshape/permute at transformer_chronoedit.py:463-467)
+__global__ void unpatchify_kernel(const bf16* __restrict__ y, bf16* __restrict__ out, int Cout, int T, int H, int W, int ldy) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Cout * T * H * W;
+  if (idx >= total) return;
+  const int w = idx % W, h = (idx / W) % H, t = (idx / ((size_t)W * H)) % T, c = idx / ((size_t)W * H * T);
+  const int h2 = H >> 1, w2 = W >> 1;
+  const size_t tok = ((size_t)t * h2 + (h >> 1)) * w2 + (w >> 1);
+  out[idx] = y[tok * ldy + ((h & 1) * 2 + (w & 1)) * Cout + c];
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+extern "C" int ce_ln_affine_bf16(const void* x, void* y, const float* a, const float* b, int M, int D, int ldx, int ldy,
+                                 float eps, hipStream_t stream) {
+  if (!x || !y || !a || !b) return CE_ERR_ARG;
+  if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldy & 7)) return CE_ERR_SHAPE;
+  hipLaunchKernelGGL(ln_affine_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M, D, ldx,
+                     ldy, eps);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_rmsnorm_rope_bf16(void* x, const float* w, const float* cos_sin, int M, int D, int ld, int head_dim,
+                                    float eps, hipStream_t stream) {
+  if (!x || !w) return CE_ERR_ARG;
+  if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ld & 7) || (head_dim & 7) || D % head_dim) return CE_ERR_SHAPE;
+  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (bf16*)x, w, cos_sin, M, D, ld, head_dim,
+                     eps);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_timestep_sinusoid(const int64_t* t, float* out, int dim, hipStream_t stream) {
+  if (!t || !out || dim <= 0 || (dim & 1)) return CE_ERR_ARG;
+  hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, t, out, dim);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_gemv(const void* W, int w_is_bf16, const float* x, const float* bias, float* y, int N, int K, int flags,
+                       hipStream_t stream) {
+  if (!W || !x || !y || N <= 0 || K <= 0) return CE_ERR_ARG;
+  if (w_is_bf16)
+    hipLaunchKernelGGL(gemv_kernel<bf16>, dim3((N + 3) / 4), dim3(256), 0, stream, (const bf16*)W, x, bias, y, N, K, flags);
+  else
+    hipLaunchKernelGGL(gemv_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, stream, (const float*)W, x, bias, y, N, K, flags);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_modulation(const float* table, const float* v, float* mod, int L, int J, int D, int v_rows, int one_mask,
+                             hipStream_t stream) {
+  if (!table || !v || !mod || L <= 0 || J <= 0 || D <= 0 || (v_rows != 1 && v_rows != J)) return CE_ERR_ARG;
+  const size_t total = (size_t)L * J * D;
+  hipLaunchKernelGGL(modulation_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, v, mod, L, J, D,
+                     v_rows, one_mask);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_patchify_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, hipStream_t stream) {
+  if (!x || !cols || (H & 1) || (W & 1) || Kpad < C * 4) return CE_ERR_ARG;
+  const size_t total = (size_t)T * (H / 2) * (W / 2) * Kpad;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)x, (bf16*)cols,
+                     C, T, H, W, Kpad);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_unpatchify_bf16(const void* y, void* out, int Cout, int T, int H, int W, int ldy, hipStream_t stream) {
+  if (!y || !out || (H & 1) || (W & 1) || ldy < 4 * Cout) return CE_ERR_ARG;
+  const size_t total = (size_t)Cout * T * H * W;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)y, (bf16*)out,
+                     Cout, T, H, W, ldy);
+  return (int)hipGetLastError();
+}

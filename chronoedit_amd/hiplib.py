@@ -1,0 +1,87 @@
+"""Build + load libchronoedit_hip.so (the C-ABI HIP library) through ctypes.
+
+The library is built in-tree (``chronoedit_amd/lib/``) with ``hipcc --offload-arch=gfx950`` so that
+it travels with the source tree; nothing is JIT-compiled at run time.  Loading fails loudly when
+the library is missing or lacks a symbol declared in include/chronoedit_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+from typing import Dict, List
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
+HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
+
+SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_attn.hip", "ce_sched.hip"]
+
+_c = ctypes
+_P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
+
+# symbol -> argtypes (restype is always int)
+SIGNATURES: Dict[str, List] = {
+    "ce_ln_affine_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "ce_rmsnorm_rope_bf16": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_attention_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "ce_timestep_sinusoid": [_P, _P, _I, _P],
+    "ce_gemv": [_P, _I, _P, _P, _P, _I, _I, _I, _P],
+    "ce_modulation": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "ce_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ce_unpatchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ce_cfg_unipc_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_longlong, _I, _P],
+}
+
+
+def header_symbols() -> List[str]:
+    """Every function declared in include/chronoedit_hip.h."""
+    txt = open(HEADER).read()
+    return re.findall(r"^int (ce_\w+)\(", txt, flags=re.M)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every csrc/*.hip into lib/libchronoedit_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, "ce_common.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_LIB = None
+
+
+def load() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension is the only compute path of chronoedit_amd "
+            "(no CPU/eager fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'`."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in header_symbols():
+        if not hasattr(lib, name):
+            raise RuntimeError(f"{LIB_PATH} does not export {name} declared in include/chronoedit_hip.h")
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}")
+        fn.argtypes = argtypes
+        fn.restype = _c.c_int
+    _LIB = lib
+    return lib

@@ -1,0 +1,260 @@
+"""torch-tensor front end of the C ABI (include/chronoedit_hip.h).
+
+Every function checks device/dtype/contiguity, then hands raw device pointers and the current
+torch stream to libchronoedit_hip.so.  There is no fallback: a CPU tensor or a missing library
+raises.  PyTorch is used here only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import hiplib
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_GATE_RES, EPI_BIAS_GELU_ERF = 0, 1, 2, 3
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = hiplib.load()
+    return _lib
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+# ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) ----
+_PROF = None  # list of (key, flops_or_bytes, start_event, end_event) while profiling
+
+
+class profile:
+    """with ops.profile() as prof: ...; prof.summary() -> {key: {n, total_ms, avg_ms, work}} (events on the
+    current torch stream, which is the stream every launcher enqueues on)."""
+
+    def __enter__(self):
+        global _PROF
+        _PROF = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PROF
+        self.records, _PROF = _PROF, None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, work, st, en in self.records:
+            d = out.setdefault(key, {"n": 0, "total_ms": 0.0, "work": work})
+            d["n"] += 1
+            d["total_ms"] += st.elapsed_time(en)
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["n"]
+        return out
+
+
+def _prof_begin():
+    if _PROF is None:
+        return None
+    st = torch.cuda.Event(enable_timing=True)
+    st.record()
+    return st
+
+
+def _prof_end(st, key, work):
+    if st is not None:
+        en = torch.cuda.Event(enable_timing=True)
+        en.record()
+        _PROF.append((key, work, st, en))
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "unsupported shape", -3: "misaligned stride"}.get(rc, f"hipError {rc}")
+        raise HipKernelError(f"{name} failed: {kind}")
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dev(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise HipKernelError(f"{name}: tensor must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _rows(t: torch.Tensor, name: str):
+    """2-D view with unit inner stride -> (M, D, ld)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+def ln_affine(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None):
+    """out = LN_fp32(x) * a + b  (bf16 in/out, fp32 a/b)."""
+    _dev(x, torch.bfloat16, "x"), _dev(a, torch.float32, "a"), _dev(b, torch.float32, "b")
+    M, D, ldx = _rows(x, "x")
+    if out is None:
+        out = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    _, _, ldy = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_ln_affine_bf16(_ptr(x), _ptr(out), _ptr(a), _ptr(b), M, D, ldx, ldy, float(eps), _stream()), "ce_ln_affine_bf16")
+    _prof_end(st, f"ln_affine_{M}x{D}", 4.0 * M * D)
+    return out
+
+
+def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tensor], head_dim: int, eps: float):
+    """In place RMSNorm-across-heads (+ RoPE when cos_sin [M, head_dim/2, 2] fp32 is given)."""
+    _dev(x, torch.bfloat16, "x"), _dev(w, torch.float32, "w")
+    M, D, ld = _rows(x, "x")
+    if cos_sin is not None:
+        _dev(cos_sin, torch.float32, "cos_sin")
+        assert cos_sin.is_contiguous() and cos_sin.shape == (M, head_dim // 2, 2), (cos_sin.shape, M, head_dim)
+    st = _prof_begin()
+    _check(lib().ce_rmsnorm_rope_bf16(_ptr(x), _ptr(w), _ptr(cos_sin), M, D, ld, head_dim, float(eps), _stream()), "ce_rmsnorm_rope_bf16")
+    _prof_end(st, f"rmsnorm_rope_{M}x{D}", 4.0 * M * D)
+    return x
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+         epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias)."""
+    _dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w")
+    M, K, lda = _rows(a, "a")
+    N, K2, ldw = _rows(w, "w")
+    if K != K2:
+        raise ValueError(f"gemm: K mismatch {K} vs {K2}")
+    if bias is not None:
+        _dev(bias, torch.float32, "bias")
+        assert bias.numel() == N and bias.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    _dev(out, torch.bfloat16, "out")
+    Mo, No, ldc = _rows(out, "out")
+    assert (Mo, No) == (M, N), ((Mo, No), (M, N))
+    ldres = 0
+    if epilogue == EPI_GATE_RES:
+        if res is None:
+            raise ValueError("EPI_GATE_RES needs res")
+        _dev(res, torch.bfloat16, "res")
+        _, _, ldres = _rows(res, "res")
+        if gate is not None:
+            _dev(gate, torch.float32, "gate")
+            assert gate.numel() == N and gate.is_contiguous()
+    st = _prof_begin()
+    _check(lib().ce_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), epilogue, _ptr(gate), _ptr(res), M, N, K, lda, ldw, ldc,
+                              ldres, _stream()), "ce_gemm_bf16")
+    _prof_end(st, f"gemm_{M}x{N}x{K}_epi{epilogue}", 2.0 * M * N * K)
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
+              k2: Optional[torch.Tensor] = None, v2: Optional[torch.Tensor] = None, scale: Optional[float] = None):
+    """q [Nq, H*128], k/v [Nkv, H*128] (row strides free) -> out [Nq, H*128]; optional 2nd kv segment."""
+    for n, t in (("q", q), ("k", k), ("v", v)):
+        _dev(t, torch.bfloat16, n)
+    Nq, Dq, ldq = _rows(q, "q")
+    head_dim = Dq // heads
+    L1, _, ldk = _rows(k, "k")
+    L1v, _, ldv = _rows(v, "v")
+    assert L1 == L1v
+    if out is None:
+        out = torch.empty((Nq, Dq), dtype=torch.bfloat16, device=q.device)
+    _, _, ldo = _rows(out, "out")
+    L2 = ldk2 = ldv2 = 0
+    if k2 is not None:
+        _dev(k2, torch.bfloat16, "k2"), _dev(v2, torch.bfloat16, "v2")
+        L2, _, ldk2 = _rows(k2, "k2")
+        _, _, ldv2 = _rows(v2, "v2")
+    if scale is None:
+        scale = head_dim ** -0.5
+    st = _prof_begin()
+    _check(lib().ce_attention_bf16(_ptr(q), _ptr(k), _ptr(v), L1, ldk, ldv, _ptr(k2), _ptr(v2), L2, ldk2, ldv2, _ptr(out), Nq,
+                                   heads, head_dim, ldq, ldo, float(scale), _stream()), "ce_attention_bf16")
+    _prof_end(st, f"attention_{Nq}x{L1}+{L2}_h{heads}", 4.0 * Nq * (L1 + L2) * head_dim * heads)
+    return out
+
+
+def timestep_sinusoid(t: torch.Tensor, dim: int, out: Optional[torch.Tensor] = None):
+    _dev(t, torch.int64, "timestep")
+    if out is None:
+        out = torch.empty((dim,), dtype=torch.float32, device=t.device)
+    _check(lib().ce_timestep_sinusoid(_ptr(t), _ptr(out), dim, _stream()), "ce_timestep_sinusoid")
+    return out
+
+
+def gemv(w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], flags: int = 0, out: Optional[torch.Tensor] = None):
+    """y = post(w @ pre(x) + bias); x/y fp32, w fp32 or bf16 (see include/chronoedit_hip.h for flags)."""
+    _dev(x, torch.float32, "x")
+    assert w.is_cuda and w.dtype in (torch.float32, torch.bfloat16) and w.is_contiguous()
+    N, K = w.shape
+    assert x.numel() == K
+    if bias is not None:
+        _dev(bias, torch.float32, "bias")
+    if out is None:
+        out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    _check(lib().ce_gemv(_ptr(w), int(w.dtype == torch.bfloat16), _ptr(x), _ptr(bias), _ptr(out), N, K, flags, _stream()), "ce_gemv")
+    return out
+
+
+def modulation(table: torch.Tensor, v: torch.Tensor, one_mask: int, out: Optional[torch.Tensor] = None):
+    """out[L,J,D] = table[L,J,D] + v[J or 1, D]  (+1 on rows in one_mask)."""
+    _dev(table, torch.float32, "table"), _dev(v, torch.float32, "v")
+    L, J, D = table.shape
+    v_rows = v.numel() // D
+    assert table.is_contiguous() and v.is_contiguous() and v_rows in (1, J)
+    if out is None:
+        out = torch.empty_like(table)
+    _check(lib().ce_modulation(_ptr(table), _ptr(v), _ptr(out), L, J, D, v_rows, one_mask, _stream()), "ce_modulation")
+    return out
+
+
+def patchify(x: torch.Tensor, kpad: int, out: Optional[torch.Tensor] = None):
+    """x [C,T,H,W] bf16 -> [T*(H/2)*(W/2), kpad]."""
+    _dev(x, torch.bfloat16, "x")
+    assert x.is_contiguous() and x.dim() == 4
+    C, T, H, W = x.shape
+    n = T * (H // 2) * (W // 2)
+    if out is None:
+        out = torch.empty((n, kpad), dtype=torch.bfloat16, device=x.device)
+    _check(lib().ce_patchify_bf16(_ptr(x), _ptr(out), C, T, H, W, kpad, _stream()), "ce_patchify_bf16")
+    return out
+
+
+def unpatchify(y: torch.Tensor, cout: int, T: int, H: int, W: int, out: Optional[torch.Tensor] = None):
+    _dev(y, torch.bfloat16, "y")
+    _, _, ldy = _rows(y, "y")
+    if out is None:
+        out = torch.empty((cout, T, H, W), dtype=torch.bfloat16, device=y.device)
+    _check(lib().ce_unpatchify_bf16(_ptr(y), _ptr(out), cout, T, H, W, ldy, _stream()), "ce_unpatchify_bf16")
+    return out
+
+
+def cfg_unipc_step(v_cond: torch.Tensor, v_uncond: Optional[torch.Tensor], x: torch.Tensor, x_last: torch.Tensor, m0: torch.Tensor,
+                   m1: torch.Tensor, coef: torch.Tensor, x0_out: Optional[torch.Tensor] = None, round_sigma_v: bool = True):
+    """Fused CFG + flow-UniPC update, in place on (x, x_last, m0, m1).  coef = device float[10]."""
+    _dev(v_cond, torch.bfloat16, "v_cond")
+    for n, t in (("x", x), ("x_last", x_last), ("m0", m0), ("m1", m1), ("coef", coef)):
+        _dev(t, torch.float32, n)
+        assert t.is_contiguous()
+    if v_uncond is not None:
+        _dev(v_uncond, torch.bfloat16, "v_uncond")
+        assert v_uncond.is_contiguous()
+    assert v_cond.is_contiguous() and coef.numel() >= 10
+    n = x.numel()
+    assert v_cond.numel() == n == x_last.numel() == m0.numel() == m1.numel()
+    _check(lib().ce_cfg_unipc_step(_ptr(v_cond), _ptr(v_uncond), _ptr(x), _ptr(x_last), _ptr(m0), _ptr(m1), _ptr(x0_out), _ptr(coef),
+                                   _ptr(None), n, int(round_sigma_v), _stream()), "ce_cfg_unipc_step")
+    return x

@@ -1,0 +1,520 @@
+"""Drop-in `ChronoEditTransformer3DModel` whose forward runs on the gfx950 HIP kernels.
+
+Mirrors /root/reference/chronoedit_diffusers/transformer_chronoedit.py:298-476:
+  * same constructor keyword arguments and `.config` fields (:341-360);
+  * same parameter tree with the diffusers state-dict names (key list:
+    chronoedit_diffsynth/wan_video_dit_chronoedit.py:439-496), built from real nn.Linear / nn.Conv3d
+    / nn.LayerNorm modules so `load_state_dict`, `.to`, PEFT LoRA injection/fusion keep working;
+  * same `forward(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_image,
+    return_dict, attention_kwargs)` signature, return types and error behaviour (:397-476);
+  * same dtype islands: `_keep_in_fp32_modules` parameters stay fp32 (:338).
+The modules only HOLD parameters; the arithmetic is `DiTEngine` below, which sequences
+libchronoedit_hip.so launches on the current stream (no torch math on the hot path).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Any, Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+@dataclass
+class Transformer2DModelOutput:
+    sample: torch.Tensor
+
+
+class _Config(SimpleNamespace):
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def get(self, k, d=None):
+        return getattr(self, k, d)
+
+
+class RMSNormParams(nn.Module):
+    """Parameter holder for diffusers RMSNorm (norm_q / norm_k / norm_added_k)."""
+
+    def __init__(self, dim: int, eps: float, device=None, dtype=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=dtype))
+
+
+class AttentionParams(nn.Module):
+    """Parameter holder with diffusers `Attention` attribute names (transformer_chronoedit.py:231-258)."""
+
+    def __init__(self, dim: int, heads: int, eps: float, added_kv_proj_dim: Optional[int], device=None, dtype=None):
+        super().__init__()
+        kw = dict(device=device, dtype=dtype)
+        self.heads = heads
+        self.to_q = nn.Linear(dim, dim, **kw)
+        self.to_k = nn.Linear(dim, dim, **kw)
+        self.to_v = nn.Linear(dim, dim, **kw)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim, **kw), nn.Dropout(0.0)])
+        self.norm_q = RMSNormParams(dim, eps, **kw)
+        self.norm_k = RMSNormParams(dim, eps, **kw)
+        self.add_k_proj = self.add_v_proj = self.norm_added_k = None
+        if added_kv_proj_dim is not None:
+            self.add_k_proj = nn.Linear(added_kv_proj_dim, dim, **kw)
+            self.add_v_proj = nn.Linear(added_kv_proj_dim, dim, **kw)
+            self.norm_added_k = RMSNormParams(dim, eps, **kw)
+
+
+class _GELUProj(nn.Module):
+    def __init__(self, din, dout, device=None, dtype=None):
+        super().__init__()
+        self.proj = nn.Linear(din, dout, device=device, dtype=dtype)
+
+
+class FeedForwardParams(nn.Module):
+    """diffusers FeedForward layout: net.0.proj, net.1 (Dropout), net.2."""
+
+    def __init__(self, dim, inner, dim_out=None, device=None, dtype=None):
+        super().__init__()
+        self.net = nn.ModuleList([
+            _GELUProj(dim, inner, device=device, dtype=dtype),
+            nn.Dropout(0.0),
+            nn.Linear(inner, dim_out if dim_out is not None else dim, device=device, dtype=dtype),
+        ])
+
+
+class BlockParams(nn.Module):
+    """ChronoEditTransformerBlock parameters (transformer_chronoedit.py:216-265)."""
+
+    def __init__(self, dim, ffn_dim, heads, cross_attn_norm, eps, added_kv_proj_dim, device=None, dtype=None):
+        super().__init__()
+        self.attn1 = AttentionParams(dim, heads, eps, None, device=device, dtype=dtype)
+        self.attn2 = AttentionParams(dim, heads, eps, added_kv_proj_dim, device=device, dtype=dtype)
+        # norm1 / norm3 have no affine parameters; norm2 is FP32LayerNorm(affine) kept in fp32 (:338)
+        self.norm2 = nn.LayerNorm(dim, eps, elementwise_affine=True, device=device, dtype=torch.float32) if cross_attn_norm else nn.Identity()
+        self.ffn = FeedForwardParams(dim, ffn_dim, device=device, dtype=dtype)
+        self.scale_shift_table = nn.Parameter(torch.randn(1, 6, dim, device=device, dtype=torch.float32) / dim**0.5)
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, din, dim, device=None):
+        super().__init__()
+        self.linear_1 = nn.Linear(din, dim, device=device, dtype=torch.float32)
+        self.linear_2 = nn.Linear(dim, dim, device=device, dtype=torch.float32)
+
+
+class _TextProjection(nn.Module):
+    def __init__(self, din, dim, device=None, dtype=None):
+        super().__init__()
+        self.linear_1 = nn.Linear(din, dim, device=device, dtype=dtype)
+        self.linear_2 = nn.Linear(dim, dim, device=device, dtype=dtype)
+
+
+class _ImageEmbedding(nn.Module):
+    def __init__(self, din, dout, device=None, dtype=None):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(din, device=device, dtype=torch.float32)
+        self.ff = FeedForwardParams(din, din, dout, device=device, dtype=dtype)
+        self.norm2 = nn.LayerNorm(dout, device=device, dtype=torch.float32)
+
+
+class ConditionEmbedderParams(nn.Module):
+    """ChronoEditTimeTextImageEmbedding parameters (transformer_chronoedit.py:126-145)."""
+
+    def __init__(self, dim, time_freq_dim, time_proj_dim, text_embed_dim, image_embed_dim, device=None, dtype=None):
+        super().__init__()
+        self.time_embedder = _TimestepEmbedding(time_freq_dim, dim, device=device)
+        self.time_proj = nn.Linear(dim, time_proj_dim, device=device, dtype=dtype)
+        self.text_embedder = _TextProjection(text_embed_dim, dim, device=device, dtype=dtype)
+        self.image_embedder = None
+        if image_embed_dim is not None:
+            self.image_embedder = _ImageEmbedding(image_embed_dim, dim, device=device, dtype=dtype)
+
+
+class ChronoEditTransformer3DModel(nn.Module):
+    """MI355X drop-in for the reference class of the same name (transformer_chronoedit.py:298)."""
+
+    _supports_gradient_checkpointing = False
+    _no_split_modules = ["BlockParams"]
+    _keep_in_fp32_modules = ["time_embedder", "scale_shift_table", "norm1", "norm2", "norm3"]
+    _keys_to_ignore_on_load_unexpected = ["norm_added_q"]
+
+    def __init__(
+        self,
+        patch_size: Tuple[int, int, int] = (1, 2, 2),
+        num_attention_heads: int = 40,
+        attention_head_dim: int = 128,
+        in_channels: int = 16,
+        out_channels: int = 16,
+        text_dim: int = 4096,
+        freq_dim: int = 256,
+        ffn_dim: int = 13824,
+        num_layers: int = 40,
+        cross_attn_norm: bool = True,
+        qk_norm: Optional[str] = "rms_norm_across_heads",
+        eps: float = 1e-6,
+        image_dim: Optional[int] = None,
+        added_kv_proj_dim: Optional[int] = None,
+        rope_max_seq_len: int = 1024,
+        rope_temporal_skip_len: int = 8,
+        device=None,
+        dtype: torch.dtype = torch.bfloat16,
+    ) -> None:
+        super().__init__()
+        if qk_norm != "rms_norm_across_heads":
+            raise NotImplementedError("only qk_norm='rms_norm_across_heads' (the ChronoEdit/Wan setting) is supported")
+        if tuple(patch_size) != (1, 2, 2):
+            raise NotImplementedError("patch_size must be (1, 2, 2)")
+        if attention_head_dim != 128:
+            raise NotImplementedError("the gfx950 attention kernel is specialised for head_dim 128")
+        self.config = _Config(
+            patch_size=tuple(patch_size), num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+            in_channels=in_channels, out_channels=out_channels or in_channels, text_dim=text_dim, freq_dim=freq_dim,
+            ffn_dim=ffn_dim, num_layers=num_layers, cross_attn_norm=cross_attn_norm, qk_norm=qk_norm, eps=eps,
+            image_dim=image_dim, added_kv_proj_dim=added_kv_proj_dim, rope_max_seq_len=rope_max_seq_len,
+            rope_temporal_skip_len=rope_temporal_skip_len,
+        )
+        inner = num_attention_heads * attention_head_dim
+        kw = dict(device=device, dtype=dtype)
+        self.patch_embedding = nn.Conv3d(in_channels, inner, kernel_size=patch_size, stride=patch_size, **kw)
+        self.condition_embedder = ConditionEmbedderParams(inner, freq_dim, inner * 6, text_dim, image_dim, **kw)
+        self.blocks = nn.ModuleList(
+            [BlockParams(inner, ffn_dim, num_attention_heads, cross_attn_norm, eps, added_kv_proj_dim, **kw) for _ in range(num_layers)]
+        )
+        self.proj_out = nn.Linear(inner, self.config.out_channels * math.prod(patch_size), **kw)
+        self.scale_shift_table = nn.Parameter(torch.randn(1, 2, inner, device=device, dtype=torch.float32) / inner**0.5)
+        self._engine: Optional["DiTEngine"] = None
+        self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
+
+    # -- reference-compatible helpers --------------------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.proj_out.weight.dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self.proj_out.weight.device
+
+    def load_synthetic_(self, params: Dict[str, torch.Tensor]):
+        """Copy a {diffusers key: tensor} dict (e.g. oracle.make_synthetic_params) into the tree."""
+        own = dict(self.named_parameters())
+        missing = set(own) - set(params)
+        extra = set(params) - set(own)
+        if missing or extra:
+            raise KeyError(f"state mismatch: missing {sorted(missing)[:4]} unexpected {sorted(extra)[:4]}")
+        with torch.no_grad():
+            for k, p in own.items():
+                p.copy_(params[k].to(p.dtype))
+        self.invalidate()
+        return self
+
+    def invalidate(self):
+        """Call after changing parameters in place (LoRA fuse, load_state_dict): re-packs on next forward."""
+        self._engine = None
+
+    def _apply(self, fn, *a, **kw):  # .to() / .cuda() / .cpu() re-create storages
+        self._engine = None
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._engine = None
+        return super().load_state_dict(*a, **kw)
+
+    def engine(self) -> "DiTEngine":
+        if self._engine is None:
+            self._engine = DiTEngine(self)
+        return self._engine
+
+    @torch.no_grad()
+    def forward(
+        self,
+        hidden_states: torch.Tensor,
+        timestep: torch.LongTensor,
+        encoder_hidden_states: torch.Tensor,
+        encoder_hidden_states_image: Optional[torch.Tensor] = None,
+        return_dict: bool = True,
+        attention_kwargs: Optional[Dict[str, Any]] = None,
+    ) -> Union[Transformer2DModelOutput, Tuple[torch.Tensor]]:
+        if not hidden_states.is_cuda:
+            raise ops.HipKernelError("ChronoEditTransformer3DModel (chronoedit_amd) runs only on an MI355X device: "
+                                     "there is no CPU fallback (use oracle/ for CPU reference numbers)")
+        outs = []
+        for b in range(hidden_states.shape[0]):
+            ts = timestep[b : b + 1] if timestep.dim() > 0 else timestep.reshape(1)
+            img = None if encoder_hidden_states_image is None else encoder_hidden_states_image[b]
+            outs.append(self.engine().forward_one(hidden_states[b], ts, encoder_hidden_states[b], img))
+        output = torch.stack(outs, dim=0).to(hidden_states.dtype)
+        if not return_dict:
+            return (output,)
+        return Transformer2DModelOutput(sample=output)
+
+
+# ------------------------------------------------------------------------------------------
+def rope_cos_sin(head_dim: int, max_len: int, skip_len: int, T: int, Hp: int, Wp: int, theta: float = 10000.0) -> torch.Tensor:
+    """[T*Hp*Wp, head_dim/2, 2] fp32 (cos, sin) of ChronoEditRotaryPosEmbed
+    (transformer_chronoedit.py:168-213): per-axis dims (t, h, w) = (hd - 4*(hd//6), 2*(hd//6), 2*(hd//6)),
+    angles in fp64; temporal indices {0, skip_len-1} when T == 2 (:205-207)."""
+    assert T == 2 or T == skip_len, f"num_frames must be 2 or {skip_len}, but got {T}"
+    h_dim = w_dim = 2 * (head_dim // 6)
+    t_dim = head_dim - h_dim - w_dim
+
+    def ang(dim, idx):
+        f = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64)[: dim // 2] / dim))
+        return torch.outer(idx.to(torch.float64), f)
+
+    t_idx = torch.tensor([0, skip_len - 1]) if T == 2 else torch.arange(T)
+    assert max(T, Hp, Wp, skip_len) <= max_len
+    a_t = ang(t_dim, t_idx).view(T, 1, 1, -1).expand(T, Hp, Wp, -1)
+    a_h = ang(h_dim, torch.arange(Hp)).view(1, Hp, 1, -1).expand(T, Hp, Wp, -1)
+    a_w = ang(w_dim, torch.arange(Wp)).view(1, 1, Wp, -1).expand(T, Hp, Wp, -1)
+    a = torch.cat([a_t, a_h, a_w], dim=-1).reshape(T * Hp * Wp, head_dim // 2)
+    return torch.stack([torch.cos(a), torch.sin(a)], dim=-1).to(torch.float32).contiguous()
+
+
+def _pad_k(w: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    K = w.shape[1]
+    Kp = (K + mult - 1) // mult * mult
+    if Kp == K:
+        return w.contiguous()
+    out = torch.zeros((w.shape[0], Kp), dtype=w.dtype, device=w.device)
+    out[:, :K] = w
+    return out
+
+
+def _pad_n(w: torch.Tensor, b: Optional[torch.Tensor], mult: int = 8):
+    N = w.shape[0]
+    Np = (N + mult - 1) // mult * mult
+    if Np == N:
+        return w, b
+    w2 = torch.zeros((Np, w.shape[1]), dtype=w.dtype, device=w.device)
+    w2[:N] = w
+    b2 = None
+    if b is not None:
+        b2 = torch.zeros((Np,), dtype=b.dtype, device=b.device)
+        b2[:N] = b
+    return w2, b2
+
+
+class DiTEngine:
+    """Packs the parameters once and runs the forward as a fixed sequence of HIP launches."""
+
+    def __init__(self, model: ChronoEditTransformer3DModel):
+        cfg = model.config
+        self.cfg = cfg
+        self.model = model
+        dev = model.device
+        if dev.type != "cuda":
+            raise ops.HipKernelError("DiTEngine needs the model on the GPU")
+        if model.dtype != torch.bfloat16:
+            raise TypeError("the HIP path computes in bf16 (run_inference_diffusers.py hard-codes bf16, :344-362); "
+                            f"got model dtype {model.dtype}")
+        self.dev = dev
+        self.D = cfg.num_attention_heads * cfg.attention_head_dim
+        self.H = cfg.num_attention_heads
+        self.F = cfg.ffn_dim
+        self.L = cfg.num_layers
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        ce = model.condition_embedder
+
+        # K1 patch embedding as a GEMM over im2col columns; K = C*4 zero-padded to 64
+        self.kpatch = (cfg.in_channels * 4 + 63) // 64 * 64
+        self.w_patch = _pad_k(model.patch_embedding.weight.detach().reshape(self.D, -1))
+        self.b_patch = f32(model.patch_embedding.bias)
+
+        # K2
+        self.te_w1, self.te_b1 = ce.time_embedder.linear_1.weight.detach().contiguous(), f32(ce.time_embedder.linear_1.bias)
+        self.te_w2, self.te_b2 = ce.time_embedder.linear_2.weight.detach().contiguous(), f32(ce.time_embedder.linear_2.bias)
+        self.tp_w, self.tp_b = ce.time_proj.weight.detach().contiguous(), f32(ce.time_proj.bias)
+
+        # K3
+        self.tx_w1, self.tx_b1 = _pad_k(ce.text_embedder.linear_1.weight.detach()), f32(ce.text_embedder.linear_1.bias)
+        self.tx_w2, self.tx_b2 = ce.text_embedder.linear_2.weight.detach().contiguous(), f32(ce.text_embedder.linear_2.bias)
+        self.has_image = ce.image_embedder is not None
+        if self.has_image:
+            ie = ce.image_embedder
+            self.im_n1 = (f32(ie.norm1.weight), f32(ie.norm1.bias), ie.norm1.eps)
+            self.im_w1, self.im_b1 = _pad_k(ie.ff.net[0].proj.weight.detach()), f32(ie.ff.net[0].proj.bias)
+            self.im_w2, self.im_b2 = _pad_k(ie.ff.net[2].weight.detach()), f32(ie.ff.net[2].bias)
+            self.im_n2 = (f32(ie.norm2.weight), f32(ie.norm2.bias), ie.norm2.eps)
+
+        # per-block packs.  Fused QKV / KV weights are single buffers; the module parameters are
+        # re-pointed at views of them so the 14B model keeps ONE copy of every weight in HBM.
+        self.blk = []
+        tables = []
+        for blk in model.blocks:
+            p = SimpleNamespace()
+            a1, a2 = blk.attn1, blk.attn2
+            p.w_qkv = self._fuse([a1.to_q, a1.to_k, a1.to_v])
+            p.b_qkv = torch.cat([f32(a1.to_q.bias), f32(a1.to_k.bias), f32(a1.to_v.bias)])
+            p.nq1, p.nk1 = f32(a1.norm_q.weight), f32(a1.norm_k.weight)
+            p.w_o1, p.b_o1 = a1.to_out[0].weight.detach().contiguous(), f32(a1.to_out[0].bias)
+            p.w_q2, p.b_q2 = a2.to_q.weight.detach().contiguous(), f32(a2.to_q.bias)
+            p.nq2, p.nk2 = f32(a2.norm_q.weight), f32(a2.norm_k.weight)
+            p.w_kv_t = self._fuse([a2.to_k, a2.to_v])
+            p.b_kv_t = torch.cat([f32(a2.to_k.bias), f32(a2.to_v.bias)])
+            p.has_img = a2.add_k_proj is not None
+            if p.has_img:
+                p.w_kv_i = self._fuse([a2.add_k_proj, a2.add_v_proj])
+                p.b_kv_i = torch.cat([f32(a2.add_k_proj.bias), f32(a2.add_v_proj.bias)])
+                p.nk_i = f32(a2.norm_added_k.weight)
+            p.w_o2, p.b_o2 = a2.to_out[0].weight.detach().contiguous(), f32(a2.to_out[0].bias)
+            if cfg.cross_attn_norm:
+                p.n2w, p.n2b = f32(blk.norm2.weight), f32(blk.norm2.bias)
+            else:
+                p.n2w = p.n2b = None
+            p.w_f1, p.b_f1 = blk.ffn.net[0].proj.weight.detach().contiguous(), f32(blk.ffn.net[0].proj.bias)
+            p.w_f2, p.b_f2 = blk.ffn.net[2].weight.detach().contiguous(), f32(blk.ffn.net[2].bias)
+            tables.append(f32(blk.scale_shift_table).reshape(6, self.D))
+            self.blk.append(p)
+        self.tables = torch.stack(tables, 0).contiguous()  # [L, 6, D]
+        self.table_out = f32(model.scale_shift_table).reshape(1, 2, self.D)
+        self.w_out, self.b_out = _pad_n(model.proj_out.weight.detach().contiguous(), f32(model.proj_out.bias))
+        self.ones = torch.ones(self.D, dtype=torch.float32, device=dev)
+        self.zeros = torch.zeros(self.D, dtype=torch.float32, device=dev)
+        self._rope = {}
+        self._ws = {}
+        self._ctx_key = None
+        self._ctx = None
+
+    def _fuse(self, linears) -> torch.Tensor:
+        """cat the [out,in] weights into one buffer and re-point the module parameters at its rows."""
+        w = torch.cat([l.weight.detach() for l in linears], dim=0).contiguous()
+        o = 0
+        for l in linears:
+            n = l.weight.shape[0]
+            l.weight.data = w[o : o + n]
+            o += n
+        return w
+
+    # -- workspaces --------------------------------------------------------------------
+    def _workspace(self, N: int):
+        ws = self._ws.get(N)
+        if ws is None:
+            D, F, dev = self.D, self.F, self.dev
+            e = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)
+            ws = SimpleNamespace(x=e(N, D), h=e(N, D), qkv=e(N, 3 * D), att=e(N, D), q2=e(N, D), ffn=e(N, F),
+                                 cols=e(N, self.kpatch), head=e(N, self.w_out.shape[0]))
+            self._ws = {N: ws}  # keep one shape resident
+        return ws
+
+    def _rope_table(self, T, Hp, Wp):
+        key = (T, Hp, Wp)
+        if key not in self._rope:
+            c = self.cfg
+            self._rope = {key: rope_cos_sin(c.attention_head_dim, c.rope_max_seq_len, c.rope_temporal_skip_len, T, Hp, Wp).to(self.dev)}
+        return self._rope[key]
+
+    # -- K3 + K13: conditioning-side work (step-invariant) -------------------------------
+    def _context(self, text: torch.Tensor, image: Optional[torch.Tensor]):
+        key = None
+        if self.model.cache_context:
+            key = (text.data_ptr(), text._version, tuple(text.shape),
+                   None if image is None else (image.data_ptr(), image._version, tuple(image.shape)))
+            if key == self._ctx_key:
+                return self._ctx
+        D = self.D
+        text = text.to(torch.bfloat16)
+        if text.shape[1] != self.tx_w1.shape[1]:
+            tp = torch.zeros((text.shape[0], self.tx_w1.shape[1]), dtype=torch.bfloat16, device=self.dev)
+            tp[:, : text.shape[1]] = text
+            text = tp
+        t1 = ops.gemm(text.contiguous(), self.tx_w1, self.tx_b1, epilogue=ops.EPI_BIAS_GELU)
+        enc_t = ops.gemm(t1, self.tx_w2, self.tx_b2)
+        enc_i = None
+        if image is not None:
+            if not self.has_image:
+                raise ValueError("encoder_hidden_states_image given but the model has no image_embedder (image_dim=None)")
+            image = image.to(torch.bfloat16).contiguous()
+            w, b, eps = self.im_n1
+            h = ops.ln_affine(image, w, b, eps)
+            if h.shape[1] != self.im_w1.shape[1]:
+                hp = torch.zeros((h.shape[0], self.im_w1.shape[1]), dtype=torch.bfloat16, device=self.dev)
+                hp[:, : h.shape[1]] = h
+                h = hp
+            h = ops.gemm(h, self.im_w1, self.im_b1, epilogue=ops.EPI_BIAS_GELU_ERF)
+            if h.shape[1] != self.im_w2.shape[1]:
+                hp = torch.zeros((h.shape[0], self.im_w2.shape[1]), dtype=torch.bfloat16, device=self.dev)
+                hp[:, : h.shape[1]] = h
+                h = hp
+            h = ops.gemm(h, self.im_w2, self.im_b2)
+            w, b, eps = self.im_n2
+            enc_i = ops.ln_affine(h, w, b, eps)
+        # K13: per-layer cross-attention K/V of the text and image context
+        kv = []
+        eps = self.cfg.eps
+        hd = self.cfg.attention_head_dim
+        for p in self.blk:
+            kv_t = ops.gemm(enc_t, p.w_kv_t, p.b_kv_t)  # [Tt, 2D] = [k | v]
+            ops.rmsnorm_rope_(kv_t[:, :D], p.nk2, None, hd, eps)
+            kv_i = None
+            if enc_i is not None and p.has_img:
+                kv_i = ops.gemm(enc_i, p.w_kv_i, p.b_kv_i)
+                ops.rmsnorm_rope_(kv_i[:, :D], p.nk_i, None, hd, eps)
+            kv.append((kv_t, kv_i))
+        ctx = SimpleNamespace(kv=kv)
+        if key is not None:
+            self._ctx_key, self._ctx = key, ctx
+        return ctx
+
+    # -- the forward (transformer_chronoedit.py:397-476) ---------------------------------
+    def forward_one(self, hidden: torch.Tensor, timestep: torch.Tensor, text: torch.Tensor, image: Optional[torch.Tensor]):
+        cfg, D, H = self.cfg, self.D, self.H
+        C, T, Hh, Ww = hidden.shape
+        if C != cfg.in_channels:
+            raise ValueError(f"expected {cfg.in_channels} input channels, got {C}")
+        Hp, Wp = Hh // 2, Ww // 2
+        N = T * Hp * Wp
+        hd = cfg.attention_head_dim
+        eps = cfg.eps
+        cs = self._rope_table(T, Hp, Wp)  # raises AssertionError for unsupported frame counts (:205)
+        ws = self._workspace(N)
+
+        # K1
+        ops.patchify(hidden.to(torch.bfloat16).contiguous(), self.kpatch, out=ws.cols)
+        ops.gemm(ws.cols, self.w_patch, self.b_patch, out=ws.x)
+
+        # K2: sinusoid -> time_embedder (fp32) -> temb (bf16-rounded) -> silu -> time_proj
+        sin = ops.timestep_sinusoid(timestep.to(device=self.dev, dtype=torch.int64).contiguous(), cfg.freq_dim)
+        h1 = ops.gemv(self.te_w1, sin, self.te_b1, flags=2)
+        temb = ops.gemv(self.te_w2, h1, self.te_b2, flags=4)
+        tproj = ops.gemv(self.tp_w, temb, self.tp_b, flags=1 | 4)  # [6*D]
+        mod = ops.modulation(self.tables, tproj.view(6, D), one_mask=0b010010)  # [L,6,D]: shift,1+scale,gate,...
+        mod_out = ops.modulation(self.table_out, temb.view(1, D), one_mask=0b10)  # [1,2,D]: shift, 1+scale
+
+        ctx = self._context(text, image)
+
+        x = ws.x
+        for li, p in enumerate(self.blk):
+            m = mod[li]
+            # 1. self-attention
+            ops.ln_affine(x, m[1], m[0], eps, out=ws.h)
+            ops.gemm(ws.h, p.w_qkv, p.b_qkv, out=ws.qkv)
+            q, k, v = ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :]
+            ops.rmsnorm_rope_(q, p.nq1, cs, hd, eps)
+            ops.rmsnorm_rope_(k, p.nk1, cs, hd, eps)
+            ops.attention(q, k, v, H, out=ws.att)
+            ops.gemm(ws.att, p.w_o1, p.b_o1, out=x, epilogue=ops.EPI_GATE_RES, gate=m[2], res=x)
+            # 2. cross-attention (text + image segments)
+            if p.n2w is not None:
+                ops.ln_affine(x, p.n2w, p.n2b, eps, out=ws.h)
+                hq = ws.h
+            else:
+                hq = x
+            ops.gemm(hq, p.w_q2, p.b_q2, out=ws.q2)
+            ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
+            kv_t, kv_i = ctx.kv[li]
+            if kv_i is not None:
+                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, k2=kv_i[:, :D], v2=kv_i[:, D:])
+            else:
+                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att)
+            ops.gemm(ws.att, p.w_o2, p.b_o2, out=x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
+            # 3. feed-forward
+            ops.ln_affine(x, m[4], m[3], eps, out=ws.h)
+            ops.gemm(ws.h, p.w_f1, p.b_f1, out=ws.ffn, epilogue=ops.EPI_BIAS_GELU)
+            ops.gemm(ws.ffn, p.w_f2, p.b_f2, out=x, epilogue=ops.EPI_GATE_RES, gate=m[5], res=x)
+
+        # K18
+        ops.ln_affine(x, mod_out[0, 1], mod_out[0, 0], eps, out=ws.h)
+        ops.gemm(ws.h, self.w_out, self.b_out, out=ws.head)
+        return ops.unpatchify(ws.head, cfg.out_channels, T, Hh, Ww)

@@ -1,0 +1,103 @@
+/* C ABI of libchronoedit_hip.so — the MI355X (gfx950) kernels behind the ChronoEdit DiT hot path.
+ *
+ * Conventions (SURVEY.md §8b "C-ABI for the HIP library"):
+ *   - plain pointers + sizes; no torch types; every pointer is a DEVICE pointer unless noted;
+ *   - no allocation, no synchronisation, no host reads inside: every launcher only enqueues
+ *     kernels on `stream`, so whole denoising steps are hipGraph-capturable;
+ *   - the caller owns every buffer; the library is stateless;
+ *   - return value: 0 = ok, CE_ERR_* (<0) = rejected arguments (nothing was launched),
+ *     >0 = hipError_t of the launch.  Never throws.
+ *   - bf16 tensors are raw 16-bit patterns (`void*`); "ld*" are row strides in ELEMENTS.
+ *
+ * Each entry point cites the reference interface (file:line under /root/reference) it replaces.
+ */
+#ifndef CHRONOEDIT_HIP_H
+#define CHRONOEDIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define CE_OK 0
+#define CE_ERR_ARG (-1)
+#define CE_ERR_SHAPE (-2)
+#define CE_ERR_ALIGN (-3)
+
+/* GEMM epilogues */
+#define CE_EPI_BIAS 0      /* C = bf16(A.W^T + bias) */
+#define CE_EPI_BIAS_GELU 1 /* C = bf16(gelu_tanh(bf16(A.W^T + bias)))   diffusers FeedForward("gelu-approximate") */
+#define CE_EPI_GATE_RES 2  /* C = bf16(res + bf16(A.W^T + bias) * gate[n]); gate == NULL -> 1 */
+#define CE_EPI_BIAS_GELU_ERF 3 /* exact-erf GELU: diffusers FeedForward("gelu") of the image embedder */
+
+/* y = LayerNorm_fp32(x, eps) * a[d] + b[d] -> bf16.   One wave64 per row; D % 8 == 0, D <= 5120.
+ * Replaces `(self.norm1(h.float()) * (1 + scale) + shift).type_as(h)` and FP32LayerNorm(affine)
+ * (chronoedit_diffusers/transformer_chronoedit.py:279,284,289,460). */
+int ce_ln_affine_bf16(const void* x, void* y, const float* a, const float* b, int M, int D, int ldx, int ldy, float eps,
+                      hipStream_t stream);
+
+/* In place: x = RMSNorm_across_heads(x; w, eps), then (cos_sin != NULL) 3-D RoPE on (even, odd)
+ * channel pairs of every head; cos_sin = [M][head_dim/2][2] fp32 (cos, sin).
+ * Replaces attn.norm_q / norm_k / norm_added_k + apply_rotary_emb
+ * (transformer_chronoedit.py:62-65,73-79,85). */
+int ce_rmsnorm_rope_bf16(void* x, const float* w, const float* cos_sin, int M, int D, int ld, int head_dim, float eps,
+                         hipStream_t stream);
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 in/out, fp32 accumulate on MFMA.
+ * K % 64 == 0, N % 8 == 0; res may alias C.  Replaces every nn.Linear on the path
+ * (transformer_chronoedit.py:58-60,84-86,106, FeedForward :262, patch_embedding :429, proj_out :461). */
+int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res,
+                 int M, int N, int K, int lda, int ldw, int ldc, int ldres, hipStream_t stream);
+
+/* O = softmax(Q K1^T * scale) V1 [ + softmax(Q K2^T * scale) V2 ], per head, head_dim == 128, bf16.
+ * Each segment's result is rounded to bf16 before the add (SDPA output dtype).
+ * Replaces F.scaled_dot_product_attention at transformer_chronoedit.py:91-104. */
+int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
+                      const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq, int ldo,
+                      float softmax_scale, hipStream_t stream);
+
+/* out[dim] = [cos(t f_i), sin(t f_i)], f_i = 1e4^(-i/(dim/2)), fp32; t is a device int64.
+ * Replaces diffusers Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0)
+ * (transformer_chronoedit.py:137,153). */
+int ce_timestep_sinusoid(const int64_t* t, float* out, int dim, hipStream_t stream);
+
+/* y[N] = post(W[N,K] . pre(x[K]) + bias); W fp32 (w_is_bf16 = 0) or bf16.
+ * flags: 1 = pre: x <- bf16(silu(x)); 2 = post: silu; 4 = post: round result to bf16 (still stored fp32).
+ * Replaces TimestepEmbedding + act_fn + time_proj (transformer_chronoedit.py:153-159). */
+int ce_gemv(const void* W, int w_is_bf16, const float* x, const float* bias, float* y, int N, int K, int flags,
+            hipStream_t stream);
+
+/* mod[L][J][D] = table[L][J][D] + v[(v_rows==1 ? 0 : j)][D], plus 1.0 on rows j with bit j of one_mask set.
+ * Replaces `(scale_shift_table + temb.float()).chunk(6)` and the `(1 + scale)` terms
+ * (transformer_chronoedit.py:274-279,289,451,460). */
+int ce_modulation(const float* table, const float* v, float* mod, int L, int J, int D, int v_rows, int one_mask,
+                  hipStream_t stream);
+
+/* im2col of the k = s = (1,2,2) patch Conv3d: x [C][T][H][W] -> cols [T*(H/2)*(W/2)][Kpad] (zero padded).
+ * Replaces patch_embedding + flatten/transpose (transformer_chronoedit.py:429-430). */
+int ce_patchify_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, hipStream_t stream);
+
+/* y [N][ldy] (col = (dh*2+dw)*Cout + c) -> out [Cout][T][H][W].
+ * Replaces the reshape/permute/flatten at transformer_chronoedit.py:463-467. */
+int ce_unpatchify_bf16(const void* y, void* out, int Cout, int T, int H, int W, int ldy, hipStream_t stream);
+
+/* One denoising-loop tail, fused over the latents (n elements):
+ *   v   = v_uncond ? bf16(u + bf16(g * bf16(c - u))) : c            pipeline_chronoedit.py:736
+ *   x0  = x - sigma * v                                              fm_solvers_unipc.py:335-337
+ *   xc  = use_corr ? a0*x_last + a1*m0 + a2*m1 + a3*x0 : x           UniC, fm_solvers_unipc.py:501-641
+ *   x   = p0*xc + p1*x0 + p2*m0 ; x_last = xc ; m1 = m0 ; m0 = x0    UniP + history, :365-499,706-751
+ * coef = device float[10] {g, sigma, use_corr, a0..a3, p0..p2} precomputed on the host per step.
+ * flags bit0: round sigma*v to bf16 (the reference multiplies a 0-dim fp32 sigma into a bf16 tensor).
+ * Replaces scheduler.step + the CFG line of ChronoEditPipeline.__call__ (pipeline_chronoedit.py:736-739). */
+int ce_cfg_unipc_step(const void* v_cond, const void* v_uncond, float* x, float* x_last, float* m0, float* m1,
+                      float* x0_out, const float* coef, const void* reserved, long long n, int flags, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHRONOEDIT_HIP_H */

@@ -6,6 +6,16 @@ from types import SimpleNamespace
 class ConfigMixin:
     config_name = "config.json"
 
+    def register_to_config(self, **kwargs):
+        if not hasattr(self, "config"):
+            self.config = _CfgHolder()
+        for k, v in kwargs.items():
+            setattr(self.config, k, v)
+
+
+class _CfgHolder(SimpleNamespace):
+    pass
+
 
 class _Cfg(SimpleNamespace):
     def __getitem__(self, k):

@@ -18,3 +18,11 @@ def scale_lora_layers(model, weight):
 
 def unscale_lora_layers(model, weight=None):
     pass
+
+
+def deprecate(*args, **kwargs):
+    pass
+
+
+def is_scipy_available():
+    return False

@@ -1,0 +1,240 @@
+"""GPU parity tests for every entry point of libchronoedit_hip.so, called through the C ABI
+(chronoedit_amd.ops -> ctypes).  The reference for each op is plain fp32 PyTorch evaluating the
+same formula as the oracle (oracle/dit_oracle.py), with the reference's bf16 rounding points.
+Tolerances are stated per test: bf16 outputs are compared at <= 2 bf16 ulp-ish relative error
+(2^-7) element-wise on normalised data, or rel-L2 for accumulated results."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_l2(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_library_loaded_is_in_tree():
+    from chronoedit_amd import hiplib, ops
+    lib = ops.lib()
+    assert hiplib.LIB_PATH.endswith("chronoedit_amd/lib/libchronoedit_hip.so")
+    for name in hiplib.header_symbols():
+        assert hasattr(lib, name)
+
+
+@pytest.mark.parametrize("M,D", [(37, 256), (200, 5120), (7200, 5120)])
+def test_ln_affine(M, D):
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = (torch.randn(M, D, generator=g) * 3 + 0.5).to(BF).to(dev)
+    a = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    b = (0.1 * torch.randn(D, generator=g)).to(dev)
+    y = ops.ln_affine(x, a, b, 1e-6)
+    ref = (torch.nn.functional.layer_norm(x.float(), (D,), None, None, 1e-6) * a + b).to(BF)
+    err = (y.float() - ref.float()).abs().max().item()
+    assert err <= 2 ** -6 * ref.float().abs().max().item(), err
+    assert rel_l2(y, ref) < 3e-3
+
+
+@pytest.mark.parametrize("M,H,rope", [(50, 2, True), (300, 40, True), (257, 40, False)])
+def test_rmsnorm_rope(M, H, rope):
+    from chronoedit_amd import ops
+    dev = _dev()
+    D = H * 128
+    g = torch.Generator().manual_seed(1)
+    buf = torch.randn(M, 3 * D, generator=g).to(BF).to(dev)  # strided view like the fused qkv buffer
+    before = buf.clone()
+    x = buf[:, D:2 * D]
+    x0 = x.clone()
+    w = (1 + 0.05 * torch.randn(D, generator=g)).to(BF).to(dev)
+    cs = None
+    if rope:
+        ang = torch.rand(M, 64, generator=g, dtype=torch.float64) * 6.28
+        cs = torch.stack([ang.cos(), ang.sin()], -1).float().to(dev)
+    ops.rmsnorm_rope_(x, w.float(), cs, 128, 1e-6)
+    # reference: diffusers RMSNorm rounding points, RoPE in fp64 (transformer_chronoedit.py:73-76)
+    xf = x0.float()
+    y = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(BF) * w
+    if rope:
+        yc = torch.view_as_complex(y.double().view(M, H, 64, 2))
+        f = torch.view_as_complex(cs.double()).view(M, 1, 64)
+        y = torch.view_as_real(yc * f).reshape(M, D).to(BF)
+    assert torch.equal(buf[:, :D], before[:, :D]) and torch.equal(buf[:, 2 * D:], before[:, 2 * D:])  # neighbours untouched
+    assert rel_l2(x, y) < 4e-3, rel_l2(x, y)
+    frac_exact = (x == y).float().mean().item()
+    assert frac_exact > 0.97, frac_exact  # fp32-vs-fp64 rope differs only at bf16 rounding ties
+
+
+GEMM_SHAPES = [
+    (128, 128, 64), (100, 264, 192), (7200, 5120, 5120), (769, 10240, 5120), (512, 5120, 4096), (333, 64, 5120),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bias(M, N, K):
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(dev)
+    # asymmetric, transpose-detecting content
+    w[: min(N, 7), :] *= 3
+    bias = torch.randn(N, generator=g).to(dev)
+    out = ops.gemm(a, w, bias)
+    ref = (a.float() @ w.float().t() + bias)
+    assert rel_l2(out, ref) < 4e-3, rel_l2(out, ref)
+    assert (out.float() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item() + 1e-3
+
+
+def test_gemm_epilogues():
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 300, 384, 256
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.08).to(BF).to(dev)
+    bias = torch.randn(N, generator=g).to(dev) * 0.2
+    lin = (a.float() @ w.float().t() + bias).to(BF)
+    out = ops.gemm(a, w, bias, epilogue=ops.EPI_BIAS_GELU)
+    ref = torch.nn.functional.gelu(lin.float(), approximate="tanh").to(BF)
+    assert rel_l2(out, ref) < 5e-3
+    out = ops.gemm(a, w, bias, epilogue=ops.EPI_BIAS_GELU_ERF)
+    ref = torch.nn.functional.gelu(lin.float()).to(BF)
+    assert rel_l2(out, ref) < 5e-3
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    gate = torch.randn(N, generator=g).to(dev)
+    x = res.clone()
+    ops.gemm(a, w, bias, out=x, epilogue=ops.EPI_GATE_RES, gate=gate, res=x)  # in place, as the block uses it
+    ref = (res.float() + lin.float() * gate).to(BF)
+    assert rel_l2(x, ref) < 5e-3
+    x = res.clone()
+    ops.gemm(a, w, bias, out=x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
+    ref = (res.float() + lin.float()).to(BF)
+    assert rel_l2(x, ref) < 5e-3
+
+
+def test_gemm_rejects_bad_shapes():
+    from chronoedit_amd import ops
+    dev = _dev()
+    a = torch.zeros(8, 100, dtype=BF, device=dev)
+    w = torch.zeros(16, 100, dtype=BF, device=dev)
+    with pytest.raises(ops.HipKernelError):
+        ops.gemm(a, w, None)
+    with pytest.raises(ops.HipKernelError):
+        ops.gemm(a.cpu(), w.cpu(), None)
+
+
+def _sdpa_ref(q, k, v, H):
+    Nq, D = q.shape
+    qh = q.float().view(Nq, H, 128).transpose(0, 1)
+    kh = k.float().view(-1, H, 128).transpose(0, 1)
+    vh = v.float().view(-1, H, 128).transpose(0, 1)
+    o = torch.nn.functional.scaled_dot_product_attention(qh[None], kh[None], vh[None])[0]
+    return o.transpose(0, 1).reshape(Nq, D)
+
+
+@pytest.mark.parametrize("Nq,Nkv,H", [(64, 64, 2), (300, 257, 2), (1000, 1000, 8), (7200, 7200, 8), (33, 512, 3)])
+def test_attention_single_segment(Nq, Nkv, H):
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    D = H * 128
+    qkv = torch.randn(max(Nq, Nkv), 3 * D, generator=g).to(BF).to(dev)
+    q, k, v = qkv[:Nq, :D], qkv[:Nkv, D:2 * D], qkv[:Nkv, 2 * D:]
+    # make v asymmetric across dv so a transposed/permuted PV shows up
+    v.mul_(torch.linspace(0.5, 1.5, D, device=dev).to(BF))
+    out = ops.attention(q, k, v, H)
+    ref = _sdpa_ref(q, k, v, H)
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+    assert (out.float() - ref).abs().max().item() < 3e-2
+
+
+def test_attention_spiked_scores_force_rescale():
+    """One key per tile has a much larger score than everything before it: exercises the online-softmax
+    rescale path on every tile (cdna guide rule 26)."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    H, N = 2, 512
+    q = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
+    k = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
+    v = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
+    for t in range(N // 64):
+        k[t * 64 + 5] = q[7] * (0.5 + 0.5 * t)
+    out = ops.attention(q, k, v, H)
+    ref = _sdpa_ref(q, k, v, H)
+    assert rel_l2(out, ref) < 1e-2
+    assert torch.isfinite(out.float()).all()
+
+
+def test_attention_two_segments():
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(6)
+    H, Nq = 4, 700
+    D = H * 128
+    q = torch.randn(Nq, D, generator=g).to(BF).to(dev)
+    kv_t = torch.randn(512, 2 * D, generator=g).to(BF).to(dev)
+    kv_i = torch.randn(257, 2 * D, generator=g).to(BF).to(dev)
+    out = ops.attention(q, kv_t[:, :D], kv_t[:, D:], H, k2=kv_i[:, :D], v2=kv_i[:, D:])
+    ref = (_sdpa_ref(q, kv_t[:, :D], kv_t[:, D:], H).to(BF).float() + _sdpa_ref(q, kv_i[:, :D], kv_i[:, D:], H).to(BF).float())
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+
+
+def test_timestep_chain_and_modulation():
+    from chronoedit_amd import ops
+    from oracle import dit_oracle as O
+    dev = _dev()
+    t = torch.tensor([637], device=dev)
+    s = ops.timestep_sinusoid(t, 256)
+    ref = O.timestep_sinusoid(torch.tensor([637]), 256)[0]
+    assert (s.cpu() - ref).abs().max().item() < 2e-4  # fp32 sin/cos of arguments up to 637 rad
+    g = torch.Generator().manual_seed(7)
+    W = torch.randn(96, 256, generator=g).to(dev)
+    b = torch.randn(96, generator=g).to(dev)
+    y = ops.gemv(W, s, b, flags=2)
+    yr = torch.nn.functional.silu(W @ s + b)
+    assert rel_l2(y, yr) < 1e-5
+    Wb = W.to(BF)
+    y = ops.gemv(Wb, s, b, flags=1 | 4)
+    xin = torch.nn.functional.silu(s).to(BF).float()
+    yr = (Wb.float() @ xin + b).to(BF).float()
+    assert rel_l2(y, yr) < 2e-3
+    table = torch.randn(3, 6, 64, generator=g).to(dev)
+    v = torch.randn(6, 64, generator=g).to(dev)
+    m = ops.modulation(table, v, 0b010010)
+    r = table + v
+    r[:, 1] += 1
+    r[:, 4] += 1
+    assert torch.allclose(m, r, atol=1e-6)
+
+
+def test_patchify_unpatchify_roundtrip_against_conv():
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(8)
+    C, T, H, W, D = 36, 2, 12, 20, 128
+    x = torch.randn(C, T, H, W, generator=g).to(BF).to(dev)
+    wt = (torch.randn(D, C, 1, 2, 2, generator=g) * 0.1).to(BF).to(dev)
+    cols = ops.patchify(x, 192)
+    wp = torch.zeros(D, 192, dtype=BF, device=dev)
+    wp[:, :144] = wt.reshape(D, -1)
+    y = ops.gemm(cols, wp, None)
+    ref = torch.nn.functional.conv3d(x[None].float(), wt.float(), stride=(1, 2, 2)).flatten(2).transpose(1, 2)[0]
+    assert rel_l2(y, ref) < 4e-3
+    # unpatchify == reshape/permute of transformer_chronoedit.py:463-467
+    Cout = 16
+    z = torch.randn(T * (H // 2) * (W // 2), 64, generator=g).to(BF).to(dev)
+    out = ops.unpatchify(z, Cout, T, H, W)
+    r = z.reshape(1, T, H // 2, W // 2, 1, 2, 2, Cout).permute(0, 7, 1, 4, 2, 5, 3, 6).flatten(6, 7).flatten(4, 5).flatten(2, 3)[0]
+    assert torch.equal(out, r)

@@ -1,0 +1,85 @@
+"""Per-kernel timings on the GPU box (HIP events on the launch stream), with the vendor library
+(torch.matmul -> hipBLASLt, torch SDPA) timed beside each kernel as a yardstick — not as a fallback.
+Writes gpurun_out/microbench.json."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chronoedit_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st.record()
+    for _ in range(iters):
+        fn()
+    en.record()
+    torch.cuda.synchronize()
+    return st.elapsed_time(en) / iters * 1e-3
+
+
+def main():
+    res = {}
+    only = sys.argv[1:] or ["gemm", "attn", "row"]
+    g = torch.Generator().manual_seed(0)
+    if "gemm" in only:
+        for (M, N, K, epi) in [(7200, 15360, 5120, 0), (7200, 5120, 5120, 2), (7200, 13824, 5120, 1), (7200, 5120, 13824, 2),
+                               (28800, 13824, 5120, 1), (512, 5120, 5120, 0)]:
+            a = torch.randn(M, K, generator=g).to(BF).to(dev)
+            w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
+            b = torch.zeros(N, device=dev)
+            out = torch.empty(M, N, dtype=BF, device=dev)
+            gate = torch.ones(N, device=dev)
+            t = timeit(lambda: ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None))
+            t_ref = timeit(lambda: torch.matmul(a, w.t()))
+            fl = 2.0 * M * N * K
+            res[f"gemm_{M}x{N}x{K}_epi{epi}"] = {"ms": t * 1e3, "tflops": fl / t / 1e12, "hipblaslt_ms": t_ref * 1e3, "hipblaslt_tflops": fl / t_ref / 1e12}
+            print(f"gemm {M}x{N}x{K} epi{epi}: {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | hipblaslt {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
+            del a, w, out
+    if "attn" in only:
+        for (Nq, Nkv, H) in [(7200, 7200, 40), (28800, 28800, 40), (7200, 512, 40)]:
+            D = H * 128
+            qkv = torch.randn(max(Nq, Nkv), 3 * D, generator=g).to(BF).to(dev)
+            q, k, v = qkv[:Nq, :D], qkv[:Nkv, D:2 * D], qkv[:Nkv, 2 * D:]
+            out = torch.empty(Nq, D, dtype=BF, device=dev)
+            t = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            qh = q.reshape(Nq, H, 128).transpose(0, 1)[None].contiguous()
+            kh = k.reshape(Nkv, H, 128).transpose(0, 1)[None].contiguous()
+            vh = v.reshape(Nkv, H, 128).transpose(0, 1)[None].contiguous()
+            try:
+                t_ref = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh), iters=5)
+            except Exception as e:  # yardstick only
+                print("sdpa yardstick failed:", e)
+                t_ref = float("nan")
+            fl = 4.0 * Nq * Nkv * 128 * H
+            res[f"attn_{Nq}x{Nkv}x{H}"] = {"ms": t * 1e3, "tflops": fl / t / 1e12, "sdpa_ms": t_ref * 1e3, "sdpa_tflops": fl / t_ref / 1e12}
+            print(f"attn {Nq}x{Nkv} H{H}: {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | torch sdpa {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
+            del qkv, qh, kh, vh
+    if "row" in only:
+        M, D = 7200, 5120
+        x = torch.randn(M, D, generator=g).to(BF).to(dev)
+        y = torch.empty_like(x)
+        a = torch.ones(D, device=dev)
+        b = torch.zeros(D, device=dev)
+        t = timeit(lambda: ops.ln_affine(x, a, b, 1e-6, out=y), iters=20)
+        res["ln_affine_7200x5120"] = {"us": t * 1e6, "GBps": 2 * M * D * 2 / t / 1e9}
+        cs = torch.rand(M, 64, 2, device=dev)
+        t = timeit(lambda: ops.rmsnorm_rope_(x, a, cs, 128, 1e-6), iters=20)
+        res["rmsnorm_rope_7200x5120"] = {"us": t * 1e6, "GBps": 2 * M * D * 2 / t / 1e9}
+        print(res["ln_affine_7200x5120"], res["rmsnorm_rope_7200x5120"], flush=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/microbench.json", "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
