@@ -186,6 +186,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
 
 }  // namespace
 
+extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw);
+extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                                 hipStream_t stream);
+
+// kernel selection: -1 = automatic (256-tile LDS-DMA kernel for large shapes), 0 = always the 128-tile kernel,
+// 1 = the 256-tile kernel whenever the shape allows it
+static int g_gemm_variant = -1;
+extern "C" int ce_set_gemm_variant(int v) {
+  const int old = g_gemm_variant;
+  g_gemm_variant = v;
+  return old;
+}
+
 extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                             const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                             hipStream_t stream) {
@@ -193,6 +207,13 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7)) return CE_ERR_SHAPE;
   if ((lda & 7) || (ldw & 7) || (ldc & 7)) return CE_ERR_ALIGN;
   if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
+  if (epilogue < 0 || epilogue > 3) return CE_ERR_ARG;
+  {
+    const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
+    const bool want = g_gemm_variant == 1 || (g_gemm_variant == -1 && big);
+    if (want && ce_gemm256_supported(M, N, K, lda, ldw))
+      return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, stream);
+  }
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(256);
 #define CE_LAUNCH(E)                                                                                              \

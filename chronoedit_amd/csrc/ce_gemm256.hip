@@ -1,0 +1,317 @@
+// 256x256x64 bf16 GEMM for the large DiT projections — the MI355X-tuned variant of ce_gemm.hip
+// (same contract, same epilogues; selected by ce_gemm_bf16 when the shape allows it).
+//
+// Structure (CDNA4):
+//  * 512-thread workgroup, 8 waves as 2(M) x 4(N); wave (wm, wn) owns rows {i*128 + wm*64 + [0,64)}
+//    and cols {j*128 + wn*32 + [0,32)}, i,j in {0,1}: four 64x32 "quadrants" Q(i,j), each
+//    4x2 v_mfma_f32_16x16x32_bf16 accumulators (128 accumulator VGPRs per lane).
+//  * Operand K-tiles (64 deep) live in LDS as eight 16-KiB half-tile slots
+//    {even,odd K-tile} x {A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255}  (128 KiB);
+//    with the interleaved row ownership above, quadrant operands map 1:1 onto half-tile slots.
+//  * Global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPR
+//    round trip).  The DMA image is lane-linear, so the 16-B-chunk XOR swizzle that makes the
+//    ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address and to
+//    the read address (cdna guide rule 21).
+//  * 8 phases per 2 K-tiles.  Phase p: issue this phase's fragment reads (<= 12 ds_read_b128),
+//    [counted vmcnt at p4/p8], ONE s_barrier, stage one half-tile of a FUTURE K-tile (2 LDS-DMA
+//    per lane), lgkmcnt(0), 16 MFMAs under s_setprio 1.  A slot is restaged one phase after its
+//    last read (all waves passed lgkmcnt(0) of that phase before the barrier), and read at the
+//    earliest one barrier after the counted vmcnt that retires it:
+//        phase      1      2      3      4        5      6      7      8
+//        reads  A0,B0,B1    -     A1     -     A0,B0,B1   -      A1     -      (even tile | odd tile)
+//        MFMA      Q00    Q01    Q11    Q10      Q00    Q01    Q11    Q10
+//        stage   O.A1'   E.A0"  E.B0"  E.B1"    E.A1"  O.A0"' O.B0"' O.B1"'   (' = this odd tile,
+//        wait       -      -      -   vmcnt(4)    -      -      -   vmcnt(4)    " = tile+2, "' = tile+3)
+//    vmcnt(4) leaves the two most recent half-tiles in flight across the barrier; LDS-DMA is never
+//    drained to zero inside the loop.
+//  * Epilogue: the accumulators go through LDS in two 128-row passes so that bias/GELU/gated-residual
+//    math and the global stores run on 16-B row-contiguous chunks (same rounding points as ce_gemm.hip).
+#include "ce_common.h"
+
+#define EPI_BIAS 0
+#define EPI_BIAS_GELU 1
+#define EPI_GATE_RES 2
+#define EPI_BIAS_GELU_ERF 3
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int SLOT = 128 * BK * 2;        // 16 KiB half-tile
+constexpr int LDS_TILES = 8 * SLOT;       // 128 KiB
+constexpr int CROW = BN * 2 + 16;         // padded epilogue staging row (528 B)
+constexpr int LDS_BYTES = LDS_TILES > 128 * CROW ? LDS_TILES : 128 * CROW;
+
+// slot ids
+constexpr int S_A0 = 0, S_A1 = 1, S_B0 = 2, S_B1 = 3;  // + 4 for the odd K-tile
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+struct Stager {
+  // per-lane byte offsets (row * ld * 2 + swizzled chunk * 16) of the two DMA rounds of each half-tile
+  uint32_t a_off[2][2];  // [half][round]
+  uint32_t w_off[2][2];
+  const char* a_base;
+  const char* w_base;
+  int wave;              // wave-uniform
+  int kt_last;
+};
+
+template <int SLOT_ID>
+__device__ __forceinline__ void stage_half(unsigned char* smem, const Stager& s, int tile) {
+  constexpr int half = SLOT_ID & 1;
+  constexpr bool isB = (SLOT_ID & 2) != 0;
+  const int t = tile < s.kt_last ? tile : s.kt_last;  // clamp: surplus prefetches re-read the last K-tile
+  const char* base = (isB ? s.w_base : s.a_base) + (size_t)t * (BK * 2);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint32_t off = isB ? s.w_off[half][r] : s.a_off[half][r];
+    unsigned char* dst = smem + SLOT_ID * SLOT + (r * 8 + s.wave) * 1024;  // wave-uniform; lane l lands at +16 l
+    __builtin_amdgcn_global_load_lds((gbl_void*)(base + off), (lds_void*)dst, 16, 0, 0);
+  }
+}
+
+// 64 rows x K64 of A-sub -> 8 fragments [f][ks];  32 rows x K64 of W-sub -> 4 fragments [g][ks]
+template <int SLOT_ID>
+__device__ __forceinline__ void read_a(const unsigned char* smem, int wm, int fr, int fg, bf16x8 (&a)[4][2]) {
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int row = wm * 64 + f * 16 + fr;
+    const unsigned char* p = smem + SLOT_ID * SLOT + row * (BK * 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a[f][ks] = *reinterpret_cast<const bf16x8*>(p + (((fg + 4 * ks) ^ swz(row)) << 4));
+  }
+}
+template <int SLOT_ID>
+__device__ __forceinline__ void read_b(const unsigned char* smem, int wn, int fr, int fg, bf16x8 (&b)[2][2]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int row = wn * 32 + g * 16 + fr;
+    const unsigned char* p = smem + SLOT_ID * SLOT + row * (BK * 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b[g][ks] = *reinterpret_cast<const bf16x8*>(p + (((fg + 4 * ks) ^ swz(row)) << 4));
+  }
+}
+
+__device__ __forceinline__ void mma_quadrant(f32x4 (&acc)[4][2], const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2]) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][ks], b[g][ks], acc[f][g], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+}
+
+#define CE_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#define CE_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define CE_BAR() __builtin_amdgcn_s_barrier()
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                     bf16* __restrict__ C, const float* __restrict__ bias,
+                                                     const float* __restrict__ gate, const bf16* __restrict__ res, int M,
+                                                     int N, int K, int lda, int ldw, int ldc, int ldres, int tiles_m,
+                                                     int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  const int nwg = tiles_m * tiles_n;
+  const int wg = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP = 4;
+  const int group_sz = GROUP * tiles_n;
+  const int gid = wg / group_sz;
+  const int first_m = gid * GROUP;
+  const int gm = min(tiles_m - first_m, GROUP);
+  const int tm = first_m + (wg % group_sz) % gm;
+  const int tn = (wg % group_sz) / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  Stager st;
+  st.a_base = reinterpret_cast<const char*>(A);
+  st.w_base = reinterpret_cast<const char*>(W);
+  st.wave = wave;
+  st.kt_last = K / BK - 1;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = (r * 8 + wave) * 8 + (lane >> 3);        // row inside the 128-row half-tile
+      const int chunk = (lane & 7) ^ swz(row);                 // logical chunk that must land at position lane&7
+      st.a_off[h][r] = (uint32_t)min(m0 + h * 128 + row, M - 1) * (uint32_t)(lda * 2) + chunk * 16;
+      st.w_off[h][r] = (uint32_t)min(n0 + h * 128 + row, N - 1) * (uint32_t)(ldw * 2) + chunk * 16;
+    }
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[i][j][f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: even tile 0 (4 halves) + odd tile 1 (A0, B0, B1); O.A1 follows in phase 1
+  stage_half<S_A0>(smem, st, 0);
+  stage_half<S_B0>(smem, st, 0);
+  stage_half<S_B1>(smem, st, 0);
+  stage_half<S_A1>(smem, st, 0);
+  stage_half<4 + S_A0>(smem, st, 1);
+  stage_half<4 + S_B0>(smem, st, 1);
+  stage_half<4 + S_B1>(smem, st, 1);
+  CE_VM(4);  // everything but the last two half-tiles (O.B0, O.B1) has landed
+  CE_BAR();
+
+  bf16x8 ra[4][2], rb0[2][2], rb1[2][2];
+  const int npairs = (K / BK) >> 1;
+  for (int it = 0; it < npairs; ++it) {
+    const int t = 2 * it;
+    // ---- phase 1
+    read_a<S_A0>(smem, wm, fr, fg, ra);
+    read_b<S_B0>(smem, wn, fr, fg, rb0);
+    read_b<S_B1>(smem, wn, fr, fg, rb1);
+    CE_BAR();
+    stage_half<4 + S_A1>(smem, st, t + 1);
+    CE_LGKM0();
+    mma_quadrant(acc[0][0], ra, rb0);
+    // ---- phase 2
+    CE_BAR();
+    stage_half<S_A0>(smem, st, t + 2);
+    mma_quadrant(acc[0][1], ra, rb1);
+    // ---- phase 3
+    read_a<S_A1>(smem, wm, fr, fg, ra);
+    CE_BAR();
+    stage_half<S_B0>(smem, st, t + 2);
+    CE_LGKM0();
+    mma_quadrant(acc[1][1], ra, rb1);
+    // ---- phase 4
+    CE_VM(4);  // retires every stage up to phase 1's O.A1: the odd tile is complete after the barrier
+    CE_BAR();
+    stage_half<S_B1>(smem, st, t + 2);
+    mma_quadrant(acc[1][0], ra, rb0);
+    // ---- phase 5
+    read_a<4 + S_A0>(smem, wm, fr, fg, ra);
+    read_b<4 + S_B0>(smem, wn, fr, fg, rb0);
+    read_b<4 + S_B1>(smem, wn, fr, fg, rb1);
+    CE_BAR();
+    stage_half<S_A1>(smem, st, t + 2);
+    CE_LGKM0();
+    mma_quadrant(acc[0][0], ra, rb0);
+    // ---- phase 6
+    CE_BAR();
+    stage_half<4 + S_A0>(smem, st, t + 3);
+    mma_quadrant(acc[0][1], ra, rb1);
+    // ---- phase 7
+    read_a<4 + S_A1>(smem, wm, fr, fg, ra);
+    CE_BAR();
+    stage_half<4 + S_B0>(smem, st, t + 3);
+    CE_LGKM0();
+    mma_quadrant(acc[1][1], ra, rb1);
+    // ---- phase 8
+    CE_VM(4);  // retires every stage up to phase 5's E.A1: the next even tile is complete after the barrier
+    CE_BAR();
+    stage_half<4 + S_B1>(smem, st, t + 3);
+    mma_quadrant(acc[1][0], ra, rb0);
+  }
+  CE_VM(0);  // surplus prefetches must land before the epilogue reuses the LDS
+  CE_BAR();
+
+  // ---- epilogue, two passes of 128 tile rows (i = 0, 1)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i == 1) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int cl = j * 128 + wn * 32 + g * 16 + fr;
+        const int n = n0 + cl;
+        const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = wm * 64 + f * 16 + fg * 4 + r;
+            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] + bv);
+          }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const int c = tid + 512 * tt;
+      const int rl = c >> 5, cc = c & 31;
+      const int m = m0 + i * 128 + rl, n = n0 + cc * 8;
+      if (m < M && n < N) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16);
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_tanh(bf16lo(v[q])), gelu_tanh(bf16hi(v[q])));
+        } else if (EPI == EPI_BIAS_GELU_ERF) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_erf(bf16lo(v[q])), gelu_erf(bf16hi(v[q])));
+        } else if (EPI == EPI_GATE_RES) {
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
+          float gt[8];
+          if (gate != nullptr) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + n), g1 = *reinterpret_cast<const f32x4*>(gate + n + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              gt[q] = g0[q];
+              gt[4 + q] = g1[q];
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gt[q] = 1.0f;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * gt[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * gt[2 * q + 1]);
+        }
+        *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// returns 1 when the 256-tile kernel can take the shape
+extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw) {
+  const int kt = K / BK;
+  if ((K % BK) || (kt & 1) || kt < 2) return 0;
+  if ((long long)M * lda * 2 >= (1ll << 32) || (long long)N * ldw * 2 >= (1ll << 32)) return 0;  // 32-bit DMA offsets
+  return 1;
+}
+
+extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                                 hipStream_t stream) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n), block(512);
+  static bool attr_done[4] = {false, false, false, false};
+#define CE_LAUNCH(E)                                                                                                  \
+  do {                                                                                                                \
+    if (!attr_done[E]) {                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      attr_done[E] = true;                                                                                            \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(gemm_bf16_256<E>, grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, \
+                       gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, tiles_m, tiles_n);                       \
+  } while (0)
+  switch (epilogue) {
+    case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;
+    case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;
+    case EPI_GATE_RES: CE_LAUNCH(EPI_GATE_RES); break;
+    case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
+    default: return CE_ERR_ARG;
+  }
+#undef CE_LAUNCH
+  return (int)hipGetLastError();
+}

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
 HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
 
-SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_attn.hip", "ce_sched.hip"]
+SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_attn.hip", "ce_sched.hip"]
 
 _c = ctypes
 _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
@@ -29,6 +29,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_ln_affine_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ce_rmsnorm_rope_bf16": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_set_gemm_variant": [_I],
     "ce_attention_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "ce_timestep_sinusoid": [_P, _P, _I, _P],
     "ce_gemv": [_P, _I, _P, _P, _P, _I, _I, _I, _P],

@@ -160,6 +160,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Op
     return out
 
 
+def set_gemm_variant(v: int) -> int:
+    """-1 auto, 0 force the 128-tile kernel, 1 force the 256-tile LDS-DMA kernel; returns the previous setting."""
+    return lib().ce_set_gemm_variant(int(v))
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
               k2: Optional[torch.Tensor] = None, v2: Optional[torch.Tensor] = None, scale: Optional[float] = None):
     """q [Nq, H*128], k/v [Nkv, H*128] (row strides free) -> out [Nq, H*128]; optional 2nd kv segment."""

@@ -54,6 +54,10 @@ int ce_rmsnorm_rope_bf16(void* x, const float* w, const float* cos_sin, int M, i
 int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res,
                  int M, int N, int K, int lda, int ldw, int ldc, int ldres, hipStream_t stream);
 
+/* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default), 0 force the 128x128
+ * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows.  Host-side test/bench knob. */
+int ce_set_gemm_variant(int variant);
+
 /* O = softmax(Q K1^T * scale) V1 [ + softmax(Q K2^T * scale) V2 ], per head, head_dim == 128, bf16.
  * Each segment's result is rounded to bf16 before the add (SDPA output dtype).
  * Replaces F.scaled_dot_product_attention at transformer_chronoedit.py:91-104. */

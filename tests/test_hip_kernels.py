@@ -80,8 +80,16 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_bias(M, N, K):
+@pytest.fixture(params=[0, 1], ids=["tile128", "tile256"])
+def gemm_variant(request):
+    from chronoedit_amd import ops
+    old = ops.set_gemm_variant(request.param)
+    yield request.param
+    ops.set_gemm_variant(old)
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES + [(256, 256, 128), (7200, 13824, 5120), (1000, 520, 13824)])
+def test_gemm_bias(M, N, K, gemm_variant):
     from chronoedit_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(2)
@@ -96,7 +104,7 @@ def test_gemm_bias(M, N, K):
     assert (out.float() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item() + 1e-3
 
 
-def test_gemm_epilogues():
+def test_gemm_epilogues(gemm_variant):
     from chronoedit_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(3)
