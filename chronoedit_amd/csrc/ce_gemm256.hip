@@ -12,18 +12,18 @@
 //    round trip).  The DMA image is lane-linear, so the 16-B-chunk XOR swizzle that makes the
 //    ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address and to
 //    the read address (cdna guide rule 21).
-//  * 8 phases per 2 K-tiles.  Phase p: issue this phase's fragment reads (<= 12 ds_read_b128),
-//    [counted vmcnt at p4/p8], ONE s_barrier, stage one half-tile of a FUTURE K-tile (2 LDS-DMA
-//    per lane), lgkmcnt(0), 16 MFMAs under s_setprio 1.  A slot is restaged one phase after its
-//    last read (all waves passed lgkmcnt(0) of that phase before the barrier), and read at the
-//    earliest one barrier after the counted vmcnt that retires it:
-//        phase      1      2      3      4        5      6      7      8
-//        reads  A0,B0,B1    -     A1     -     A0,B0,B1   -      A1     -      (even tile | odd tile)
-//        MFMA      Q00    Q01    Q11    Q10      Q00    Q01    Q11    Q10
-//        stage   O.A1'   E.A0"  E.B0"  E.B1"    E.A1"  O.A0"' O.B0"' O.B1"'   (' = this odd tile,
-//        wait       -      -      -   vmcnt(4)    -      -      -   vmcnt(4)    " = tile+2, "' = tile+3)
-//    vmcnt(4) leaves the two most recent half-tiles in flight across the barrier; LDS-DMA is never
-//    drained to zero inside the loop.
+//  * 4 phases per K-tile (8 per even/odd pair).  Phase p: [counted vmcnt at phase 4], ONE s_barrier,
+//    stage one half-tile of a FUTURE K-tile (2 LDS-DMA per lane), 16 MFMAs under s_setprio 1 with
+//    the NEXT phase's fragment reads (ds_read_b128) issued between the two 8-MFMA k-steps, into the
+//    operand registers the k-step just released (software pipelining without extra VGPRs):
+//        phase of tile T      1          2              3            4
+//        MFMA                Q00        Q01            Q11          Q10
+//        fragment reads       -     A1(T) -> ra         -     B1,A0,B0 of tile T+1
+//        stage           other.A1(T+1)  cur.A0(T+2)  cur.B0(T+2)  cur.B1(T+2)
+//        wait                 -          -              -         vmcnt(4)
+//    A slot is restaged at the earliest one barrier after the lgkmcnt(0) that completed its last
+//    read, and read at the earliest one barrier after the counted vmcnt that retires it; vmcnt(4)
+//    leaves the two most recent half-tiles in flight, LDS-DMA is never drained inside the loop.
 //  * Epilogue: the accumulators go through LDS in two 128-row passes so that bias/GELU/gated-residual
 //    math and the global stores run on 16-B row-contiguous chunks (same rounding points as ce_gemm.hip).
 #include "ce_common.h"
@@ -73,36 +73,31 @@ __device__ __forceinline__ void stage_half(unsigned char* smem, const Stager& s,
   }
 }
 
-// 64 rows x K64 of A-sub -> 8 fragments [f][ks];  32 rows x K64 of W-sub -> 4 fragments [g][ks]
-template <int SLOT_ID>
-__device__ __forceinline__ void read_a(const unsigned char* smem, int wm, int fr, int fg, bf16x8 (&a)[4][2]) {
+// fragment reads of one k-step (32 deep): 64 rows of an A half-tile -> 4 fragments, 32 rows of a W half-tile -> 2
+template <int SLOT_ID, int KS>
+__device__ __forceinline__ void read_a(const unsigned char* smem, int wm, int fr, int fg, bf16x8 (&a)[4]) {
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
     const int row = wm * 64 + f * 16 + fr;
-    const unsigned char* p = smem + SLOT_ID * SLOT + row * (BK * 2);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a[f][ks] = *reinterpret_cast<const bf16x8*>(p + (((fg + 4 * ks) ^ swz(row)) << 4));
+    a[f] = *reinterpret_cast<const bf16x8*>(smem + SLOT_ID * SLOT + row * (BK * 2) + (((fg + 4 * KS) ^ swz(row)) << 4));
   }
 }
-template <int SLOT_ID>
-__device__ __forceinline__ void read_b(const unsigned char* smem, int wn, int fr, int fg, bf16x8 (&b)[2][2]) {
+template <int SLOT_ID, int KS>
+__device__ __forceinline__ void read_b(const unsigned char* smem, int wn, int fr, int fg, bf16x8 (&b)[2]) {
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const int row = wn * 32 + g * 16 + fr;
-    const unsigned char* p = smem + SLOT_ID * SLOT + row * (BK * 2);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) b[g][ks] = *reinterpret_cast<const bf16x8*>(p + (((fg + 4 * ks) ^ swz(row)) << 4));
+    b[g] = *reinterpret_cast<const bf16x8*>(smem + SLOT_ID * SLOT + row * (BK * 2) + (((fg + 4 * KS) ^ swz(row)) << 4));
   }
 }
 
-__device__ __forceinline__ void mma_quadrant(f32x4 (&acc)[4][2], const bf16x8 (&a)[4][2], const bf16x8 (&b)[2][2]) {
+// 8 MFMAs: one k-step of a 64x32 quadrant
+__device__ __forceinline__ void mma_half(f32x4 (&acc)[4][2], const bf16x8 (&a)[4], const bf16x8 (&b)[2]) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
+  for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f][ks], b[g][ks], acc[f][g], 0, 0, 0);
+    for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f], b[g], acc[f][g], 0, 0, 0);
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -169,58 +164,64 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   CE_VM(4);  // everything but the last two half-tiles (O.B0, O.B1) has landed
   CE_BAR();
 
-  bf16x8 ra[4][2], rb0[2][2], rb1[2][2];
+  // Operand registers, software-pipelined across phases: a register set is refilled (ds_read) right after the
+  // last MFMA that consumed it, so the next phase's fragments are already in flight when its barrier opens.
+  bf16x8 ra0[4], ra1[4], b0k0[2], b0k1[2], b1k0[2], b1k1[2];  // A-sub (k-step 0/1), W-sub0, W-sub1
+  read_a<S_A0, 0>(smem, wm, fr, fg, ra0);
+  read_a<S_A0, 1>(smem, wm, fr, fg, ra1);
+  read_b<S_B0, 0>(smem, wn, fr, fg, b0k0);
+  read_b<S_B0, 1>(smem, wn, fr, fg, b0k1);
+  read_b<S_B1, 0>(smem, wn, fr, fg, b1k0);
+  read_b<S_B1, 1>(smem, wn, fr, fg, b1k1);
+
+#define CE_STAGE(SLOT_EVEN, SLOT_ODD, CURV, TILEV) \
+  if (CURV == 0) stage_half<SLOT_EVEN>(smem, st, (TILEV)); else stage_half<SLOT_ODD>(smem, st, (TILEV));
+
+  // The LDS-DMA issue (address math + M0 + 2 global_load_lds) sits BETWEEN the two 8-MFMA k-steps of a phase, so it
+  // overlaps the matrix pipe instead of extending the barrier-to-first-MFMA gap.
+#define CE_TILE_PHASES(CUR, NXT, TILE)                                                                      \
+  /* phase 1: Q00 */                                                                                        \
+  CE_BAR();                                                                                                 \
+  CE_LGKM0();                                                                                               \
+  mma_half(acc[0][0], ra0, b0k0);                                                                           \
+  CE_STAGE(4 + S_A1, S_A1, CUR, (TILE) + 1)                                                                 \
+  mma_half(acc[0][0], ra1, b0k1);                                                                           \
+  /* phase 2: Q01, refill the A registers with A-sub1 as they drain */                                      \
+  CE_BAR();                                                                                                 \
+  mma_half(acc[0][1], ra0, b1k0);                                                                           \
+  read_a<CUR * 4 + S_A1, 0>(smem, wm, fr, fg, ra0);                                                         \
+  CE_STAGE(S_A0, 4 + S_A0, CUR, (TILE) + 2)                                                                 \
+  mma_half(acc[0][1], ra1, b1k1);                                                                           \
+  read_a<CUR * 4 + S_A1, 1>(smem, wm, fr, fg, ra1);                                                         \
+  /* phase 3: Q11 */                                                                                        \
+  CE_BAR();                                                                                                 \
+  CE_LGKM0();                                                                                               \
+  mma_half(acc[1][1], ra0, b1k0);                                                                           \
+  CE_STAGE(S_B0, 4 + S_B0, CUR, (TILE) + 2)                                                                 \
+  mma_half(acc[1][1], ra1, b1k1);                                                                           \
+  /* phase 4: Q10; the counted wait retires the NEXT tile's slots, whose fragments are prefetched here */   \
+  CE_VM(4);                                                                                                 \
+  CE_BAR();                                                                                                 \
+  read_b<NXT * 4 + S_B1, 0>(smem, wn, fr, fg, b1k0);                                                        \
+  read_b<NXT * 4 + S_B1, 1>(smem, wn, fr, fg, b1k1);                                                        \
+  mma_half(acc[1][0], ra0, b0k0);                                                                           \
+  read_a<NXT * 4 + S_A0, 0>(smem, wm, fr, fg, ra0);                                                         \
+  read_b<NXT * 4 + S_B0, 0>(smem, wn, fr, fg, b0k0);                                                        \
+  CE_STAGE(S_B1, 4 + S_B1, CUR, (TILE) + 2)                                                                 \
+  mma_half(acc[1][0], ra1, b0k1);                                                                           \
+  read_a<NXT * 4 + S_A0, 1>(smem, wm, fr, fg, ra1);                                                         \
+  read_b<NXT * 4 + S_B0, 1>(smem, wn, fr, fg, b0k1);
+
   const int npairs = (K / BK) >> 1;
   for (int it = 0; it < npairs; ++it) {
     const int t = 2 * it;
-    // ---- phase 1
-    read_a<S_A0>(smem, wm, fr, fg, ra);
-    read_b<S_B0>(smem, wn, fr, fg, rb0);
-    read_b<S_B1>(smem, wn, fr, fg, rb1);
-    CE_BAR();
-    stage_half<4 + S_A1>(smem, st, t + 1);
-    CE_LGKM0();
-    mma_quadrant(acc[0][0], ra, rb0);
-    // ---- phase 2
-    CE_BAR();
-    stage_half<S_A0>(smem, st, t + 2);
-    mma_quadrant(acc[0][1], ra, rb1);
-    // ---- phase 3
-    read_a<S_A1>(smem, wm, fr, fg, ra);
-    CE_BAR();
-    stage_half<S_B0>(smem, st, t + 2);
-    CE_LGKM0();
-    mma_quadrant(acc[1][1], ra, rb1);
-    // ---- phase 4
-    CE_VM(4);  // retires every stage up to phase 1's O.A1: the odd tile is complete after the barrier
-    CE_BAR();
-    stage_half<S_B1>(smem, st, t + 2);
-    mma_quadrant(acc[1][0], ra, rb0);
-    // ---- phase 5
-    read_a<4 + S_A0>(smem, wm, fr, fg, ra);
-    read_b<4 + S_B0>(smem, wn, fr, fg, rb0);
-    read_b<4 + S_B1>(smem, wn, fr, fg, rb1);
-    CE_BAR();
-    stage_half<S_A1>(smem, st, t + 2);
-    CE_LGKM0();
-    mma_quadrant(acc[0][0], ra, rb0);
-    // ---- phase 6
-    CE_BAR();
-    stage_half<4 + S_A0>(smem, st, t + 3);
-    mma_quadrant(acc[0][1], ra, rb1);
-    // ---- phase 7
-    read_a<4 + S_A1>(smem, wm, fr, fg, ra);
-    CE_BAR();
-    stage_half<4 + S_B0>(smem, st, t + 3);
-    CE_LGKM0();
-    mma_quadrant(acc[1][1], ra, rb1);
-    // ---- phase 8
-    CE_VM(4);  // retires every stage up to phase 5's E.A1: the next even tile is complete after the barrier
-    CE_BAR();
-    stage_half<4 + S_B1>(smem, st, t + 3);
-    mma_quadrant(acc[1][0], ra, rb0);
+    CE_TILE_PHASES(0, 1, t)      // even K-tile t   (slots 0-3); stages O.A1(t+1), E.A0/E.B0/E.B1(t+2)
+    CE_TILE_PHASES(1, 0, t + 1)  // odd  K-tile t+1 (slots 4-7); stages E.A1(t+2), O.A0/O.B0/O.B1(t+3)
   }
-  CE_VM(0);  // surplus prefetches must land before the epilogue reuses the LDS
+#undef CE_TILE_PHASES
+#undef CE_STAGE
+  CE_VM(0);  // surplus prefetches (LDS-DMA and fragment reads) must retire before the epilogue reuses the LDS
+  CE_LGKM0();
   CE_BAR();
 
   // ---- epilogue, two passes of 128 tile rows (i = 0, 1)

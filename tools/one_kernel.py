@@ -1,0 +1,34 @@
+"""Launch ONE kernel shape a few times (for rocprofv3 --pmc passes).  usage:
+   one_kernel.py gemm M N K epi variant [iters]   |   one_kernel.py attn Nq Nkv H [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chronoedit_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+BF = torch.bfloat16
+g = torch.Generator().manual_seed(0)
+kind = sys.argv[1]
+if kind == "gemm":
+    M, N, K, epi, var = map(int, sys.argv[2:7])
+    iters = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
+    b = torch.zeros(N, device=dev)
+    out = torch.zeros(M, N, dtype=BF, device=dev)
+    gate = torch.ones(N, device=dev)
+    ops.set_gemm_variant(var)
+    for _ in range(iters):
+        ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+else:
+    Nq, Nkv, H = map(int, sys.argv[2:5])
+    iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    D = H * 128
+    qkv = torch.randn(max(Nq, Nkv), 3 * D, generator=g).to(BF).to(dev)
+    out = torch.empty(Nq, D, dtype=BF, device=dev)
+    for _ in range(iters):
+        ops.attention(qkv[:Nq, :D], qkv[:Nkv, D:2 * D], qkv[:Nkv, 2 * D:], H, out=out)
+torch.cuda.synchronize()
