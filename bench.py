@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--guidance", type=float, default=5.0)
     ap.add_argument("--cache-context", action="store_true", help="reuse step-invariant text/image K/V across steps")
+    ap.add_argument("--sequential-cfg", action="store_true", help="two B=1 forwards per step instead of one batched B=2 forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     dev = torch.device("cuda", local if world > 1 else 0)
 
     from chronoedit_amd import ops
-    from chronoedit_amd.pipeline import denoise_step
+    from chronoedit_amd.pipeline import denoise_step, make_cfg_inputs
     from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
     from oracle.dit_oracle import DiTConfig, flops_per_forward
 
@@ -131,8 +132,11 @@ def main():
     sched.set_timesteps(max(50, total), device=dev)
     fwd_per_step = 2 if a.guidance > 1.0 else 1
 
+    cfg_inputs = make_cfg_inputs(prompt, negative, image)  # resident before the timed region, like every other input
+
     def one_step(i):
-        denoise_step(model, sched, latents, condition, sched.timesteps[i], prompt, negative, image, a.guidance)
+        denoise_step(model, sched, latents, condition, sched.timesteps[i], prompt, negative, image, a.guidance,
+                     batch_cfg=not a.sequential_cfg, cfg_inputs=cfg_inputs)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -183,6 +187,7 @@ def main():
                                    f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
                                    "BASELINE.json configs[1]",
                        "tokens": N, "forwards_per_step": fwd_per_step, "parallelism": f"replica x{world}",
+                       "cfg": "sequential (2 x B=1)" if a.sequential_cfg else "batched (1 x B=2)",
                        "context_cache": bool(a.cache_context)},
             "model_tflops_per_step": round(fl / 1e12, 2),
             "achieved_tflops_per_gpu": round(fl * a.steps / dt / 1e12, 1),

@@ -38,8 +38,8 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                      bf16* __restrict__ C, const float* __restrict__ bias,
                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
-                                                     int N, int K, int lda, int ldw, int ldc, int ldres, int tiles_m,
-                                                     int tiles_n) {
+                                                     int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                                     int tiles_m, int tiles_n) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];  // [buf][A|W]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
         const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
         float g[8];
         if (gate != nullptr) {
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + n), g1 = *reinterpret_cast<const f32x4*>(gate + n + 4);
+          const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;  // per-sample gate rows
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             g[q] = g0[q];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
 
 extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw);
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
-                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  hipStream_t stream);
 
 // kernel selection: -1 = automatic (256-tile LDS-DMA kernel for large shapes), 0 = always the 128-tile kernel,
@@ -201,7 +202,7 @@ extern "C" int ce_set_gemm_variant(int v) {
 }
 
 extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
-                            const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                            const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                             hipStream_t stream) {
   if (!A || !W || !C) return CE_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7)) return CE_ERR_SHAPE;
@@ -212,13 +213,13 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant == 1 || (g_gemm_variant == -1 && big);
     if (want && ce_gemm256_supported(M, N, K, lda, ldw))
-      return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, stream);
+      return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, stream);
   }
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(256);
 #define CE_LAUNCH(E)                                                                                              \
   hipLaunchKernelGGL(gemm_bf16_128<E>, grid, block, 0, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
-                     (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, tiles_m, tiles_n)
+                     (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n)
   switch (epilogue) {
     case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;
     case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;

@@ -109,8 +109,8 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                      bf16* __restrict__ C, const float* __restrict__ bias,
                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
-                                                     int N, int K, int lda, int ldw, int ldc, int ldres, int tiles_m,
-                                                     int tiles_n) {
+                                                     int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                                     int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -261,7 +261,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
           const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
           float gt[8];
           if (gate != nullptr) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gate + n), g1 = *reinterpret_cast<const f32x4*>(gate + n + 4);
+            const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;  // per-sample gate rows
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               gt[q] = g0[q];
@@ -292,7 +293,7 @@ extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw) {
 }
 
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
-                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(512);
@@ -304,7 +305,7 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
       attr_done[E] = true;                                                                                            \
     }                                                                                                                 \
     hipLaunchKernelGGL(gemm_bf16_256<E>, grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, \
-                       gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, tiles_m, tiles_n);                       \
+                       gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n);                       \
   } while (0)
   switch (epilogue) {
     case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;

@@ -28,7 +28,7 @@ _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
 SIGNATURES: Dict[str, List] = {
     "ce_ln_affine_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "ce_rmsnorm_rope_bf16": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_gemm_variant": [_I],
     "ce_attention_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "ce_timestep_sinusoid": [_P, _P, _I, _P],

@@ -129,8 +129,8 @@ def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tens
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
-         epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None):
-    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias)."""
+         epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, gate_rows: int = 0):
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias).  gate [N] or, with gate_rows > 0, [M/gate_rows, N] (one per sample)."""
     _dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w")
     M, K, lda = _rows(a, "a")
     N, K2, ldw = _rows(w, "w")
@@ -152,10 +152,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Op
         _, _, ldres = _rows(res, "res")
         if gate is not None:
             _dev(gate, torch.float32, "gate")
-            assert gate.numel() == N and gate.is_contiguous()
+            assert gate.is_contiguous() and gate.numel() == (N if gate_rows <= 0 else (M + gate_rows - 1) // gate_rows * N)
     st = _prof_begin()
     _check(lib().ce_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), epilogue, _ptr(gate), _ptr(res), M, N, K, lda, ldw, ldc,
-                              ldres, _stream()), "ce_gemm_bf16")
+                              ldres, int(gate_rows), _stream()), "ce_gemm_bf16")
     _prof_end(st, f"gemm_{M}x{N}x{K}_epi{epilogue}", 2.0 * M * N * K)
     return out
 

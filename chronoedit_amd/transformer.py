@@ -239,12 +239,11 @@ class ChronoEditTransformer3DModel(nn.Module):
         if not hidden_states.is_cuda:
             raise ops.HipKernelError("ChronoEditTransformer3DModel (chronoedit_amd) runs only on an MI355X device: "
                                      "there is no CPU fallback (use oracle/ for CPU reference numbers)")
-        outs = []
-        for b in range(hidden_states.shape[0]):
-            ts = timestep[b : b + 1] if timestep.dim() > 0 else timestep.reshape(1)
-            img = None if encoder_hidden_states_image is None else encoder_hidden_states_image[b]
-            outs.append(self.engine().forward_one(hidden_states[b], ts, encoder_hidden_states[b], img))
-        output = torch.stack(outs, dim=0).to(hidden_states.dtype)
+        B = hidden_states.shape[0]
+        ts = timestep.reshape(-1)
+        if ts.numel() == 1 and B > 1:
+            ts = ts.expand(B)
+        output = self.engine().forward(hidden_states, ts, encoder_hidden_states, encoder_hidden_states_image).to(hidden_states.dtype)
         if not return_dict:
             return (output,)
         return Transformer2DModelOutput(sample=output)
@@ -407,6 +406,7 @@ class DiTEngine:
 
     # -- K3 + K13: conditioning-side work (step-invariant) -------------------------------
     def _context(self, text: torch.Tensor, image: Optional[torch.Tensor]):
+        """text [B, Tt, text_dim], image [B, Ti, image_dim] -> per-layer cross-attention K/V, samples stacked along rows."""
         key = None
         if self.model.cache_context:
             key = (text.data_ptr(), text._version, tuple(text.shape),
@@ -414,7 +414,8 @@ class DiTEngine:
             if key == self._ctx_key:
                 return self._ctx
         D = self.D
-        text = text.to(torch.bfloat16)
+        B, Tt = text.shape[0], text.shape[1]
+        text = text.to(torch.bfloat16).reshape(B * Tt, -1)
         if text.shape[1] != self.tx_w1.shape[1]:
             tp = torch.zeros((text.shape[0], self.tx_w1.shape[1]), dtype=torch.bfloat16, device=self.dev)
             tp[:, : text.shape[1]] = text
@@ -422,10 +423,12 @@ class DiTEngine:
         t1 = ops.gemm(text.contiguous(), self.tx_w1, self.tx_b1, epilogue=ops.EPI_BIAS_GELU)
         enc_t = ops.gemm(t1, self.tx_w2, self.tx_b2)
         enc_i = None
+        Ti = 0
         if image is not None:
             if not self.has_image:
                 raise ValueError("encoder_hidden_states_image given but the model has no image_embedder (image_dim=None)")
-            image = image.to(torch.bfloat16).contiguous()
+            Ti = image.shape[1]
+            image = image.to(torch.bfloat16).reshape(B * Ti, -1).contiguous()
             w, b, eps = self.im_n1
             h = ops.ln_affine(image, w, b, eps)
             if h.shape[1] != self.im_w1.shape[1]:
@@ -445,22 +448,27 @@ class DiTEngine:
         eps = self.cfg.eps
         hd = self.cfg.attention_head_dim
         for p in self.blk:
-            kv_t = ops.gemm(enc_t, p.w_kv_t, p.b_kv_t)  # [Tt, 2D] = [k | v]
+            kv_t = ops.gemm(enc_t, p.w_kv_t, p.b_kv_t)  # [B*Tt, 2D] = [k | v]
             ops.rmsnorm_rope_(kv_t[:, :D], p.nk2, None, hd, eps)
             kv_i = None
             if enc_i is not None and p.has_img:
                 kv_i = ops.gemm(enc_i, p.w_kv_i, p.b_kv_i)
                 ops.rmsnorm_rope_(kv_i[:, :D], p.nk_i, None, hd, eps)
             kv.append((kv_t, kv_i))
-        ctx = SimpleNamespace(kv=kv)
+        ctx = SimpleNamespace(kv=kv, Tt=Tt, Ti=Ti)
         if key is not None:
             self._ctx_key, self._ctx = key, ctx
         return ctx
 
     # -- the forward (transformer_chronoedit.py:397-476) ---------------------------------
-    def forward_one(self, hidden: torch.Tensor, timestep: torch.Tensor, text: torch.Tensor, image: Optional[torch.Tensor]):
+    def forward(self, hidden: torch.Tensor, timestep: torch.Tensor, text: torch.Tensor, image: Optional[torch.Tensor]):
+        """hidden [B,C,T,H,W], timestep [B], text [B,Tt,text_dim], image [B,Ti,image_dim] -> [B,Cout,T,H,W] (bf16).
+
+        The B samples' tokens are stacked along the GEMM M axis (weights stream from HBM once for all of them —
+        this is how the two classifier-free-guidance passes of pipeline_chronoedit.py:715-735 are batched);
+        attention, RoPE and the AdaLN tables stay per sample."""
         cfg, D, H = self.cfg, self.D, self.H
-        C, T, Hh, Ww = hidden.shape
+        B, C, T, Hh, Ww = hidden.shape
         if C != cfg.in_channels:
             raise ValueError(f"expected {cfg.in_channels} input channels, got {C}")
         Hp, Wp = Hh // 2, Ww // 2
@@ -468,33 +476,49 @@ class DiTEngine:
         hd = cfg.attention_head_dim
         eps = cfg.eps
         cs = self._rope_table(T, Hp, Wp)  # raises AssertionError for unsupported frame counts (:205)
-        ws = self._workspace(N)
+        ws = self._workspace(B * N)
+        hidden = hidden.to(torch.bfloat16).contiguous()
+        timestep = timestep.to(device=self.dev, dtype=torch.int64).contiguous()
+        rows = [slice(b * N, (b + 1) * N) for b in range(B)]
 
         # K1
-        ops.patchify(hidden.to(torch.bfloat16).contiguous(), self.kpatch, out=ws.cols)
+        for b in range(B):
+            ops.patchify(hidden[b], self.kpatch, out=ws.cols[rows[b]])
         ops.gemm(ws.cols, self.w_patch, self.b_patch, out=ws.x)
 
-        # K2: sinusoid -> time_embedder (fp32) -> temb (bf16-rounded) -> silu -> time_proj
-        sin = ops.timestep_sinusoid(timestep.to(device=self.dev, dtype=torch.int64).contiguous(), cfg.freq_dim)
-        h1 = ops.gemv(self.te_w1, sin, self.te_b1, flags=2)
-        temb = ops.gemv(self.te_w2, h1, self.te_b2, flags=4)
-        tproj = ops.gemv(self.tp_w, temb, self.tp_b, flags=1 | 4)  # [6*D]
-        mod = ops.modulation(self.tables, tproj.view(6, D), one_mask=0b010010)  # [L,6,D]: shift,1+scale,gate,...
-        mod_out = ops.modulation(self.table_out, temb.view(1, D), one_mask=0b10)  # [1,2,D]: shift, 1+scale
+        # K2 per sample: sinusoid -> time_embedder (fp32) -> temb (bf16-rounded) -> silu -> time_proj -> AdaLN tables
+        mods, gates1, gates2, mods_out = [], [], [], []
+        for b in range(B):
+            sin = ops.timestep_sinusoid(timestep[b : b + 1], cfg.freq_dim)
+            h1 = ops.gemv(self.te_w1, sin, self.te_b1, flags=2)
+            temb = ops.gemv(self.te_w2, h1, self.te_b2, flags=4)
+            tproj = ops.gemv(self.tp_w, temb, self.tp_b, flags=1 | 4)  # [6*D]
+            mods.append(ops.modulation(self.tables, tproj.view(6, D), one_mask=0b010010))  # [L,6,D]: shift,1+scale,gate,...
+            mods_out.append(ops.modulation(self.table_out, temb.view(1, D), one_mask=0b10))  # [1,2,D]: shift, 1+scale
+        if B > 1:  # per-sample gate vectors, stacked [L, B, D] for the GEMM epilogue (gate_rows = N)
+            gate_msa = torch.stack([m[:, 2] for m in mods], dim=1).contiguous()
+            gate_ffn = torch.stack([m[:, 5] for m in mods], dim=1).contiguous()
 
+        if text.shape[0] != B or (image is not None and image.shape[0] != B):
+            raise ValueError("encoder_hidden_states / encoder_hidden_states_image batch size must match hidden_states")
         ctx = self._context(text, image)
+        Tt, Ti = ctx.Tt, ctx.Ti
+        grow = N if B > 1 else 0
 
         x = ws.x
         for li, p in enumerate(self.blk):
-            m = mod[li]
             # 1. self-attention
-            ops.ln_affine(x, m[1], m[0], eps, out=ws.h)
+            for b in range(B):
+                ops.ln_affine(x[rows[b]], mods[b][li, 1], mods[b][li, 0], eps, out=ws.h[rows[b]])
             ops.gemm(ws.h, p.w_qkv, p.b_qkv, out=ws.qkv)
-            q, k, v = ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :]
-            ops.rmsnorm_rope_(q, p.nq1, cs, hd, eps)
-            ops.rmsnorm_rope_(k, p.nk1, cs, hd, eps)
-            ops.attention(q, k, v, H, out=ws.att)
-            ops.gemm(ws.att, p.w_o1, p.b_o1, out=x, epilogue=ops.EPI_GATE_RES, gate=m[2], res=x)
+            for b in range(B):
+                qkv = ws.qkv[rows[b]]
+                q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
+                ops.rmsnorm_rope_(q, p.nq1, cs, hd, eps)
+                ops.rmsnorm_rope_(k, p.nk1, cs, hd, eps)
+                ops.attention(q, k, v, H, out=ws.att[rows[b]])
+            ops.gemm(ws.att, p.w_o1, p.b_o1, out=x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
+                     res=x, gate_rows=grow)
             # 2. cross-attention (text + image segments)
             if p.n2w is not None:
                 ops.ln_affine(x, p.n2w, p.n2b, eps, out=ws.h)
@@ -504,17 +528,26 @@ class DiTEngine:
             ops.gemm(hq, p.w_q2, p.b_q2, out=ws.q2)
             ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
             kv_t, kv_i = ctx.kv[li]
-            if kv_i is not None:
-                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, k2=kv_i[:, :D], v2=kv_i[:, D:])
-            else:
-                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att)
+            for b in range(B):
+                kt = kv_t[b * Tt : (b + 1) * Tt]
+                if kv_i is not None:
+                    ki = kv_i[b * Ti : (b + 1) * Ti]
+                    ops.attention(ws.q2[rows[b]], kt[:, :D], kt[:, D:], H, out=ws.att[rows[b]], k2=ki[:, :D], v2=ki[:, D:])
+                else:
+                    ops.attention(ws.q2[rows[b]], kt[:, :D], kt[:, D:], H, out=ws.att[rows[b]])
             ops.gemm(ws.att, p.w_o2, p.b_o2, out=x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
-            ops.ln_affine(x, m[4], m[3], eps, out=ws.h)
+            for b in range(B):
+                ops.ln_affine(x[rows[b]], mods[b][li, 4], mods[b][li, 3], eps, out=ws.h[rows[b]])
             ops.gemm(ws.h, p.w_f1, p.b_f1, out=ws.ffn, epilogue=ops.EPI_BIAS_GELU)
-            ops.gemm(ws.ffn, p.w_f2, p.b_f2, out=x, epilogue=ops.EPI_GATE_RES, gate=m[5], res=x)
+            ops.gemm(ws.ffn, p.w_f2, p.b_f2, out=x, epilogue=ops.EPI_GATE_RES, gate=gate_ffn[li] if B > 1 else mods[0][li, 5],
+                     res=x, gate_rows=grow)
 
         # K18
-        ops.ln_affine(x, mod_out[0, 1], mod_out[0, 0], eps, out=ws.h)
+        for b in range(B):
+            ops.ln_affine(x[rows[b]], mods_out[b][0, 1], mods_out[b][0, 0], eps, out=ws.h[rows[b]])
         ops.gemm(ws.h, self.w_out, self.b_out, out=ws.head)
-        return ops.unpatchify(ws.head, cfg.out_channels, T, Hh, Ww)
+        out = torch.empty((B, cfg.out_channels, T, Hh, Ww), dtype=torch.bfloat16, device=self.dev)
+        for b in range(B):
+            ops.unpatchify(ws.head[rows[b]], cfg.out_channels, T, Hh, Ww, out=out[b])
+        return out

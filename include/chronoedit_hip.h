@@ -49,10 +49,11 @@ int ce_rmsnorm_rope_bf16(void* x, const float* w, const float* cos_sin, int M, i
                          hipStream_t stream);
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 in/out, fp32 accumulate on MFMA.
- * K % 64 == 0, N % 8 == 0; res may alias C.  Replaces every nn.Linear on the path
+ * K % 64 == 0, N % 8 == 0; res may alias C.  gate_rows > 0: row m uses gate[(m / gate_rows) * N + n] (one gate
+ * vector per sample when several samples' tokens are stacked along M); gate_rows == 0: one gate vector.  Replaces every nn.Linear on the path
  * (transformer_chronoedit.py:58-60,84-86,106, FeedForward :262, patch_embedding :429, proj_out :461). */
 int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res,
-                 int M, int N, int K, int lda, int ldw, int ldc, int ldres, hipStream_t stream);
+                 int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, hipStream_t stream);
 
 /* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default), 0 force the 128x128
  * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows.  Host-side test/bench knob. */

@@ -73,3 +73,23 @@ def test_forward_signature_and_errors():
     a = model(lat.cuda(), ts, text.cuda(), image.cuda()).sample
     b = model(lat.cuda(), ts, text.cuda(), image.cuda()).sample
     assert torch.equal(a, b) and torch.equal(a, out.sample)
+
+
+def test_batched_forward_equals_sequential():
+    """B=2 (the batched classifier-free-guidance form) == two B=1 forwards, bit for bit with the same GEMM kernel."""
+    from chronoedit_amd import ops
+    cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    model = _build(cfg, O.make_synthetic_params(cfg, dtype=torch.bfloat16))
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 16, 16, dtype=torch.bfloat16, text_len=48, real_text=8)
+    text_b = torch.randn(1, 48, 128, generator=torch.Generator().manual_seed(3)).to(torch.bfloat16)
+    ts = torch.tensor([500], device="cuda:0")
+    old = ops.set_gemm_variant(0)
+    try:
+        a = model(lat.cuda(), ts, text.cuda(), image.cuda()).sample
+        b = model(lat.cuda(), ts, text_b.cuda(), image.cuda()).sample
+        both = model(torch.cat([lat, lat]).cuda(), torch.cat([ts, ts]), torch.cat([text, text_b]).cuda(),
+                     torch.cat([image, image]).cuda()).sample
+    finally:
+        ops.set_gemm_variant(old)
+    assert torch.equal(both[0], a[0]) and torch.equal(both[1], b[0])
+    assert not torch.equal(a, b)
