@@ -27,18 +27,26 @@ namespace {
 
 constexpr int HD = 128;            // head dim
 constexpr int QW = 32;             // query rows per wave
-constexpr int NWAVE = 8;
-constexpr int QB = QW * NWAVE;     // 256 query rows per workgroup
 constexpr int KVB = 64;            // kv rows per tile
 constexpr int K_TILE_BYTES = KVB * HD * 2;   // 16 KiB, row = 256 B
 constexpr int VT_TILE_BYTES = HD * KVB * 2;  // 16 KiB, row (one dv) = 128 B
 constexpr int BUF_BYTES = K_TILE_BYTES + VT_TILE_BYTES;
 constexpr int OST_ROW = HD * 2 + 16;         // 272-B padded output staging row
-constexpr int SMEM_BYTES = QB * OST_ROW;     // 69632 B >= 2 * BUF_BYTES (65536): staging overlays the tile buffers
-constexpr int SMEM_BYTES_2SEG = 2 * BUF_BYTES + QB * OST_ROW;  // 2-segment form: staging kept beside the tiles
+// dynamic LDS: the output staging (NWAVE*32 rows x 272 B) overlays the two tile buffers in the 1-segment form and sits
+// beside them in the 2-segment form (the segment-0 result waits there while segment 1 streams through the tiles)
+constexpr int smem_bytes(int nwave, bool two_seg) {
+  const int stage = nwave * QW * OST_ROW;
+  return two_seg ? 2 * BUF_BYTES + stage : (stage > 2 * BUF_BYTES ? stage : 2 * BUF_BYTES);
+}
 constexpr float NEG_BIG = -1.0e30f;
 
-__device__ __forceinline__ int vt_swz(int dv) { return (((dv >> 2) & 7) << 1) | (((dv >> 1) ^ (dv >> 5)) & 1); }
+// 8-B chunk swizzle of the V^T rows.  Conflict-free for the ds_write_b64 side (16 contiguous lanes: dv = 4*dvq + j) and the
+// ds_read_b64 side (32 lanes: dv = 32*m + lane).  The (dv >> 6) term makes rows 64 apart differ by an XOR instead of a
+// constant byte offset, which keeps hipcc from fusing two conflict-free ds_read_b64 into one ds_read2st64_b64 (half
+// rate, 32-bank addressing -> 2-way conflicts).
+__device__ __forceinline__ int vt_swz(int dv) {
+  return ((((dv >> 2) & 7) << 1) | (((dv >> 1) ^ (dv >> 5)) & 1)) ^ (((dv >> 6) & 1) << 1);
+}
 
 struct KVSeg {
   const bf16* k;
@@ -48,8 +56,8 @@ struct KVSeg {
   int ldv;
 };
 
-template <bool TWO_SEG>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
+template <bool TWO_SEG, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 2) void attn_fwd_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
                                                        KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
                                                        float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,6 +73,8 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
     head = blockIdx.x / nqb;
     qb = blockIdx.x % nqb;
   }
+  constexpr int QB = QW * NWAVE;  // query rows per workgroup
+  constexpr int NT = NWAVE * 64;  // threads
   const int q0 = qb * QB + wave * QW;
   const int hoff = head * HD;
 
@@ -77,9 +87,11 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
   }
 
   // staging maps
-  // K: 64 rows x 16 chunks(16 B); thread handles chunks tid and tid + 512
-  const int k_ck = tid & 15, k_row0 = tid >> 4;  // rows k_row0, k_row0 + 32
-  // V: thread handles a 4(kv) x 4(dv) patch: dv = 4*dvq.., kv = 4*kvq..
+  // K: 64 rows x 16 chunks(16 B) = 1024 chunks, KREP per thread (rows k_row0 + i * NT/16)
+  constexpr int KREP = 1024 / NT, KROWS = NT / 16;
+  const int k_ck = tid & 15, k_row0 = tid >> 4;
+  // V: 4(kv) x 4(dv) patches, 512 of them, VREP per thread: dv = 4*dvq.., kv = 4*(kvq + i * NT/32)..
+  constexpr int VREP = 512 / NT, VKQ = NT / 32;
   const int v_dvq = tid & 31, v_kvq = tid >> 5;
 
   // output staging rows; in the 2-segment form they live beside the tile buffers so that the
@@ -98,45 +110,49 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
       for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
 
-    u32x4 kreg[2];
-    u32x2 vreg[4];
+    u32x4 kreg[KREP];
+    u32x2 vreg[VREP][4];
     auto load_tile = [&](int t) {
       const int kv0 = t * KVB;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = min(kv0 + k_row0 + 32 * i, sg.len - 1);
+      for (int i = 0; i < KREP; ++i) {
+        const int r = min(kv0 + k_row0 + KROWS * i, sg.len - 1);
         kreg[i] = *reinterpret_cast<const u32x4*>(sg.k + (size_t)r * sg.ldk + hoff + k_ck * 8);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = min(kv0 + 4 * v_kvq + i, sg.len - 1);
-        vreg[i] = *reinterpret_cast<const u32x2*>(sg.v + (size_t)r * sg.ldv + hoff + v_dvq * 4);
-      }
+      for (int p = 0; p < VREP; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = min(kv0 + 4 * (v_kvq + VKQ * p) + i, sg.len - 1);
+          vreg[p][i] = *reinterpret_cast<const u32x2*>(sg.v + (size_t)r * sg.ldv + hoff + v_dvq * 4);
+        }
     };
     auto store_tile = [&](int buf) {
       unsigned char* sK = smem + buf * BUF_BYTES;
       unsigned char* sV = sK + K_TILE_BYTES;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = k_row0 + 32 * i;
+      for (int i = 0; i < KREP; ++i) {
+        const int r = k_row0 + KROWS * i;
         *reinterpret_cast<u32x4*>(sK + r * (HD * 2) + ((k_ck ^ (r & 15)) << 4)) = kreg[i];
       }
-      // 4x4 transpose of 16-bit elements: vreg[i] = {dv0,dv1 | dv2,dv3} of kv row i
+      // 4x4 transpose of 16-bit elements: vreg[p][i] = {dv0,dv1 | dv2,dv3} of kv row i
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int w = j >> 1;
-        uint32_t lo, hi;
-        if ((j & 1) == 0) {
-          lo = (vreg[0][w] & 0xffffu) | (vreg[1][w] << 16);
-          hi = (vreg[2][w] & 0xffffu) | (vreg[3][w] << 16);
-        } else {
-          lo = (vreg[0][w] >> 16) | (vreg[1][w] & 0xffff0000u);
-          hi = (vreg[2][w] >> 16) | (vreg[3][w] & 0xffff0000u);
+      for (int p = 0; p < VREP; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int w = j >> 1;
+          uint32_t lo, hi;
+          if ((j & 1) == 0) {
+            lo = (vreg[p][0][w] & 0xffffu) | (vreg[p][1][w] << 16);
+            hi = (vreg[p][2][w] & 0xffffu) | (vreg[p][3][w] << 16);
+          } else {
+            lo = (vreg[p][0][w] >> 16) | (vreg[p][1][w] & 0xffff0000u);
+            hi = (vreg[p][2][w] >> 16) | (vreg[p][3][w] & 0xffff0000u);
+          }
+          const int dv = 4 * v_dvq + j;
+          u32x2 val = {lo, hi};
+          *reinterpret_cast<u32x2*>(sV + dv * (KVB * 2) + (((v_kvq + VKQ * p) ^ vt_swz(dv)) << 3)) = val;
         }
-        const int dv = 4 * v_dvq + j;
-        u32x2 val = {lo, hi};
-        *reinterpret_cast<u32x2*>(sV + dv * (KVB * 2) + ((v_kvq ^ vt_swz(dv)) << 3)) = val;
-      }
     };
 
     load_tile(0);
@@ -196,10 +212,12 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
           psum += p;
         }
       l_run = l_run * alpha + psum;
+      if (__any(alpha != 1.0f)) {  // wave-uniform: skip the 64-register O rescale when no row's running max moved
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha;
+      }
 
       // ---- O^T += V^T . P^T : 4 k-steps of 16 kv; step s uses st[s>>1] regs 8*(s&1) .. +8
 #pragma unroll
@@ -262,6 +280,14 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const bf16* __restrict__ 
 
 }  // namespace
 
+// waves per workgroup: 8 (256 query rows, 1 workgroup/CU) or 4 (128 query rows, 2 independent workgroups/CU)
+static int g_attn_nwave = 8;
+extern "C" int ce_set_attention_waves(int nwave) {
+  const int old = g_attn_nwave;
+  if (nwave == 4 || nwave == 8) g_attn_nwave = nwave;
+  return old;
+}
+
 // Q [Nq][ldq], K*/V* [len][ld*], O [Nq][ldo]; all bf16, head h occupies columns [128 h, 128 h + 128).
 // Second kv segment optional (k2 == nullptr or len2 == 0): O = bf16(attn(seg1)) + bf16(attn(seg2)).
 extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
@@ -272,27 +298,28 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
   if ((ldq & 7) || (ldo & 7) || (ldk1 & 7) || (ldv1 & 3)) return CE_ERR_ALIGN;
   const bool two = (K2 != nullptr && V2 != nullptr && len2 > 0);
   if (two && ((ldk2 & 7) || (ldv2 & 3))) return CE_ERR_ALIGN;
-  const int nqb = (Nq + QB - 1) / QB;
   KVSeg s0{(const bf16*)K1, (const bf16*)V1, len1, ldk1, ldv1};
   KVSeg s1{(const bf16*)K2, (const bf16*)V2, two ? len2 : 0, ldk2, ldv2};
   const float sl2 = softmax_scale * 1.4426950408889634f;
-  dim3 grid(nqb * H), block(512);
+  const int nwave = g_attn_nwave;
+  const int nqb = (Nq + nwave * QW - 1) / (nwave * QW);
+  dim3 grid(nqb * H), block(nwave * 64);
+#define CE_ATTN_LAUNCH(TWO, NW)                                                                                     \
+  do {                                                                                                              \
+    static bool done = false;                                                                                       \
+    if (!done) {                                                                                                    \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<TWO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                smem_bytes(NW, TWO));                                                               \
+      done = true;                                                                                                  \
+    }                                                                                                               \
+    hipLaunchKernelGGL((attn_fwd_kernel<TWO, NW>), grid, block, smem_bytes(NW, TWO), stream, (const bf16*)Q, (bf16*)O, \
+                       s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                          \
+  } while (0)
   if (two) {
-    static bool attr_done2 = false;
-    if (!attr_done2) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES_2SEG);
-      attr_done2 = true;
-    }
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, block, SMEM_BYTES_2SEG, stream, (const bf16*)Q, (bf16*)O, s0, s1, Nq, H, ldq,
-                       ldo, nqb, sl2);
+    if (nwave == 8) CE_ATTN_LAUNCH(true, 8); else CE_ATTN_LAUNCH(true, 4);
   } else {
-    static bool attr_done1 = false;
-    if (!attr_done1) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-      attr_done1 = true;
-    }
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, block, SMEM_BYTES, stream, (const bf16*)Q, (bf16*)O, s0, s1, Nq, H, ldq,
-                       ldo, nqb, sl2);
+    if (nwave == 8) CE_ATTN_LAUNCH(false, 8); else CE_ATTN_LAUNCH(false, 4);
   }
+#undef CE_ATTN_LAUNCH
   return (int)hipGetLastError();
 }

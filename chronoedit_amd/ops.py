@@ -165,6 +165,11 @@ def set_gemm_variant(v: int) -> int:
     return lib().ce_set_gemm_variant(int(v))
 
 
+def set_attention_waves(n: int) -> int:
+    """8 (256 query rows / workgroup) or 4 (128 rows, two workgroups per CU); returns the previous value."""
+    return lib().ce_set_attention_waves(int(n))
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
               k2: Optional[torch.Tensor] = None, v2: Optional[torch.Tensor] = None, scale: Optional[float] = None):
     """q [Nq, H*128], k/v [Nkv, H*128] (row strides free) -> out [Nq, H*128]; optional 2nd kv segment."""

@@ -66,6 +66,10 @@ int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, i
                       const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq, int ldo,
                       float softmax_scale, hipStream_t stream);
 
+/* Workgroup shape of ce_attention_bf16 (returns the previous value): 8 waves = 256 query rows per workgroup, one
+ * workgroup per CU; 4 waves = 128 query rows, two independent workgroups per CU.  Host-side tuning knob. */
+int ce_set_attention_waves(int nwave);
+
 /* out[dim] = [cos(t f_i), sin(t f_i)], f_i = 1e4^(-i/(dim/2)), fp32; t is a device int64.
  * Replaces diffusers Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0)
  * (transformer_chronoedit.py:137,153). */

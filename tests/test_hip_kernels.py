@@ -151,8 +151,16 @@ def _sdpa_ref(q, k, v, H):
     return o.transpose(0, 1).reshape(Nq, D)
 
 
+@pytest.fixture(params=[8, 4], ids=["wg8", "wg4"])
+def attn_waves(request):
+    from chronoedit_amd import ops
+    old = ops.set_attention_waves(request.param)
+    yield request.param
+    ops.set_attention_waves(old)
+
+
 @pytest.mark.parametrize("Nq,Nkv,H", [(64, 64, 2), (300, 257, 2), (1000, 1000, 8), (7200, 7200, 8), (33, 512, 3)])
-def test_attention_single_segment(Nq, Nkv, H):
+def test_attention_single_segment(Nq, Nkv, H, attn_waves):
     from chronoedit_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(4)
@@ -167,7 +175,7 @@ def test_attention_single_segment(Nq, Nkv, H):
     assert (out.float() - ref).abs().max().item() < 3e-2
 
 
-def test_attention_spiked_scores_force_rescale():
+def test_attention_spiked_scores_force_rescale(attn_waves):
     """One key per tile has a much larger score than everything before it: exercises the online-softmax
     rescale path on every tile (cdna guide rule 26)."""
     from chronoedit_amd import ops
@@ -185,7 +193,7 @@ def test_attention_spiked_scores_force_rescale():
     assert torch.isfinite(out.float()).all()
 
 
-def test_attention_two_segments():
+def test_attention_two_segments(attn_waves):
     from chronoedit_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(6)
