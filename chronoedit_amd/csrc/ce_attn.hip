@@ -278,13 +278,274 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 2) void attn_fwd_kerne
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant (8 waves): P.V of tile t-1 is issued INSIDE the softmax of tile t, so the
+// matrix pipe works on O^T += V^T.P^T while the VALU does max / exp2 / row-sum of the next tile:
+//     iteration t:  barrier | prefetch tile t+1 -> VGPR | S(t) = K(t).Q^T | O *= alpha(t-1) (rare)
+//                   | { 16 MFMA of PV(t-1) interleaved with softmax(t) } | pack P(t) | tile t+1 -> LDS
+// LDS: K double-buffered, V^T triple-buffered (V(t-1) is still being read while V(t+1) is written), one
+// barrier per tile.  The "tile -1" V buffer is zeroed so the first iteration needs no special case.
+// ------------------------------------------------------------------------------------------------
+constexpr int PIPE_TILE_BYTES = 2 * K_TILE_BYTES + 3 * VT_TILE_BYTES;  // 80 KiB
+constexpr int pipe_smem_bytes(bool two_seg) {
+  const int stage = 8 * QW * OST_ROW;
+  return two_seg ? PIPE_TILE_BYTES + stage : (stage > PIPE_TILE_BYTES ? stage : PIPE_TILE_BYTES);
+}
+
+template <bool TWO_SEG>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
+                                                                KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
+                                                                float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NWAVE = 8, QB = QW * NWAVE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * QB + wave * QW;
+  const int hoff = head * HD;
+
+  bf16x8 qf[8];
+  {
+    const bf16* qrow = Q + (size_t)min(q0 + l31, Nq - 1) * ldq + hoff + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+  }
+
+  const int k_ck = tid & 15, k_row0 = tid >> 4;   // K: rows k_row0, k_row0 + 32; 16-B chunk k_ck
+  const int v_dvq = tid & 31, v_kvq = tid >> 5;   // V: 4(kv) x 4(dv) patch
+  unsigned char* ost = smem + (TWO_SEG ? PIPE_TILE_BYTES : 0) + (size_t)(wave * QW + l31) * OST_ROW;
+
+#pragma unroll
+  for (int sidx = 0; sidx < (TWO_SEG ? 2 : 1); ++sidx) {
+    const KVSeg sg = sidx == 0 ? seg0 : seg1;
+    const int ntiles = (sg.len + KVB - 1) / KVB;
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f, alpha_prev = 1.0f;
+    bf16x8 ppk[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ppk[s4][e] = (bf16)0.f;
+
+    u32x4 kreg[2];
+    u32x2 vreg[4];
+    auto load_tile = [&](int t) {
+      const int kv0 = t * KVB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = min(kv0 + k_row0 + 32 * i, sg.len - 1);
+        kreg[i] = *reinterpret_cast<const u32x4*>(sg.k + (size_t)r * sg.ldk + hoff + k_ck * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = min(kv0 + 4 * v_kvq + i, sg.len - 1);
+        vreg[i] = *reinterpret_cast<const u32x2*>(sg.v + (size_t)r * sg.ldv + hoff + v_dvq * 4);
+      }
+    };
+    auto store_tile = [&](int kbuf, int vbuf) {
+      unsigned char* sK = smem + kbuf * K_TILE_BYTES;
+      unsigned char* sV = smem + 2 * K_TILE_BYTES + vbuf * VT_TILE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = k_row0 + 32 * i;
+        *reinterpret_cast<u32x4*>(sK + r * (HD * 2) + ((k_ck ^ (r & 15)) << 4)) = kreg[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = j >> 1;
+        uint32_t lo, hi;
+        if ((j & 1) == 0) {
+          lo = (vreg[0][w] & 0xffffu) | (vreg[1][w] << 16);
+          hi = (vreg[2][w] & 0xffffu) | (vreg[3][w] << 16);
+        } else {
+          lo = (vreg[0][w] >> 16) | (vreg[1][w] & 0xffff0000u);
+          hi = (vreg[2][w] >> 16) | (vreg[3][w] & 0xffff0000u);
+        }
+        const int dv = 4 * v_dvq + j;
+        u32x2 val = {lo, hi};
+        *reinterpret_cast<u32x2*>(sV + dv * (KVB * 2) + ((v_kvq ^ vt_swz(dv)) << 3)) = val;
+      }
+    };
+    // one P.V k-step: O^T[m] += V^T(m, s4) . P^T(s4)
+    auto pv_mfma = [&](const unsigned char* sV, int s4, int m) {
+      const int dv = 32 * m + l31;
+      const unsigned char* vrow = sV + dv * (KVB * 2);
+      const int sw = vt_swz(dv), c0 = 4 * s4 + hh;
+      const bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow + ((c0 ^ sw) << 3));
+      const bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + (((c0 + 2) ^ sw) << 3));
+      const bf16x8 vf = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+      oacc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, ppk[s4], oacc[m], 0, 0, 0);
+    };
+
+    load_tile(0);
+    __syncthreads();  // previous segment's readers are done with the tile buffers
+    {                 // V buffer 2 plays "tile -1": zero it (P(-1) = 0, but 0 * garbage could be NaN)
+      u32x4 z = {0u, 0u, 0u, 0u};
+      unsigned char* vz = smem + 2 * K_TILE_BYTES + 2 * VT_TILE_BYTES;
+      *reinterpret_cast<u32x4*>(vz + tid * 32) = z;
+      *reinterpret_cast<u32x4*>(vz + tid * 32 + 16) = z;
+    }
+    store_tile(0, 0);
+
+    int vcur = 0, vprev = 2;  // V buffer of tile t / tile t-1
+    for (int t = 0; t < ntiles; ++t) {
+      __syncthreads();
+      if (t + 1 < ntiles) load_tile(t + 1);
+      const unsigned char* sK = smem + (t & 1) * K_TILE_BYTES;
+      const unsigned char* sVp = smem + 2 * K_TILE_BYTES + vprev * VT_TILE_BYTES;
+
+      // ---- S^T(t) = K(t) . Q^T
+      f32x16 st[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[f][r] = 0.f;
+        const int r = 32 * f + l31;
+        const unsigned char* krow = sK + r * (HD * 2);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * ks + hh) ^ (r & 15)) << 4));
+          st[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[f], 0, 0, 0);
+        }
+      }
+      if ((t + 1) * KVB > sg.len) {
+        const int base = t * KVB + 4 * hh;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
+            if (kv >= sg.len) st[f][r] = NEG_BIG;
+          }
+      }
+      // ---- bring O to the scale of m(t-1) before P(t-1).V(t-1) is added (rare after the first tiles)
+      if (__any(alpha_prev != 1.0f)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
+      }
+      // ---- P.V of tile t-1 (matrix pipe) interleaved with the softmax of tile t (VALU)
+      // k-step 0 beside the row max
+      float mx0 = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+      pv_mfma(sVp, 0, 0);
+#pragma unroll
+      for (int r = 4; r < 16; ++r) mx0 = fmaxf(mx0, st[0][r]);
+      pv_mfma(sVp, 0, 1);
+      float mx1 = fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3]));
+#pragma unroll
+      for (int r = 4; r < 16; ++r) mx1 = fmaxf(mx1, st[1][r]);
+      pv_mfma(sVp, 0, 2);
+      float mx = fmaxf(mx0, mx1);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      pv_mfma(sVp, 0, 3);
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      const float mc = m_new * scale_log2e;
+      m_run = m_new;
+      float psum = 0.f;
+      // k-steps 1..3 (12 MFMAs) beside the 32 exp2: 3 / 3 / 2 elements per MFMA
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        pv_mfma(sVp, 1 + i / 4, i % 4);
+        const int e0 = i < 8 ? 3 * i : 24 + 2 * (i - 8);
+        const int ne = i < 8 ? 3 : 2;
+#pragma unroll
+        for (int e = e0; e < e0 + ne; ++e) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[e >> 4][e & 15], scale_log2e, -mc));
+          st[e >> 4][e & 15] = p;
+          psum += p;
+        }
+      }
+      l_run = l_run * alpha + psum;
+      alpha_prev = alpha;
+      // ---- P(t) -> bf16 B-operand fragments (k-slot order = accumulator register order, see header)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int f = s4 >> 1, rb = 8 * (s4 & 1);
+        f32x2 t0 = {st[f][rb + 0], st[f][rb + 1]}, t1 = {st[f][rb + 2], st[f][rb + 3]};
+        f32x2 t2 = {st[f][rb + 4], st[f][rb + 5]}, t3 = {st[f][rb + 6], st[f][rb + 7]};
+        const bf16x2 p0 = __builtin_convertvector(t0, bf16x2), p1 = __builtin_convertvector(t1, bf16x2);
+        const bf16x2 p2 = __builtin_convertvector(t2, bf16x2), p3 = __builtin_convertvector(t3, bf16x2);
+        ppk[s4] = bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+      }
+      // V(t-1) (vprev) was read in this iteration and V(t) (vcur) is read in the next: tile t+1 goes to the third buffer
+      const int vfree = 3 - vcur - vprev;
+      if (t + 1 < ntiles) store_tile((t + 1) & 1, vfree);
+      vprev = vcur;
+      vcur = vfree;
+    }
+    // ---- drain: P(ntiles-1) . V(ntiles-1)
+    if (__any(alpha_prev != 1.0f)) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
+    }
+    {
+      const unsigned char* sVp = smem + 2 * K_TILE_BYTES + vprev * VT_TILE_BYTES;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pv_mfma(sVp, s4, m);
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (!TWO_SEG) __syncthreads();  // staging overlays the tile buffers: every wave must be done reading them
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        uint32_t w0 = pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv);
+        uint32_t w1 = pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv);
+        u32x2* slot = reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2);
+        if (TWO_SEG && sidx == 1) {
+          const u32x2 pv = *slot;
+          w0 = pack_bf16(bf16lo(pv[0]) + bf16lo(w0), bf16hi(pv[0]) + bf16hi(w0));
+          w1 = pack_bf16(bf16lo(pv[1]) + bf16lo(w1), bf16hi(pv[1]) + bf16hi(w1));
+        }
+        u32x2 val = {w0, w1};
+        *slot = val;
+      }
+  }
+
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = q0 + rl;
+    if (q < Nq) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? PIPE_TILE_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    }
+  }
+}
+
 }  // namespace
 
 // waves per workgroup: 8 (256 query rows, 1 workgroup/CU) or 4 (128 query rows, 2 independent workgroups/CU)
-static int g_attn_nwave = 8;
+// 16 selects the software-pipelined 8-wave kernel (P.V of tile t-1 under the softmax of tile t)
+static int g_attn_nwave = 16;
 extern "C" int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
-  if (nwave == 4 || nwave == 8) g_attn_nwave = nwave;
+  if (nwave == 4 || nwave == 8 || nwave == 16) g_attn_nwave = nwave;
   return old;
 }
 
@@ -301,9 +562,26 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
   KVSeg s0{(const bf16*)K1, (const bf16*)V1, len1, ldk1, ldv1};
   KVSeg s1{(const bf16*)K2, (const bf16*)V2, two ? len2 : 0, ldk2, ldv2};
   const float sl2 = softmax_scale * 1.4426950408889634f;
-  const int nwave = g_attn_nwave;
+  const bool pipe = g_attn_nwave == 16;
+  const int nwave = pipe ? 8 : g_attn_nwave;
   const int nqb = (Nq + nwave * QW - 1) / (nwave * QW);
   dim3 grid(nqb * H), block(nwave * 64);
+#define CE_ATTN_PIPE(TWO)                                                                                          \
+  do {                                                                                                             \
+    static bool done = false;                                                                                      \
+    if (!done) {                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<TWO>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                pipe_smem_bytes(TWO));                                                             \
+      done = true;                                                                                                 \
+    }                                                                                                              \
+    hipLaunchKernelGGL((attn_fwd_pipe_kernel<TWO>), grid, block, pipe_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, \
+                       s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                         \
+  } while (0)
+  if (pipe) {
+    if (two) CE_ATTN_PIPE(true); else CE_ATTN_PIPE(false);
+    return (int)hipGetLastError();
+  }
+#undef CE_ATTN_PIPE
 #define CE_ATTN_LAUNCH(TWO, NW)                                                                                     \
   do {                                                                                                              \
     static bool done = false;                                                                                       \
