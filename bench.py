@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--guidance", type=float, default=5.0)
     ap.add_argument("--cache-context", action="store_true", help="reuse step-invariant text/image K/V across steps")
     ap.add_argument("--sequential-cfg", action="store_true", help="two B=1 forwards per step instead of one batched B=2 forward")
+    ap.add_argument("--parallel", choices=["replica", "ulysses"], default="replica",
+                    help="N>1: independent edits per GPU (weak scaling, default) or ONE edit with the token axis sharded "
+                         "over the GPUs (Ulysses all-to-all over RCCL/xGMI, strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -116,9 +119,13 @@ def main():
     ops.lib()  # fail loudly if the HIP library is missing
     model = build_model(a.layers, dev)
     model.cache_context = a.cache_context
+    ulysses = world > 1 and a.parallel == "ulysses"
+    if ulysses:
+        model.enable_sequence_parallel()
+        a.sequential_cfg = True  # the token shard is per sample
     T, h, w = a.frames, a.height // 8, a.width // 8
     N = T * (h // 2) * (w // 2)
-    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    g = torch.Generator(device=dev).manual_seed(42 + (0 if ulysses else rank))  # Ulysses: replicated inputs
     latents = torch.randn((1, 16, T, h, w), generator=g, device=dev, dtype=torch.float32)
     condition = torch.randn((1, 20, T, h, w), generator=g, device=dev).to(torch.bfloat16)
     prompt = torch.randn((1, 512, 4096), generator=g, device=dev)
@@ -177,21 +184,21 @@ def main():
                     "launches": summ[dom]["n"], "avg_ms": round(summ[dom]["avg_ms"], 4)}
 
     if rank == 0:
-        steps_per_s = a.steps / dt * world
+        steps_per_s = a.steps / dt * (1 if ulysses else world)
         fl = flops_per_forward(DiTConfig(num_layers=a.layers), N) * fwd_per_step
         out = {
             "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": "denoising-steps/sec (ChronoEdit-14B, 720p)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
                                    f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
                                    "BASELINE.json configs[1]",
-                       "tokens": N, "forwards_per_step": fwd_per_step, "parallelism": f"replica x{world}",
+                       "tokens": N, "forwards_per_step": fwd_per_step, "parallelism": f"ulysses sp{world}" if ulysses else f"replica x{world}",
                        "cfg": "sequential (2 x B=1)" if a.sequential_cfg else "batched (1 x B=2)",
                        "context_cache": bool(a.cache_context)},
             "model_tflops_per_step": round(fl / 1e12, 2),
-            "achieved_tflops_per_gpu": round(fl * a.steps / dt / 1e12, 1),
-            "mfma_roofline_frac_whole_step": round(fl * a.steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "achieved_tflops_per_gpu": round(fl * a.steps / dt / 1e12 / (world if ulysses else 1), 1),
+            "mfma_roofline_frac_whole_step": round(fl * a.steps / dt / 1e12 / (world if ulysses else 1) / PEAK_BF16_TFLOPS, 4),
             "finite": finite,
             "roofline": roofline,
             "kernel_breakdown": breakdown,

@@ -186,6 +186,7 @@ class ChronoEditTransformer3DModel(nn.Module):
         self.scale_shift_table = nn.Parameter(torch.randn(1, 2, inner, device=device, dtype=torch.float32) / inner**0.5)
         self._engine: Optional["DiTEngine"] = None
         self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
+        self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
 
     # -- reference-compatible helpers --------------------------------------------------
     @property
@@ -207,6 +208,15 @@ class ChronoEditTransformer3DModel(nn.Module):
             for k, p in own.items():
                 p.copy_(params[k].to(p.dtype))
         self.invalidate()
+        return self
+
+    def enable_sequence_parallel(self, group=None):
+        """Shard the token axis over the ranks of `group` (Ulysses: two all-to-all per self-attention).  Every rank
+        must call forward with the same (replicated) inputs and receives the full output."""
+        from .parallel import Ulysses
+        self._sp = Ulysses(group)
+        if self.config.num_attention_heads % self._sp.world:
+            raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
         return self
 
     def invalidate(self):
@@ -476,14 +486,29 @@ class DiTEngine:
         hd = cfg.attention_head_dim
         eps = cfg.eps
         cs = self._rope_table(T, Hp, Wp)  # raises AssertionError for unsupported frame counts (:205)
-        ws = self._workspace(B * N)
+        sp = self.model._sp
+        if sp is not None and sp.world > 1:
+            if B != 1:
+                raise ValueError("sequence parallelism shards the tokens of ONE sample; call with batch size 1")
+            Nl = sp.shard(N)[0]  # local (zero-padded) token rows
+            key = ("sp", T, Hp, Wp, sp.rank, sp.world)
+            if key not in self._rope:
+                self._rope[key] = sp.take_rows(cs, N).contiguous()
+            cs = self._rope[key]
+        else:
+            sp = None
+            Nl = N
+        ws = self._workspace(B * Nl)
         hidden = hidden.to(torch.bfloat16).contiguous()
         timestep = timestep.to(device=self.dev, dtype=torch.int64).contiguous()
-        rows = [slice(b * N, (b + 1) * N) for b in range(B)]
+        rows = [slice(b * Nl, (b + 1) * Nl) for b in range(B)]
 
         # K1
-        for b in range(B):
-            ops.patchify(hidden[b], self.kpatch, out=ws.cols[rows[b]])
+        if sp is None:
+            for b in range(B):
+                ops.patchify(hidden[b], self.kpatch, out=ws.cols[rows[b]])
+        else:
+            ws.cols.copy_(sp.take_rows(ops.patchify(hidden[0], self.kpatch), N))
         ops.gemm(ws.cols, self.w_patch, self.b_patch, out=ws.x)
 
         # K2 per sample: sinusoid -> time_embedder (fp32) -> temb (bf16-rounded) -> silu -> time_proj -> AdaLN tables
@@ -503,7 +528,7 @@ class DiTEngine:
             raise ValueError("encoder_hidden_states / encoder_hidden_states_image batch size must match hidden_states")
         ctx = self._context(text, image)
         Tt, Ti = ctx.Tt, ctx.Ti
-        grow = N if B > 1 else 0
+        grow = Nl if B > 1 else 0
 
         x = ws.x
         for li, p in enumerate(self.blk):
@@ -516,7 +541,13 @@ class DiTEngine:
                 q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
                 ops.rmsnorm_rope_(q, p.nq1, cs, hd, eps)
                 ops.rmsnorm_rope_(k, p.nk1, cs, hd, eps)
-                ops.attention(q, k, v, H, out=ws.att[rows[b]])
+                if sp is None:
+                    ops.attention(q, k, v, H, out=ws.att[rows[b]])
+                else:  # Ulysses: tokens gathered / heads scattered around the attention kernel
+                    Dl = D // sp.world
+                    g = sp.scatter_heads(qkv, H, hd)  # [W*Nl, 3*Dl]
+                    og = ops.attention(g[:, :Dl], g[:N, Dl : 2 * Dl], g[:N, 2 * Dl :], H // sp.world)
+                    ws.att[rows[b]].copy_(sp.gather_heads(og, H, hd))
             ops.gemm(ws.att, p.w_o1, p.b_o1, out=x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
                      res=x, gate_rows=grow)
             # 2. cross-attention (text + image segments)
@@ -548,6 +579,10 @@ class DiTEngine:
             ops.ln_affine(x[rows[b]], mods_out[b][0, 1], mods_out[b][0, 0], eps, out=ws.h[rows[b]])
         ops.gemm(ws.h, self.w_out, self.b_out, out=ws.head)
         out = torch.empty((B, cfg.out_channels, T, Hh, Ww), dtype=torch.bfloat16, device=self.dev)
-        for b in range(B):
-            ops.unpatchify(ws.head[rows[b]], cfg.out_channels, T, Hh, Ww, out=out[b])
+        if sp is None:
+            for b in range(B):
+                ops.unpatchify(ws.head[rows[b]], cfg.out_channels, T, Hh, Ww, out=out[b])
+        else:
+            full = sp.all_gather_rows(ws.head)[:N].contiguous()
+            ops.unpatchify(full, cfg.out_channels, T, Hh, Ww, out=out[0])
         return out
