@@ -1,0 +1,63 @@
+"""Golden vectors for the VAE from the REFERENCE's own class definitions.
+
+/root/reference/chronoedit/_src/tokenizers/wan2pt1.py cannot be imported (module-level loguru / easy_io / lazy_config),
+but lines 38-581 (CACHE_T ... WanVAE_) use only torch + einops.  This script exec's exactly that source range in a
+namespace that provides those imports, loads the seeded synthetic weights of oracle/vae_oracle.make_synthetic_params and
+stores encode/decode outputs in tests/golden/vae_*.pt.  Build container only."""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from einops import rearrange
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import vae_oracle as V  # noqa: E402
+
+REF = "/root/reference/chronoedit/_src/tokenizers/wan2pt1.py"
+
+
+def load_reference_classes():
+    src = open(REF).read().split("\n")
+    start = next(i for i, l in enumerate(src) if l.startswith("CACHE_T = 2"))
+    end = next(i for i, l in enumerate(src) if l.startswith("def _video_vae("))
+    ns = {"torch": torch, "nn": nn, "F": F, "rearrange": rearrange}
+    exec(compile("\n".join(src[start:end]), REF, "exec"), ns)
+    return ns
+
+
+CASES = {
+    # name: (cfg kwargs, frames, H, W)
+    "small_5f": (dict(dim=32, z_dim=16), 5, 32, 48),
+    "small_9f": (dict(dim=32, z_dim=16), 9, 16, 32),
+}
+
+
+def main():
+    ns = load_reference_classes()
+    for name, (kw, T, H, W) in CASES.items():
+        cfg = V.VAEConfig(**kw)
+        p = V.make_synthetic_params(cfg)
+        m = ns["WanVAE_"](dim=cfg.dim, z_dim=cfg.z_dim, dim_mult=list(cfg.dim_mult), num_res_blocks=cfg.num_res_blocks,
+                          attn_scales=[], temperal_downsample=list(cfg.temperal_downsample), dropout=0.0).eval()
+        sd = m.state_dict()
+        assert set(sd) == set(p), (sorted(set(sd) - set(p))[:5], sorted(set(p) - set(sd))[:5])
+        m.load_state_dict(p)
+        x = torch.rand((1, 3, T, H, W), generator=torch.Generator().manual_seed(5)) * 2 - 1
+        zero_scale = [0.0, 1.0]
+        with torch.no_grad():
+            mu = m.encode(x, zero_scale)
+            z = torch.randn(mu.shape, generator=torch.Generator().manual_seed(6))
+            rec = m.decode(z, zero_scale)
+        fx = {"cfg": kw, "T": T, "H": H, "W": W, "mu": mu.contiguous(), "rec": rec.contiguous(),
+              "source": "reference wan2pt1.py:38-581 exec'd; weights oracle.vae_oracle.make_synthetic_params(seed 4321)"}
+        path = os.path.join(ROOT, "tests", "golden", f"vae_{name}.pt")
+        torch.save(fx, path)
+        print(name, tuple(mu.shape), tuple(rec.shape), float(mu.abs().mean()), float(rec.abs().mean()), os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    main()
