@@ -1,0 +1,306 @@
+// Wan-2.1 VAE kernels (K20/K21): implicit-GEMM causal conv3d / conv2d on MFMA over channels-last frames,
+// plus the HBM-bound companions (RMS_norm+SiLU, nearest 2x upsample, row softmax for the mid-block attention).
+// Reference spec: chronoedit/_src/tokenizers/wan2pt1.py (CausalConv3d :42-60, RMS_norm :63-75, Resample :86-165,
+// ResidualBlock :186-220, AttentionBlock :223-259); call sites pipeline_chronoedit.py:442,776-781.
+//
+// Data layout: every activation frame is channels-last with a one-pixel ZERO border, [H+2][W+2][C] bf16.  Spatial zero
+// padding of the reference's convs is then just addressing; temporal causal padding is a list of frame pointers
+// (cache frames of the previous chunk or a shared zero frame in front of the chunk's own frames), so nothing is ever
+// concatenated or padded in memory.
+//
+// conv_igemm: out[t][h][w][co] = bias[co] + sum_{kt,kh,kw,ci} W[co][(kt,kh,kw)][ci] * in[t*st+kt][h*ss+kh+oh][w*ss+kw+ow][ci]
+//   GEMM view M = T_out*H_out*W_out output pixels, N = Cout, K = taps * Cin, both operands K(=ci)-contiguous.
+//   128 x BN x 32 block tile, 4 waves x (32 rows x BN cols) of v_mfma_f32_16x16x32_bf16, register-staged double-buffered
+//   LDS tiles (16-B chunk XOR swizzle), epilogue through LDS for 16-B stores.  Bound: bf16 MFMA for >= 192 channels,
+//   HBM for the 96-channel full-resolution layers.
+#include "ce_common.h"
+
+namespace {
+
+constexpr int CBM = 128, CBK = 32;
+constexpr int MAX_FRAMES = 16;
+
+struct ConvParams {
+  const bf16* in_frames[MAX_FRAMES];
+  bf16* out_frames[MAX_FRAMES];
+  const bf16* res_frames[MAX_FRAMES];
+  const bf16* weight;   // [Cout][taps][Cin]
+  const float* bias;
+  int n_out_frames, Cin, Cout, KT, KH, KW, st, ss;
+  int H_out, W_out, in_Wp, in_off_h, in_off_w;
+  int out_Wp, out_border, out_cstride, out_coff;
+  int has_res;
+};
+
+__device__ __forceinline__ int cswz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+  constexpr int NF = BN / 16;                 // n fragments per wave
+  constexpr int A_BYTES = CBM * CBK * 2;      // 8 KiB
+  constexpr int W_BYTES = BN * CBK * 2;
+  constexpr int CROW = BN * 2 + 16;           // padded epilogue row
+  constexpr int TILE_BYTES = 2 * (A_BYTES + W_BYTES);
+  constexpr int SMEM = TILE_BYTES > CBM * CROW ? TILE_BYTES : CBM * CROW;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  __shared__ const bf16* s_in[MAX_FRAMES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  if (tid < MAX_FRAMES) s_in[tid] = p.in_frames[tid];
+  __syncthreads();
+
+  const int HW = p.H_out * p.W_out;
+  const int M = p.n_out_frames * HW;
+  const int tiles_n = (p.Cout + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * CBM, n0 = tn * BN;
+  const int taps = p.KT * p.KH * p.KW;
+  const int cchunks = p.Cin / CBK;
+  const int KTILES = taps * cchunks;
+
+  // A staging: 128 rows x 4 chunks(16 B) = 512 chunks, 2 per thread: rows (tid>>2) and (tid>>2)+64, chunk tid&3
+  const int a_ck = tid & 3;
+  int a_t[2], a_sp[2];   // output frame index, spatial element offset (without tap) into the bordered input frame
+  int a_lds[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (tid >> 2) + 64 * i;
+    const int m = min(m0 + r, M - 1);
+    const int t = m / HW, rem = m - t * HW;
+    const int h = rem / p.W_out, w = rem - h * p.W_out;
+    a_t[i] = t * p.st;
+    a_sp[i] = ((h * p.ss + p.in_off_h) * p.in_Wp + (w * p.ss + p.in_off_w)) * p.Cin + a_ck * 8;
+    a_lds[i] = r * (CBK * 2) + (cswz(r, a_ck) << 4);
+  }
+  // W staging: BN rows x 4 chunks; BN*4/256 per thread
+  constexpr int WREP = (BN * 4 + 255) / 256;
+  const bf16* w_src[WREP];
+  int w_lds[WREP];
+  bool w_on[WREP];
+#pragma unroll
+  for (int i = 0; i < WREP; ++i) {
+    const int c = tid + 256 * i;
+    const int r = c >> 2, ck = c & 3;
+    w_on[i] = r < BN;
+    const int n = min(n0 + r, p.Cout - 1);
+    w_src[i] = p.weight + (size_t)n * taps * p.Cin + ck * 8;
+    w_lds[i] = r * (CBK * 2) + (cswz(r, ck) << 4);
+  }
+
+  f32x4 acc[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[2], rw[WREP];
+  auto load_tile = [&](int kt) {
+    const int tap = kt / cchunks, cc = kt - tap * cchunks;
+    const int kw = tap % p.KW, kh = (tap / p.KW) % p.KH, kti = tap / (p.KW * p.KH);
+    const int tap_off = (kh * p.in_Wp + kw) * p.Cin + cc * CBK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const u32x4*>(s_in[a_t[i] + kti] + a_sp[i] + tap_off);
+#pragma unroll
+    for (int i = 0; i < WREP; ++i)
+      if (w_on[i]) rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + (size_t)tap * p.Cin + cc * CBK);
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* sA = smem + buf * (A_BYTES + W_BYTES);
+    unsigned char* sW = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(sA + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < WREP; ++i)
+      if (w_on[i]) *reinterpret_cast<u32x4*>(sW + w_lds[i]) = rw[i];
+  };
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < KTILES; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KTILES) load_tile(kt + 1);
+    const unsigned char* sA = smem + cur * (A_BYTES + W_BYTES);
+    const unsigned char* sW = sA + A_BYTES;
+    bf16x8 af[2], wf[NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = wave * 32 + i * 16 + fr;
+      af[i] = *reinterpret_cast<const bf16x8*>(sA + r * (CBK * 2) + (cswz(r, fg) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const int r = j * 16 + fr;
+      wf[j] = *reinterpret_cast<const bf16x8*>(sW + r * (CBK * 2) + (cswz(r, fg) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+    if (kt + 1 < KTILES) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: bf16(acc + bias) -> LDS rows -> 16-B chunks (+ residual) -> bordered output frame
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int cl = j * 16 + fr;
+    const int n = n0 + cl;
+    const float bv = (p.bias != nullptr && n < p.Cout) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = wave * 32 + i * 16 + fg * 4 + r;
+        *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][r] + bv);
+      }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;  // 16-B chunks per row
+  for (int c = tid; c < CBM * CPR; c += 256) {
+    const int rl = c / CPR, cc = c % CPR;
+    const int m = m0 + rl, n = n0 + cc * 8;
+    if (m < M && n < p.Cout) {
+      const int t = m / HW, rem = m - t * HW;
+      const int h = rem / p.W_out, w = rem - h * p.W_out;
+      const size_t off = ((size_t)(h + p.out_border) * p.out_Wp + (w + p.out_border)) * p.out_cstride + p.out_coff + n;
+      u32x4 v = *reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16);
+      if (p.has_res) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res_frames[t] + off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]), bf16hi(rv[q]) + bf16hi(v[q]));
+      }
+      *reinterpret_cast<u32x4*>(p.out_frames[t] + off) = v;
+    }
+  }
+}
+
+// ---- RMS_norm over channels (+ SiLU), channels-last, in -> out (both bordered frames or plain rows) ---------------
+// y = silu( x / max(||x||_2, 1e-12) * sqrt(C) * gamma )     (F.normalize semantics, wan2pt1.py:74)
+// 16 lanes per pixel, each lane C/16 channels (C % 16 == 0, C <= 512)
+__global__ __launch_bounds__(256) void rms_silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                        const float* __restrict__ gamma, long long npix, int C, int H, int W,
+                                                        int in_Wp, int in_border, int out_Wp, int out_border, int apply_silu) {
+  const int sub = threadIdx.x & 15;
+  const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (pix >= npix) return;
+  const long long HW = (long long)H * W;
+  const long long t = pix / HW;
+  const int rem = (int)(pix - t * HW);
+  const int h = rem / W, w = rem - h * W;
+  const bf16* xp = x + ((t * (H + 2 * in_border) + h + in_border) * in_Wp + (w + in_border)) * C;
+  bf16* yp = y + ((t * (H + 2 * out_border) + h + out_border) * out_Wp + (w + out_border)) * C;
+  const int per = C >> 4;  // channels per lane (multiple of 2)
+  float ss = 0.f;
+  for (int i = 0; i < per; i += 2) {
+    const uint32_t pk = *reinterpret_cast<const uint32_t*>(xp + sub * per + i);
+    ss += bf16lo(pk) * bf16lo(pk) + bf16hi(pk) * bf16hi(pk);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
+  const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+  for (int i = 0; i < per; i += 2) {  // second pass re-reads the pixel (L1 hit) instead of holding it in an indexed array
+    const int c = sub * per + i;
+    const uint32_t pk = *reinterpret_cast<const uint32_t*>(xp + c);
+    float a = bf16lo(pk) * scale * gamma[c], b = bf16hi(pk) * scale * gamma[c + 1];
+    if (apply_silu) {
+      a = silu(a);
+      b = silu(b);
+    }
+    *reinterpret_cast<uint32_t*>(yp + c) = pack_bf16(a, b);
+  }
+}
+
+// ---- nearest-exact 2x spatial upsample, channels-last bordered frames (wan2pt1.py:78-83) ----------------------------
+__global__ void upsample2x_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, long long nchunks, int C8, int H, int W,
+                                  int in_Wp, int out_Wp) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nchunks) return;
+  const int c = idx % C8;
+  long long r = idx / C8;
+  const int wo = r % (2 * W);
+  r /= 2 * W;
+  const int ho = r % (2 * H);
+  const long long t = r / (2 * H);
+  const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((t * (H + 2) + (ho >> 1) + 1) * in_Wp + (wo >> 1) + 1) * (long long)C8 + c) * 8);
+  *reinterpret_cast<u32x4*>(y + (((t * (2 * H + 2) + ho + 1) * out_Wp + wo + 1) * (long long)C8 + c) * 8) = v;
+}
+
+// ---- row softmax: fp32 scores [M][ld] -> bf16 probabilities [M][ldp] (columns >= n zero-filled up to npad) ----------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, bf16* __restrict__ pr, int n, int npad, int ld,
+                                                           int ldp, float scale) {
+  __shared__ float red[8];
+  const float* row = s + (size_t)blockIdx.x * ld;
+  bf16* out = pr + (size_t)blockIdx.x * ldp;
+  const int tid = threadIdx.x;
+  float mx = -3.0e38f;
+  for (int i = tid; i < n; i += 256) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = tid; i < n; i += 256) sum += __expf((row[i] - mx) * scale);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = tid; i < npad; i += 256) out[i] = (bf16)(i < n ? __expf((row[i] - mx) * scale) * inv : 0.f);
+}
+
+}  // namespace
+
+extern "C" int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias,
+                                  void* const* out_frames, int n_out_frames, const void* const* res_frames, int Cin, int Cout,
+                                  int KT, int KH, int KW, int st, int ss, int H_out, int W_out, int in_Wp, int in_off_h,
+                                  int in_off_w, int out_Wp, int out_border, int out_cstride, int out_coff, hipStream_t stream) {
+  if (!in_frames || !weight || !out_frames) return CE_ERR_ARG;
+  if (n_in_frames <= 0 || n_in_frames > MAX_FRAMES || n_out_frames <= 0 || n_out_frames > MAX_FRAMES) return CE_ERR_SHAPE;
+  if ((Cin % CBK) || (Cout & 7) || (out_cstride & 7) || (out_coff & 7) || KT < 1 || KH < 1 || KW < 1) return CE_ERR_SHAPE;
+  if ((n_out_frames - 1) * st + KT > n_in_frames) return CE_ERR_SHAPE;
+  ConvParams p;
+  for (int i = 0; i < MAX_FRAMES; ++i) {
+    p.in_frames[i] = (const bf16*)in_frames[i < n_in_frames ? i : n_in_frames - 1];
+    p.out_frames[i] = (bf16*)out_frames[i < n_out_frames ? i : n_out_frames - 1];
+    p.res_frames[i] = res_frames ? (const bf16*)res_frames[i < n_out_frames ? i : n_out_frames - 1] : nullptr;
+  }
+  p.weight = (const bf16*)weight;
+  p.bias = bias;
+  p.n_out_frames = n_out_frames;
+  p.Cin = Cin; p.Cout = Cout; p.KT = KT; p.KH = KH; p.KW = KW; p.st = st; p.ss = ss;
+  p.H_out = H_out; p.W_out = W_out; p.in_Wp = in_Wp; p.in_off_h = in_off_h; p.in_off_w = in_off_w;
+  p.out_Wp = out_Wp; p.out_border = out_border; p.out_cstride = out_cstride; p.out_coff = out_coff;
+  p.has_res = res_frames != nullptr;
+  const long long M = (long long)n_out_frames * H_out * W_out;
+  const int tiles_m = (int)((M + CBM - 1) / CBM);
+  if (Cout <= 32) {
+    hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3(tiles_m * ((Cout + 31) / 32)), dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3(tiles_m * ((Cout + 127) / 128)), dim3(256), 0, stream, p);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,
+                                int out_border, int apply_silu, hipStream_t stream) {
+  if (!x || !y || !gamma || npix <= 0) return CE_ERR_ARG;
+  if ((C & 31) || C > 512 || H <= 0 || W <= 0) return CE_ERR_SHAPE;
+  hipLaunchKernelGGL(rms_silu_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, gamma,
+                     npix, C, H, W, W + 2 * in_border, in_border, W + 2 * out_border, out_border, apply_silu);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipStream_t stream) {
+  if (!x || !y || (C & 7) || T <= 0) return CE_ERR_ARG;
+  const long long n = (long long)T * (2 * H) * (2 * W) * (C / 8);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n, C / 8,
+                     H, W, W + 2, 2 * W + 2);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int npad, int ld, int ldp, float scale,
+                                        hipStream_t stream) {
+  if (!scores || !probs || M <= 0 || n <= 0 || npad < n || npad > ldp) return CE_ERR_ARG;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, stream, scores, (bf16*)probs, n, npad, ld, ldp, scale);
+  return (int)hipGetLastError();
+}

@@ -25,6 +25,7 @@
 #define EPI_BIAS_GELU 1
 #define EPI_GATE_RES 2
 #define EPI_BIAS_GELU_ERF 3
+#define EPI_F32 4  // C is float*: raw fp32 accumulators (attention scores of the VAE mid block)
 
 namespace {
 
@@ -132,8 +133,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
     __syncthreads();
   }
 
-  // ---- epilogue: bf16(acc + bias) -> LDS (row-major, padded) -> 16-B row-contiguous stores
   // C fragment layout (16x16x32): col = lane & 15, row = 4 * (lane >> 4) + reg
+  if (EPI == EPI_F32) {  // fp32 result straight from the accumulators (small GEMMs only)
+    float* Cf = reinterpret_cast<float*>(C);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
+          if (m < M && n < N) Cf[(size_t)m * ldc + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
+  // ---- epilogue: bf16(acc + bias) -> LDS (row-major, padded) -> 16-B row-contiguous stores
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int cl = wn * 64 + j * 16 + fr;
@@ -208,8 +224,8 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7)) return CE_ERR_SHAPE;
   if ((lda & 7) || (ldw & 7) || (ldc & 7)) return CE_ERR_ALIGN;
   if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
-  if (epilogue < 0 || epilogue > 3) return CE_ERR_ARG;
-  {
+  if (epilogue < 0 || epilogue > 4) return CE_ERR_ARG;
+  if (epilogue != EPI_F32) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant == 1 || (g_gemm_variant == -1 && big);
     if (want && ce_gemm256_supported(M, N, K, lda, ldw))
@@ -225,6 +241,7 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
     case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;
     case EPI_GATE_RES: CE_LAUNCH(EPI_GATE_RES); break;
     case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
+    case EPI_F32: CE_LAUNCH(EPI_F32); break;
     default: return CE_ERR_ARG;
   }
 #undef CE_LAUNCH

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
 HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
 
-SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_attn.hip", "ce_sched.hip"]
+SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_attn.hip", "ce_sched.hip", "ce_conv.hip"]
 
 _c = ctypes
 _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
@@ -37,6 +37,10 @@ SIGNATURES: Dict[str, List] = {
     "ce_modulation": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ce_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ce_unpatchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "ce_conv_igemm_bf16": [_P, _I, _P, _P, _P, _I, _P] + [_I] * 16 + [_P],
+    "ce_rms_silu_bf16": [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _P],
+    "ce_upsample2x_bf16": [_P, _P, _I, _I, _I, _I, _P],
+    "ce_softmax_rows_f32_bf16": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
     "ce_cfg_unipc_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_longlong, _I, _P],
 }
 

@@ -268,3 +268,66 @@ def cfg_unipc_step(v_cond: torch.Tensor, v_uncond: Optional[torch.Tensor], x: to
     _check(lib().ce_cfg_unipc_step(_ptr(v_cond), _ptr(v_uncond), _ptr(x), _ptr(x_last), _ptr(m0), _ptr(m1), _ptr(x0_out), _ptr(coef),
                                    _ptr(None), n, int(round_sigma_v), _stream()), "ce_cfg_unipc_step")
     return x
+
+
+# ---- Wan VAE ------------------------------------------------------------------------------------------------------
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def conv_igemm(in_frames, weight: torch.Tensor, bias: Optional[torch.Tensor], out_frames, res_frames, *, Cin: int, Cout: int,
+               KT: int, KH: int, KW: int, st: int, ss: int, H_out: int, W_out: int, in_Wp: int, in_off: int, out_Wp: int,
+               out_border: int, out_cstride: int, out_coff: int = 0):
+    """Implicit-GEMM conv over lists of channels-last frames (see include/chronoedit_hip.h)."""
+    for t in list(in_frames) + list(out_frames) + list(res_frames or []):
+        _dev(t, torch.bfloat16, "frame")
+    _dev(weight, torch.bfloat16, "weight")
+    assert weight.is_contiguous() and weight.numel() >= Cout * KT * KH * KW * Cin
+    ia, oa = _ptr_array(in_frames), _ptr_array(out_frames)
+    ra = _ptr_array(res_frames) if res_frames else None
+    st_ev = _prof_begin()
+    _check(lib().ce_conv_igemm_bf16(ia, len(in_frames), _ptr(weight), _ptr(bias), oa, len(out_frames), ra, Cin, Cout, KT, KH, KW,
+                                    st, ss, H_out, W_out, in_Wp, in_off, in_off, out_Wp, out_border, out_cstride, out_coff,
+                                    _stream()), "ce_conv_igemm_bf16")
+    _prof_end(st_ev, f"conv_{KT}x{KH}x{KW}_{Cin}->{Cout}_{len(out_frames)}x{H_out}x{W_out}",
+              2.0 * len(out_frames) * H_out * W_out * Cout * Cin * KT * KH * KW)
+
+
+def rms_silu(x: torch.Tensor, gamma: torch.Tensor, out: torch.Tensor, T: int, C: int, H: int, W: int, in_border: int,
+             out_border: int, silu: bool = True):
+    _dev(x, torch.bfloat16, "x"), _dev(out, torch.bfloat16, "out"), _dev(gamma, torch.float32, "gamma")
+    _check(lib().ce_rms_silu_bf16(_ptr(x), _ptr(out), _ptr(gamma), T * H * W, C, H, W, in_border, out_border, int(silu), _stream()),
+           "ce_rms_silu_bf16")
+    return out
+
+
+def upsample2x(x: torch.Tensor, out: torch.Tensor, T: int, C: int, H: int, W: int):
+    _dev(x, torch.bfloat16, "x"), _dev(out, torch.bfloat16, "out")
+    _check(lib().ce_upsample2x_bf16(_ptr(x), _ptr(out), T, C, H, W, _stream()), "ce_upsample2x_bf16")
+    return out
+
+
+def softmax_rows(scores: torch.Tensor, probs: torch.Tensor, n: int, scale: float):
+    _dev(scores, torch.float32, "scores"), _dev(probs, torch.bfloat16, "probs")
+    M, _, ld = _rows(scores, "scores")
+    _, npad, ldp = _rows(probs, "probs")
+    _check(lib().ce_softmax_rows_f32_bf16(_ptr(scores), _ptr(probs), M, n, npad, ld, ldp, float(scale), _stream()),
+           "ce_softmax_rows_f32_bf16")
+    return probs
+
+
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """out[M,N] (fp32) = a[M,K] @ w[N,K]^T, no bias (CE_EPI_F32)."""
+    _dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w")
+    M, K, lda = _rows(a, "a")
+    N, K2, ldw = _rows(w, "w")
+    assert K == K2
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _, _, ldc = _rows(out, "out")
+    _check(lib().ce_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(None), 4, _ptr(None), _ptr(None), M, N, K, lda, ldw, ldc, 0, 0,
+                              _stream()), "ce_gemm_bf16(f32)")
+    return out

@@ -1,0 +1,363 @@
+"""Wan-2.1 causal-3D-conv VAE on the gfx950 kernels — the `pipe.vae` slot of ChronoEditPipeline.
+
+Interface parity (SURVEY.md §8b "VAE slot"; pipeline_chronoedit.py:119-129,185-186,427-434,442,672,765,776-781):
+`.encode(x[B,3,F,H,W]).latent_dist.mode()`, `.decode(z, return_dict=False)[0]`,
+`.config.{z_dim, latents_mean, latents_std}`, `.temperal_downsample`, `.dtype`.
+Arithmetic spec: chronoedit/_src/tokenizers/wan2pt1.py:38-581 (the in-repo rendering of diffusers AutoencoderKLWan);
+parameter names are that file's (`encoder.downsamples.3.residual.2.weight`, ...).
+
+MI355X-first layout: activations are channels-last frames with a one-pixel zero border ([T][H+2][W+2][C] bf16), so
+every conv of the network is the same implicit-GEMM kernel (`ce_conv_igemm_bf16`) with the taps as address offsets;
+the causal temporal padding and the reference's chunk-to-chunk `feat_cache` (:571-580) are lists of frame POINTERS
+(cache frames / a shared zero frame in front of the chunk), never concatenations.  The residual add of ResidualBlock
+is fused into the second conv's epilogue, RMS_norm+SiLU is one pass, the temporal-upsample channel->frame interleave
+(:137-139) is done by writing the two weight halves to the even / odd output frames.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+CACHE_T = 2
+LATENTS_MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508, 0.4134, -0.0715, 0.5517, -0.3632,
+                -0.1922, -0.9497, 0.2503, -0.2921]
+LATENTS_STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743, 3.2687, 2.1526, 2.8652, 1.5579, 1.6382,
+               1.1253, 2.8251, 1.9160]
+
+
+def _pad32(c):
+    return (c + 31) // 32 * 32
+
+
+class Frames:
+    """T channels-last frames with a zero border: data [T, H+2, W+2, C] bf16."""
+
+    def __init__(self, T, H, W, C, device, data=None):
+        self.T, self.H, self.W, self.C = T, H, W, C
+        self.data = data if data is not None else torch.zeros((T, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
+
+    def frame_list(self):
+        return [self.data[t] for t in range(self.T)]
+
+    def last(self, k):
+        return self.data[self.T - k :].clone()
+
+
+class _ConvPack:
+    def __init__(self, w: torch.Tensor, b: Optional[torch.Tensor], cin_pad=None, split_out=False):
+        """[Cout, Cin, *k] (conv3d or conv2d) -> [Cout_pad8][taps][Cin_pad32] bf16 (+ fp32 bias)."""
+        if w.dim() == 4:
+            w = w.unsqueeze(2)
+        Cout, Cin, KT, KH, KW = w.shape
+        cin_p = cin_pad or _pad32(Cin)
+        cout_p = (Cout + 7) // 8 * 8
+        wp = torch.zeros((cout_p, KT * KH * KW, cin_p), dtype=torch.bfloat16, device=w.device)
+        wp[:Cout, :, :Cin] = w.permute(0, 2, 3, 4, 1).reshape(Cout, KT * KH * KW, Cin).to(torch.bfloat16)
+        self.w = wp.contiguous()
+        self.b = None
+        if b is not None:
+            self.b = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
+            self.b[:Cout] = b.float()
+        self.Cout, self.Cout_p, self.Cin_p, self.k = Cout, cout_p, cin_p, (KT, KH, KW)
+
+
+class WanVAEEngine:
+    def __init__(self, params: Dict[str, torch.Tensor], dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2,
+                 temperal_downsample=(False, True, True), temporal_window=4):
+        self.cfg = SimpleNamespace(dim=dim, z_dim=z_dim, dim_mult=tuple(dim_mult), num_res_blocks=num_res_blocks,
+                                   temperal_downsample=tuple(temperal_downsample), temporal_window=temporal_window)
+        some = next(iter(params.values()))
+        if not some.is_cuda:
+            raise ops.HipKernelError("WanVAEEngine needs its parameters on the GPU (no CPU fallback)")
+        self.dev = some.device
+        self.p = params
+        self.packs: Dict[str, _ConvPack] = {}
+        self.gammas: Dict[str, torch.Tensor] = {}
+        for k, v in params.items():
+            if k.endswith(".weight"):
+                name = k[: -len(".weight")]
+                self.packs[name] = _ConvPack(v, params.get(name + ".bias"))
+            elif k.endswith("gamma"):
+                self.gammas[k] = v.float().reshape(-1).contiguous()
+        self._zero: Dict[tuple, torch.Tensor] = {}
+        self._layers()
+
+    # -- architecture (wan2pt1.py:283-305, 384-415) ------------------------------------------------
+    def _layers(self):
+        c = self.cfg
+        dims = [c.dim * u for u in (1,) + c.dim_mult]
+        enc, idx = [], 0
+        for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+            for _ in range(c.num_res_blocks):
+                enc.append(("res", f"encoder.downsamples.{idx}", cin, cout))
+                idx += 1
+                cin = cout
+            if i != len(c.dim_mult) - 1:
+                enc.append(("down3d" if c.temperal_downsample[i] else "down2d", f"encoder.downsamples.{idx}", cout))
+                idx += 1
+        ce = dims[-1]
+        self.enc = enc + [("res", "encoder.middle.0", ce, ce), ("attn", "encoder.middle.1", ce), ("res", "encoder.middle.2", ce, ce)]
+        up = c.temperal_downsample[::-1]
+        ddims = [c.dim * u for u in (c.dim_mult[-1],) + c.dim_mult[::-1]]
+        c0 = ddims[0]
+        dec = [("res", "decoder.middle.0", c0, c0), ("attn", "decoder.middle.1", c0), ("res", "decoder.middle.2", c0, c0)]
+        idx = 0
+        for i, (cin, cout) in enumerate(zip(ddims[:-1], ddims[1:])):
+            if i in (1, 2, 3):
+                cin //= 2
+            for _ in range(c.num_res_blocks + 1):
+                dec.append(("res", f"decoder.upsamples.{idx}", cin, cout))
+                idx += 1
+                cin = cout
+            if i != len(c.dim_mult) - 1:
+                dec.append(("up3d" if up[i] else "up2d", f"decoder.upsamples.{idx}", cout))
+                idx += 1
+        self.dec = dec
+
+    # -- primitives ----------------------------------------------------------------------------------
+    def _zero_frame(self, H, W, C):
+        key = (H, W, C)
+        if key not in self._zero:
+            self._zero[key] = torch.zeros((H + 2, W + 2, C), dtype=torch.bfloat16, device=self.dev)
+        return self._zero[key]
+
+    def _conv(self, name, in_frames: List[torch.Tensor], T_out, H_out, W_out, in_W, *, st=1, ss=1, in_off=0, res: Optional[Frames] = None,
+              out: Optional[Frames] = None, out_frames=None, rows=None, cout_slice=None, out_C=None):
+        """Run conv `name` over a list of input frames; returns the output Frames (bordered) unless `rows` is given
+        (an un-bordered [T*H*W, C] matrix written in place)."""
+        pk = self.packs[name]
+        KT, KH, KW = pk.k
+        w, b, Cout = pk.w, pk.b, pk.Cout_p
+        if cout_slice is not None:  # a contiguous range of output channels (temporal-upsample halves)
+            lo, hi = cout_slice
+            w, b, Cout = pk.w[lo:hi], (None if pk.b is None else pk.b[lo:hi].contiguous()), hi - lo
+        if rows is not None:
+            ops.conv_igemm(in_frames, w, b, [rows[t] for t in range(T_out)], None, Cin=pk.Cin_p, Cout=Cout, KT=KT, KH=KH, KW=KW, st=st,
+                           ss=ss, H_out=H_out, W_out=W_out, in_Wp=in_W + 2, in_off=in_off, out_Wp=W_out, out_border=0,
+                           out_cstride=rows.shape[-1])
+            return rows
+        if out is None and out_frames is None:
+            out = Frames(T_out, H_out, W_out, out_C or Cout, self.dev)
+        of = out_frames if out_frames is not None else out.frame_list()
+        oC = out.C if out is not None else out_C
+        ops.conv_igemm(in_frames, w, b, of, res.frame_list() if res is not None else None, Cin=pk.Cin_p, Cout=Cout, KT=KT, KH=KH, KW=KW,
+                       st=st, ss=ss, H_out=H_out, W_out=W_out, in_Wp=in_W + 2, in_off=in_off, out_Wp=W_out + 2, out_border=1,
+                       out_cstride=oC)
+        return out
+
+    def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None) -> Frames:
+        """3x3x3 causal conv with the chunk-to-chunk frame cache (wan2pt1.py:200-210): two frames in front of the chunk."""
+        i = caches["i"]
+        caches["i"] += 1
+        prev = caches["slots"].get(i)
+        z = self._zero_frame(x.H, x.W, x.C)
+        if prev is None:
+            front = [z, z]
+        elif prev.shape[0] == 1:
+            front = [z, prev[0]]
+        else:
+            front = [prev[0], prev[1]]
+        if x.T >= CACHE_T:
+            keep = x.last(CACHE_T)
+        elif prev is not None:
+            keep = torch.cat([prev[-1:], x.data], 0)
+        else:
+            keep = x.data.clone()
+        out = self._conv(name, front + x.frame_list(), x.T, x.H, x.W, x.W, res=res, out_C=out_C)
+        caches["slots"][i] = keep
+        return out
+
+    def _rms_silu(self, x: Frames, gname, silu=True, border=1) -> Frames:
+        out = Frames(x.T, x.H, x.W, x.C, self.dev) if border else None
+        if border:
+            ops.rms_silu(x.data, self.gammas[gname], out.data, x.T, x.C, x.H, x.W, 1, 1, silu)
+            return out
+        rows = torch.empty((x.T, x.H * x.W, x.C), dtype=torch.bfloat16, device=self.dev)
+        ops.rms_silu(x.data, self.gammas[gname], rows, x.T, x.C, x.H, x.W, 1, 0, silu)
+        return rows
+
+    def _res(self, name, x: Frames, cin, cout, caches) -> Frames:
+        h = x
+        if (name + ".shortcut") in self.packs:
+            h = self._conv(name + ".shortcut", x.frame_list(), x.T, x.H, x.W, x.W, in_off=1)
+        y = self._rms_silu(x, name + ".residual.0.gamma")
+        y = self._cached_conv(name + ".residual.2", y, caches)
+        y = self._rms_silu(y, name + ".residual.3.gamma")
+        return self._cached_conv(name + ".residual.6", y, caches, res=h)
+
+    def _attn(self, name, x: Frames) -> Frames:
+        """Per-frame single-head attention over h*w (wan2pt1.py:240-259): 1x1 qkv conv -> fp32 scores GEMM -> row softmax
+        -> P.V GEMM -> 1x1 proj conv with the identity fused as residual."""
+        C, HW = x.C, x.H * x.W
+        xn = self._rms_silu(x, name + ".norm.gamma", silu=False)  # bordered
+        qkv = torch.empty((x.T, HW, 3 * C), dtype=torch.bfloat16, device=self.dev)
+        self._conv(name + ".to_qkv", xn.frame_list(), x.T, x.H, x.W, x.W, in_off=1, rows=qkv)
+        hwp = (HW + 63) // 64 * 64
+        o = torch.empty((x.T, HW, C), dtype=torch.bfloat16, device=self.dev)
+        for t in range(x.T):
+            q, k, v = qkv[t, :, :C], qkv[t, :, C : 2 * C], qkv[t, :, 2 * C :]
+            s = ops.gemm_f32(q, k)  # [HW, HW] fp32
+            pr = torch.empty((HW, hwp), dtype=torch.bfloat16, device=self.dev)
+            ops.softmax_rows(s, pr, HW, C ** -0.5)
+            vt = torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev)
+            vt[:, :HW] = v.t()
+            ops.gemm(pr, vt, None, out=o[t])
+        # proj (1x1) on the un-bordered rows, + identity, into a bordered stack
+        out = Frames(x.T, x.H, x.W, C, self.dev)
+        pk = self.packs[name + ".proj"]
+        ops.conv_igemm([o[t] for t in range(x.T)], pk.w, pk.b, out.frame_list(), x.frame_list(), Cin=pk.Cin_p, Cout=pk.Cout_p, KT=1, KH=1,
+                       KW=1, st=1, ss=1, H_out=x.H, W_out=x.W, in_Wp=x.W, in_off=0, out_Wp=x.W + 2, out_border=1, out_cstride=C)
+        return out
+
+    def _down(self, kind, name, x: Frames, caches) -> Frames:
+        """Resample downsample2d/3d (wan2pt1.py:108-112,150-165)."""
+        y = self._conv(name + ".resample.1", x.frame_list(), x.T, x.H // 2, x.W // 2, x.W, ss=2, in_off=1)
+        if kind == "down3d":
+            i = caches["i"]
+            caches["i"] += 1
+            prev = caches["slots"].get(i)
+            if prev is None:
+                caches["slots"][i] = y.data.clone()
+            else:
+                frames = [prev[-1]] + y.frame_list()
+                keep = y.last(1)
+                T_out = (len(frames) - 3) // 2 + 1
+                y2 = self._conv(name + ".time_conv", frames, T_out, y.H, y.W, y.W, st=2, in_off=1)
+                caches["slots"][i] = keep
+                y = y2
+        return y
+
+    def _up(self, kind, name, x: Frames, caches) -> Frames:
+        """Resample upsample2d/3d (wan2pt1.py:99-104,118-139)."""
+        C = x.C
+        if kind == "up3d":
+            i = caches["i"]
+            caches["i"] += 1
+            prev = caches["slots"].get(i)
+            if prev is None:
+                caches["slots"][i] = "Rep"
+            else:
+                z = self._zero_frame(x.H, x.W, C)
+                if isinstance(prev, str):
+                    front = [z, z]
+                else:
+                    front = [prev[0], prev[1]]
+                if x.T >= CACHE_T:
+                    keep = x.last(CACHE_T)
+                elif isinstance(prev, str):
+                    keep = torch.cat([z[None], x.data], 0)
+                else:
+                    keep = torch.cat([prev[-1:], x.data], 0)
+                y = Frames(2 * x.T, x.H, x.W, C, self.dev)
+                fl = y.frame_list()
+                ins = front + x.frame_list()
+                # time_conv has 2C output channels: channels [0,C) are frame 2t, [C,2C) frame 2t+1 (:137-139)
+                self._conv(name + ".time_conv", ins, x.T, x.H, x.W, x.W, in_off=1, out_frames=fl[0::2], cout_slice=(0, C), out_C=C)
+                self._conv(name + ".time_conv", ins, x.T, x.H, x.W, x.W, in_off=1, out_frames=fl[1::2], cout_slice=(C, 2 * C), out_C=C)
+                caches["slots"][i] = keep
+                x = y
+        u = Frames(x.T, 2 * x.H, 2 * x.W, C, self.dev)
+        ops.upsample2x(x.data, u.data, x.T, C, x.H, x.W)
+        return self._conv(name + ".resample.1", u.frame_list(), u.T, u.H, u.W, u.W)
+
+    def _run(self, layers, x, caches):
+        for l in layers:
+            kind = l[0]
+            if kind == "res":
+                x = self._res(l[1], x, l[2], l[3], caches)
+            elif kind == "attn":
+                x = self._attn(l[1], x)
+            elif kind in ("down2d", "down3d"):
+                x = self._down(kind, l[1], x, caches)
+            else:
+                x = self._up(kind, l[1], x, caches)
+        return x
+
+    def _to_frames(self, x: torch.Tensor, C_pad: int) -> Frames:
+        """[C, T, H, W] (any float dtype) -> bordered channels-last bf16 frames with channels zero-padded to C_pad."""
+        C, T, H, W = x.shape
+        f = Frames(T, H, W, C_pad, self.dev)
+        f.data[:, 1 : H + 1, 1 : W + 1, :C] = x.permute(1, 2, 3, 0).to(torch.bfloat16)
+        return f
+
+    # -- encode / decode (wan2pt1.py:502-560) -----------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        """x [3, T, H, W] -> mu [z, T', H/8, W/8] (un-normalised mode of the posterior), chunks of 1, 4, 4, ... frames."""
+        c = self.cfg
+        T = x.shape[1]
+        caches = {"slots": {}, "i": 0}
+        chunks = [x[:, :1]]
+        n = 1 + (T - 1) // c.temporal_window
+        for i in range(1, n):
+            chunks.append(x[:, 1 + c.temporal_window * (i - 1) : 1 + c.temporal_window * i])
+        if (T - 1) % c.temporal_window:
+            chunks.append(x[:, 1 + c.temporal_window * (n - 1) :])
+        outs = []
+        for ch in chunks:
+            caches["i"] = 0
+            f = self._to_frames(ch, 32)
+            f = self._cached_conv("encoder.conv1", f, caches)
+            f = self._run(self.enc, f, caches)
+            f = self._rms_silu(f, "encoder.head.0.gamma")
+            f = self._cached_conv("encoder.head.2", f, caches)  # 2*z channels
+            f = self._conv("conv1", f.frame_list(), f.T, f.H, f.W, f.W, in_off=1)
+            outs.append(f.data[:, 1:-1, 1:-1, : c.z_dim])
+        mu = torch.cat(outs, 0)  # [T', h, w, z]
+        return mu.permute(3, 0, 1, 2).contiguous()
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        """z [z_dim, T', h, w] (already de-normalised) -> video [3, T, 8h, 8w], one latent frame at a time."""
+        c = self.cfg
+        caches = {"slots": {}, "i": 0}
+        zin = self._to_frames(z, 32)
+        x = self._conv("conv2", zin.frame_list(), zin.T, zin.H, zin.W, zin.W, in_off=1, out_C=32)  # 16 live + 16 zero channels
+        outs = []
+        for i in range(x.T):
+            caches["i"] = 0
+            f = Frames(1, x.H, x.W, x.C, self.dev, data=x.data[i : i + 1])
+            f = self._cached_conv("decoder.conv1", f, caches)
+            f = self._run(self.dec, f, caches)
+            f = self._rms_silu(f, "decoder.head.0.gamma")
+            f = self._cached_conv("decoder.head.2", f, caches)  # 3 (+5 pad) channels
+            outs.append(f.data[:, 1:-1, 1:-1, :3])
+        v = torch.cat(outs, 0)  # [T, H, W, 3]
+        return v.permute(3, 0, 1, 2).contiguous()
+
+
+class AutoencoderKLWan(torch.nn.Module):
+    """`pipe.vae`-compatible wrapper around WanVAEEngine (parameters held as a flat buffer dict)."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2,
+                 temperal_downsample=(False, True, True)):
+        super().__init__()
+        self.config = SimpleNamespace(z_dim=z_dim, latents_mean=LATENTS_MEAN[:z_dim], latents_std=LATENTS_STD[:z_dim], base_dim=dim,
+                                      dim_mult=list(dim_mult), num_res_blocks=num_res_blocks,
+                                      temperal_downsample=list(temperal_downsample))
+        self.temperal_downsample = list(temperal_downsample)
+        self._params = params
+        self._engine = None
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
+
+    def engine(self) -> WanVAEEngine:
+        if self._engine is None:
+            c = self.config
+            self._engine = WanVAEEngine(self._params, c.base_dim, c.z_dim, tuple(c.dim_mult), c.num_res_blocks, tuple(c.temperal_downsample))
+        return self._engine
+
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        mu = torch.stack([self.engine().encode(x[b]) for b in range(x.shape[0])], 0).to(x.dtype)
+        dist = SimpleNamespace(mode=lambda: mu, mean=mu)
+        return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
+
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        v = torch.stack([self.engine().decode(z[b]) for b in range(z.shape[0])], 0).to(z.dtype)
+        return SimpleNamespace(sample=v) if return_dict else (v,)

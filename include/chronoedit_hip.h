@@ -34,6 +34,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define CE_EPI_BIAS_GELU 1 /* C = bf16(gelu_tanh(bf16(A.W^T + bias)))   diffusers FeedForward("gelu-approximate") */
 #define CE_EPI_GATE_RES 2  /* C = bf16(res + bf16(A.W^T + bias) * gate[n]); gate == NULL -> 1 */
 #define CE_EPI_BIAS_GELU_ERF 3 /* exact-erf GELU: diffusers FeedForward("gelu") of the image embedder */
+#define CE_EPI_F32 4           /* C is float* (ldc in floats): raw fp32 A.W^T, no bias (VAE mid-block attention scores) */
 
 /* y = LayerNorm_fp32(x, eps) * a[d] + b[d] -> bf16.   One wave64 per row; D % 8 == 0, D <= 5120.
  * Replaces `(self.norm1(h.float()) * (1 + scale) + shift).type_as(h)` and FP32LayerNorm(affine)
@@ -105,6 +106,33 @@ int ce_unpatchify_bf16(const void* y, void* out, int Cout, int T, int H, int W, 
  * Replaces scheduler.step + the CFG line of ChronoEditPipeline.__call__ (pipeline_chronoedit.py:736-739). */
 int ce_cfg_unipc_step(const void* v_cond, const void* v_uncond, float* x, float* x_last, float* m0, float* m1,
                       float* x0_out, const float* coef, const void* reserved, long long n, int flags, hipStream_t stream);
+
+/* ---- Wan-2.1 VAE (chronoedit/_src/tokenizers/wan2pt1.py; call sites pipeline_chronoedit.py:442,776-781) ----------
+ * Activation frames are channels-last with a 1-pixel zero border: [H+2][W+2][C] bf16. */
+
+/* Implicit-GEMM conv: out[t][h][w][co] = bias[co] + sum_{kt,kh,kw,ci} W[co][(kt,kh,kw)][ci] *
+ *   in_frames[t*st + kt][h*ss + kh + in_off_h][w*ss + kw + in_off_w][ci]   (+ res_frames[t][...] when given).
+ * in_frames / out_frames / res_frames are HOST arrays of device frame pointers (<= 16): temporal causal padding is
+ * expressed by listing cache / zero frames in front.  weight [Cout][KT*KH*KW][Cin] bf16; Cin % 32 == 0, Cout % 8 == 0.
+ * Output pixel (h,w) is stored at [(h+out_border)*out_Wp + (w+out_border)]*out_cstride + out_coff + co.
+ * Replaces CausalConv3d / nn.Conv2d of Encoder3d/Decoder3d (wan2pt1.py:42-60,99-112,195-203,237-238). */
+int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias,
+                       void* const* out_frames, int n_out_frames, const void* const* res_frames, int Cin, int Cout, int KT,
+                       int KH, int KW, int st, int ss, int H_out, int W_out, int in_Wp, int in_off_h, int in_off_w, int out_Wp,
+                       int out_border, int out_cstride, int out_coff, hipStream_t stream);
+
+/* y = [silu]( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ) per pixel over C channels; x, y are stacks of npix/(H*W) frames
+ * with in_border / out_border zero borders.  Replaces RMS_norm (+ nn.SiLU) (wan2pt1.py:63-75,193-200). */
+int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,
+                     int out_border, int apply_silu, hipStream_t stream);
+
+/* nearest-exact 2x spatial upsample of T bordered frames [H+2][W+2][C] -> [2H+2][2W+2][C] (wan2pt1.py:78-83,99-104). */
+int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipStream_t stream);
+
+/* probs[m][0:npad] = bf16(softmax(scale * scores[m][0:n])) (zeros beyond n); scores fp32.  Mid-block attention
+ * (wan2pt1.py:247-252) runs as GEMM (CE_EPI_F32) -> this -> GEMM. */
+int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int npad, int ld, int ldp, float scale,
+                             hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,62 @@
+"""Wan VAE on the HIP kernels vs (a) the golden vectors from the reference's own classes (fp32) and (b) the oracle run
+in bf16 on the CPU (the reference's eager precision).  Tolerance: rel-L2 <= 5e-2 vs fp32 through ~60 bf16 conv layers and
+<= 3x the bf16 eager oracle's own error."""
+import os
+
+import pytest
+import torch
+
+from oracle import vae_oracle as V
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_conv_igemm_matches_conv3d():
+    from chronoedit_amd import ops
+    from chronoedit_amd.vae import Frames, _ConvPack
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    Cin, Cout, T, H, W = 64, 96, 3, 10, 14
+    x = torch.randn(Cin, T, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(x.float()[None], (1, 1, 1, 1, 2, 0)), w.float(), b)[0]  # causal
+    f = Frames(T, H, W, Cin, dev)
+    f.data[:, 1:-1, 1:-1] = x.permute(1, 2, 3, 0).to(dev)
+    pk = _ConvPack(w.to(dev), b.to(dev))
+    z = torch.zeros_like(f.data[0])
+    out = Frames(T, H, W, Cout, dev)
+    ops.conv_igemm([z, z] + f.frame_list(), pk.w, pk.b, out.frame_list(), None, Cin=Cin, Cout=Cout, KT=3, KH=3, KW=3, st=1, ss=1,
+                   H_out=H, W_out=W, in_Wp=W + 2, in_off=0, out_Wp=W + 2, out_border=1, out_cstride=Cout)
+    got = out.data[:, 1:-1, 1:-1].permute(3, 0, 1, 2)
+    assert rel_l2(got, ref) < 6e-3, rel_l2(got, ref)
+    assert float(out.data[:, 0].abs().max()) == 0.0 and float(out.data[:, :, 0].abs().max()) == 0.0  # border untouched
+
+
+@pytest.mark.parametrize("name", ["small_5f", "small_9f"])
+def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
+    from chronoedit_amd.vae import AutoencoderKLWan
+    fx = torch.load(os.path.join(golden_dir, f"vae_{name}.pt"))
+    cfg = V.VAEConfig(**fx["cfg"])
+    p = V.make_synthetic_params(cfg)
+    x = torch.rand((1, 3, fx["T"], fx["H"], fx["W"]), generator=torch.Generator().manual_seed(5)) * 2 - 1
+    z = torch.randn(fx["mu"].shape, generator=torch.Generator().manual_seed(6))
+    vae = AutoencoderKLWan({k: v.cuda() for k, v in p.items()}, dim=cfg.dim, z_dim=cfg.z_dim)
+    mu = vae.encode(x.cuda().to(torch.bfloat16)).latent_dist.mode()
+    rec = vae.decode(z.cuda().to(torch.bfloat16), return_dict=False)[0]
+    assert mu.shape == fx["mu"].shape and rec.shape == fx["rec"].shape
+    # the bf16 eager error of the reference arithmetic itself, for scale
+    pb = {k: v.to(torch.bfloat16) for k, v in p.items()}
+    with torch.no_grad():
+        mu_b = V.encode(pb, cfg, x.to(torch.bfloat16))
+        rec_b = V.decode(pb, cfg, z.to(torch.bfloat16))
+    e_mu, e_rec = rel_l2(mu, fx["mu"]), rel_l2(rec, fx["rec"])
+    b_mu, b_rec = rel_l2(mu_b, fx["mu"]), rel_l2(rec_b, fx["rec"])
+    print(f"{name}: encode hip {e_mu:.3e} (bf16 eager {b_mu:.3e})  decode hip {e_rec:.3e} (bf16 eager {b_rec:.3e})")
+    assert e_mu < 5e-2 and e_rec < 5e-2
+    assert e_mu < 3 * b_mu + 5e-3 and e_rec < 3 * b_rec + 5e-3
