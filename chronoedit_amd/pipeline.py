@@ -49,18 +49,86 @@ def denoise_step(transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPC
     return scheduler.step_cfg(noise_pred, noise_uncond, guidance_scale, latents)
 
 
+class GraphedDenoiser:
+    """One denoising step captured as a hipGraph and replayed per step (north star: "the 50-step / 8-step sampling loops
+    are hipGraph-captured").  Everything a step reads lives at fixed device addresses: the fp32 latents (updated in place),
+    the condition, the stacked CFG conditioning, the scheduler history, and two small staging buffers that receive the
+    step's timestep and UniPC coefficient row (device-to-device copies enqueued in front of the replay - no host sync).
+    A new graph is needed when the latent shape changes (temporal-reasoning truncation 8 -> 2 frames)."""
+
+    def __init__(self, transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
+                 guidance_scale: float, batch_cfg: bool = True):
+        assert latents.dtype == torch.float32 and latents.is_contiguous()
+        self.tr, self.sch, self.latents, self.condition = transformer, scheduler, latents, condition
+        self.prompt, self.negative, self.image, self.g, self.batch_cfg = prompt_embeds, negative_prompt_embeds, image_embeds, guidance_scale, batch_cfg
+        dev = latents.device
+        self.cfg_inputs = None
+        if guidance_scale > 1.0 and negative_prompt_embeds is not None:
+            self.cfg_inputs = make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)
+        self.t_buf = torch.zeros((), dtype=torch.int64, device=dev)
+        self.coef_buf = torch.zeros(10, dtype=torch.float32, device=dev)
+        scheduler._ensure_state(latents)
+        # warm-up (lazy initialisations: packed weights, workspaces, function attributes) on saved state, then capture
+        saved = (latents.clone(), [m.clone() for m in scheduler.model_outputs], scheduler.last_sample.clone(), scheduler._step_index)
+        self._stage(scheduler._step_index or 0)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self._restore(saved)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body()
+        self._restore(saved)
+
+    def _restore(self, saved):
+        lat, mos, last, idx = saved
+        self.latents.copy_(lat)
+        for m, s in zip(self.sch.model_outputs, mos):
+            m.copy_(s)
+        self.sch.last_sample.copy_(last)
+        self.sch._step_index = idx
+
+    def _stage(self, i):
+        self.t_buf.copy_(self.sch.timesteps[i])
+        self.coef_buf.copy_(self.sch.coef_row(i, self.g, self.latents.device))
+
+    def _body(self):
+        inp = torch.cat([self.latents.to(torch.bfloat16), self.condition], dim=1)
+        B = inp.shape[0]
+        ts = self.t_buf.expand(B)
+        if self.cfg_inputs is not None and self.batch_cfg:
+            out = self.tr(torch.cat([inp, inp], 0), torch.cat([ts, ts], 0), self.cfg_inputs[0], self.cfg_inputs[1], return_dict=False)[0]
+            c, u = out[:B].contiguous(), out[B:].contiguous()
+        elif self.cfg_inputs is not None:
+            c = self.tr(inp, ts, self.prompt, self.image, return_dict=False)[0]
+            u = self.tr(inp, ts, self.negative, self.image, return_dict=False)[0]
+        else:
+            c, u = self.tr(inp, ts, self.prompt, self.image, return_dict=False)[0], None
+        self.sch.step_cfg(c, u, self.g, self.latents, coef=self.coef_buf)
+
+    def step(self, i: int) -> torch.Tensor:
+        self._stage(i)
+        self.graph.replay()
+        self.sch._step_index = i + 1
+        return self.latents
+
+
 @torch.no_grad()
 def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
             num_inference_steps: int, guidance_scale: float = 5.0, enable_temporal_reasoning: bool = False,
-            num_temporal_reasoning_steps: int = 0):
+            num_temporal_reasoning_steps: int = 0, use_graph: bool = False):
     """The whole loop, including the temporal-reasoning truncation 8 -> 2 latent frames (pipeline_chronoedit.py:700-709)."""
     scheduler.set_timesteps(num_inference_steps, device=latents.device)
     latents = latents.to(torch.float32).contiguous()
     cfg_inputs = None
     if guidance_scale > 1.0 and negative_prompt_embeds is not None:
         cfg_inputs = make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)
+    graphed = None
     for i, t in enumerate(scheduler.timesteps):
         if enable_temporal_reasoning and i == num_temporal_reasoning_steps:
+            graphed = None  # new latent shape -> new graph
             latents = latents[:, :, [0, -1]].contiguous()
             condition = condition[:, :, [0, -1]].contiguous()
             for j in range(len(scheduler.model_outputs)):
@@ -69,8 +137,16 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
                     scheduler.model_outputs[j] = mo[:, :, [0, -1]].contiguous()
             if scheduler.last_sample is not None and scheduler.last_sample.shape[-3] != latents.shape[-3]:
                 scheduler.last_sample = scheduler.last_sample[:, :, [0, -1]].contiguous()
-        latents = denoise_step(transformer, scheduler, latents, condition, t, prompt_embeds, negative_prompt_embeds,
-                               image_embeds, guidance_scale, cfg_inputs=cfg_inputs)
+        if use_graph:
+            if graphed is None:
+                if scheduler._step_index is None:
+                    scheduler._step_index = i
+                graphed = GraphedDenoiser(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds,
+                                          image_embeds, guidance_scale)
+            latents = graphed.step(i)
+        else:
+            latents = denoise_step(transformer, scheduler, latents, condition, t, prompt_embeds, negative_prompt_embeds,
+                                   image_embeds, guidance_scale, cfg_inputs=cfg_inputs)
     return latents
 
 

@@ -170,6 +170,10 @@ class FlowUniPCMultistepScheduler:
         self._step_index = None
         self._g_cache = {}
 
+    def coef_row(self, i: int, guidance_scale: float, device) -> torch.Tensor:
+        """Device view of step i's coefficient row (guidance scale in column 0)."""
+        return self._coef_row(i, guidance_scale, device)
+
     # -- state helpers -----------------------------------------------------------------
     def _ensure_state(self, like: torch.Tensor):
         """History buffers (fp32, latent-shaped).  Re-created when the pipeline sliced them to a new frame count."""
@@ -194,20 +198,23 @@ class FlowUniPCMultistepScheduler:
         return self._coef_dev[i]
 
     # -- fused fast path -----------------------------------------------------------------
-    def step_cfg(self, v_cond: torch.Tensor, v_uncond: Optional[torch.Tensor], guidance_scale: float, sample: torch.Tensor) -> torch.Tensor:
+    def step_cfg(self, v_cond: torch.Tensor, v_uncond: Optional[torch.Tensor], guidance_scale: float, sample: torch.Tensor,
+                 coef: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One loop tail (pipeline_chronoedit.py:736-739) as a single HIP launch.  `sample` must be fp32 and
-        is updated IN PLACE and returned."""
+        is updated IN PLACE and returned.  `coef`: explicit device coefficient row (hipGraph replay feeds the row of the
+        current step through one fixed buffer); default = this step's row of the table."""
         if self._step_index is None:
             self._step_index = 0
         i = self._step_index
-        if i >= self.num_inference_steps:
+        if coef is None and i >= self.num_inference_steps:
             raise IndexError("scheduler stepped past the last timestep")
         assert sample.dtype == torch.float32 and sample.is_contiguous()
         self._ensure_state(sample)
         m1, m0 = (self.model_outputs[0], self.model_outputs[1]) if len(self.model_outputs) == 2 else (self.model_outputs[0], self.model_outputs[0])
         if len(self.model_outputs) == 1:
             m1 = torch.zeros_like(m0)
-        coef = self._coef_row(i, guidance_scale, sample.device)
+        if coef is None:
+            coef = self._coef_row(i, guidance_scale, sample.device)
         ops.cfg_unipc_step(v_cond.to(torch.bfloat16).contiguous(), None if v_uncond is None else v_uncond.to(torch.bfloat16).contiguous(),
                            sample, self.last_sample, m0, m1, coef, round_sigma_v=False)
         self._step_index = i + 1

@@ -50,3 +50,30 @@ def test_edit_end_to_end_vs_oracle():
     print(f"edit: latents rel-L2 {e_lat:.3e}, video rel-L2 {e_vid:.3e}")
     assert vid.shape == (1, 3, F, H, W)
     assert e_lat < 6e-2 and e_vid < 8e-2
+
+
+def test_hipgraph_replay_equals_eager_loop():
+    """The hipGraph-captured step replayed over the schedule reproduces the eager loop bit for bit, including the
+    temporal-reasoning truncation (8 -> 2 latent frames, second graph)."""
+    from chronoedit_amd.pipeline import denoise
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    dcfg = D.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    dp = D.make_synthetic_params(dcfg, dtype=torch.bfloat16)
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
+    g = torch.Generator().manual_seed(1)
+    bf = torch.bfloat16
+    lat0 = torch.randn(1, 16, 8, 8, 12, generator=g).cuda()
+    cond = torch.randn(1, 20, 8, 8, 12, generator=g).cuda().to(bf)
+    prompt = torch.randn(1, 40, 128, generator=g).cuda().to(bf)
+    negative = torch.randn(1, 40, 128, generator=g).cuda().to(bf)
+    img = torch.randn(1, 257, 64, generator=g).cuda().to(bf)
+    outs = []
+    for use_graph in (False, True):
+        sch = FlowUniPCMultistepScheduler(flow_shift=5.0)
+        outs.append(denoise(m, sch, lat0.clone(), cond, prompt, negative, img, 6, 5.0, enable_temporal_reasoning=True,
+                            num_temporal_reasoning_steps=3, use_graph=use_graph).clone())
+    assert outs[0].shape == (1, 16, 2, 8, 12)
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max()
