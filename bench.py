@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--parallel", choices=["replica", "ulysses"], default="replica",
                     help="N>1: independent edits per GPU (weak scaling, default) or ONE edit with the token axis sharded "
                          "over the GPUs (Ulysses all-to-all over RCCL/xGMI, strong scaling)")
+    ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
+    ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -112,7 +114,7 @@ def main():
     dev = torch.device("cuda", local if world > 1 else 0)
 
     from chronoedit_amd import ops
-    from chronoedit_amd.pipeline import denoise_step, make_cfg_inputs
+    from chronoedit_amd.pipeline import GraphedDenoiser, denoise_step, make_cfg_inputs
     from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
     from oracle.dit_oracle import DiTConfig, flops_per_forward
 
@@ -145,6 +147,15 @@ def main():
         denoise_step(model, sched, latents, condition, sched.timesteps[i], prompt, negative, image, a.guidance,
                      batch_cfg=not a.sequential_cfg, cfg_inputs=cfg_inputs)
 
+    graphed = None
+    if a.graph:
+        sched._step_index = 0
+        graphed = GraphedDenoiser(model, sched, latents, condition, prompt, negative, image, a.guidance, batch_cfg=not a.sequential_cfg)
+        eager_step = one_step
+
+        def one_step(i):  # noqa: F811
+            graphed.step(i)
+
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
@@ -170,7 +181,7 @@ def main():
     breakdown = None
     if not a.no_profile and rank == 0:
         with ops.profile() as prof:
-            one_step(a.warmup + a.steps)
+            (eager_step if a.graph else one_step)(a.warmup + a.steps)
         summ = prof.summary()
         tot = sum(d["total_ms"] for d in summ.values())
         breakdown = {k: {"n": d["n"], "avg_ms": round(d["avg_ms"], 4), "share": round(d["total_ms"] / tot, 4),
@@ -182,6 +193,26 @@ def main():
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches": summ[dom]["n"], "avg_ms": round(summ[dom]["avg_ms"], 4)}
+
+    # ---- VAE encode + decode at the same resolution (once per edit) -> composed sec/edit for the 50-step schedule
+    vae_s = None
+    if not a.no_vae and rank == 0:
+        from chronoedit_amd.vae import AutoencoderKLWan
+        from oracle import vae_oracle as V
+        vae = AutoencoderKLWan({k: v.to(dev) for k, v in V.make_synthetic_params(V.VAEConfig()).items()})
+        nf = 4 * (T - 1) + 1
+        vid = (torch.rand(1, 3, nf, a.height, a.width, device=dev) * 2 - 1).to(torch.bfloat16)
+        zl = torch.randn(1, 16, T, h, w, device=dev).to(torch.bfloat16)
+        vae.encode(vid), vae.decode(zl)  # warm-up
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        vae.encode(vid).latent_dist.mode()
+        torch.cuda.synchronize()
+        te = time.perf_counter() - tv
+        tv = time.perf_counter()
+        vae.decode(zl, return_dict=False)
+        torch.cuda.synchronize()
+        vae_s = {"encode_s": round(te, 4), "decode_s": round(time.perf_counter() - tv, 4)}
 
     if rank == 0:
         steps_per_s = a.steps / dt * (1 if ulysses else world)
@@ -200,6 +231,9 @@ def main():
             "achieved_tflops_per_gpu": round(fl * a.steps / dt / 1e12 / (world if ulysses else 1), 1),
             "mfma_roofline_frac_whole_step": round(fl * a.steps / dt / 1e12 / (world if ulysses else 1) / PEAK_BF16_TFLOPS, 4),
             "finite": finite,
+            "launch": "hipGraph replay" if a.graph else "eager",
+            "vae": vae_s,
+            "sec_per_edit_50_steps": None if vae_s is None else round(50 * dt / a.steps + vae_s["encode_s"] + vae_s["decode_s"], 2),
             "roofline": roofline,
             "kernel_breakdown": breakdown,
         }
