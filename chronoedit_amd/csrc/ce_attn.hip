@@ -568,6 +568,258 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(const bf16* __res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant: the two wave groups of the workgroup (waves 0-3 / 4-7; every SIMD hosts one wave of each) run
+// the SAME program one barrier apart, so that in every epoch one group is in a matrix-heavy segment while the other
+// is in its VALU-heavy segment (cdna guide "Two waves per SIMD"):
+//     phase 1(t): [store K(t+1) -> LDS, fetch V(t+1) -> VGPR]  S(t) = K(t).Q^T (16 MFMA)   row max / alpha (short VALU)
+//     phase 2(t): [fetch K(t+2) -> VGPR]  P = exp2(..), row sum, pack (VALU)   O^T += V^T(t).P^T (16 MFMA)  [store V(t+1)]
+//     group 0 runs phase 1(t) in epoch 2t and phase 2(t) in epoch 2t+1; group 1 one epoch later.
+// While group 0 exponentiates, group 1 multiplies K.Q^T; while group 1 exponentiates, group 0 multiplies V^T.P^T.
+// LDS hazards (K and V^T double-buffered, every wave stages its share of every tile):
+//   K(t+1) is stored in phase 1(t)  -> epochs 2t / 2t+1; its buffer held K(t-1), last read in epoch 2t-1; first read 2t+2.
+//   V(t+1) is stored at the end of phase 2(t) -> epochs 2t+1 / 2t+2; its buffer held V(t-1), last read in epoch 2t; first
+//   read 2t+3.  One s_barrier per epoch (preceded by lgkmcnt(0) for the stores); group 1 takes one extra barrier before
+//   the loop and group 0 one after it.
+// ------------------------------------------------------------------------------------------------
+#define CE_EPOCH_BARRIER()                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+  __builtin_amdgcn_s_barrier()
+
+template <bool TWO_SEG>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
+                                                              KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
+                                                              float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NWAVE = 8, QB = QW * NWAVE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;  // 0: leads, 1: one epoch behind
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * QB + wave * QW;
+  const int hoff = head * HD;
+
+  bf16x8 qf[8];
+  {
+    const bf16* qrow = Q + (size_t)min(q0 + l31, Nq - 1) * ldq + hoff + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+  }
+
+  const int k_ck = tid & 15, k_row0 = tid >> 4;  // K share: rows k_row0, k_row0 + 32, 16-B chunk k_ck
+  const int v_dvq = tid & 31, v_kvq = tid >> 5;  // V share: 4(kv) x 4(dv) patch
+  unsigned char* ost = smem + (TWO_SEG ? 2 * BUF_BYTES : 0) + (size_t)(wave * QW + l31) * OST_ROW;
+  const int k_rowoff0 = l31 * (HD * 2), k_rowoff1 = (32 + l31) * (HD * 2), k_x0 = l31 & 15;
+
+#pragma unroll
+  for (int sidx = 0; sidx < (TWO_SEG ? 2 : 1); ++sidx) {
+    const KVSeg sg = sidx == 0 ? seg0 : seg1;
+    const int ntiles = (sg.len + KVB - 1) / KVB;
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    u32x4 kreg[2];
+    u32x2 vreg[4];
+    auto load_k = [&](int t) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = min(t * KVB + k_row0 + 32 * i, sg.len - 1);
+        kreg[i] = *reinterpret_cast<const u32x4*>(sg.k + (size_t)r * sg.ldk + hoff + k_ck * 8);
+      }
+    };
+    auto load_v = [&](int t) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = min(t * KVB + 4 * v_kvq + i, sg.len - 1);
+        vreg[i] = *reinterpret_cast<const u32x2*>(sg.v + (size_t)r * sg.ldv + hoff + v_dvq * 4);
+      }
+    };
+    auto store_k = [&](int buf) {
+      unsigned char* sK = smem + buf * BUF_BYTES;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = k_row0 + 32 * i;
+        *reinterpret_cast<u32x4*>(sK + r * (HD * 2) + ((k_ck ^ (r & 15)) << 4)) = kreg[i];
+      }
+    };
+    auto store_v = [&](int buf) {
+      unsigned char* sV = smem + buf * BUF_BYTES + K_TILE_BYTES;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = j >> 1;
+        uint32_t lo, hi;
+        if ((j & 1) == 0) {
+          lo = (vreg[0][w] & 0xffffu) | (vreg[1][w] << 16);
+          hi = (vreg[2][w] & 0xffffu) | (vreg[3][w] << 16);
+        } else {
+          lo = (vreg[0][w] >> 16) | (vreg[1][w] & 0xffff0000u);
+          hi = (vreg[2][w] >> 16) | (vreg[3][w] & 0xffff0000u);
+        }
+        const int dv = 4 * v_dvq + j;
+        u32x2 val = {lo, hi};
+        *reinterpret_cast<u32x2*>(sV + dv * (KVB * 2) + ((v_kvq ^ vt_swz(dv)) << 3)) = val;
+      }
+    };
+
+    // ---- prologue: tile 0 into buffer 0 (all waves), K(1) fetched
+    load_k(0);
+    load_v(0);
+    store_k(0);
+    store_v(0);
+    if (ntiles > 1) load_k(1);
+    if (grp) { CE_EPOCH_BARRIER(); }  // group 1 lags one epoch
+
+    for (int t = 0; t < ntiles; ++t) {
+      const int cur = t & 1;
+      const unsigned char* sK = smem + cur * BUF_BYTES;
+      const unsigned char* sV = sK + K_TILE_BYTES;
+      // ================= phase 1(t) =================
+      CE_EPOCH_BARRIER();
+      if (t + 1 < ntiles) {
+        store_k(cur ^ 1);
+        load_v(t + 1);
+      }
+      f32x16 st[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[f][r] = 0.f;
+      {
+        auto ld_k = [&](int i) -> bf16x8 {  // i = 8 f + ks
+          const unsigned char* krow = sK + ((i >> 3) ? k_rowoff1 : k_rowoff0);
+          return *reinterpret_cast<const bf16x8*>(krow + (((2 * (i & 7) + hh) ^ k_x0) << 4));
+        };
+        bf16x8 kf[3];
+        kf[0] = ld_k(0);
+        kf[1] = ld_k(1);
+        kf[2] = ld_k(2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          st[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % 3], qf[i & 7], st[i >> 3], 0, 0, 0);
+          if (i + 3 < 16) kf[i % 3] = ld_k(i + 3);
+        }
+      }
+      if ((t + 1) * KVB > sg.len) {
+        const int base = t * KVB + 4 * hh;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
+            if (kv >= sg.len) st[f][r] = NEG_BIG;
+          }
+      }
+      float mx = st[0][0];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[f][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      const float mc = m_new * scale_log2e;
+      m_run = m_new;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha;
+      }
+      // ================= phase 2(t) =================
+      CE_EPOCH_BARRIER();
+      if (t + 2 < ntiles) load_k(t + 2);
+      float psum = 0.f;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[f][r], scale_log2e, -mc));
+          st[f][r] = p;
+          psum += p;
+        }
+      l_run = l_run * alpha + psum;
+      bf16x8 ppk[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int f = s4 >> 1, rb = 8 * (s4 & 1);
+        f32x2 t0 = {st[f][rb + 0], st[f][rb + 1]}, t1 = {st[f][rb + 2], st[f][rb + 3]};
+        f32x2 t2 = {st[f][rb + 4], st[f][rb + 5]}, t3 = {st[f][rb + 6], st[f][rb + 7]};
+        const bf16x2 p0 = __builtin_convertvector(t0, bf16x2), p1 = __builtin_convertvector(t1, bf16x2);
+        const bf16x2 p2 = __builtin_convertvector(t2, bf16x2), p3 = __builtin_convertvector(t3, bf16x2);
+        ppk[s4] = bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+      }
+      {
+        auto ld_v = [&](int u) -> bf16x8 {
+          const int dv = 32 * (u & 3) + l31;
+          const unsigned char* vrow = sV + dv * (KVB * 2);
+          const int sw = vt_swz(dv), c0 = 4 * (u >> 2) + hh;
+          const bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow + ((c0 ^ sw) << 3));
+          const bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + (((c0 + 2) ^ sw) << 3));
+          return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        };
+        bf16x8 vf[3];
+        vf[0] = ld_v(0);
+        vf[1] = ld_v(1);
+        vf[2] = ld_v(2);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % 3], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+          if (u + 3 < 16) vf[u % 3] = ld_v(u + 3);
+        }
+      }
+      if (t + 1 < ntiles) store_v(cur ^ 1);
+    }
+    if (!grp) { CE_EPOCH_BARRIER(); }  // group 0 waits for group 1's last epoch
+    CE_EPOCH_BARRIER();                // common: every wave is done with the tile buffers
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        uint32_t w0 = pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv);
+        uint32_t w1 = pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv);
+        u32x2* slot = reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2);
+        if (TWO_SEG && sidx == 1) {
+          const u32x2 pv = *slot;
+          w0 = pack_bf16(bf16lo(pv[0]) + bf16lo(w0), bf16hi(pv[0]) + bf16hi(w0));
+          w1 = pack_bf16(bf16lo(pv[1]) + bf16lo(w1), bf16hi(pv[1]) + bf16hi(w1));
+        }
+        u32x2 val = {w0, w1};
+        *slot = val;
+      }
+  }
+
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = q0 + rl;
+    if (q < Nq) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? 2 * BUF_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    }
+  }
+}
+
 }  // namespace
 
 // waves per workgroup: 8 (256 query rows, 1 workgroup/CU) or 4 (128 query rows, 2 independent workgroups/CU)
@@ -577,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(const bf16* __res
 static int g_attn_nwave = 0;
 extern "C" int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
-  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16) g_attn_nwave = nwave;
+  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16 || nwave == 32) g_attn_nwave = nwave;
   return old;
 }
 
@@ -594,8 +846,9 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
   KVSeg s0{(const bf16*)K1, (const bf16*)V1, len1, ldk1, ldv1};
   KVSeg s1{(const bf16*)K2, (const bf16*)V2, two ? len2 : 0, ldk2, ldv2};
   const float sl2 = softmax_scale * 1.4426950408889634f;
+  const bool pp = g_attn_nwave == 32;  // ping-pong (two wave groups one barrier apart)
   const bool pipe = g_attn_nwave == 16 || (g_attn_nwave == 0 && !two && len1 <= 16384);
-  const int nwave = (pipe || g_attn_nwave == 0) ? 8 : g_attn_nwave;
+  const int nwave = (pp || pipe || g_attn_nwave == 0) ? 8 : g_attn_nwave;
   const int nqb = (Nq + nwave * QW - 1) / (nwave * QW);
   dim3 grid(nqb * H), block(nwave * 64);
 #define CE_ATTN_PIPE(TWO)                                                                                          \
@@ -609,6 +862,22 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
     hipLaunchKernelGGL((attn_fwd_pipe_kernel<TWO>), grid, block, pipe_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, \
                        s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                         \
   } while (0)
+  if (pp) {
+#define CE_ATTN_PP(TWO)                                                                                              \
+  do {                                                                                                               \
+    static bool done = false;                                                                                        \
+    if (!done) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<TWO>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                smem_bytes(8, TWO));                                                                 \
+      done = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<TWO>), grid, block, smem_bytes(8, TWO), stream, (const bf16*)Q, (bf16*)O, s0, \
+                       s1, Nq, H, ldq, ldo, nqb, sl2);                                                               \
+  } while (0)
+    if (two) CE_ATTN_PP(true); else CE_ATTN_PP(false);
+#undef CE_ATTN_PP
+    return (int)hipGetLastError();
+  }
   if (pipe) {
     if (two) CE_ATTN_PIPE(true); else CE_ATTN_PIPE(false);
     return (int)hipGetLastError();

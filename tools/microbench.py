@@ -61,8 +61,11 @@ def main():
             t4 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(8)
             t8 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            ops.set_attention_waves(32)
+            tpp = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(16)
             t = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            ops.set_attention_waves(0)
             qh = q.reshape(Nq, H, 128).transpose(0, 1)[None].contiguous()
             kh = k.reshape(Nkv, H, 128).transpose(0, 1)[None].contiguous()
             vh = v.reshape(Nkv, H, 128).transpose(0, 1)[None].contiguous()
@@ -73,7 +76,7 @@ def main():
                 t_ref = float("nan")
             fl = 4.0 * Nq * Nkv * 128 * H
             res[f"attn_{Nq}x{Nkv}x{H}"] = {"ms": t * 1e3, "tflops": fl / t / 1e12, "sdpa_ms": t_ref * 1e3, "sdpa_tflops": fl / t_ref / 1e12}
-            print(f"attn {Nq}x{Nkv} H{H}: 4-wave {fl/t4/1e12:.1f} TF | 8-wave {fl/t8/1e12:.1f} TF | pipelined {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | torch sdpa {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
+            print(f"attn {Nq}x{Nkv} H{H}: 4-wave {fl/t4/1e12:.1f} TF | 8-wave {fl/t8/1e12:.1f} TF | ping-pong {fl/tpp/1e12:.1f} TF | pipelined {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | torch sdpa {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
             del qkv, qh, kh, vh
     if "row" in only:
         M, D = 7200, 5120

@@ -27,6 +27,7 @@ else:
     Nq, Nkv, H = map(int, sys.argv[2:5])
     iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
     D = H * 128
+    ops.set_attention_waves(int(os.environ.get("CE_ATTN_WAVES", "0")))
     qkv = torch.randn(max(Nq, Nkv), 3 * D, generator=g).to(BF).to(dev)
     out = torch.empty(Nq, D, dtype=BF, device=dev)
     for _ in range(iters):
