@@ -587,6 +587,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(const bf16* __res
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
   __builtin_amdgcn_s_barrier()
 
+// LDS images of the ping-pong kernel: PADDED rows instead of XOR swizzles, so that every fragment read of a tile is
+// "one per-lane base + an immediate offset" (the XOR form cost ~150 address VALU ops per tile and wave - more VALU issue
+// time than the softmax itself; PMC: VALU busy 49 % vs MFMA busy 39 %).
+//   K   [64 kv][272 B]: ds_read_b128 of 16 rows (distinct mod 16) at one chunk hit slots (r + c) mod 16 - conflict-free.
+//   V^T [128 dv][144 B]: within every 16-kv k-step the 4-kv chunks are stored in the order (h, b) instead of (b, h)
+//   (kv = 16 s + 8 b + 4 h + i), so the 8 values of an MFMA A-fragment (b = 0,1 for this lane's h) are 16 contiguous
+//   bytes: ONE ds_read_b128 per fragment (hipcc fused the two ds_read_b64 of the plain layout into half-rate
+//   ds_read2_b64).  16 lanes of a b128 group (dv distinct mod 16... x9) hit 16 distinct slots: conflict-free; the
+//   ds_write_b64 side is conflict-free through the thread -> patch map (below).
+constexpr int PK_ROW = HD * 2 + 16;           // 272
+constexpr int PV_ROW = KVB * 2 + 16;          // 144
+constexpr int PK_TILE = KVB * PK_ROW;         // 17408
+constexpr int PV_TILE = HD * PV_ROW;          // 18432
+constexpr int PBUF = PK_TILE + PV_TILE;       // 35840; two buffers (71680) also hold the O staging (69632)
+typedef __attribute__((ext_vector_type(4))) unsigned pp_u4;
+typedef __attribute__((ext_vector_type(2))) unsigned pp_u2;
+
+constexpr int pp_smem_bytes(bool two_seg) { return two_seg ? 2 * PBUF + 8 * QW * OST_ROW : 2 * PBUF; }
+
 template <bool TWO_SEG>
 __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
                                                               KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
@@ -617,15 +636,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
   }
 
-  const int k_ck = tid & 15, k_row0 = tid >> 4;  // K share: rows k_row0, k_row0 + 32, 16-B chunk k_ck
-  const int v_dvq = tid & 31, v_kvq = tid >> 5;  // V share: 4(kv) x 4(dv) patch
-  unsigned char* ost = smem + (TWO_SEG ? 2 * BUF_BYTES : 0) + (size_t)(wave * QW + l31) * OST_ROW;
-  const int k_rowoff0 = l31 * (HD * 2), k_rowoff1 = (32 + l31) * (HD * 2), k_x0 = l31 & 15;
+  // The Q loads must be retired HERE: otherwise hipcc keeps their vmcnt waits in front of the first eight MFMAs of every
+  // tile, where they also drain the K/V prefetch that was just issued (a global-latency stall per tile).
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+
+  // K share: rows k_row0, k_row0 + 32, 16-B chunk k_ck.  V share: a 4(kv) x 4(dv) patch; within 16 consecutive lanes the
+  // patches differ in (dvq & 1, kvq & 7), which spreads the transposed ds_write_b64 over all 32 banks.
+  const int k_ck = tid & 15, k_row0 = tid >> 4;
+  const int v_dvq = (tid & 1) | (((tid >> 4) & 15) << 1), v_kvq = ((tid >> 1) & 7) | (((tid >> 8) & 1) << 3);
+  const int v_chunk = (v_kvq & ~3) | ((v_kvq & 1) << 1) | ((v_kvq >> 1) & 1);  // (b, h) -> (h, b) inside each k-step
+  unsigned char* ost = smem + (TWO_SEG ? 2 * PBUF : 0) + (size_t)(wave * QW + l31) * OST_ROW;
+  // per-lane LDS bases; every access below is base + compile-time offset (+ buffer offset)
+  const unsigned char* k_rd = smem + l31 * PK_ROW + hh * 16;             // + f*32*PK_ROW + ks*32
+  const unsigned char* v_rd = smem + PK_TILE + l31 * PV_ROW + hh * 16;   // + m*32*PV_ROW + s*32
+  unsigned char* k_wr = smem + k_row0 * PK_ROW + k_ck * 16;              // + i*32*PK_ROW
+  unsigned char* v_wr = smem + PK_TILE + (4 * v_dvq) * PV_ROW + v_chunk * 8;  // + j*PV_ROW
 
 #pragma unroll
   for (int sidx = 0; sidx < (TWO_SEG ? 2 : 1); ++sidx) {
     const KVSeg sg = sidx == 0 ? seg0 : seg1;
     const int ntiles = (sg.len + KVB - 1) / KVB;
+    // buffer descriptors (wave-uniform): rows >= len read as zeros, so no clamping / per-tile pointer arithmetic
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (sg.len - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + hoff), 0, (sg.len - 1) * sg.ldv * 2 + HD * 2, 0x00020000);
+    const int k_voff0 = k_row0 * sg.ldk * 2 + k_ck * 16, k_voff1 = k_voff0 + 32 * sg.ldk * 2;
+    int v_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v_voff[i] = (4 * v_kvq + i) * sg.ldv * 2 + v_dvq * 8;
+    const int k_tile_bytes = KVB * sg.ldk * 2, v_tile_bytes = KVB * sg.ldv * 2;
 
     f32x16 oacc[4];
 #pragma unroll
@@ -634,32 +673,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
       for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
 
-    u32x4 kreg[2];
-    u32x2 vreg[4];
+    pp_u4 kreg[2];
+    pp_u2 vreg[4];
     auto load_k = [&](int t) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = min(t * KVB + k_row0 + 32 * i, sg.len - 1);
-        kreg[i] = *reinterpret_cast<const u32x4*>(sg.k + (size_t)r * sg.ldk + hoff + k_ck * 8);
-      }
+      const int so = t * k_tile_bytes;
+      kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff0, so, 0);
+      kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff1, so, 0);
     };
     auto load_v = [&](int t) {
+      const int so = t * v_tile_bytes;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = min(t * KVB + 4 * v_kvq + i, sg.len - 1);
-        vreg[i] = *reinterpret_cast<const u32x2*>(sg.v + (size_t)r * sg.ldv + hoff + v_dvq * 4);
-      }
+      for (int i = 0; i < 4; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_voff[i], so, 0);
     };
     auto store_k = [&](int buf) {
-      unsigned char* sK = smem + buf * BUF_BYTES;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = k_row0 + 32 * i;
-        *reinterpret_cast<u32x4*>(sK + r * (HD * 2) + ((k_ck ^ (r & 15)) << 4)) = kreg[i];
-      }
+      *reinterpret_cast<pp_u4*>(k_wr + buf * PBUF) = kreg[0];
+      *reinterpret_cast<pp_u4*>(k_wr + buf * PBUF + 32 * PK_ROW) = kreg[1];
     };
     auto store_v = [&](int buf) {
-      unsigned char* sV = smem + buf * BUF_BYTES + K_TILE_BYTES;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int w = j >> 1;
@@ -671,9 +701,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
           lo = (vreg[0][w] >> 16) | (vreg[1][w] & 0xffff0000u);
           hi = (vreg[2][w] >> 16) | (vreg[3][w] & 0xffff0000u);
         }
-        const int dv = 4 * v_dvq + j;
-        u32x2 val = {lo, hi};
-        *reinterpret_cast<u32x2*>(sV + dv * (KVB * 2) + ((v_kvq ^ vt_swz(dv)) << 3)) = val;
+        pp_u2 val = {lo, hi};
+        *reinterpret_cast<pp_u2*>(v_wr + buf * PBUF + j * PV_ROW) = val;
       }
     };
 
@@ -687,8 +716,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 
     for (int t = 0; t < ntiles; ++t) {
       const int cur = t & 1;
-      const unsigned char* sK = smem + cur * BUF_BYTES;
-      const unsigned char* sV = sK + K_TILE_BYTES;
+      const unsigned char* kb = k_rd + cur * PBUF;
+      const unsigned char* vb = v_rd + cur * PBUF;
       // ================= phase 1(t) =================
       CE_EPOCH_BARRIER();
       if (t + 1 < ntiles) {
@@ -696,24 +725,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
         load_v(t + 1);
       }
       f32x16 st[2];
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[f][r] = 0.f;
       {
-        auto ld_k = [&](int i) -> bf16x8 {  // i = 8 f + ks
-          const unsigned char* krow = sK + ((i >> 3) ? k_rowoff1 : k_rowoff0);
-          return *reinterpret_cast<const bf16x8*>(krow + (((2 * (i & 7) + hh) ^ k_x0) << 4));
-        };
         bf16x8 kf[3];
-        kf[0] = ld_k(0);
-        kf[1] = ld_k(1);
-        kf[2] = ld_k(2);
+#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + ((i) >> 3) * 32 * PK_ROW + ((i) & 7) * 32))
+        kf[0] = CE_LDK(0);
+        kf[1] = CE_LDK(1);
+        kf[2] = CE_LDK(2);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          st[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % 3], qf[i & 7], st[i >> 3], 0, 0, 0);
-          if (i + 3 < 16) kf[i % 3] = ld_k(i + 3);
+          st[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % 3], qf[i & 7], (i & 7) == 0 ? zero16 : st[i >> 3], 0, 0, 0);
+          if (i + 3 < 16) kf[i % 3] = CE_LDK(i + 3);
         }
+#undef CE_LDK
+        // keep the K fragment reads three MFMAs ahead of their use
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       }
       if ((t + 1) * KVB > sg.len) {
         const int base = t * KVB + 4 * hh;
@@ -765,23 +797,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
         ppk[s4] = bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
       }
       {
-        auto ld_v = [&](int u) -> bf16x8 {
-          const int dv = 32 * (u & 3) + l31;
-          const unsigned char* vrow = sV + dv * (KVB * 2);
-          const int sw = vt_swz(dv), c0 = 4 * (u >> 2) + hh;
-          const bf16x4 va = *reinterpret_cast<const bf16x4*>(vrow + ((c0 ^ sw) << 3));
-          const bf16x4 vb = *reinterpret_cast<const bf16x4*>(vrow + (((c0 + 2) ^ sw) << 3));
-          return bf16x8{va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
-        };
+        // V^T fragment of unit u = (k-step s4 = u >> 2, dv fragment m = u & 3): 16 contiguous bytes (see layout note)
+#define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vb + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
         bf16x8 vf[3];
-        vf[0] = ld_v(0);
-        vf[1] = ld_v(1);
-        vf[2] = ld_v(2);
+        vf[0] = CE_LDV(0);
+        vf[1] = CE_LDV(1);
+        vf[2] = CE_LDV(2);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % 3], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
-          if (u + 3 < 16) vf[u % 3] = ld_v(u + 3);
+          if (u + 3 < 16) vf[u % 3] = CE_LDV(u + 3);
         }
+#undef CE_LDV
       }
       if (t + 1 < ntiles) store_v(cur ^ 1);
     }
@@ -814,7 +841,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
     const int rl = c >> 4, cc = c & 15;
     const int q = q0 + rl;
     if (q < Nq) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? 2 * BUF_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? 2 * PBUF : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
       *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
     }
   }
@@ -868,10 +895,10 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
     static bool done = false;                                                                                        \
     if (!done) {                                                                                                     \
       (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<TWO>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                smem_bytes(8, TWO));                                                                 \
+                                pp_smem_bytes(TWO));                                                                 \
       done = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((attn_fwd_pp_kernel<TWO>), grid, block, smem_bytes(8, TWO), stream, (const bf16*)Q, (bf16*)O, s0, \
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<TWO>), grid, block, pp_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, s0, \
                        s1, Nq, H, ldq, ldo, nqb, sl2);                                                               \
   } while (0)
     if (two) CE_ATTN_PP(true); else CE_ATTN_PP(false);
