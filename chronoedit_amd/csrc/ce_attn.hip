@@ -726,26 +726,28 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
       }
       f32x16 st[2];
       {
-        bf16x8 kf[3];
-#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + ((i) >> 3) * 32 * PK_ROW + ((i) & 7) * 32))
-        kf[0] = CE_LDK(0);
-        kf[1] = CE_LDK(1);
-        kf[2] = CE_LDK(2);
+        constexpr int RING = 6;  // fragment reads run RING MFMAs (~190 cycles) ahead of their use
+        bf16x8 kf[RING];
+// MFMA i works on kv fragment f = i & 1, k-step ks = i >> 1: the two accumulators alternate, so a dependent
+        // 32x32x16 MFMA is never issued right behind its producer (that would stall on the result latency while the
+        // partner wave - in its VALU segment by design - cannot fill the pipe)
+#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + ((i) & 1) * 32 * PK_ROW + ((i) >> 1) * 32))
+#pragma unroll
+        for (int i = 0; i < RING; ++i) kf[i] = CE_LDK(i);
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          st[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % 3], qf[i & 7], (i & 7) == 0 ? zero16 : st[i >> 3], 0, 0, 0);
-          if (i + 3 < 16) kf[i % 3] = CE_LDK(i + 3);
+          st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], i < 2 ? zero16 : st[i & 1], 0, 0, 0);
+          if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
         }
 #undef CE_LDK
-        // keep the K fragment reads three MFMAs ahead of their use
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
 #pragma unroll
-        for (int i = 0; i < 13; ++i) {
+        for (int i = 0; i < 16 - RING; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, RING, 0);
       }
       if ((t + 1) * KVB > sg.len) {
         const int base = t * KVB + 4 * hh;
@@ -799,14 +801,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
       {
         // V^T fragment of unit u = (k-step s4 = u >> 2, dv fragment m = u & 3): 16 contiguous bytes (see layout note)
 #define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vb + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
-        bf16x8 vf[3];
-        vf[0] = CE_LDV(0);
-        vf[1] = CE_LDV(1);
-        vf[2] = CE_LDV(2);
+        constexpr int VRING = 6;
+        bf16x8 vf[VRING];
+#pragma unroll
+        for (int u = 0; u < VRING; ++u) vf[u] = CE_LDV(u);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-          oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % 3], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
-          if (u + 3 < 16) vf[u % 3] = CE_LDV(u + 3);
+          oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+          if (u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
         }
 #undef CE_LDV
       }
@@ -850,9 +852,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 }  // namespace
 
 // waves per workgroup: 8 (256 query rows, 1 workgroup/CU) or 4 (128 query rows, 2 independent workgroups/CU)
-// 16 selects the software-pipelined 8-wave kernel (P.V of tile t-1 under the softmax of tile t);
-// 0 = automatic: pipelined for single-segment attention up to 16k keys (measured +3 % at 7200 keys, -2 % at 28800,
-// -10 % on the short two-segment cross-attention), plain 8-wave otherwise
+// 16 selects the software-pipelined 8-wave kernel (P.V of tile t-1 under the softmax of tile t), 32 the ping-pong kernel;
+// 0 = automatic: ping-pong for single-segment (self) attention (measured 0.90-0.91 PFLOP/s at 7200 keys, 1.02 at 28800,
+// vs 0.77-0.79 / 0.93 for the plain 8-wave kernel), plain 8-wave for the short two-segment cross-attention
 static int g_attn_nwave = 0;
 extern "C" int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
@@ -873,8 +875,8 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
   KVSeg s0{(const bf16*)K1, (const bf16*)V1, len1, ldk1, ldv1};
   KVSeg s1{(const bf16*)K2, (const bf16*)V2, two ? len2 : 0, ldk2, ldv2};
   const float sl2 = softmax_scale * 1.4426950408889634f;
-  const bool pp = g_attn_nwave == 32;  // ping-pong (two wave groups one barrier apart)
-  const bool pipe = g_attn_nwave == 16 || (g_attn_nwave == 0 && !two && len1 <= 16384);
+  const bool pp = g_attn_nwave == 32 || (g_attn_nwave == 0 && !two);  // ping-pong (two wave groups one barrier apart)
+  const bool pipe = g_attn_nwave == 16;
   const int nwave = (pp || pipe || g_attn_nwave == 0) ? 8 : g_attn_nwave;
   const int nqb = (Nq + nwave * QW - 1) / (nwave * QW);
   dim3 grid(nqb * H), block(nwave * 64);
