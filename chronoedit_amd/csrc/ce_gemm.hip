@@ -208,12 +208,16 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  hipStream_t stream);
 
+extern "C" void ce_gemm256_set_staggered(int on);
+
 // kernel selection: -1 = automatic (256-tile LDS-DMA kernel for large shapes), 0 = always the 128-tile kernel,
-// 1 = the 256-tile kernel whenever the shape allows it
+// 1 = the 256-tile kernel whenever the shape allows it, 2 = same with the staggered (two wave groups one barrier apart)
+// main loop
 static int g_gemm_variant = -1;
 extern "C" int ce_set_gemm_variant(int v) {
   const int old = g_gemm_variant;
   g_gemm_variant = v;
+  ce_gemm256_set_staggered(v == 2);
   return old;
 }
 
@@ -227,7 +231,7 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
   if (epilogue < 0 || epilogue > 4) return CE_ERR_ARG;
   if (epilogue != EPI_F32) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
-    const bool want = g_gemm_variant == 1 || (g_gemm_variant == -1 && big);
+    const bool want = g_gemm_variant >= 1 || (g_gemm_variant == -1 && big);
     if (want && ce_gemm256_supported(M, N, K, lda, ldw))
       return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, stream);
   }

@@ -105,7 +105,7 @@ __device__ __forceinline__ void mma_half(f32x4 (&acc)[4][2], const bf16x8 (&a)[4
 #define CE_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define CE_BAR() __builtin_amdgcn_s_barrier()
 
-template <int EPI>
+template <int EPI, bool STAG>
 __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A, const bf16* __restrict__ W,
                                                      bf16* __restrict__ C, const float* __restrict__ bias,
                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   CE_VM(4);  // everything but the last two half-tiles (O.B0, O.B1) has landed
   CE_BAR();
 
+  if constexpr (!STAG) {
   // Operand registers, software-pipelined across phases: a register set is refilled (ds_read) right after the
   // last MFMA that consumed it, so the next phase's fragments are already in flight when its barrier opens.
   bf16x8 ra0[4], ra1[4], b0k0[2], b0k1[2], b1k0[2], b1k1[2];  // A-sub (k-step 0/1), W-sub0, W-sub1
@@ -220,6 +221,69 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   }
 #undef CE_TILE_PHASES
 #undef CE_STAGE
+  } else {
+    // ---- staggered form (cdna guide 8-phase template): every phase is a LOAD segment (this phase's fragment reads +
+    // one LDS-DMA stage) and a pure 16-MFMA segment, each closed by an s_barrier; the wave group wm = 1 runs one barrier
+    // behind wm = 0, so on every SIMD one wave multiplies while its partner loads.
+    //     phase of tile T     1                 2               3               4
+    //     reads (LOAD seg.)   A0(T), B0(T)      B1(T)           A1(T)           -
+    //     stage (LOAD seg.)   other.A1(T+1)     cur.A0(T+2)     cur.B0(T+2)     cur.B1(T+2), then vmcnt(6)
+    //     MFMA segment        Q00               Q01             Q11             Q10
+    // Hazards with the one-barrier lag: a slot is restaged >= 1 phase after the phase that issued its last reads, and
+    // read >= 1 phase after the phase whose LOAD segment ends with the counted vmcnt that retires it (three half-tiles
+    // stay in flight across the wait).
+    bf16x8 ra0[4], ra1[4], b0k0[2], b0k1[2], b1k0[2], b1k1[2];
+    if (wm == 1) CE_BAR();
+#define CE_STAGE(SLOT_EVEN, SLOT_ODD, CURV, TILEV) \
+  if (CURV == 0) stage_half<SLOT_EVEN>(smem, st, (TILEV)); else stage_half<SLOT_ODD>(smem, st, (TILEV));
+#define CE_TILE_STAG(CUR, TILE)                                                                              \
+  /* phase 1 */                                                                                              \
+  read_a<CUR * 4 + S_A0, 0>(smem, wm, fr, fg, ra0);                                                          \
+  read_a<CUR * 4 + S_A0, 1>(smem, wm, fr, fg, ra1);                                                          \
+  read_b<CUR * 4 + S_B0, 0>(smem, wn, fr, fg, b0k0);                                                         \
+  read_b<CUR * 4 + S_B0, 1>(smem, wn, fr, fg, b0k1);                                                         \
+  CE_STAGE(4 + S_A1, S_A1, CUR, (TILE) + 1)                                                                  \
+  CE_BAR();                                                                                                  \
+  CE_LGKM0();                                                                                                \
+  mma_half(acc[0][0], ra0, b0k0);                                                                            \
+  mma_half(acc[0][0], ra1, b0k1);                                                                            \
+  CE_BAR();                                                                                                  \
+  /* phase 2 */                                                                                              \
+  read_b<CUR * 4 + S_B1, 0>(smem, wn, fr, fg, b1k0);                                                         \
+  read_b<CUR * 4 + S_B1, 1>(smem, wn, fr, fg, b1k1);                                                         \
+  CE_STAGE(S_A0, 4 + S_A0, CUR, (TILE) + 2)                                                                  \
+  CE_BAR();                                                                                                  \
+  CE_LGKM0();                                                                                                \
+  mma_half(acc[0][1], ra0, b1k0);                                                                            \
+  mma_half(acc[0][1], ra1, b1k1);                                                                            \
+  CE_BAR();                                                                                                  \
+  /* phase 3 */                                                                                              \
+  read_a<CUR * 4 + S_A1, 0>(smem, wm, fr, fg, ra0);                                                          \
+  read_a<CUR * 4 + S_A1, 1>(smem, wm, fr, fg, ra1);                                                          \
+  CE_STAGE(S_B0, 4 + S_B0, CUR, (TILE) + 2)                                                                  \
+  CE_BAR();                                                                                                  \
+  CE_LGKM0();                                                                                                \
+  mma_half(acc[1][1], ra0, b1k0);                                                                            \
+  mma_half(acc[1][1], ra1, b1k1);                                                                            \
+  CE_BAR();                                                                                                  \
+  /* phase 4 */                                                                                              \
+  CE_STAGE(S_B1, 4 + S_B1, CUR, (TILE) + 2)                                                                  \
+  CE_VM(6);                                                                                                  \
+  CE_BAR();                                                                                                  \
+  mma_half(acc[1][0], ra0, b0k0);                                                                            \
+  mma_half(acc[1][0], ra1, b0k1);                                                                            \
+  CE_BAR();
+
+    const int npairs = (K / BK) >> 1;
+    for (int it = 0; it < npairs; ++it) {
+      const int t = 2 * it;
+      CE_TILE_STAG(0, t)
+      CE_TILE_STAG(1, t + 1)
+    }
+#undef CE_TILE_STAG
+#undef CE_STAGE
+    if (wm == 0) CE_BAR();
+  }
   CE_VM(0);  // surplus prefetches (LDS-DMA and fragment reads) must retire before the epilogue reuses the LDS
   CE_LGKM0();
   CE_BAR();
@@ -292,6 +356,9 @@ extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw) {
   return 1;
 }
 
+static bool staggered = false;
+extern "C" void ce_gemm256_set_staggered(int on) { staggered = on != 0; }
+
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  hipStream_t stream) {
@@ -301,11 +368,16 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
 #define CE_LAUNCH(E)                                                                                                  \
   do {                                                                                                                \
     if (!attr_done[E]) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);  \
       attr_done[E] = true;                                                                                            \
     }                                                                                                                 \
-    hipLaunchKernelGGL(gemm_bf16_256<E>, grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, \
-                       gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n);                       \
+    if (staggered)                                                                                                    \
+      hipLaunchKernelGGL((gemm_bf16_256<E, true>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n);   \
+    else                                                                                                              \
+      hipLaunchKernelGGL((gemm_bf16_256<E, false>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n);   \
   } while (0)
   switch (epilogue) {
     case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;

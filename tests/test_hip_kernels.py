@@ -80,7 +80,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1], ids=["tile128", "tile256"])
+@pytest.fixture(params=[0, 1, 2], ids=["tile128", "tile256", "tile256stag"])
 def gemm_variant(request):
     from chronoedit_amd import ops
     old = ops.set_gemm_variant(request.param)

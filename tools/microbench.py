@@ -43,13 +43,15 @@ def main():
             run = lambda: ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
             ops.set_gemm_variant(0)
             t128 = timeit(run)
+            ops.set_gemm_variant(2)
+            tst = timeit(run)
             ops.set_gemm_variant(1)
             t = timeit(run)
             ops.set_gemm_variant(-1)
             t_ref = timeit(lambda: torch.matmul(a, w.t()))
             res[f"gemm_{M}x{N}x{K}_epi{epi}"] = {"ms": t * 1e3, "tflops": fl / t / 1e12, "tile128_tflops": fl / t128 / 1e12,
                                                  "hipblaslt_ms": t_ref * 1e3, "hipblaslt_tflops": fl / t_ref / 1e12}
-            print(f"gemm {M}x{N}x{K} epi{epi}: tile256 {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | tile128 {fl/t128/1e12:.1f} TF | hipblaslt {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
+            print(f"gemm {M}x{N}x{K} epi{epi}: tile256 {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | staggered {fl/tst/1e12:.1f} TF | tile128 {fl/t128/1e12:.1f} TF | hipblaslt {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
             del a, w, out
     if "attn" in only:
         for (Nq, Nkv, H) in [(7200, 7200, 40), (28800, 28800, 40), (7200, 512, 40)]:
