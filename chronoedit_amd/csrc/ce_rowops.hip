@@ -14,10 +14,14 @@
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                         const float* __restrict__ a, const float* __restrict__ b,
-                                                        int M, int D, int ldx, int ldy, float eps) {
+                                                        int M, int D, int ldx, int ldy, float eps, int ab_rows, int ab_stride) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  if (ab_rows > 0) {  // one (a, b) pair per group of ab_rows rows (samples stacked along M)
+    a += (size_t)(row / ab_rows) * ab_stride;
+    b += (size_t)(row / ab_rows) * ab_stride;
+  }
   const int nch = D >> 3;
   const bf16* xr = x + (size_t)row * ldx;
   u32x4 raw[ROW_MAXC];
@@ -71,12 +75,16 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__
 // RoPE is evaluated in fp32 on the bf16-rounded values (reference uses fp64: the two
 // agree to ~1e-7 relative before the final bf16 rounding).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x0, const float* __restrict__ w0,
+                                                           bf16* __restrict__ x1, const float* __restrict__ w1,
                                                            const float* __restrict__ cs, int M, int D, int ld,
-                                                           int head_dim, float eps) {
+                                                           int head_dim, float eps, int rope_rows) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  bf16* __restrict__ x = blockIdx.y ? x1 : x0;         // blockIdx.y selects the tensor (q / k of one fused qkv buffer)
+  const float* __restrict__ w = blockIdx.y ? w1 : w0;
+  const int cs_row = rope_rows > 0 ? row % rope_rows : row;  // RoPE table period when samples are stacked along M
   const int nch = D >> 3;
   bf16* xr = x + (size_t)row * ld;
   u32x4 raw[ROW_MAXC];
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x,
       f32x4 cs0, cs1;
       if (cs != nullptr) {
         const int pair0 = ((c * 8) % head_dim) >> 1;  // first of the 4 (even,odd) pairs of this chunk
-        const float* p = cs + ((size_t)row * half + pair0) * 2;
+        const float* p = cs + ((size_t)cs_row * half + pair0) * 2;
         cs0 = *reinterpret_cast<const f32x4*>(p);
         cs1 = *reinterpret_cast<const f32x4*>(p + 4);
       }
@@ -216,20 +224,20 @@ __global__ void unpatchify_kernel(const bf16* __restrict__ y, bf16* __restrict__
 // launchers
 // ------------------------------------------------------------------------------------
 extern "C" int ce_ln_affine_bf16(const void* x, void* y, const float* a, const float* b, int M, int D, int ldx, int ldy,
-                                 float eps, hipStream_t stream) {
+                                 float eps, int ab_rows, int ab_stride, hipStream_t stream) {
   if (!x || !y || !a || !b) return CE_ERR_ARG;
-  if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldy & 7)) return CE_ERR_SHAPE;
+  if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldy & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
   hipLaunchKernelGGL(ln_affine_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M, D, ldx,
-                     ldy, eps);
+                     ldy, eps, ab_rows, ab_stride);
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_rmsnorm_rope_bf16(void* x, const float* w, const float* cos_sin, int M, int D, int ld, int head_dim,
-                                    float eps, hipStream_t stream) {
-  if (!x || !w) return CE_ERR_ARG;
+extern "C" int ce_rmsnorm_rope_bf16(void* x, const float* w, void* x2, const float* w2, const float* cos_sin, int M, int D, int ld,
+                                    int head_dim, float eps, int rope_rows, hipStream_t stream) {
+  if (!x || !w || (x2 && !w2)) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ld & 7) || (head_dim & 7) || D % head_dim) return CE_ERR_SHAPE;
-  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (bf16*)x, w, cos_sin, M, D, ld, head_dim,
-                     eps);
+  hipLaunchKernelGGL(rmsnorm_rope_kernel, dim3((M + 3) / 4, x2 ? 2 : 1), dim3(256), 0, stream, (bf16*)x, w, (bf16*)x2, w2, cos_sin, M,
+                     D, ld, head_dim, eps, rope_rows);
   return (int)hipGetLastError();
 }
 

@@ -26,8 +26,8 @@ _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
 
 # symbol -> argtypes (restype is always int)
 SIGNATURES: Dict[str, List] = {
-    "ce_ln_affine_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
-    "ce_rmsnorm_rope_bf16": [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "ce_ln_affine_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
+    "ce_rmsnorm_rope_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_gemm_variant": [_I],
     "ce_set_attention_waves": [_I],

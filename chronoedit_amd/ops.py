@@ -102,29 +102,39 @@ def _rows(t: torch.Tensor, name: str):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
-def ln_affine(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None):
-    """out = LN_fp32(x) * a + b  (bf16 in/out, fp32 a/b)."""
+def ln_affine(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None,
+              ab_rows: int = 0, ab_stride: int = 0):
+    """out = LN_fp32(x) * a + b  (bf16 in/out, fp32 a/b).  ab_rows > 0: row m uses a/b + (m // ab_rows) * ab_stride."""
     _dev(x, torch.bfloat16, "x"), _dev(a, torch.float32, "a"), _dev(b, torch.float32, "b")
     M, D, ldx = _rows(x, "x")
     if out is None:
         out = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
     _, _, ldy = _rows(out, "out")
     st = _prof_begin()
-    _check(lib().ce_ln_affine_bf16(_ptr(x), _ptr(out), _ptr(a), _ptr(b), M, D, ldx, ldy, float(eps), _stream()), "ce_ln_affine_bf16")
+    _check(lib().ce_ln_affine_bf16(_ptr(x), _ptr(out), _ptr(a), _ptr(b), M, D, ldx, ldy, float(eps), int(ab_rows), int(ab_stride),
+                                   _stream()), "ce_ln_affine_bf16")
     _prof_end(st, f"ln_affine_{M}x{D}", 4.0 * M * D)
     return out
 
 
-def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tensor], head_dim: int, eps: float):
-    """In place RMSNorm-across-heads (+ RoPE when cos_sin [M, head_dim/2, 2] fp32 is given)."""
+def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tensor], head_dim: int, eps: float,
+                  x2: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None):
+    """In place RMSNorm-across-heads (+ RoPE when cos_sin [R, head_dim/2, 2] fp32 is given; row m uses entry m % R).
+    (x2, w2): a second tensor of the same geometry (k beside q in the fused qkv buffer) handled by the same launch."""
     _dev(x, torch.bfloat16, "x"), _dev(w, torch.float32, "w")
     M, D, ld = _rows(x, "x")
+    rope_rows = 0
     if cos_sin is not None:
         _dev(cos_sin, torch.float32, "cos_sin")
-        assert cos_sin.is_contiguous() and cos_sin.shape == (M, head_dim // 2, 2), (cos_sin.shape, M, head_dim)
+        assert cos_sin.is_contiguous() and cos_sin.shape[1:] == (head_dim // 2, 2) and M % cos_sin.shape[0] == 0, (cos_sin.shape, M)
+        rope_rows = cos_sin.shape[0]
+    if x2 is not None:
+        _dev(x2, torch.bfloat16, "x2"), _dev(w2, torch.float32, "w2")
+        assert _rows(x2, "x2") == (M, D, ld)
     st = _prof_begin()
-    _check(lib().ce_rmsnorm_rope_bf16(_ptr(x), _ptr(w), _ptr(cos_sin), M, D, ld, head_dim, float(eps), _stream()), "ce_rmsnorm_rope_bf16")
-    _prof_end(st, f"rmsnorm_rope_{M}x{D}", 4.0 * M * D)
+    _check(lib().ce_rmsnorm_rope_bf16(_ptr(x), _ptr(w), _ptr(x2), _ptr(w2), _ptr(cos_sin), M, D, ld, head_dim, float(eps), rope_rows,
+                                      _stream()), "ce_rmsnorm_rope_bf16")
+    _prof_end(st, f"rmsnorm_rope_{M}x{D}" + ("x2" if x2 is not None else ""), (8.0 if x2 is not None else 4.0) * M * D)
     return x
 
 

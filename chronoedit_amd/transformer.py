@@ -520,9 +520,11 @@ class DiTEngine:
             tproj = ops.gemv(self.tp_w, temb, self.tp_b, flags=1 | 4)  # [6*D]
             mods.append(ops.modulation(self.tables, tproj.view(6, D), one_mask=0b010010))  # [L,6,D]: shift,1+scale,gate,...
             mods_out.append(ops.modulation(self.table_out, temb.view(1, D), one_mask=0b10))  # [1,2,D]: shift, 1+scale
-        if B > 1:  # per-sample gate vectors, stacked [L, B, D] for the GEMM epilogue (gate_rows = N)
-            gate_msa = torch.stack([m[:, 2] for m in mods], dim=1).contiguous()
-            gate_ffn = torch.stack([m[:, 5] for m in mods], dim=1).contiguous()
+        mod = torch.stack(mods, dim=1).contiguous()  # [L, B, 6, D]: per-sample AdaLN rows (ab_rows / gate_rows = tokens per sample)
+        mod_out = torch.stack(mods_out, dim=0).contiguous()  # [B, 1, 2, D]
+        if B > 1:  # per-sample gate vectors, stacked [L, B, D] for the GEMM epilogue
+            gate_msa = mod[:, :, 2].contiguous()
+            gate_ffn = mod[:, :, 5].contiguous()
 
         if text.shape[0] != B or (image is not None and image.shape[0] != B):
             raise ValueError("encoder_hidden_states / encoder_hidden_states_image batch size must match hidden_states")
@@ -533,14 +535,12 @@ class DiTEngine:
         x = ws.x
         for li, p in enumerate(self.blk):
             # 1. self-attention
-            for b in range(B):
-                ops.ln_affine(x[rows[b]], mods[b][li, 1], mods[b][li, 0], eps, out=ws.h[rows[b]])
+            ops.ln_affine(x, mod[li, 0, 1], mod[li, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
             ops.gemm(ws.h, p.w_qkv, p.b_qkv, out=ws.qkv)
+            ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)  # q and k, all samples
             for b in range(B):
                 qkv = ws.qkv[rows[b]]
                 q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
-                ops.rmsnorm_rope_(q, p.nq1, cs, hd, eps)
-                ops.rmsnorm_rope_(k, p.nk1, cs, hd, eps)
                 if sp is None:
                     ops.attention(q, k, v, H, out=ws.att[rows[b]])
                 else:  # Ulysses: tokens gathered / heads scattered around the attention kernel
@@ -568,15 +568,13 @@ class DiTEngine:
                     ops.attention(ws.q2[rows[b]], kt[:, :D], kt[:, D:], H, out=ws.att[rows[b]])
             ops.gemm(ws.att, p.w_o2, p.b_o2, out=x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
-            for b in range(B):
-                ops.ln_affine(x[rows[b]], mods[b][li, 4], mods[b][li, 3], eps, out=ws.h[rows[b]])
+            ops.ln_affine(x, mod[li, 0, 4], mod[li, 0, 3], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
             ops.gemm(ws.h, p.w_f1, p.b_f1, out=ws.ffn, epilogue=ops.EPI_BIAS_GELU)
             ops.gemm(ws.ffn, p.w_f2, p.b_f2, out=x, epilogue=ops.EPI_GATE_RES, gate=gate_ffn[li] if B > 1 else mods[0][li, 5],
                      res=x, gate_rows=grow)
 
         # K18
-        for b in range(B):
-            ops.ln_affine(x[rows[b]], mods_out[b][0, 1], mods_out[b][0, 0], eps, out=ws.h[rows[b]])
+        ops.ln_affine(x, mod_out[0, 0, 1], mod_out[0, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=2 * D)
         ops.gemm(ws.h, self.w_out, self.b_out, out=ws.head)
         out = torch.empty((B, cfg.out_channels, T, Hh, Ww), dtype=torch.bfloat16, device=self.dev)
         if sp is None:

@@ -37,17 +37,19 @@ typedef struct ihipStream_t* hipStream_t;
 #define CE_EPI_F32 4           /* C is float* (ldc in floats): raw fp32 A.W^T, no bias (VAE mid-block attention scores) */
 
 /* y = LayerNorm_fp32(x, eps) * a[d] + b[d] -> bf16.   One wave64 per row; D % 8 == 0, D <= 5120.
+ * ab_rows > 0: row m uses a/b + (m / ab_rows) * ab_stride (one AdaLN vector pair per sample when samples are stacked).
  * Replaces `(self.norm1(h.float()) * (1 + scale) + shift).type_as(h)` and FP32LayerNorm(affine)
  * (chronoedit_diffusers/transformer_chronoedit.py:279,284,289,460). */
 int ce_ln_affine_bf16(const void* x, void* y, const float* a, const float* b, int M, int D, int ldx, int ldy, float eps,
-                      hipStream_t stream);
+                      int ab_rows, int ab_stride, hipStream_t stream);
 
 /* In place: x = RMSNorm_across_heads(x; w, eps), then (cos_sin != NULL) 3-D RoPE on (even, odd)
- * channel pairs of every head; cos_sin = [M][head_dim/2][2] fp32 (cos, sin).
+ * channel pairs of every head; cos_sin = [rope_rows or M][head_dim/2][2] fp32 (cos, sin), row m uses entry m % rope_rows.
+ * (x2, w2) optional: a second tensor with the same geometry handled by the same launch (q and k of a fused buffer).
  * Replaces attn.norm_q / norm_k / norm_added_k + apply_rotary_emb
  * (transformer_chronoedit.py:62-65,73-79,85). */
-int ce_rmsnorm_rope_bf16(void* x, const float* w, const float* cos_sin, int M, int D, int ld, int head_dim, float eps,
-                         hipStream_t stream);
+int ce_rmsnorm_rope_bf16(void* x, const float* w, void* x2, const float* w2, const float* cos_sin, int M, int D, int ld,
+                         int head_dim, float eps, int rope_rows, hipStream_t stream);
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 in/out, fp32 accumulate on MFMA.
  * K % 64 == 0, N % 8 == 0; res may alias C.  gate_rows > 0: row m uses gate[(m / gate_rows) * N + n] (one gate
