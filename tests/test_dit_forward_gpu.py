@@ -93,3 +93,22 @@ def test_batched_forward_equals_sequential():
         ops.set_gemm_variant(old)
     assert torch.equal(both[0], a[0]) and torch.equal(both[1], b[0])
     assert not torch.equal(a, b)
+
+
+def test_full_width_block_at_720p_vs_fp32_reference():
+    """BASELINE configs[1] shapes (D = 5120, 40 heads, F = 13824, N = 7200 tokens, 512 + 257 context rows) on ONE block:
+    the 256-tile LDS-DMA GEMM, the ping-pong attention at 7200 keys x 40 heads and the 14B row kernels, against the fp32
+    CPU oracle (~20 s on the GPU box's host cores)."""
+    cfg = O.DiTConfig(num_layers=1)
+    p_bf = O.make_synthetic_params(cfg, seed=7, dtype=torch.bfloat16)
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 90, 160, dtype=torch.bfloat16)
+    model = _build(cfg, p_bf)
+    ts = torch.tensor([800], device="cuda:0")
+    out = model(lat.cuda(), ts, text.cuda(), image.cuda(), return_dict=False)[0]
+    p32 = {k: v.float() for k, v in p_bf.items()}
+    with torch.no_grad():
+        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([800]), text.float(), image.float())
+    e = rel_l2(out, ref)
+    print(f"full-width block @N=7200: rel-L2 vs fp32 {e:.3e}")
+    assert out.shape == (1, 16, 2, 90, 160) and torch.isfinite(out.float()).all()
+    assert e < 1e-2
