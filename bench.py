@@ -99,6 +99,17 @@ def cpu_baseline(N: int, steps_fwd: int):
             "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, {dt:.2f} s measured; x40 blocks x{steps_fwd} forwards/step"}
 
 
+def _baseline_config_name(a, T) -> str:
+    """Which BASELINE.json configuration the chosen shape corresponds to (label only)."""
+    if (a.width, a.height) == (1280, 720) and T == 2:
+        return "BASELINE.json configs[1]" if a.guidance > 1 else "BASELINE.json configs[2] (distilled: 1 forward/step)"
+    if (a.width, a.height) == (1280, 720) and T == 8:
+        return "BASELINE.json configs[3] shape (temporal reasoning, 8 latent frames)"
+    if (a.width, a.height) == (1584, 1056):
+        return "BASELINE.json configs[4] shape, run in bf16 (the fp8 variant is not built)"
+    return "non-BASELINE shape"
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -218,12 +229,12 @@ def main():
         steps_per_s = a.steps / dt * (1 if ulysses else world)
         fl = flops_per_forward(DiTConfig(num_layers=a.layers), N) * fwd_per_step
         out = {
-            "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": "denoising-steps/sec (ChronoEdit-14B, 720p)",
+            "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
                                    f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
-                                   "BASELINE.json configs[1]",
+                                   + _baseline_config_name(a, T),
                        "tokens": N, "forwards_per_step": fwd_per_step, "parallelism": f"ulysses sp{world}" if ulysses else f"replica x{world}",
                        "cfg": "sequential (2 x B=1)" if a.sequential_cfg else "batched (1 x B=2)",
                        "context_cache": bool(a.cache_context)},

@@ -48,12 +48,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// tanh-approximated GELU exactly as torch's F.gelu(x, approximate="tanh") evaluates it in fp32
+// tanh-approximated GELU, F.gelu(x, approximate="tanh") in fp32:  0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),
+// u = sqrt(2/pi) (x + 0.044715 x^3).  One v_exp_f32 + one v_rcp_f32 (1 ulp each) instead of libm tanhf: the result is
+// rounded to bf16 by every caller, and this runs in GEMM epilogues where VALU time is not hidden behind MFMA.
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
-  const float kKappa = 0.044715f;
-  float inner = kBeta * (x + kKappa * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
+  constexpr float kC1 = -2.0f * 1.4426950408889634f * 0.7978845608028654f;  // -2 log2(e) sqrt(2/pi)
+  constexpr float kC2 = kC1 * 0.044715f;
+  const float x2 = x * x;
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(kC2, x2, kC1));  // exp(-2u); +inf / 0 at the tails
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

@@ -26,6 +26,8 @@
 //    leaves the two most recent half-tiles in flight, LDS-DMA is never drained inside the loop.
 //  * Epilogue: the accumulators go through LDS in two 128-row passes so that bias/GELU/gated-residual
 //    math and the global stores run on 16-B row-contiguous chunks (same rounding points as ce_gemm.hip).
+#include <algorithm>
+
 #include "ce_common.h"
 
 #define EPI_BIAS 0
@@ -105,20 +107,7 @@ __device__ __forceinline__ void mma_half(f32x4 (&acc)[4][2], const bf16x8 (&a)[4
 #define CE_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 #define CE_BAR() __builtin_amdgcn_s_barrier()
 
-template <int EPI, bool STAG>
-__global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A, const bf16* __restrict__ W,
-                                                     bf16* __restrict__ C, const float* __restrict__ bias,
-                                                     const float* __restrict__ gate, const bf16* __restrict__ res, int M,
-                                                     int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                                     int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  const int nwg = tiles_m * tiles_n;
-  const int wg = xcd_remap(blockIdx.x, nwg);
+__device__ __forceinline__ void tile_origin(int wg, int tiles_m, int tiles_n, int& m0, int& n0) {
   constexpr int GROUP = 4;
   const int group_sz = GROUP * tiles_n;
   const int gid = wg / group_sz;
@@ -126,13 +115,109 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   const int gm = min(tiles_m - first_m, GROUP);
   const int tm = first_m + (wg % group_sz) % gm;
   const int tn = (wg % group_sz) / gm;
-  const int m0 = tm * BM, n0 = tn * BN;
+  m0 = tm * BM;
+  n0 = tn * BN;
+}
+
+// Epilogue shared by the GEMM kernel and the split-K reduce kernel: the accumulators go through LDS in two passes
+// of 128 tile rows so that the global stores (and the residual reads) are 16-byte row-contiguous.
+template <int EPI>
+__device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2][2][4][2], unsigned char* smem, int tid, int wm, int wn,
+                                            int fr, int fg, int m0, int n0, bf16* __restrict__ C,
+                                            const float* __restrict__ bias, const float* __restrict__ gate,
+                                            const bf16* __restrict__ res, int M, int N, int ldc, int ldres, int gate_rows) {
+  // ---- epilogue, two passes of 128 tile rows (i = 0, 1)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i == 1) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int cl = j * 128 + wn * 32 + g * 16 + fr;
+        const int n = n0 + cl;
+        const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = wm * 64 + f * 16 + fg * 4 + r;
+            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] + bv);
+          }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) {
+      const int c = tid + 512 * tt;
+      const int rl = c >> 5, cc = c & 31;
+      const int m = m0 + i * 128 + rl, n = n0 + cc * 8;
+      if (m < M && n < N) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16);
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_tanh(bf16lo(v[q])), gelu_tanh(bf16hi(v[q])));
+        } else if (EPI == EPI_BIAS_GELU_ERF) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_erf(bf16lo(v[q])), gelu_erf(bf16hi(v[q])));
+        } else if (EPI == EPI_GATE_RES) {
+          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
+          float gt[8];
+          if (gate != nullptr) {
+            const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;  // per-sample gate rows
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              gt[q] = g0[q];
+              gt[4 + q] = g1[q];
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) gt[q] = 1.0f;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * gt[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * gt[2 * q + 1]);
+        }
+        *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
+      }
+    }
+  }
+}
+
+template <int EPI, bool STAG>
+__global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A, const bf16* __restrict__ W,
+                                                     bf16* __restrict__ C, const float* __restrict__ bias,
+                                                     const float* __restrict__ gate, const bf16* __restrict__ res, int M,
+                                                     int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                                     int tiles_m, int tiles_n, int t_full, int split,
+                                                     float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // Blocks [0, t_full) own whole tiles (t_full is a multiple of the CU count, or every tile when nothing is split).
+  // The tail tiles that would otherwise run as a partially filled last round are cut `split` ways along K; each
+  // tail block leaves an fp32 slab in `ws` and gemm256_reduce sums the slabs and applies the epilogue.
+  const bool partial = (int)blockIdx.x >= t_full;
+  int wg, kt0 = 0, ktn = K / BK;
+  if (!partial) {
+    wg = xcd_remap(blockIdx.x, t_full);
+  } else {
+    const int tb = blockIdx.x - t_full;
+    wg = t_full + tb / split;
+    ktn = ktn / split;
+    kt0 = (tb % split) * ktn;
+  }
+  int m0, n0;
+  tile_origin(wg, tiles_m, tiles_n, m0, n0);
 
   Stager st;
-  st.a_base = reinterpret_cast<const char*>(A);
-  st.w_base = reinterpret_cast<const char*>(W);
+  st.a_base = reinterpret_cast<const char*>(A) + (size_t)kt0 * (BK * 2);
+  st.w_base = reinterpret_cast<const char*>(W) + (size_t)kt0 * (BK * 2);
   st.wave = wave;
-  st.kt_last = K / BK - 1;
+  st.kt_last = ktn - 1;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -213,7 +298,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   read_a<NXT * 4 + S_A0, 1>(smem, wm, fr, fg, ra1);                                                         \
   read_b<NXT * 4 + S_B0, 1>(smem, wn, fr, fg, b0k1);
 
-  const int npairs = (K / BK) >> 1;
+  const int npairs = ktn >> 1;
   for (int it = 0; it < npairs; ++it) {
     const int t = 2 * it;
     CE_TILE_PHASES(0, 1, t)      // even K-tile t   (slots 0-3); stages O.A1(t+1), E.A0/E.B0/E.B1(t+2)
@@ -274,7 +359,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   mma_half(acc[1][0], ra1, b0k1);                                                                            \
   CE_BAR();
 
-    const int npairs = (K / BK) >> 1;
+    const int npairs = ktn >> 1;
     for (int it = 0; it < npairs; ++it) {
       const int t = 2 * it;
       CE_TILE_STAG(0, t)
@@ -288,62 +373,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   CE_LGKM0();
   CE_BAR();
 
-  // ---- epilogue, two passes of 128 tile rows (i = 0, 1)
+  if (partial) {
+    float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if (i == 1) __syncthreads();
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const int cl = j * 128 + wn * 32 + g * 16 + fr;
-        const int n = n0 + cl;
-        const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rl = wm * 64 + f * 16 + fg * 4 + r;
-            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] + bv);
-          }
-      }
-    __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
-      const int c = tid + 512 * tt;
-      const int rl = c >> 5, cc = c & 31;
-      const int m = m0 + i * 128 + rl, n = n0 + cc * 8;
-      if (m < M && n < N) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16);
-        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_tanh(bf16lo(v[q])), gelu_tanh(bf16hi(v[q])));
-        } else if (EPI == EPI_BIAS_GELU_ERF) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_erf(bf16lo(v[q])), gelu_erf(bf16hi(v[q])));
-        } else if (EPI == EPI_GATE_RES) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
-          float gt[8];
-          if (gate != nullptr) {
-            const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;  // per-sample gate rows
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              gt[q] = g0[q];
-              gt[4 + q] = g1[q];
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) gt[q] = 1.0f;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * gt[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * gt[2 * q + 1]);
-        }
-        *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
-      }
-    }
+          for (int g = 0; g < 2; ++g)
+            *reinterpret_cast<f32x4*>(slab + ((((i * 2 + j) * 4 + f) * 2 + g) * 512 + tid) * 4) = acc[i][j][f][g];
+    return;
   }
+  epilogue256<EPI>(acc, smem, tid, wm, wn, fr, fg, m0, n0, C, bias, gate, res, M, N, ldc, ldres, gate_rows);
+}
+
+// Sums the `split` fp32 slabs of one tail tile (same thread <-> accumulator mapping as the GEMM kernel) and runs the
+// common epilogue.  grid = number of tail tiles.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_reduce(bf16* __restrict__ C, const float* __restrict__ bias,
+                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
+                                                      int N, int ldc, int ldres, int gate_rows, int tiles_m, int tiles_n,
+                                                      int t_full, int split, const float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  int m0, n0;
+  tile_origin(t_full + blockIdx.x, tiles_m, tiles_n, m0, n0);
+  f32x4 acc[2][2][4][2];
+  const float* slab = ws + (size_t)blockIdx.x * split * (BM * BN);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int e = ((((i * 2 + j) * 4 + f) * 2 + g) * 512 + tid) * 4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
+          for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
+          acc[i][j][f][g] = v;
+        }
+  epilogue256<EPI>(acc, smem, tid, wm, wn, fr, fg, m0, n0, C, bias, gate, res, M, N, ldc, ldres, gate_rows);
 }
 
 }  // namespace
@@ -359,25 +434,56 @@ extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw) {
 static bool staggered = false;
 extern "C" void ce_gemm256_set_staggered(int on) { staggered = on != 0; }
 
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+static int g_cus = 256;
+// Scratch for the split-K tail (fp32 slabs); without it every tile runs whole.  Host-side knob, not on the data path.
+extern "C" int ce_set_gemm_workspace(void* ptr, size_t bytes) {
+  g_ws = reinterpret_cast<float*>(ptr);
+  g_ws_bytes = ptr ? bytes : 0;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+    g_cus = cus;
+  return CE_OK;
+}
+
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  dim3 grid(tiles_m * tiles_n), block(512);
+  const int nwg = tiles_m * tiles_n, kt = K / BK;
+  // split-K only for the tail of the last, partially filled round of workgroups
+  int tail = nwg % g_cus, split = 1;
+  if (tail > 0 && g_ws != nullptr) {
+    for (int s = std::min(g_cus / tail, 8); s >= 2; --s)
+      if (kt % (2 * s) == 0 && (size_t)tail * s * BM * BN * sizeof(float) <= g_ws_bytes) {
+        split = s;
+        break;
+      }
+  }
+  if (split == 1) tail = 0;
+  const int t_full2 = nwg - tail;
+  dim3 grid(t_full2 + tail * split), block(512);
   static bool attr_done[4] = {false, false, false, false};
 #define CE_LAUNCH(E)                                                                                                  \
   do {                                                                                                                \
     if (!attr_done[E]) {                                                                                              \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);  \
+      (void)hipFuncSetAttribute((const void*)gemm256_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CROW);     \
       attr_done[E] = true;                                                                                            \
     }                                                                                                                 \
     if (staggered)                                                                                                    \
       hipLaunchKernelGGL((gemm_bf16_256<E, true>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
-                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n);   \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n,    \
+                         t_full2, split, g_ws);                                                                       \
     else                                                                                                              \
       hipLaunchKernelGGL((gemm_bf16_256<E, false>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
-                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n);   \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n,    \
+                         t_full2, split, g_ws);                                                                       \
+    if (tail)                                                                                                         \
+      hipLaunchKernelGGL((gemm256_reduce<E>), dim3(tail), block, 128 * CROW, stream, (bf16*)C, bias, gate,            \
+                         (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);      \
   } while (0)
   switch (epilogue) {
     case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;

@@ -163,11 +163,40 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Op
         if gate is not None:
             _dev(gate, torch.float32, "gate")
             assert gate.is_contiguous() and gate.numel() == (N if gate_rows <= 0 else (M + gate_rows - 1) // gate_rows * N)
+    ensure_gemm_workspace(a.device)
     st = _prof_begin()
     _check(lib().ce_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), epilogue, _ptr(gate), _ptr(res), M, N, K, lda, ldw, ldc,
                               ldres, int(gate_rows), _stream()), "ce_gemm_bf16")
     _prof_end(st, f"gemm_{M}x{N}x{K}_epi{epilogue}", 2.0 * M * N * K)
     return out
+
+
+_gemm_ws = {}
+_gemm_split = True
+GEMM_WS_BYTES = 256 * 256 * 256 * 4  # one fp32 256x256 slab per CU
+
+
+def ensure_gemm_workspace(device: torch.device) -> None:
+    """Hand the library its split-K scratch for `device` (allocated once, outside any graph capture)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _gemm_split)
+    if _gemm_ws.get("active") == key:
+        return
+    if _gemm_split:
+        buf = _gemm_ws.get(key[0])
+        if buf is None:
+            buf = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+            _gemm_ws[key[0]] = buf
+        _check(lib().ce_set_gemm_workspace(buf.data_ptr(), buf.numel()), "ce_set_gemm_workspace")
+    else:
+        _check(lib().ce_set_gemm_workspace(None, 0), "ce_set_gemm_workspace")
+    _gemm_ws["active"] = key
+
+
+def set_gemm_split(on: bool) -> bool:
+    """Enable/disable the split-K tail of the 256-tile GEMM; returns the previous setting."""
+    global _gemm_split
+    prev, _gemm_split = _gemm_split, bool(on)
+    return prev
 
 
 def set_gemm_variant(v: int) -> int:

@@ -14,6 +14,7 @@
 #ifndef CHRONOEDIT_HIP_H
 #define CHRONOEDIT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -61,6 +62,12 @@ int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int e
 /* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default), 0 force the 128x128
  * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows.  Host-side test/bench knob. */
 int ce_set_gemm_variant(int variant);
+
+/* Scratch for the split-K tail of ce_gemm_bf16's 256-tile kernel: the tiles that would run as a partially filled last
+ * round of workgroups are cut along K into fp32 slabs (256 KiB each, at most one per CU) and summed by a second
+ * launch that applies the epilogue.  ptr is device memory owned by the caller (NULL switches the split off; that is
+ * the default); the library never allocates.  Host-side knob, returns CE_OK. */
+int ce_set_gemm_workspace(void* ptr, size_t bytes);
 
 /* O = softmax(Q K1^T * scale) V1 [ + softmax(Q K2^T * scale) V2 ], per head, head_dim == 128, bf16.
  * Each segment's result is rounded to bf16 before the add (SDPA output dtype).

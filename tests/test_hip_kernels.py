@@ -131,6 +131,41 @@ def test_gemm_epilogues(gemm_variant):
     assert rel_l2(x, ref) < 5e-3
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(4352, 4096, 1024, "bias"), (7200, 5120, 5120, "gate"), (1538, 10240, 5120, "gelu"),
+                                       (600, 512, 1024, "bias")])
+def test_gemm_split_k_tail(M, N, K, epi):
+    """Tail tiles of the 256-tile kernel are cut along K (fp32 slabs + reduce launch); same result as running whole."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(BF).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(BF).to(dev)
+    gate = torch.randn(N, generator=g).to(dev)
+    kw = {"bias": dict(), "gelu": dict(epilogue=ops.EPI_BIAS_GELU),
+          "gate": dict(epilogue=ops.EPI_GATE_RES, gate=gate, res=res)}[epi]
+    old_v = ops.set_gemm_variant(1)
+    try:
+        old_s = ops.set_gemm_split(False)
+        whole = ops.gemm(a, w, bias, **kw)
+        ops.set_gemm_split(True)
+        split = ops.gemm(a, w, bias, **kw)
+        split2 = ops.gemm(a, w, bias, **kw)
+        ops.set_gemm_split(old_s)
+    finally:
+        ops.set_gemm_variant(old_v)
+    assert torch.equal(split, split2)                         # fixed reduction order: deterministic
+    lin = a.float() @ w.float().t() + bias
+    ref = {"bias": lin, "gelu": torch.nn.functional.gelu(lin.to(BF).float(), approximate="tanh"),
+           "gate": res.float() + lin.to(BF).float() * gate}[epi]
+    assert rel_l2(split, ref) < 4e-3 and rel_l2(whole, ref) < 4e-3
+    # only fp32 summation order differs between the two paths: at most one bf16 ulp on a few elements
+    d = (split.float() - whole.float()).abs()
+    assert d.max().item() <= 2 ** -7 * ref.abs().max().item()
+    assert (d > 0).float().mean().item() < 0.05
+
+
 def test_gemm_rejects_bad_shapes():
     from chronoedit_amd import ops
     dev = _dev()

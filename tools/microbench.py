@@ -53,6 +53,30 @@ def main():
                                                  "hipblaslt_ms": t_ref * 1e3, "hipblaslt_tflops": fl / t_ref / 1e12}
             print(f"gemm {M}x{N}x{K} epi{epi}: tile256 {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | staggered {fl/tst/1e12:.1f} TF | tile128 {fl/t128/1e12:.1f} TF | hipblaslt {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
             del a, w, out
+    if "split" in only:
+        # split-K tail on/off for the shapes of one batched-CFG step (M = 2 x 7200) and the context GEMMs
+        for (M, N, K, epi) in [(14400, 15360, 5120, 0), (14400, 5120, 5120, 2), (14400, 13824, 5120, 1), (14400, 5120, 13824, 2),
+                               (7200, 15360, 5120, 0), (7200, 5120, 5120, 2), (7200, 13824, 5120, 1), (7200, 5120, 13824, 2),
+                               (1538, 10240, 5120, 0), (28800, 5120, 5120, 2)]:
+            a = torch.randn(M, K, generator=g).to(BF).to(dev)
+            w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
+            b = torch.zeros(N, device=dev)
+            out = torch.empty(M, N, dtype=BF, device=dev)
+            gate = torch.ones(N, device=dev)
+            fl = 2.0 * M * N * K
+            run = lambda: ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+            ops.set_gemm_variant(1)
+            t0 = t1 = 1e9
+            for _ in range(3):  # interleaved: clocks drift with temperature, so A/B/A/B and keep the best of each
+                ops.set_gemm_split(False)
+                t0 = min(t0, timeit(run, iters=20))
+                ops.set_gemm_split(True)
+                t1 = min(t1, timeit(run, iters=20))
+            ops.set_gemm_variant(-1)
+            tiles = ((M + 255) // 256) * ((N + 255) // 256)
+            res[f"split_{M}x{N}x{K}_epi{epi}"] = {"whole_ms": t0 * 1e3, "split_ms": t1 * 1e3, "tiles": tiles}
+            print(f"gemm {M}x{N}x{K} epi{epi}: tiles {tiles} (tail {tiles % 256}) whole {t0*1e3:.3f} ms {fl/t0/1e12:.1f} TF | split {t1*1e3:.3f} ms {fl/t1/1e12:.1f} TF", flush=True)
+            del a, w, out
     if "attn" in only:
         for (Nq, Nkv, H) in [(7200, 7200, 40), (28800, 28800, 40), (7200, 512, 40)]:
             D = H * 128
