@@ -61,6 +61,17 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 2) void attn_fwd_kerne
                                                        KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
                                                        float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {  // stacked samples: sample b = blockIdx.y owns rows [b Nq, (b+1) Nq) of Q/O and [b len, (b+1) len) of each K/V segment
+    const size_t bz = blockIdx.y;
+    Q += bz * Nq * ldq;
+    O += bz * Nq * ldo;
+    seg0.k += bz * seg0.len * seg0.ldk;
+    seg0.v += bz * seg0.len * seg0.ldv;
+    if (TWO_SEG) {
+      seg1.k += bz * seg1.len * seg1.ldk;
+      seg1.v += bz * seg1.len * seg1.ldv;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
 
@@ -298,6 +309,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pipe_kernel(const bf16* __res
                                                                 KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
                                                                 float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {  // stacked samples: sample b = blockIdx.y owns rows [b Nq, (b+1) Nq) of Q/O and [b len, (b+1) len) of each K/V segment
+    const size_t bz = blockIdx.y;
+    Q += bz * Nq * ldq;
+    O += bz * Nq * ldo;
+    seg0.k += bz * seg0.len * seg0.ldk;
+    seg0.v += bz * seg0.len * seg0.ldv;
+    if (TWO_SEG) {
+      seg1.k += bz * seg1.len * seg1.ldk;
+      seg1.v += bz * seg1.len * seg1.ldv;
+    }
+  }
   constexpr int NWAVE = 8, QB = QW * NWAVE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -606,11 +628,44 @@ typedef __attribute__((ext_vector_type(2))) unsigned pp_u2;
 
 constexpr int pp_smem_bytes(bool two_seg) { return two_seg ? 2 * PBUF + 8 * QW * OST_ROW : 2 * PBUF; }
 
-template <bool TWO_SEG>
+#ifdef CE_ATTN_ABLATE
+__device__ unsigned long long g_attn_ts[8][16][4];  // [wave][tile - 40][stamp]: ABL == 10, workgroup 300
+__device__ unsigned long long g_attn_ts6[8][16][6];
+extern "C" int ce_attn_read_ts6(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_ts6), sizeof(g_attn_ts6)); }
+extern "C" int ce_attn_read_ts(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_ts), sizeof(g_attn_ts)); }
+#define CE_STAMP(p)                                                                                       \
+  if (ABL == 10 && blockIdx.x == 300 && t >= 40 && t < 56) {                                              \
+    const unsigned long long ts = __builtin_amdgcn_s_memtime();                                           \
+    if (lane == 0) g_attn_ts[wave][t - 40][p] = ts;                                                       \
+  }
+// sp kernel: stamp p of tile t (issue time of the s_memtime at that point of the stream)
+#define CE_SPSTAMP(p)                                                                                     \
+  if (ABL == 10 && blockIdx.x == 300 && t >= 40 && t < 56) {                                              \
+    const unsigned long long ts = __builtin_amdgcn_s_memtime();                                           \
+    if (lane == 0) g_attn_ts6[wave][t - 40][p] = ts;                                                      \
+  }
+#else
+#define CE_STAMP(p)
+#define CE_SPSTAMP(p)
+#endif
+// ABL != 0 only in the ablation build (tools/attn_ablate.py, -DCE_ATTN_ABLATE): timing experiments that drop one
+// ingredient of the loop (results are garbage); the product library instantiates ABL == 0 only.
+template <bool TWO_SEG, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
                                                               KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
                                                               float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {  // stacked samples: sample b = blockIdx.y owns rows [b Nq, (b+1) Nq) of Q/O and [b len, (b+1) len) of each K/V segment
+    const size_t bz = blockIdx.y;
+    Q += bz * Nq * ldq;
+    O += bz * Nq * ldo;
+    seg0.k += bz * seg0.len * seg0.ldk;
+    seg0.v += bz * seg0.len * seg0.ldv;
+    if (TWO_SEG) {
+      seg1.k += bz * seg1.len * seg1.ldk;
+      seg1.v += bz * seg1.len * seg1.ldv;
+    }
+  }
   constexpr int NWAVE = 8, QB = QW * NWAVE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -713,17 +768,23 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
     store_v(0);
     if (ntiles > 1) load_k(1);
     if (grp) { CE_EPOCH_BARRIER(); }  // group 1 lags one epoch
+    if (ABL == 8 && grp) __builtin_amdgcn_s_setprio(1);
 
     for (int t = 0; t < ntiles; ++t) {
       const int cur = t & 1;
       const unsigned char* kb = k_rd + cur * PBUF;
       const unsigned char* vb = v_rd + cur * PBUF;
       // ================= phase 1(t) =================
-      CE_EPOCH_BARRIER();
-      if (t + 1 < ntiles) {
+      CE_STAMP(3)  // end of phase 2(t-1) as seen before the barrier: stored under tile t, slot 3
+      if (ABL != 5) { CE_EPOCH_BARRIER(); }
+      CE_STAMP(0)
+      if (ABL != 4 && t + 1 < ntiles) {
         store_k(cur ^ 1);
         load_v(t + 1);
       }
+      // K(t+2) is fetched as soon as its staging registers are free: two full epochs (one tile time) before the store
+      // in phase 1(t+1).  Issued one epoch later (in phase 2) the global latency showed up as a vmcnt stall per tile.
+      if (ABL != 4 && t + 2 < ntiles) load_k(t + 2);
       f32x16 st[2];
       {
         constexpr int RING = 6;  // fragment reads run RING MFMAs (~190 cycles) ahead of their use
@@ -737,7 +798,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], i < 2 ? zero16 : st[i & 1], 0, 0, 0);
+          if (ABL == 3) {
+            if (i < 2) st[i & 1] = zero16;
+            asm volatile("" ::"v"(kf[i % RING]));
+          } else {
+            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], i < 2 ? zero16 : st[i & 1], 0, 0, 0);
+          }
           if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
         }
 #undef CE_LDK
@@ -776,14 +842,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
           for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha;
       }
       // ================= phase 2(t) =================
-      CE_EPOCH_BARRIER();
-      if (t + 2 < ntiles) load_k(t + 2);
+      CE_STAMP(1)
+      if (ABL != 5) { CE_EPOCH_BARRIER(); }
+      CE_STAMP(2)
+      if (ABL == 6 || ABL == 7) __builtin_amdgcn_s_setprio(3);
+      if (ABL == 9) __builtin_amdgcn_s_setprio(0);
       float psum = 0.f;
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(st[f][r], scale_log2e, -mc));
+          const float p = ABL == 1 ? fmaf(st[f][r], scale_log2e, -mc) : __builtin_amdgcn_exp2f(fmaf(st[f][r], scale_log2e, -mc));
           st[f][r] = p;
           psum += p;
         }
@@ -798,6 +867,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
         const bf16x2 p2 = __builtin_convertvector(t2, bf16x2), p3 = __builtin_convertvector(t3, bf16x2);
         ppk[s4] = bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
       }
+      if (ABL == 6) __builtin_amdgcn_s_setprio(0);
+      if (ABL == 9) __builtin_amdgcn_s_setprio(3);
       {
         // V^T fragment of unit u = (k-step s4 = u >> 2, dv fragment m = u & 3): 16 contiguous bytes (see layout note)
 #define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vb + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
@@ -807,12 +878,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
         for (int u = 0; u < VRING; ++u) vf[u] = CE_LDV(u);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-          oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+          if (ABL == 2) {
+            asm volatile("" ::"v"(vf[u % VRING]), "v"(ppk[u >> 2]));
+          } else {
+            oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+          }
           if (u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
         }
 #undef CE_LDV
       }
-      if (t + 1 < ntiles) store_v(cur ^ 1);
+      if (ABL != 4 && t + 1 < ntiles) store_v(cur ^ 1);
+      if (ABL == 7) __builtin_amdgcn_s_setprio(0);
     }
     if (!grp) { CE_EPOCH_BARRIER(); }  // group 0 waits for group 1's last epoch
     CE_EPOCH_BARRIER();                // common: every wave is done with the tile buffers
@@ -849,6 +925,351 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant on the padded LDS images ("sp").  Measured fact it is built on (tools/probes/pipe_probe.hip):
+// on one SIMD, one wave's MFMAs and ANOTHER wave's VALU work serialise at equal priority (16 MFMA + 32 v_exp per
+// iteration: 5.3 ms + 3.2 ms alone, 8.7 ms together), while the same MFMAs and v_exp interleaved in ONE wave's
+// instruction stream cost the MFMA time alone (5.6 ms; two such waves per SIMD: 10.1 ms = the matrix pipe saturated).
+// The ping-pong kernel above relied on the cross-wave overlap and its s_memtime stamps showed epochs of ~1900 cycles
+// for 1024 cycles of MFMA per SIMD.  Here every wave runs the same program and hides its own VALU:
+//     iteration t:  barrier | store K(t+1), V(t+1) (fetched one iteration ago) | fetch K(t+2), V(t+2)
+//                   | S(t) = K(t).Q^T (16 MFMA) | row max, alpha | O *= alpha(t-1) (rare)
+//                   | 16 MFMA of O += V^T(t-1).P^T(t-1), each followed by 2 v_exp + 2 fma + 2 add of P(t) | pack P(t)
+// LDS: K double-buffered, V^T triple-buffered (V(t-1) is read while V(t+1) is written): one barrier per tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow the two K buffers
+constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
+constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 * QW * OST_ROW : SP_TILE_BYTES; }
+
+template <bool TWO_SEG, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
+                                                              KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
+                                                              float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {  // stacked samples: sample b = blockIdx.y owns rows [b Nq, (b+1) Nq) of Q/O and [b len, (b+1) len) of each K/V segment
+    const size_t bz = blockIdx.y;
+    Q += bz * Nq * ldq;
+    O += bz * Nq * ldo;
+    seg0.k += bz * seg0.len * seg0.ldk;
+    seg0.v += bz * seg0.len * seg0.ldv;
+    if (TWO_SEG) {
+      seg1.k += bz * seg1.len * seg1.ldk;
+      seg1.v += bz * seg1.len * seg1.ldv;
+    }
+  }
+  constexpr int NWAVE = 8, QB = QW * NWAVE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * QB + wave * QW;
+  const int hoff = head * HD;
+
+  bf16x8 qf[8];
+  {
+    const bf16* qrow = Q + (size_t)min(q0 + l31, Nq - 1) * ldq + hoff + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+  }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));  // retire the Q loads before the loop (see ping-pong)
+
+  // staging shares and LDS bases: as in the ping-pong kernel (K rows 272 B, V^T rows 144 B, (h, b) chunk order)
+  const int k_ck = tid & 15, k_row0 = tid >> 4;
+  const int v_dvq = (tid & 1) | (((tid >> 4) & 15) << 1), v_kvq = ((tid >> 1) & 7) | (((tid >> 8) & 1) << 3);
+  const int v_chunk = (v_kvq & ~3) | ((v_kvq & 1) << 1) | ((v_kvq >> 1) & 1);
+  unsigned char* ost = smem + (TWO_SEG ? SP_TILE_BYTES : 0) + (size_t)(wave * QW + l31) * OST_ROW;
+  const unsigned char* k_rd = smem + l31 * PK_ROW + hh * 16;            // + buf*PK_TILE + f*32*PK_ROW + ks*32
+  const unsigned char* v_rd = smem + SP_V0 + l31 * PV_ROW + hh * 16;    // + buf*PV_TILE + m*32*PV_ROW + s*32
+  unsigned char* k_wr = smem + k_row0 * PK_ROW + k_ck * 16;             // + buf*PK_TILE + i*32*PK_ROW
+  unsigned char* v_wr = smem + SP_V0 + (4 * v_dvq) * PV_ROW + v_chunk * 8;  // + buf*PV_TILE + j*PV_ROW
+
+#pragma unroll
+  for (int sidx = 0; sidx < (TWO_SEG ? 2 : 1); ++sidx) {
+    const KVSeg sg = sidx == 0 ? seg0 : seg1;
+    const int ntiles = (sg.len + KVB - 1) / KVB;
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (sg.len - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + hoff), 0, (sg.len - 1) * sg.ldv * 2 + HD * 2, 0x00020000);
+    const int k_voff0 = k_row0 * sg.ldk * 2 + k_ck * 16, k_voff1 = k_voff0 + 32 * sg.ldk * 2;
+    int v_voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v_voff[i] = (4 * v_kvq + i) * sg.ldv * 2 + v_dvq * 8;
+    const int k_tile_bytes = KVB * sg.ldk * 2, v_tile_bytes = KVB * sg.ldv * 2;
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f, alpha_prev = 1.0f;
+    bf16x8 ppk[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ppk[s4][i] = (bf16)0.f;
+
+    pp_u4 kreg[2];
+    pp_u2 vreg[4];
+    auto load_k = [&](int t) {
+      const int so = t * k_tile_bytes;
+      kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff0, so, 0);
+      kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff1, so, 0);
+    };
+    auto load_v = [&](int t) {
+      const int so = t * v_tile_bytes;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_voff[i], so, 0);
+    };
+    auto store_k = [&](int buf) {
+      *reinterpret_cast<pp_u4*>(k_wr + buf * PK_TILE) = kreg[0];
+      *reinterpret_cast<pp_u4*>(k_wr + buf * PK_TILE + 32 * PK_ROW) = kreg[1];
+    };
+    auto store_v_part = [&](int buf, int j) {  // row j of this thread's transposed 4x4 patch
+      const int w = j >> 1;
+      uint32_t lo, hi;
+      if ((j & 1) == 0) {
+        lo = (vreg[0][w] & 0xffffu) | (vreg[1][w] << 16);
+        hi = (vreg[2][w] & 0xffffu) | (vreg[3][w] << 16);
+      } else {
+        lo = (vreg[0][w] >> 16) | (vreg[1][w] & 0xffff0000u);
+        hi = (vreg[2][w] >> 16) | (vreg[3][w] & 0xffff0000u);
+      }
+      pp_u2 val = {lo, hi};
+      *reinterpret_cast<pp_u2*>(v_wr + buf * PV_TILE + j * PV_ROW) = val;
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w = j >> 1;
+        uint32_t lo, hi;
+        if ((j & 1) == 0) {
+          lo = (vreg[0][w] & 0xffffu) | (vreg[1][w] << 16);
+          hi = (vreg[2][w] & 0xffffu) | (vreg[3][w] << 16);
+        } else {
+          lo = (vreg[0][w] >> 16) | (vreg[1][w] & 0xffff0000u);
+          hi = (vreg[2][w] >> 16) | (vreg[3][w] & 0xffff0000u);
+        }
+        pp_u2 val = {lo, hi};
+        *reinterpret_cast<pp_u2*>(v_wr + buf * PV_TILE + j * PV_ROW) = val;
+      }
+    };
+
+    // ---- prologue: tile 0 -> K buffer 0 / V buffer 0; V buffer 2 plays "V(-1)" (zeros: P(-1) = 0 must not meet NaNs)
+    if (TWO_SEG && sidx == 1) { CE_EPOCH_BARRIER(); }  // segment 0's drain still read the V buffers
+    load_k(0);
+    load_v(0);
+    {
+      const pp_u4 z = {0u, 0u, 0u, 0u};
+      for (int i = tid; i < PV_TILE / 16; i += NWAVE * 64) *reinterpret_cast<pp_u4*>(smem + SP_V0 + 2 * PV_TILE + i * 16) = z;
+    }
+    store_k(0);
+    store_v(0);
+    if (ntiles > 1) {
+      load_k(1);
+      load_v(1);
+    }
+    int vb_prev = 2, vb_cur = 0;  // V^T buffer of tile t-1 / tile t
+
+    for (int t = 0; t < ntiles; ++t) {
+      CE_SPSTAMP(5);
+      CE_EPOCH_BARRIER();  // K(t), V(t) visible; K(t-1) and V(t-2) no longer read by anyone
+      CE_SPSTAMP(0);
+      const int vb_next = 3 - vb_prev - vb_cur;
+      const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
+      const unsigned char* vb = v_rd + vb_prev * PV_TILE;
+
+      // ---- S^T(t) = K(t).Q^T: MFMA i works on kv fragment f = i & 1, k-step ks = i >> 1 (alternating accumulators).
+      // The staging of the NEXT tiles rides inside this MFMA stream instead of in front of it (stamps: with all eight
+      // waves storing right after the barrier the matrix pipe idled ~600 cycles per tile): K(t+1) / V(t+1) registers
+      // -> LDS after MFMAs 1, 3, 5..8, fetch of K(t+2) / V(t+2) after MFMAs 10 and 12.  Unconditional: past the last
+      // tile the stores fill buffers nobody reads and the fetches are out of range of the buffer descriptor (zeros).
+      CE_SPSTAMP(1);
+      f32x16 st[2];
+      {
+        constexpr int RING = 6;
+        bf16x8 kf[RING];
+#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + ((i) & 1) * 32 * PK_ROW + ((i) >> 1) * 32))
+#pragma unroll
+        for (int i = 0; i < RING; ++i) kf[i] = CE_LDK(i);
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (ABL == 3) {
+            if (i < 2) st[i & 1] = zero16;
+            asm volatile("" ::"v"(kf[i % RING]));
+          } else {
+            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], i < 2 ? zero16 : st[i & 1], 0, 0, 0);
+          }
+          if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
+          if (ABL != 4 && ABL != 8) {
+            if (i == 1) *reinterpret_cast<pp_u4*>(k_wr + ((t + 1) & 1) * PK_TILE) = kreg[0];
+            if (i == 3) *reinterpret_cast<pp_u4*>(k_wr + ((t + 1) & 1) * PK_TILE + 32 * PK_ROW) = kreg[1];
+            if (i >= 5 && i < 9) store_v_part(vb_next, i - 5);
+          }
+          if (ABL == 8) {  // keep the fetched registers (and their vmcnt waits) alive without the LDS stores
+            if (i == 1) asm volatile("" ::"v"(kreg[0]), "v"(kreg[1]));
+            if (i == 5) asm volatile("" ::"v"(vreg[0]), "v"(vreg[1]), "v"(vreg[2]), "v"(vreg[3]));
+          }
+          if (ABL != 4 && ABL != 7) {
+            if (i == 10) load_k(t + 2);
+            if (i == 12) load_v(t + 2);
+          }
+        }
+#undef CE_LDK
+        __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < 16 - RING) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          if (i == 1 || i == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          if (i >= 5 && i < 9) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+          if (i == 10) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          if (i == 12) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+        }
+      }
+      if ((t + 1) * KVB > sg.len) {
+        const int base = t * KVB + 4 * hh;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
+            if (kv >= sg.len) st[f][r] = NEG_BIG;
+          }
+      }
+      float mx = st[0][0];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[f][r]);
+      if (ABL != 6) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+      const float mc = m_new * scale_log2e;
+      m_run = m_new;
+      if (ABL == 10) asm volatile("" ::"v"(mc));
+      CE_SPSTAMP(2);
+      // O at the scale of m(t-1) before P(t-1).V(t-1) is added (rare after the first tiles)
+      if (__any(alpha_prev != 1.0f)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
+      }
+      // ---- O^T += V^T(t-1).P^T(t-1) on the matrix pipe, P(t) = exp2(S(t) scale - mc) on the VALU, one stream:
+      // unit u = (k-step s4 = u >> 2, dv fragment m = u & 3) is one MFMA followed by two elements of the softmax
+      float psum = 0.f;
+      {
+#define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vb + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
+        constexpr int VRING = 6;
+        bf16x8 vf[VRING];
+#pragma unroll
+        for (int u = 0; u < VRING; ++u) vf[u] = CE_LDV(u);
+        // One scheduling region per unit (sched_barrier(0) after each): hipcc may order the seven instructions of a unit
+        // as it likes but cannot pull the exp2 work of several units together (with sched_group_barrier alone it issued
+        // six MFMAs back to back and then bursts of eight or nine v_exp, longer than an MFMA's 32-cycle shadow).
+        // The row-sum add of an element runs one unit behind its v_exp (transcendental result latency).
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (ABL == 2) {
+            asm volatile("" ::"v"(vf[u % VRING]), "v"(ppk[u >> 2]));
+          } else {
+            oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+          }
+          if (u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
+#pragma unroll
+          for (int e = 2 * u; e < 2 * u + 2; ++e)
+            st[e >> 4][e & 15] = ABL == 1 ? fmaf(st[e >> 4][e & 15], scale_log2e, -mc)
+                                          : __builtin_amdgcn_exp2f(fmaf(st[e >> 4][e & 15], scale_log2e, -mc));
+          if (u > 0) {
+#pragma unroll
+            for (int e = 2 * u - 2; e < 2 * u; ++e) psum += st[e >> 4][e & 15];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        psum += st[1][14];
+        psum += st[1][15];
+#undef CE_LDV
+      }
+      l_run = l_run * alpha + psum;
+      alpha_prev = alpha;
+      if (ABL == 10) asm volatile("" ::"v"(l_run), "v"(oacc[3]));
+      CE_SPSTAMP(3);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int f = s4 >> 1, rb = 8 * (s4 & 1);
+        f32x2 t0 = {st[f][rb + 0], st[f][rb + 1]}, t1 = {st[f][rb + 2], st[f][rb + 3]};
+        f32x2 t2 = {st[f][rb + 4], st[f][rb + 5]}, t3 = {st[f][rb + 6], st[f][rb + 7]};
+        const bf16x2 p0 = __builtin_convertvector(t0, bf16x2), p1 = __builtin_convertvector(t1, bf16x2);
+        const bf16x2 p2 = __builtin_convertvector(t2, bf16x2), p3 = __builtin_convertvector(t3, bf16x2);
+        ppk[s4] = bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
+      }
+      if (ABL == 10) asm volatile("" ::"v"(ppk[3]));
+      CE_SPSTAMP(4);
+      vb_prev = vb_cur;
+      vb_cur = vb_next;
+    }
+    // ---- drain: P(ntiles-1).V(ntiles-1); its V buffer (now vb_prev) became visible at the last barrier
+    if (__any(alpha_prev != 1.0f)) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
+    }
+    {
+      const unsigned char* vb = v_rd + vb_prev * PV_TILE;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bf16x8 vfd = *reinterpret_cast<const bf16x8*>(vb + (u & 3) * 32 * PV_ROW + (u >> 2) * 32);
+        oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfd, ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+      }
+    }
+    CE_EPOCH_BARRIER();  // every wave is done with the tile buffers (the O staging overlays them when !TWO_SEG)
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        uint32_t w0 = pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv);
+        uint32_t w1 = pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv);
+        u32x2* slot = reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2);
+        if (TWO_SEG && sidx == 1) {
+          const u32x2 pv = *slot;
+          w0 = pack_bf16(bf16lo(pv[0]) + bf16lo(w0), bf16hi(pv[0]) + bf16hi(w0));
+          w1 = pack_bf16(bf16lo(pv[1]) + bf16lo(w1), bf16hi(pv[1]) + bf16hi(w1));
+        }
+        u32x2 val = {w0, w1};
+        *slot = val;
+      }
+  }
+
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = q0 + rl;
+    if (q < Nq) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? SP_TILE_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    }
+  }
+}
+
 }  // namespace
 
 // waves per workgroup: 8 (256 query rows, 1 workgroup/CU) or 4 (128 query rows, 2 independent workgroups/CU)
@@ -856,19 +1277,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 // 0 = automatic: ping-pong for single-segment (self) attention (measured 0.90-0.91 PFLOP/s at 7200 keys, 1.02 at 28800,
 // vs 0.77-0.79 / 0.93 for the plain 8-wave kernel), plain 8-wave for the short two-segment cross-attention
 static int g_attn_nwave = 0;
+#ifdef CE_ATTN_ABLATE
+static int g_attn_ablate = 0;
+extern "C" void ce_attn_set_ablation(int a) { g_attn_ablate = a; }
+#endif
 extern "C" int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
-  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16 || nwave == 32) g_attn_nwave = nwave;
+  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16 || nwave == 32 || nwave == 64) g_attn_nwave = nwave;
   return old;
 }
 
 // Q [Nq][ldq], K*/V* [len][ld*], O [Nq][ldo]; all bf16, head h occupies columns [128 h, 128 h + 128).
 // Second kv segment optional (k2 == nullptr or len2 == 0): O = bf16(attn(seg1)) + bf16(attn(seg2)).
-extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
-                                 const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq,
-                                 int ldo, float softmax_scale, hipStream_t stream) {
+// batch > 1: `batch` samples stacked along the rows of every operand (sample b: rows [b Nq, (b+1) Nq) of Q/O, rows
+// [b len, (b+1) len) of each K/V segment), one launch - more workgroups per launch, smaller last-round tail.
+extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1,
+                                         const void* K2, const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H,
+                                         int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
   if (!Q || !K1 || !V1 || !O) return CE_ERR_ARG;
-  if (head_dim != HD || Nq <= 0 || H <= 0 || len1 <= 0) return CE_ERR_SHAPE;
+  if (head_dim != HD || Nq <= 0 || H <= 0 || len1 <= 0 || batch <= 0 || batch > 65535) return CE_ERR_SHAPE;
   if ((ldq & 7) || (ldo & 7) || (ldk1 & 7) || (ldv1 & 3)) return CE_ERR_ALIGN;
   const bool two = (K2 != nullptr && V2 != nullptr && len2 > 0);
   if (two && ((ldk2 & 7) || (ldv2 & 3))) return CE_ERR_ALIGN;
@@ -877,9 +1304,10 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
   const float sl2 = softmax_scale * 1.4426950408889634f;
   const bool pp = g_attn_nwave == 32 || (g_attn_nwave == 0 && !two);  // ping-pong (two wave groups one barrier apart)
   const bool pipe = g_attn_nwave == 16;
-  const int nwave = (pp || pipe || g_attn_nwave == 0) ? 8 : g_attn_nwave;
+  const bool sp = g_attn_nwave == 64;
+  const int nwave = (pp || pipe || sp || g_attn_nwave == 0) ? 8 : g_attn_nwave;
   const int nqb = (Nq + nwave * QW - 1) / (nwave * QW);
-  dim3 grid(nqb * H), block(nwave * 64);
+  dim3 grid(nqb * H, batch), block(nwave * 64);
 #define CE_ATTN_PIPE(TWO)                                                                                          \
   do {                                                                                                             \
     static bool done = false;                                                                                      \
@@ -891,6 +1319,36 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
     hipLaunchKernelGGL((attn_fwd_pipe_kernel<TWO>), grid, block, pipe_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, \
                        s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                         \
   } while (0)
+  if (sp) {
+#define CE_ATTN_SP(TWO)                                                                                              \
+  do {                                                                                                               \
+    static bool done = false;                                                                                        \
+    if (!done) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<TWO>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                sp_smem_bytes(TWO));                                                                 \
+      done = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<TWO>), grid, block, sp_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, s0, \
+                       s1, Nq, H, ldq, ldo, nqb, sl2);                                                               \
+  } while (0)
+#ifdef CE_ATTN_ABLATE
+#define CE_SP_ABL(A)                                                                                                   \
+  case A:                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<false, A>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                              sp_smem_bytes(false));                                                                   \
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<false, A>), grid, block, sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O, \
+                       s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                             \
+    return (int)hipGetLastError();
+    if (!two) switch (g_attn_ablate) {
+        CE_SP_ABL(1) CE_SP_ABL(2) CE_SP_ABL(3) CE_SP_ABL(4) CE_SP_ABL(6) CE_SP_ABL(7) CE_SP_ABL(8) CE_SP_ABL(10)
+        default: break;
+      }
+#undef CE_SP_ABL
+#endif
+    if (two) CE_ATTN_SP(true); else CE_ATTN_SP(false);
+#undef CE_ATTN_SP
+    return (int)hipGetLastError();
+  }
   if (pp) {
 #define CE_ATTN_PP(TWO)                                                                                              \
   do {                                                                                                               \
@@ -903,6 +1361,20 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
     hipLaunchKernelGGL((attn_fwd_pp_kernel<TWO>), grid, block, pp_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, s0, \
                        s1, Nq, H, ldq, ldo, nqb, sl2);                                                               \
   } while (0)
+#ifdef CE_ATTN_ABLATE
+#define CE_ATTN_ABL(A)                                                                                                  \
+  case A:                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<false, A>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                              pp_smem_bytes(false));                                                                    \
+    hipLaunchKernelGGL((attn_fwd_pp_kernel<false, A>), grid, block, pp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O, \
+                       s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                              \
+    return (int)hipGetLastError();
+    if (!two) switch (g_attn_ablate) {
+        CE_ATTN_ABL(1) CE_ATTN_ABL(2) CE_ATTN_ABL(3) CE_ATTN_ABL(4) CE_ATTN_ABL(5) CE_ATTN_ABL(6) CE_ATTN_ABL(7) CE_ATTN_ABL(8) CE_ATTN_ABL(9) CE_ATTN_ABL(10)
+        default: break;
+      }
+#undef CE_ATTN_ABL
+#endif
     if (two) CE_ATTN_PP(true); else CE_ATTN_PP(false);
 #undef CE_ATTN_PP
     return (int)hipGetLastError();
@@ -930,4 +1402,11 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
   }
 #undef CE_ATTN_LAUNCH
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
+                                 const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq,
+                                 int ldo, float softmax_scale, hipStream_t stream) {
+  return ce_attention_batched_bf16(Q, K1, V1, len1, ldk1, ldv1, K2, V2, len2, ldk2, ldv2, O, Nq, H, head_dim, ldq, ldo,
+                                   softmax_scale, 1, stream);
 }

@@ -33,6 +33,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_set_gemm_workspace": [_P, ctypes.c_size_t],
     "ce_set_attention_waves": [_I],
     "ce_attention_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P],
+    "ce_attention_batched_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_timestep_sinusoid": [_P, _P, _I, _P],
     "ce_gemv": [_P, _I, _P, _P, _P, _I, _I, _I, _P],
     "ce_modulation": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -210,8 +210,10 @@ def set_attention_waves(n: int) -> int:
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
-              k2: Optional[torch.Tensor] = None, v2: Optional[torch.Tensor] = None, scale: Optional[float] = None):
-    """q [Nq, H*128], k/v [Nkv, H*128] (row strides free) -> out [Nq, H*128]; optional 2nd kv segment."""
+              k2: Optional[torch.Tensor] = None, v2: Optional[torch.Tensor] = None, scale: Optional[float] = None,
+              batch: int = 1):
+    """q [Nq, H*128], k/v [Nkv, H*128] (row strides free) -> out [Nq, H*128]; optional 2nd kv segment.
+    batch > 1: every operand holds `batch` samples stacked along its rows (q [batch*Nq, ...], k [batch*Nkv, ...])."""
     for n, t in (("q", q), ("k", k), ("v", v)):
         _dev(t, torch.bfloat16, n)
     Nq, Dq, ldq = _rows(q, "q")
@@ -219,6 +221,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out
     L1, _, ldk = _rows(k, "k")
     L1v, _, ldv = _rows(v, "v")
     assert L1 == L1v
+    if batch < 1 or Nq % batch or L1 % batch or (k2 is not None and k2.shape[0] % batch):
+        raise ValueError(f"attention: row counts must be multiples of batch={batch}")
     if out is None:
         out = torch.empty((Nq, Dq), dtype=torch.bfloat16, device=q.device)
     _, _, ldo = _rows(out, "out")
@@ -230,9 +234,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out
     if scale is None:
         scale = head_dim ** -0.5
     st = _prof_begin()
-    _check(lib().ce_attention_bf16(_ptr(q), _ptr(k), _ptr(v), L1, ldk, ldv, _ptr(k2), _ptr(v2), L2, ldk2, ldv2, _ptr(out), Nq,
-                                   heads, head_dim, ldq, ldo, float(scale), _stream()), "ce_attention_bf16")
-    _prof_end(st, f"attention_{Nq}x{L1}+{L2}_h{heads}", 4.0 * Nq * (L1 + L2) * head_dim * heads)
+    nq, l1, l2 = Nq // batch, L1 // batch, L2 // batch
+    _check(lib().ce_attention_batched_bf16(_ptr(q), _ptr(k), _ptr(v), l1, ldk, ldv, _ptr(k2), _ptr(v2), l2, ldk2, ldv2, _ptr(out),
+                                           nq, heads, head_dim, ldq, ldo, float(scale), batch, _stream()), "ce_attention_bf16")
+    _prof_end(st, f"attention_{nq}x{l1}+{l2}_h{heads}" + (f"_b{batch}" if batch > 1 else ""),
+              4.0 * nq * (l1 + l2) * head_dim * heads * batch)
     return out
 
 

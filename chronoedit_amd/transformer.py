@@ -538,13 +538,12 @@ class DiTEngine:
             ops.ln_affine(x, mod[li, 0, 1], mod[li, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
             ops.gemm(ws.h, p.w_qkv, p.b_qkv, out=ws.qkv)
             ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)  # q and k, all samples
-            for b in range(B):
-                qkv = ws.qkv[rows[b]]
-                q, k, v = qkv[:, :D], qkv[:, D : 2 * D], qkv[:, 2 * D :]
-                if sp is None:
-                    ops.attention(q, k, v, H, out=ws.att[rows[b]])
-                else:  # Ulysses: tokens gathered / heads scattered around the attention kernel
-                    Dl = D // sp.world
+            if sp is None:  # all samples in one launch (stacked rows)
+                ops.attention(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :], H, out=ws.att, batch=B)
+            else:  # Ulysses: tokens gathered / heads scattered around the attention kernel
+                Dl = D // sp.world
+                for b in range(B):
+                    qkv = ws.qkv[rows[b]]
                     g = sp.scatter_heads(qkv, H, hd)  # [W*Nl, 3*Dl]
                     og = ops.attention(g[:, :Dl], g[:N, Dl : 2 * Dl], g[:N, 2 * Dl :], H // sp.world)
                     ws.att[rows[b]].copy_(sp.gather_heads(og, H, hd))
@@ -559,13 +558,10 @@ class DiTEngine:
             ops.gemm(hq, p.w_q2, p.b_q2, out=ws.q2)
             ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
             kv_t, kv_i = ctx.kv[li]
-            for b in range(B):
-                kt = kv_t[b * Tt : (b + 1) * Tt]
-                if kv_i is not None:
-                    ki = kv_i[b * Ti : (b + 1) * Ti]
-                    ops.attention(ws.q2[rows[b]], kt[:, :D], kt[:, D:], H, out=ws.att[rows[b]], k2=ki[:, :D], v2=ki[:, D:])
-                else:
-                    ops.attention(ws.q2[rows[b]], kt[:, :D], kt[:, D:], H, out=ws.att[rows[b]])
+            if kv_i is not None:
+                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, k2=kv_i[:, :D], v2=kv_i[:, D:], batch=B)
+            else:
+                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, batch=B)
             ops.gemm(ws.att, p.w_o2, p.b_o2, out=x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
             ops.ln_affine(x, mod[li, 0, 4], mod[li, 0, 3], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)

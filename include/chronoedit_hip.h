@@ -76,6 +76,14 @@ int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, i
                       const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq, int ldo,
                       float softmax_scale, hipStream_t stream);
 
+/* The same for `batch` samples stacked along the rows of every operand (sample b owns rows [b Nq, (b+1) Nq) of Q / O
+ * and rows [b len, (b+1) len) of each K/V segment; strides as above), in ONE launch: the cond / uncond forwards of a
+ * classifier-free-guidance step (pipeline_chronoedit.py:715-735) are independent, and 2x the workgroups per launch
+ * halves the partially filled last round.  batch == 1 is ce_attention_bf16. */
+int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
+                              const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq,
+                              int ldo, float softmax_scale, int batch, hipStream_t stream);
+
 /* Workgroup shape of ce_attention_bf16 (returns the previous value): 8 waves = 256 query rows per workgroup, one
  * workgroup per CU; 4 waves = 128 query rows, two independent workgroups per CU.  Host-side tuning knob. */
 int ce_set_attention_waves(int nwave);

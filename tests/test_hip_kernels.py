@@ -186,12 +186,33 @@ def _sdpa_ref(q, k, v, H):
     return o.transpose(0, 1).reshape(Nq, D)
 
 
-@pytest.fixture(params=[0, 32, 16, 8, 4], ids=["auto", "pingpong", "pipe8", "wg8", "wg4"])
+@pytest.fixture(params=[0, 64, 32, 16, 8, 4], ids=["auto", "swpipe", "pingpong", "pipe8", "wg8", "wg4"])
 def attn_waves(request):
     from chronoedit_amd import ops
     old = ops.set_attention_waves(request.param)
     yield request.param
     ops.set_attention_waves(old)
+
+
+@pytest.mark.parametrize("two_seg", [False, True])
+def test_attention_batched_equals_per_sample(two_seg, attn_waves):
+    """batch samples stacked along rows, one launch == one launch per sample (bit-exact)."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(14)
+    B, Nq, L1, L2, H = 3, 333, 200 if two_seg else 333, 77, 8
+    D = H * 128
+    q = torch.randn(B * Nq, D, generator=g).to(BF).to(dev)
+    kv1 = torch.randn(B * L1, 2 * D, generator=g).to(BF).to(dev)
+    kv2 = torch.randn(B * L2, 2 * D, generator=g).to(BF).to(dev)
+    kw = dict(k2=kv2[:, :D], v2=kv2[:, D:]) if two_seg else {}
+    out = ops.attention(q, kv1[:, :D], kv1[:, D:], H, batch=B, **kw)
+    for b in range(B):
+        kwb = dict(k2=kv2[b * L2:(b + 1) * L2, :D], v2=kv2[b * L2:(b + 1) * L2, D:]) if two_seg else {}
+        ref = ops.attention(q[b * Nq:(b + 1) * Nq], kv1[b * L1:(b + 1) * L1, :D], kv1[b * L1:(b + 1) * L1, D:], H, **kwb)
+        assert torch.equal(out[b * Nq:(b + 1) * Nq], ref), b
+    with pytest.raises(ValueError):
+        ops.attention(q[:-1], kv1[:, :D], kv1[:, D:], H, batch=B)
 
 
 @pytest.mark.parametrize("Nq,Nkv,H", [(64, 64, 2), (300, 257, 2), (1000, 1000, 8), (7200, 7200, 8), (33, 512, 3)])

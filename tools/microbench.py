@@ -89,6 +89,9 @@ def main():
             t8 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(32)
             tpp = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            ops.set_attention_waves(64)
+            tsp = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            print(f"attn {Nq}x{Nkv} H{H}: sw-pipelined (sp) {tsp*1e3:.3f} ms {4.0*Nq*Nkv*128*H/tsp/1e12:.1f} TF", flush=True)
             ops.set_attention_waves(16)
             t = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(0)
@@ -100,6 +103,17 @@ def main():
             except Exception as e:  # yardstick only
                 print("sdpa yardstick failed:", e)
                 t_ref = float("nan")
+            if Nq == 7200:  # the two samples of a batched-CFG step in one launch
+                qkv2 = torch.randn(2 * max(Nq, Nkv), 3 * D, generator=g).to(BF).to(dev)
+                out2 = torch.empty(2 * Nq, D, dtype=BF, device=dev)
+                if Nq == Nkv:
+                    tb = timeit(lambda: ops.attention(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], H, out=out2, batch=2), iters=5)
+                else:
+                    q2 = qkv2[:2 * Nq, :D]
+                    tb = timeit(lambda: ops.attention(q2, qkv2[:2 * Nkv, D:2 * D], qkv2[:2 * Nkv, 2 * D:], H, out=out2, batch=2), iters=5)
+                print(f"attn {Nq}x{Nkv} H{H} batch 2 (auto kernel): {tb*1e3:.3f} ms {2*4.0*Nq*Nkv*128*H/tb/1e12:.1f} TF", flush=True)
+                res[f"attn_{Nq}x{Nkv}x{H}_b2"] = {"ms": tb * 1e3, "tflops": 2 * 4.0 * Nq * Nkv * 128 * H / tb / 1e12}
+                del qkv2, out2
             fl = 4.0 * Nq * Nkv * 128 * H
             res[f"attn_{Nq}x{Nkv}x{H}"] = {"ms": t * 1e3, "tflops": fl / t / 1e12, "sdpa_ms": t_ref * 1e3, "sdpa_tflops": fl / t_ref / 1e12}
             print(f"attn {Nq}x{Nkv} H{H}: 4-wave {fl/t4/1e12:.1f} TF | 8-wave {fl/t8/1e12:.1f} TF | ping-pong {fl/tpp/1e12:.1f} TF | pipelined {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | torch sdpa {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
