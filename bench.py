@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--attn-kernel", type=int, default=0,
+                    help="(tuning) self-attention kernel knob of ce_set_attention_waves: 0 auto, 32 ping-pong, 64 sw-pipelined, 128 w4")
     return ap.parse_args()
 
 
@@ -130,6 +132,8 @@ def main():
     from oracle.dit_oracle import DiTConfig, flops_per_forward
 
     ops.lib()  # fail loudly if the HIP library is missing
+    if a.attn_kernel:
+        ops.set_attention_waves(a.attn_kernel)
     model = build_model(a.layers, dev)
     model.cache_context = a.cache_context
     ulysses = world > 1 and a.parallel == "ulysses"

@@ -638,6 +638,7 @@ extern "C" int ce_attn_read_ts(void* host) { return (int)hipMemcpyFromSymbol(hos
     const unsigned long long ts = __builtin_amdgcn_s_memtime();                                           \
     if (lane == 0) g_attn_ts[wave][t - 40][p] = ts;                                                       \
   }
+#define W4_STAMP(x) if (ABL == 10) x = __builtin_amdgcn_s_memtime()
 // sp kernel: stamp p of tile t (issue time of the s_memtime at that point of the stream)
 #define CE_SPSTAMP(p)                                                                                     \
   if (ABL == 10 && blockIdx.x == 300 && t >= 40 && t < 56) {                                              \
@@ -647,6 +648,7 @@ extern "C" int ce_attn_read_ts(void* host) { return (int)hipMemcpyFromSymbol(hos
 #else
 #define CE_STAMP(p)
 #define CE_SPSTAMP(p)
+#define W4_STAMP(x)
 #endif
 // ABL != 0 only in the ablation build (tools/attn_ablate.py, -DCE_ATTN_ABLATE): timing experiments that drop one
 // ingredient of the loop (results are garbage); the product library instantiates ABL == 0 only.
@@ -937,6 +939,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 //                   | 16 MFMA of O += V^T(t-1).P^T(t-1), each followed by 2 v_exp + 2 fma + 2 add of P(t) | pack P(t)
 // LDS: K double-buffered, V^T triple-buffered (V(t-1) is read while V(t+1) is written): one barrier per tile.
 // ------------------------------------------------------------------------------------------------
+constexpr float SP_RESCALE_THR = 8.0f;
 constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow the two K buffers
 constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
 constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 * QW * OST_ROW : SP_TILE_BYTES; }
@@ -1010,7 +1013,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f, alpha_prev = 1.0f;
+    float m_run = NEG_BIG, l_run = 0.f, alpha_prev = 1.0f, mc = NEG_BIG * scale_log2e;
     bf16x8 ppk[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
@@ -1155,10 +1158,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[f][r]);
       if (ABL != 6) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-      const float mc = m_new * scale_log2e;
-      m_run = m_new;
+      // Lazy running max: the max in use (m_run, mc) moves only when some row's tile max exceeds it by more than 2^8 in the
+      // exp2 domain; then the whole wave rescales.  P may reach 2^8 instead of 1 - harmless in fp32 / bf16 - and on random
+      // scores the exact form rescaled O (64 accumulator registers) in about every second tile (any of 32 rows).
+      float alpha = 1.0f;
+      if (__any((mx - m_run) * scale_log2e > SP_RESCALE_THR)) {
+        const float m_new = fmaxf(m_run, mx);
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+        mc = m_new * scale_log2e;
+        m_run = m_new;
+      }
       if (ABL == 10) asm volatile("" ::"v"(mc));
       CE_SPSTAMP(2);
       // O at the scale of m(t-1) before P(t-1).V(t-1) is added (rare after the first tiles)
@@ -1270,12 +1279,408 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// "w4": four waves per workgroup = ONE wave per SIMD, 64 query rows per wave as two independent 32-row sub-blocks A and B
+// that ping-pong inside a single instruction stream.  Measured basis (tools/probes/pipe_probe.hip, this box):
+//   * two waves on one SIMD do not overlap one wave's MFMAs with the other's VALU work (times add up), with or without
+//     s_setprio; even 2 v_exp per MFMA cost +11 % when two waves share the SIMD, +3 % with one wave;
+//   * one wave alone hides ~16 cycles of VALU issue (8 plain ops or 2 v_exp) under each 32-cycle 32x32x16 MFMA.
+// So the softmax of one sub-block is spread, unit by unit, under the K.Q^T MFMAs of the other, and the staging of the next
+// K / V tiles under the P.V MFMAs:
+//     tile t:  section 1  S_A(t) = K(t).Q_A^T         | softmax_B(t-1) -> P_B(t-1)           (rescale O_B if the max jumped)
+//              section 2  O_B += V^T(t-1).P_B^T(t-1)  | K(t+1), V(t+1) registers -> LDS, fetch K(t+2)
+//              section 3  S_B(t) = K(t).Q_B^T         | softmax_A(t) -> P_A(t), fetch V(t+2)
+//              barrier                                  (K(t+1), V(t+1) visible; K(t-1), V(t-2) free)
+//              section 4  O_A += V^T(t).P_A^T(t)      | K(t+1) fragment ring for the next section 1
+// Fragment rings (6 x ds_read_b128) are refilled inside the sections; the last six units of a section load the ring of the
+// next one, so no section starts behind an LDS round trip.  LDS images as in the sp kernel (2 K + 3 V^T padded tiles).
+//
+// Instruction order is pinned by hand: hipcc's DAG linearisation moved all 32 v_exp of a section behind its 16 MFMAs
+// (sched_barrier only constrains the later machine scheduler), so every MFMA is an `asm volatile` (source order, with a
+// "memory" clobber that also keeps the LDS / buffer traffic where it is written) and every softmax slice starts with an
+// empty asm that makes its inputs opaque at that point.  What hipcc does not know about an asm MFMA (cdna guide 5.7):
+//   * its D registers need 12 wait states before a non-MFMA reader: by construction every S / O read is a section away
+//     (the two rare paths that are not - tail mask, drain - open with s_nop);
+//   * a VALU-written A/B operand needs 2: P is packed at least one unit before its first MFMA and the P.V MFMAs open
+//     with s_nop 1.
+// Fragments travel as u32x4 (a <8 x bfloat> living across basic blocks is rebuilt with v_perm_b32 by hipcc).
+// Running max: lazy (only when some row's max jumps by more than 2^8 in the exp2 domain does the wave rescale O and l);
+// on random data the exact form rescaled in most tiles (any of 32 rows), at 64 accumulator registers a time.
+// ------------------------------------------------------------------------------------------------
+constexpr int w4_start(int u) { return u <= 2 ? 0 : (u >= 16 ? 32 : ((u - 2) * 32) / 14); }  // softmax elements done before unit u
+constexpr float W4_RESCALE_THR = 8.0f;
+
+#define W4_MFMA_QK0(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b) : "memory")
+#define W4_MFMA_QK(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b) : "memory")
+#define W4_MFMA_PV(acc, a, b) \
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b) : "memory")
+
+template <int ABL = 0>
+__global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg sg, int Nq, int H,
+                                                          int ldq, int ldo, int nqb, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  {
+    const size_t bz = blockIdx.y;
+    Q += bz * Nq * ldq;
+    O += bz * Nq * ldo;
+    sg.k += bz * sg.len * sg.ldk;
+    sg.v += bz * sg.len * sg.ldv;
+  }
+  constexpr int NWAVE = 4, WQ = 64, QB = WQ * NWAVE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * QB + wave * WQ;
+  const int hoff = head * HD;
+
+  pp_u4 qf[2][8];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const bf16* qrow = Q + (size_t)min(q0 + 32 * sb + l31, Nq - 1) * ldq + hoff + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[sb][ks] = *reinterpret_cast<const pp_u4*>(qrow + 16 * ks);
+  }
+  // retire the Q loads before the loop, and park the fragments in the accumulator half of the register file (MFMA B
+  // operands may be AGPRs): the arch VGPRs are needed for S, P and the fragment rings
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[sb][ks]));
+
+  // staging shares (256 threads): K rows k_row0 + 16 i (i < 4), 16-B chunk k_ck; V two 4(kv) x 4(dv) patches (kv quads
+  // v_kvq0 and v_kvq0 + 8), transposed into the (h, b) chunk order of the V^T image
+  const int k_ck = tid & 15, k_row0 = tid >> 4;
+  const int v_dvq = (tid & 1) | (((tid >> 4) & 15) << 1), v_kvq0 = (tid >> 1) & 7;
+  const int v_chunk0 = (v_kvq0 & ~3) | ((v_kvq0 & 1) << 1) | ((v_kvq0 >> 1) & 1);
+  const unsigned char* k_rd = smem + l31 * PK_ROW + hh * 16;
+  const unsigned char* v_rd = smem + SP_V0 + l31 * PV_ROW + hh * 16;
+  unsigned char* k_wr = smem + k_row0 * PK_ROW + k_ck * 16;                    // + buf*PK_TILE + i*16*PK_ROW
+  unsigned char* v_wr = smem + SP_V0 + (4 * v_dvq) * PV_ROW + v_chunk0 * 8;    // + buf*PV_TILE + j*64 + r*PV_ROW
+
+  const int ntiles = (sg.len + KVB - 1) / KVB;
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (sg.len - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + hoff), 0, (sg.len - 1) * sg.ldv * 2 + HD * 2, 0x00020000);
+  const int k_voff0 = k_row0 * sg.ldk * 2 + k_ck * 16;
+  const int v_voff0 = (4 * v_kvq0) * sg.ldv * 2 + v_dvq * 8;
+  const int k_tile_bytes = KVB * sg.ldk * 2, v_tile_bytes = KVB * sg.ldv * 2;
+  const int k_row16 = 16 * sg.ldk * 2, v_row = sg.ldv * 2;
+
+  f32x16 oacc[2][4], st[2][2];
+  pp_u4 ppk[2][4];
+  float m_run[2], l_run[2], mc[2], psum[2], mxp[2];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[sb][m][r] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) ppk[sb][s4] = pp_u4{0u, 0u, 0u, 0u};
+    m_run[sb] = NEG_BIG;
+    mc[sb] = NEG_BIG * scale_log2e;
+    l_run[sb] = 0.f;
+    psum[sb] = 0.f;
+    mxp[sb] = 0.f;
+  }
+  // "S_B(-1)": twice as negative as the initial running max, so that softmax_B(-1) yields P = 0 and changes nothing
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[1][f][r] = 2.0f * NEG_BIG;
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[0][f][r] = 0.f;
+
+  pp_u4 kreg[4];
+  pp_u2 vreg[2][4];
+  auto load_k_part = [&](int t, int i) {
+    kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff0, t * k_tile_bytes + i * k_row16, 0);
+  };
+  auto load_v_part = [&](int t, int j, int i) {
+    vreg[j][i] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_voff0, t * v_tile_bytes + (32 * j + i) * v_row, 0);
+  };
+  auto store_k_part = [&](int buf, int i) { *reinterpret_cast<pp_u4*>(k_wr + buf * PK_TILE + i * 16 * PK_ROW) = kreg[i]; };
+  auto store_v_part = [&](int buf, int j, int r) {  // dv row r of patch j
+    const int w = r >> 1;
+    uint32_t lo, hi;
+    if ((r & 1) == 0) {
+      lo = (vreg[j][0][w] & 0xffffu) | (vreg[j][1][w] << 16);
+      hi = (vreg[j][2][w] & 0xffffu) | (vreg[j][3][w] << 16);
+    } else {
+      lo = (vreg[j][0][w] >> 16) | (vreg[j][1][w] & 0xffff0000u);
+      hi = (vreg[j][2][w] >> 16) | (vreg[j][3][w] & 0xffff0000u);
+    }
+    pp_u2 val = {lo, hi};
+    *reinterpret_cast<pp_u2*>(v_wr + buf * PV_TILE + j * 64 + r * PV_ROW) = val;
+  };
+
+  // O *= alpha and l *= alpha for the rows whose max jumped; written on AGPR operands so that the accumulators stay in
+  // the accumulator file on the common path
+  auto rescale = [&](int sb, float alpha) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float x = oacc[sb][m][r], tmp;
+        asm volatile("v_accvgpr_read_b32 %1, %0\n\ts_nop 0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1"
+                     : "+a"(x), "=&v"(tmp)
+                     : "v"(alpha));
+        oacc[sb][m][r] = x;
+      }
+  };
+  // softmax of sub-block sb, slice of unit u (see w4_start): row max in units 0-1, then exp2 / row sum / pack
+  auto sm_slice = [&](int sb, int u) {
+    if (u == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(st[sb][0][r]));
+      float m = st[sb][0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = fmaxf(m, st[sb][0][r]);
+      mxp[sb] = m;
+      asm volatile("" : "+v"(mxp[sb]));  // computed HERE (hipcc otherwise sinks pure VALU work towards its first use)
+    } else if (u == 1) {
+      asm volatile("" : "+v"(mxp[sb]));
+      float m = mxp[sb];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, st[sb][1][r]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+      mxp[sb] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      psum[sb] = 0.f;
+      asm volatile("" : "+v"(mxp[sb]));
+    } else {
+      const int n0 = w4_start(u), n1 = w4_start(u + 1), np = w4_start(u - 1);
+#pragma unroll
+      for (int n = n0; n < n1; ++n) asm volatile("" : "+v"(st[sb][n >> 4][n & 15]));
+#pragma unroll
+      for (int n = n0; n < n1; ++n)
+        st[sb][n >> 4][n & 15] = __builtin_amdgcn_exp2f(fmaf(st[sb][n >> 4][n & 15], scale_log2e, -mc[sb]));
+#pragma unroll
+      for (int n = np; n < n0; ++n) psum[sb] += st[sb][n >> 4][n & 15];  // one unit behind the v_exp
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+        if (8 * s4 + 8 <= n0 && 8 * s4 + 8 > np) {  // P rows of k-step s4 complete since the previous unit: pack them
+          const int f = s4 >> 1, rb = 8 * (s4 & 1);
+          ppk[sb][s4] = pp_u4{pack_bf16(st[sb][f][rb + 0], st[sb][f][rb + 1]), pack_bf16(st[sb][f][rb + 2], st[sb][f][rb + 3]),
+                              pack_bf16(st[sb][f][rb + 4], st[sb][f][rb + 5]), pack_bf16(st[sb][f][rb + 6], st[sb][f][rb + 7])};
+          asm volatile("" : "+v"(ppk[sb][s4]));
+        }
+      // results pinned at the end of the unit: hipcc otherwise sinks the exp2 chains below the section, next to their uses
+#pragma unroll
+      for (int n = n0; n < n1; ++n) asm volatile("" : "+v"(st[sb][n >> 4][n & 15]));
+      asm volatile("" : "+v"(psum[sb]));
+    }
+  };
+  // between units 1 and 2: does any row's max exceed the one in use by more than the threshold?  (first tile: always)
+  auto sm_update_max = [&](int sb) {
+    const float grow = (mxp[sb] - m_run[sb]) * scale_log2e;
+    if (__any(grow > W4_RESCALE_THR)) {
+      const float m_new = fmaxf(m_run[sb], mxp[sb]);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[sb] - m_new) * scale_log2e);
+      m_run[sb] = m_new;
+      mc[sb] = m_new * scale_log2e;
+      l_run[sb] *= alpha;
+      rescale(sb, alpha);
+    }
+  };
+  auto sm_finish = [&](int sb) {  // what the last unit left over: its row-sum adds, the last pack, the running sum
+#pragma unroll
+    for (int n = w4_start(15); n < 32; ++n) psum[sb] += st[sb][n >> 4][n & 15];
+    ppk[sb][3] = pp_u4{pack_bf16(st[sb][1][8], st[sb][1][9]), pack_bf16(st[sb][1][10], st[sb][1][11]),
+                       pack_bf16(st[sb][1][12], st[sb][1][13]), pack_bf16(st[sb][1][14], st[sb][1][15])};
+    l_run[sb] += psum[sb];
+  };
+  auto mask_tail = [&](int sb, int t) {
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // S was written by asm MFMAs a moment ago
+    const int base = t * KVB + 4 * hh;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
+        if (kv >= sg.len) st[sb][f][r] = NEG_BIG;
+      }
+  };
+
+#define W4_LDK(kb, i) (*reinterpret_cast<const pp_u4*>((kb) + ((i) & 1) * 32 * PK_ROW + ((i) >> 1) * 32))
+#define W4_LDV(vb, u) (*reinterpret_cast<const pp_u4*>((vb) + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
+  constexpr int RING = 6;
+  pp_u4 kf[RING], vf[RING];
+
+  // ---- prologue: tile 0 -> K buffer 0 / V buffer 0, V buffer 2 = "V(-1)" (zeros), tile 1 fetched, K(0) ring loaded
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_k_part(0, i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_v_part(0, j, i);
+  {
+    const pp_u4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < PV_TILE / 16; i += NWAVE * 64) *reinterpret_cast<pp_u4*>(smem + SP_V0 + 2 * PV_TILE + i * 16) = z;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) store_k_part(0, i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) store_v_part(0, j, r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_k_part(1, i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_v_part(1, j, i);
+  CE_EPOCH_BARRIER();
+#pragma unroll
+  for (int i = 0; i < RING; ++i) kf[i] = W4_LDK(k_rd, i);
+#pragma unroll
+  for (int i = 0; i < RING; ++i) vf[i] = pp_u4{0u, 0u, 0u, 0u};
+  int vprev = 2, vcur = 0;
+
+  for (int t = 0; t < ntiles; ++t) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+    const int vnext = 3 - vprev - vcur;
+    const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
+    const unsigned char* kb_n = k_rd + ((t + 1) & 1) * PK_TILE;
+    const unsigned char* vb_p = v_rd + vprev * PV_TILE;
+    const unsigned char* vb_c = v_rd + vcur * PV_TILE;
+    const int kbuf_n = (t + 1) & 1;
+
+    W4_STAMP(ts0);
+    // ================= section 1: S_A(t) | softmax_B(t-1)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (u == 2) sm_update_max(1);
+      if (u < 2) W4_MFMA_QK0(st[0][u & 1], kf[u % RING], qf[0][u >> 1]);
+      else W4_MFMA_QK(st[0][u & 1], kf[u % RING], qf[0][u >> 1]);
+      if (u + RING < 16) kf[u % RING] = W4_LDK(kb, u + RING);
+      else vf[u + RING - 16] = W4_LDV(vb_p, u + RING - 16);
+      sm_slice(1, u);
+    }
+    sm_finish(1);
+    if ((t + 1) * KVB > sg.len) mask_tail(0, t);
+
+    W4_STAMP(ts1);
+    // ================= section 2: O_B += V^T(t-1).P_B^T(t-1) | stage tile t+1 into LDS, fetch K(t+2)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      W4_MFMA_PV(oacc[1][u & 3], vf[u % RING], ppk[1][u >> 2]);
+      if (u + RING < 16) vf[u % RING] = W4_LDV(vb_p, u + RING);
+      else kf[u + RING - 16] = W4_LDK(kb, u + RING - 16);
+      if (u < 8 && (u & 1)) store_k_part(kbuf_n, u >> 1);
+      if (u >= 8) store_v_part(vnext, (u - 8) >> 2, (u - 8) & 3);
+      if (u >= 9 && (u & 1)) load_k_part(t + 2, (u - 9) >> 1);
+    }
+
+    W4_STAMP(ts2);
+    // ================= section 3: S_B(t) | softmax_A(t), fetch V(t+2)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (u == 2) sm_update_max(0);
+      if (u < 2) W4_MFMA_QK0(st[1][u & 1], kf[u % RING], qf[1][u >> 1]);
+      else W4_MFMA_QK(st[1][u & 1], kf[u % RING], qf[1][u >> 1]);
+      if (u + RING < 16) kf[u % RING] = W4_LDK(kb, u + RING);
+      else vf[u + RING - 16] = W4_LDV(vb_c, u + RING - 16);
+      sm_slice(0, u);
+      if (u < 8) load_v_part(t + 2, u >> 2, u & 3);
+    }
+    sm_finish(0);
+    if ((t + 1) * KVB > sg.len) mask_tail(1, t);
+    W4_STAMP(ts3);
+    CE_EPOCH_BARRIER();  // tile t+1 visible to every wave; K(t-1) / V(t-2) buffers free for the stores of the next iteration
+    W4_STAMP(ts4);
+
+    // ================= section 4: O_A += V^T(t).P_A^T(t) | K(t+1) ring for the next section 1
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      W4_MFMA_PV(oacc[0][u & 3], vf[u % RING], ppk[0][u >> 2]);
+      if (u + RING < 16) vf[u % RING] = W4_LDV(vb_c, u + RING);
+      else kf[u + RING - 16] = W4_LDK(kb_n, u + RING - 16);
+    }
+#ifdef CE_ATTN_ABLATE
+    if (ABL == 10 && blockIdx.x == 300 && t >= 40 && t < 56) {
+      const unsigned long long ts5 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        g_attn_ts6[wave][t - 40][0] = ts0;
+        g_attn_ts6[wave][t - 40][1] = ts1;
+        g_attn_ts6[wave][t - 40][2] = ts2;
+        g_attn_ts6[wave][t - 40][3] = ts3;
+        g_attn_ts6[wave][t - 40][4] = ts4;
+        g_attn_ts6[wave][t - 40][5] = ts5;
+      }
+    }
+#endif
+    vprev = vcur;
+    vcur = vnext;
+  }
+  // ---- drain: softmax_B(ntiles-1), then P_B.V of the last tile (its V buffer is now vprev)
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    if (u == 2) sm_update_max(1);
+    sm_slice(1, u);
+  }
+  sm_finish(1);
+  {
+    const unsigned char* vb = v_rd + vprev * PV_TILE;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const pp_u4 vfd = W4_LDV(vb, u);
+      W4_MFMA_PV(oacc[1][u & 3], vfd, ppk[1][u >> 2]);
+    }
+  }
+#undef W4_LDK
+#undef W4_LDV
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // O was written by asm MFMAs
+  CE_EPOCH_BARRIER();  // every wave is done with the tile buffers: the O staging overlays them
+
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    unsigned char* ost = smem + (size_t)(wave * WQ + 32 * sb + l31) * OST_ROW;
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run[sb]), __float_as_uint(l_run[sb]), false, false);
+    const float inv = 1.0f / (__uint_as_float(sw[0]) + __uint_as_float(sw[1]));
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const uint32_t w0 = pack_bf16(oacc[sb][m][4 * a + 0] * inv, oacc[sb][m][4 * a + 1] * inv);
+        const uint32_t w1 = pack_bf16(oacc[sb][m][4 * a + 2] * inv, oacc[sb][m][4 * a + 3] * inv);
+        u32x2 val = {w0, w1};
+        *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = q0 + rl;
+    if (q < Nq) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * WQ + rl) * OST_ROW + cc * 16);
+      *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    }
+  }
+}
+#undef W4_MFMA_QK0
+#undef W4_MFMA_QK
+#undef W4_MFMA_PV
+
 }  // namespace
 
-// waves per workgroup: 8 (256 query rows, 1 workgroup/CU) or 4 (128 query rows, 2 independent workgroups/CU)
-// 16 selects the software-pipelined 8-wave kernel (P.V of tile t-1 under the softmax of tile t), 32 the ping-pong kernel;
-// 0 = automatic: ping-pong for single-segment (self) attention (measured 0.90-0.91 PFLOP/s at 7200 keys, 1.02 at 28800,
-// vs 0.77-0.79 / 0.93 for the plain 8-wave kernel), plain 8-wave for the short two-segment cross-attention
+// Kernel selection (host-side knob): 0 = automatic = 64; 4 / 8 = plain kernel with 4 / 8 waves per workgroup; 16 = first
+// software-pipelined kernel (XOR-swizzled LDS); 32 = ping-pong; 64 = software-pipelined on the padded LDS images, lazy
+// running max ("sp"; in the batched-CFG step 0.89-0.91 PFLOP/s self-attention and 0.66 cross-attention, vs 0.89 / 0.62 for
+// ping-pong + plain); 128 = one wave per SIMD, 64 query rows per wave ("w4", single-segment only; 0.84-0.85 in the step).
 static int g_attn_nwave = 0;
 #ifdef CE_ATTN_ABLATE
 static int g_attn_ablate = 0;
@@ -1283,7 +1688,7 @@ extern "C" void ce_attn_set_ablation(int a) { g_attn_ablate = a; }
 #endif
 extern "C" int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
-  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16 || nwave == 32 || nwave == 64) g_attn_nwave = nwave;
+  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16 || nwave == 32 || nwave == 64 || nwave == 128) g_attn_nwave = nwave;
   return old;
 }
 
@@ -1302,10 +1707,10 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
   KVSeg s0{(const bf16*)K1, (const bf16*)V1, len1, ldk1, ldv1};
   KVSeg s1{(const bf16*)K2, (const bf16*)V2, two ? len2 : 0, ldk2, ldv2};
   const float sl2 = softmax_scale * 1.4426950408889634f;
-  const bool pp = g_attn_nwave == 32 || (g_attn_nwave == 0 && !two);  // ping-pong (two wave groups one barrier apart)
+  const bool pp = g_attn_nwave == 32;  // ping-pong (two wave groups one barrier apart)
   const bool pipe = g_attn_nwave == 16;
-  const bool sp = g_attn_nwave == 64;
-  const int nwave = (pp || pipe || sp || g_attn_nwave == 0) ? 8 : g_attn_nwave;
+  const bool sp = g_attn_nwave == 64 || g_attn_nwave == 0;  // default: software-pipelined on the padded LDS images
+  const int nwave = (pp || pipe || sp || g_attn_nwave == 0 || g_attn_nwave == 128) ? 8 : g_attn_nwave;
   const int nqb = (Nq + nwave * QW - 1) / (nwave * QW);
   dim3 grid(nqb * H, batch), block(nwave * 64);
 #define CE_ATTN_PIPE(TWO)                                                                                          \
@@ -1319,6 +1724,24 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
     hipLaunchKernelGGL((attn_fwd_pipe_kernel<TWO>), grid, block, pipe_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, \
                        s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                         \
   } while (0)
+  if (g_attn_nwave == 128 && !two) {  // one wave per SIMD, 64 query rows per wave
+#ifdef CE_ATTN_ABLATE
+    if (g_attn_ablate == 10) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_w4_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_TILE_BYTES);
+      hipLaunchKernelGGL((attn_fwd_w4_kernel<10>), grid, dim3(256), SP_TILE_BYTES, stream, (const bf16*)Q, (bf16*)O, s0, Nq, H, ldq,
+                         ldo, nqb, sl2);
+      return (int)hipGetLastError();
+    }
+#endif
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_w4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SP_TILE_BYTES);
+      done = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_w4_kernel<0>), grid, dim3(256), SP_TILE_BYTES, stream, (const bf16*)Q, (bf16*)O, s0, Nq, H, ldq,
+                       ldo, nqb, sl2);
+    return (int)hipGetLastError();
+  }
   if (sp) {
 #define CE_ATTN_SP(TWO)                                                                                              \
   do {                                                                                                               \

@@ -134,7 +134,40 @@ def stamps_sp():
                   f"pack {a[4] - a[3]:5d}  to-barrier {nxt[5] - a[4]:5d}  wait {nxt[0] - nxt[5]:5d}  total {nxt[0] - a[0]:5d}")
 
 
+def stamps_w4():
+    """w4 kernel, ABL 10: stamps of workgroup 300, tiles 40..55 at the section boundaries."""
+    import numpy as np
+    import torch
+    N, H, D = 7200, 40, 40 * 128
+    lib = ctypes.CDLL(LIB)
+    dev = torch.device("cuda:0")
+    qkv = torch.randn(N, 3 * D, device=dev).to(torch.bfloat16)
+    out = torch.empty(N, D, dtype=torch.bfloat16, device=dev)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    lib.ce_attention_bf16.argtypes = [P, P, P, I, I, I, P, P, I, I, I, P, I, I, I, I, I, ctypes.c_float, P]
+    lib.ce_attn_read_ts6.argtypes = [P]
+    lib.ce_set_attention_waves(128)
+    lib.ce_attn_set_ablation(10)
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + 2 * D, qkv.data_ptr() + 4 * D
+    for _ in range(3):
+        rc = lib.ce_attention_bf16(q, k, v, N, 3 * D, 3 * D, None, None, 0, 0, 0, out.data_ptr(), N, H, 128, 3 * D, D, 128 ** -0.5,
+                                   torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    torch.cuda.synchronize()
+    ts = np.zeros((8, 16, 6), dtype=np.uint64)
+    assert lib.ce_attn_read_ts6(ts.ctypes.data) == 0
+    ts = ts.astype(np.int64)
+    for w in range(4):
+        print(f"wave {w}: S_A|smB  PV_B|stage  S_B|smA  barrier  PV_A  total")
+        for t in range(1, 15):
+            a = ts[w, t]
+            print(f"  tile {40 + t}: {a[1] - a[0]:6d} {a[2] - a[1]:6d} {a[3] - a[2]:6d} {a[4] - a[3]:6d} {a[5] - a[4]:6d}   {ts[w, t + 1, 0] - a[0]:6d}")
+
+
 if __name__ == "__main__":
+    if sys.argv[1:2] == ["stamps_w4"]:
+        stamps_w4()
+        sys.exit(0)
     if sys.argv[1:2] == ["stamps_sp"]:
         stamps_sp()
         sys.exit(0)

@@ -89,6 +89,9 @@ def main():
             t8 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(32)
             tpp = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            ops.set_attention_waves(128)
+            tw4 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            print(f"attn {Nq}x{Nkv} H{H}: one-wave-per-SIMD (w4) {tw4*1e3:.3f} ms {4.0*Nq*Nkv*128*H/tw4/1e12:.1f} TF", flush=True)
             ops.set_attention_waves(64)
             tsp = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             print(f"attn {Nq}x{Nkv} H{H}: sw-pipelined (sp) {tsp*1e3:.3f} ms {4.0*Nq*Nkv*128*H/tsp/1e12:.1f} TF", flush=True)

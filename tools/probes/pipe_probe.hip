@@ -89,14 +89,14 @@ template <int NE, int NV, bool PRIO>
 __global__ __launch_bounds__(512) void probe_mix(int iters, float* out) { body_mix<NE, NV, PRIO>(iters, out, threadIdx.x); }
 
 template <int NE, int NV, bool PRIO>
-float run_mix(int iters, float* out) {
+float run_mix(int iters, float* out, int threads = 512) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  probe_mix<NE, NV, PRIO><<<256, 512>>>(iters, out);
+  probe_mix<NE, NV, PRIO><<<256, threads>>>(iters, out);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  probe_mix<NE, NV, PRIO><<<256, 512>>>(iters, out);
+  probe_mix<NE, NV, PRIO><<<256, threads>>>(iters, out);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -143,6 +143,8 @@ int main() {
 #define MIX(NE, NV) printf("8 waves, per MFMA %d v_exp + %d v_fma: %8.3f ms | with s_setprio 1 on the VALU part: %8.3f ms\n", NE, NV, \
                           run_mix<NE, NV, false>(it, out), run_mix<NE, NV, true>(it, out));
     MIX(0, 0) MIX(2, 0) MIX(2, 4) MIX(4, 0) MIX(2, 8) MIX(4, 8) MIX(0, 8) MIX(0, 16)
+#define MIX1(NE, NV) printf("4 waves (one per SIMD), per MFMA %d v_exp + %d v_fma: %8.3f ms\n", NE, NV, run_mix<NE, NV, false>(it, out, 256));
+    MIX1(0, 0) MIX1(2, 0) MIX1(2, 4) MIX1(4, 0) MIX1(2, 8) MIX1(4, 8) MIX1(0, 8) MIX1(0, 16)
     printf("--\n");
   }
   return 0;
