@@ -104,7 +104,11 @@ __device__ __forceinline__ void mma_half(f32x4 (&acc)[4][2], const bf16x8 (&a)[4
 }
 
 #define CE_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
+#if defined(CE_GEMM_ABL) && CE_GEMM_ABL == 6  // LDS-DMA stream with no counted waits at all: how fast can the path go?
+#define CE_VM(N) asm volatile("s_waitcnt vmcnt(63)" ::: "memory")
+#else
 #define CE_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#endif
 #define CE_BAR() __builtin_amdgcn_s_barrier()
 
 __device__ __forceinline__ void tile_origin(int wg, int tiles_m, int tiles_n, int& m0, int& n0) {
@@ -260,43 +264,68 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   read_b<S_B1, 0>(smem, wn, fr, fg, b1k0);
   read_b<S_B1, 1>(smem, wn, fr, fg, b1k1);
 
+  // CE_GEMM_ABL (tools/gemm_ablate.py only; results are garbage, durations are the point): 1 no barriers in the loop,
+  // 2 no LDS-DMA staging in the loop, 3 no fragment reads in the loop, 4 no MFMAs, 5 = 1 + 3 + 4 (LDS-DMA stream only)
+#if defined(CE_GEMM_ABL) && CE_GEMM_ABL == 2
+#define CE_STAGE(SLOT_EVEN, SLOT_ODD, CURV, TILEV)
+#else
 #define CE_STAGE(SLOT_EVEN, SLOT_ODD, CURV, TILEV) \
   if (CURV == 0) stage_half<SLOT_EVEN>(smem, st, (TILEV)); else stage_half<SLOT_ODD>(smem, st, (TILEV));
+#endif
+#if defined(CE_GEMM_ABL) && (CE_GEMM_ABL == 1 || CE_GEMM_ABL == 5 || CE_GEMM_ABL == 6)
+#define CE_LBAR()
+#else
+#define CE_LBAR() CE_BAR()
+#endif
+#if defined(CE_GEMM_ABL) && (CE_GEMM_ABL == 3 || CE_GEMM_ABL == 5 || CE_GEMM_ABL == 6)
+#define CE_RDA(S, K, R) asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]))
+#define CE_RDB(S, K, R) asm volatile("" : "+v"(R[0]), "+v"(R[1]))
+#else
+#define CE_RDA(S, K, R) read_a<S, K>(smem, wm, fr, fg, R)
+#define CE_RDB(S, K, R) read_b<S, K>(smem, wn, fr, fg, R)
+#endif
+#if defined(CE_GEMM_ABL) && (CE_GEMM_ABL == 4 || CE_GEMM_ABL == 5 || CE_GEMM_ABL == 6)
+#define CE_MMA(ACC, A, B) asm volatile("" : "+v"(ACC[0][0]), "+v"(ACC[3][1]) : "v"(A[0]), "v"(A[3]), "v"(B[0]), "v"(B[1]))
+#else
+#define CE_MMA(ACC, A, B) mma_half(ACC, A, B)
+#endif
 
   // The LDS-DMA issue (address math + M0 + 2 global_load_lds) sits BETWEEN the two 8-MFMA k-steps of a phase, so it
   // overlaps the matrix pipe instead of extending the barrier-to-first-MFMA gap.
 #define CE_TILE_PHASES(CUR, NXT, TILE)                                                                      \
   /* phase 1: Q00 */                                                                                        \
-  CE_BAR();                                                                                                 \
+  CE_LBAR();                                                                                                 \
   CE_LGKM0();                                                                                               \
-  mma_half(acc[0][0], ra0, b0k0);                                                                           \
+  CE_MMA(acc[0][0], ra0, b0k0);                                                                           \
   CE_STAGE(4 + S_A1, S_A1, CUR, (TILE) + 1)                                                                 \
-  mma_half(acc[0][0], ra1, b0k1);                                                                           \
-  /* phase 2: Q01, refill the A registers with A-sub1 as they drain */                                      \
-  CE_BAR();                                                                                                 \
-  mma_half(acc[0][1], ra0, b1k0);                                                                           \
-  read_a<CUR * 4 + S_A1, 0>(smem, wm, fr, fg, ra0);                                                         \
+  CE_MMA(acc[0][0], ra1, b0k1);                                                                           \
+  /* phase 2: Q01, refill the A registers with A-sub1 as they drain; A-sub1 of this tile (staged in phase 1 of   \
+     the previous tile, eight DMA instructions ago) is first read here, so its counted wait sits here too */     \
+  CE_VM(8);                                                                                                 \
+  CE_LBAR();                                                                                                 \
+  CE_MMA(acc[0][1], ra0, b1k0);                                                                           \
+  CE_RDA(CUR * 4 + S_A1, 0, ra0);                                                         \
   CE_STAGE(S_A0, 4 + S_A0, CUR, (TILE) + 2)                                                                 \
-  mma_half(acc[0][1], ra1, b1k1);                                                                           \
-  read_a<CUR * 4 + S_A1, 1>(smem, wm, fr, fg, ra1);                                                         \
+  CE_MMA(acc[0][1], ra1, b1k1);                                                                           \
+  CE_RDA(CUR * 4 + S_A1, 1, ra1);                                                         \
   /* phase 3: Q11 */                                                                                        \
-  CE_BAR();                                                                                                 \
+  CE_LBAR();                                                                                                 \
   CE_LGKM0();                                                                                               \
-  mma_half(acc[1][1], ra0, b1k0);                                                                           \
+  CE_MMA(acc[1][1], ra0, b1k0);                                                                           \
   CE_STAGE(S_B0, 4 + S_B0, CUR, (TILE) + 2)                                                                 \
-  mma_half(acc[1][1], ra1, b1k1);                                                                           \
+  CE_MMA(acc[1][1], ra1, b1k1);                                                                           \
   /* phase 4: Q10; the counted wait retires the NEXT tile's slots, whose fragments are prefetched here */   \
-  CE_VM(4);                                                                                                 \
-  CE_BAR();                                                                                                 \
-  read_b<NXT * 4 + S_B1, 0>(smem, wn, fr, fg, b1k0);                                                        \
-  read_b<NXT * 4 + S_B1, 1>(smem, wn, fr, fg, b1k1);                                                        \
-  mma_half(acc[1][0], ra0, b0k0);                                                                           \
-  read_a<NXT * 4 + S_A0, 0>(smem, wm, fr, fg, ra0);                                                         \
-  read_b<NXT * 4 + S_B0, 0>(smem, wn, fr, fg, b0k0);                                                        \
+  CE_VM(6);                                                                                                 \
+  CE_LBAR();                                                                                                 \
+  CE_RDB(NXT * 4 + S_B1, 0, b1k0);                                                        \
+  CE_RDB(NXT * 4 + S_B1, 1, b1k1);                                                        \
+  CE_MMA(acc[1][0], ra0, b0k0);                                                                           \
+  CE_RDA(NXT * 4 + S_A0, 0, ra0);                                                         \
+  CE_RDB(NXT * 4 + S_B0, 0, b0k0);                                                        \
   CE_STAGE(S_B1, 4 + S_B1, CUR, (TILE) + 2)                                                                 \
-  mma_half(acc[1][0], ra1, b0k1);                                                                           \
-  read_a<NXT * 4 + S_A0, 1>(smem, wm, fr, fg, ra1);                                                         \
-  read_b<NXT * 4 + S_B0, 1>(smem, wn, fr, fg, b0k1);
+  CE_MMA(acc[1][0], ra1, b0k1);                                                                           \
+  CE_RDA(NXT * 4 + S_A0, 1, ra1);                                                         \
+  CE_RDB(NXT * 4 + S_B0, 1, b0k1);
 
   const int npairs = ktn >> 1;
   for (int it = 0; it < npairs; ++it) {
