@@ -203,6 +203,15 @@ class ChronoEditPipeline:
     def __init__(self, vae, transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPCMultistepScheduler):
         self.vae, self.transformer, self.scheduler = vae, transformer, scheduler
 
+    # LoRA entry points of the reference runner (run_inference_diffusers.py:370-374); the adapters target the transformer
+    def load_lora_weights(self, path_or_state, adapter_name: str = "default"):
+        self.transformer.load_lora_weights(path_or_state, adapter_name=adapter_name)
+        return self
+
+    def fuse_lora(self, adapter_names=None, lora_scale: float = 1.0):
+        self.transformer.fuse_lora(adapter_names=adapter_names, lora_scale=lora_scale)
+        return self
+
     @torch.no_grad()
     def __call__(self, image: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor],
                  image_embeds: Optional[torch.Tensor], num_frames: int = 5, num_inference_steps: int = 50, guidance_scale: float = 5.0,

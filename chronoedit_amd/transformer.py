@@ -13,6 +13,7 @@ libchronoedit_hip.so launches on the current stream (no torch math on the hot pa
 """
 from __future__ import annotations
 
+import inspect
 import math
 from dataclasses import dataclass
 from types import SimpleNamespace
@@ -21,7 +22,8 @@ from typing import Any, Dict, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, weights
+from .weights import LoraMixin
 
 
 @dataclass
@@ -132,7 +134,7 @@ class ConditionEmbedderParams(nn.Module):
             self.image_embedder = _ImageEmbedding(image_embed_dim, dim, device=device, dtype=dtype)
 
 
-class ChronoEditTransformer3DModel(nn.Module):
+class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
     """MI355X drop-in for the reference class of the same name (transformer_chronoedit.py:298)."""
 
     _supports_gradient_checkpointing = False
@@ -196,6 +198,24 @@ class ChronoEditTransformer3DModel(nn.Module):
     @property
     def device(self) -> torch.device:
         return self.proj_out.weight.device
+
+    @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, torch_dtype: torch.dtype = torch.bfloat16,
+                        device=None, **unused) -> "ChronoEditTransformer3DModel":
+        """diffusers-layout checkpoint directory -> model (run_inference_diffusers.py:349-353): ``config.json`` gives the
+        constructor arguments, the safetensors shard(s) the parameters; fp32 islands stay fp32 (``_keep_in_fp32_modules``)
+        and ``norm_added_q`` keys are ignored (transformer_chronoedit.py:338-339)."""
+        cfg = weights.read_config(path, subfolder)
+        known = set(inspect.signature(cls.__init__).parameters) - {"self", "device", "dtype"}
+        model = cls(**{k: v for k, v in cfg.items() if k in known}, device=device, dtype=torch_dtype)
+        sd = weights.load_state_dict_files(weights.shard_files(path, subfolder))
+        weights.assign_state_dict(model, sd, ignore_unexpected=cls._keys_to_ignore_on_load_unexpected)
+        model.invalidate()
+        return model
+
+    def save_pretrained(self, path: str, max_shard_bytes: int = 5 << 30):
+        """config.json + safetensors shard(s) in the layout from_pretrained reads."""
+        return weights.save_pretrained(self, path, dict(vars(self.config)), max_shard_bytes, "ChronoEditTransformer3DModel")
 
     def load_synthetic_(self, params: Dict[str, torch.Tensor]):
         """Copy a {diffusers key: tensor} dict (e.g. oracle.make_synthetic_params) into the tree."""

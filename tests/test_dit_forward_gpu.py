@@ -112,3 +112,35 @@ def test_full_width_block_at_720p_vs_fp32_reference():
     print(f"full-width block @N=7200: rel-L2 vs fp32 {e:.3e}")
     assert out.shape == (1, 16, 2, 90, 160) and torch.isfinite(out.float()).all()
     assert e < 1e-2
+
+
+def test_lora_fuse_and_checkpoint_roundtrip_drive_the_engine(tmp_path):
+    """Weights edited through the reference's entry points (fuse_lora, from_pretrained) reach the packed HIP operands:
+    the forward of the fused model == the forward of a fresh model loaded from its saved checkpoint, and both move away
+    from the un-fused output by what the fp32 oracle predicts for the same weight edit."""
+    cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    p_bf = O.make_synthetic_params(cfg, dtype=torch.bfloat16)
+    model = _build(cfg, p_bf)
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 16, 16, dtype=torch.bfloat16)
+    ts = torch.tensor([500], device="cuda:0")
+    args = (lat.cuda(), ts, text.cuda(), image.cuda())
+    base = model(*args, return_dict=False)[0].clone()
+    g = torch.Generator().manual_seed(5)
+    lora = {}
+    for t in ["blocks.0.attn1.to_q", "blocks.0.attn1.to_v", "blocks.1.ffn.net.0.proj", "blocks.1.attn2.to_out.0"]:
+        lin = dict(model.named_modules())[t]
+        lora[f"transformer.{t}.lora_A.weight"] = torch.randn(8, lin.in_features, generator=g) * 0.05
+        lora[f"transformer.{t}.lora_B.weight"] = torch.randn(lin.out_features, 8, generator=g) * 0.05
+    model.load_lora_weights(lora, adapter_name="distill")
+    model.fuse_lora(adapter_names=["distill"], lora_scale=1.0)
+    fused = model(*args, return_dict=False)[0].clone()
+    assert rel_l2(fused, base) > 1e-3  # the edit is visible
+    model.save_pretrained(str(tmp_path / "transformer"), max_shard_bytes=1 << 20)
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    again = ChronoEditTransformer3DModel.from_pretrained(str(tmp_path), subfolder="transformer", torch_dtype=torch.bfloat16, device="cuda:0")
+    assert torch.equal(again(*args, return_dict=False)[0], fused)
+    # oracle with the fused (bf16-rounded) weights, fp32 arithmetic
+    p32 = {k: v.detach().float().cpu() for k, v in model.named_parameters()}
+    with torch.no_grad():
+        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([500]), text.float(), image.float())
+    assert rel_l2(fused, ref) <= 2e-2

@@ -1,0 +1,140 @@
+"""Checkpoint / LoRA plumbing of the drop-in transformer (host side, no GPU): diffusers-layout shards round-trip, the
+fp32 islands and the ignored key of the reference class, LoRA parse + fuse against the closed form."""
+import json
+import os
+
+import pytest
+import torch
+
+from chronoedit_amd import weights
+from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+
+TINY = dict(num_attention_heads=2, attention_head_dim=128, in_channels=36, out_channels=16, text_dim=64, freq_dim=32, ffn_dim=512,
+            num_layers=2, image_dim=48, added_kv_proj_dim=256)
+
+
+def tiny(seed=0):
+    torch.manual_seed(seed)
+    m = ChronoEditTransformer3DModel(**TINY)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape).to(p.dtype) * 0.05)
+    return m
+
+
+@pytest.mark.parametrize("shard_bytes", [5 << 30, 1 << 20])
+def test_save_load_roundtrip(tmp_path, shard_bytes):
+    m = tiny()
+    names = m.save_pretrained(str(tmp_path / "transformer"), max_shard_bytes=shard_bytes)
+    assert (len(names) > 1) == (shard_bytes == 1 << 20)
+    if len(names) > 1:
+        idx = json.load(open(tmp_path / "transformer" / weights.INDEX_NAME))
+        assert set(idx["weight_map"]) == set(dict(m.named_parameters()))
+    m2 = ChronoEditTransformer3DModel.from_pretrained(str(tmp_path), subfolder="transformer", torch_dtype=torch.bfloat16)
+    assert vars(m2.config) == vars(m.config)
+    for (k, a), (k2, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert k == k2 and a.dtype == b.dtype and torch.equal(a, b), k
+    # the fp32 islands of the reference class (transformer_chronoedit.py:338) survive torch_dtype=bf16
+    assert m2.scale_shift_table.dtype == torch.float32
+    assert m2.blocks[0].scale_shift_table.dtype == torch.float32
+    assert m2.condition_embedder.time_embedder.linear_1.weight.dtype == torch.float32
+    assert m2.blocks[0].attn1.to_q.weight.dtype == torch.bfloat16
+
+
+def test_unexpected_and_missing_keys(tmp_path):
+    from safetensors.torch import load_file, save_file
+    m = tiny()
+    d = tmp_path / "t"
+    m.save_pretrained(str(d))
+    sd = load_file(str(d / weights.WEIGHTS_NAME))
+    # norm_added_q is silently ignored like the reference (_keys_to_ignore_on_load_unexpected, :339)
+    sd["blocks.0.attn2.norm_added_q.weight"] = torch.ones(256)
+    save_file(sd, str(d / weights.WEIGHTS_NAME))
+    ChronoEditTransformer3DModel.from_pretrained(str(d))
+    sd["blocks.0.attn2.bogus.weight"] = torch.ones(4)
+    save_file(sd, str(d / weights.WEIGHTS_NAME))
+    with pytest.raises(KeyError, match="unexpected"):
+        ChronoEditTransformer3DModel.from_pretrained(str(d))
+    del sd["blocks.0.attn2.bogus.weight"], sd["proj_out.bias"]
+    save_file(sd, str(d / weights.WEIGHTS_NAME))
+    with pytest.raises(KeyError, match="missing"):
+        ChronoEditTransformer3DModel.from_pretrained(str(d))
+    with pytest.raises(FileNotFoundError):
+        ChronoEditTransformer3DModel.from_pretrained(str(tmp_path / "nope"))
+
+
+def _lora(m, targets, r=4, prefix="transformer.", style=("lora_A", "lora_B"), alpha=None, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    mods = dict(m.named_modules())
+    sd = {}
+    for t in targets:
+        lin = mods[t]
+        sd[f"{prefix}{t}.{style[0]}.weight"] = torch.randn(r, lin.in_features, generator=g) * 0.1
+        sd[f"{prefix}{t}.{style[1]}.weight"] = torch.randn(lin.out_features, r, generator=g) * 0.1
+        if alpha is not None:
+            sd[f"{prefix}{t}.alpha"] = torch.tensor(float(alpha))
+    return sd
+
+
+@pytest.mark.parametrize("prefix,style,alpha", [("transformer.", ("lora_A", "lora_B"), None), ("diffusion_model.", ("lora_down", "lora_up"), 8.0),
+                                                ("", ("lora_A", "lora_B"), 2.0)])
+def test_lora_fuse_matches_closed_form(tmp_path, prefix, style, alpha):
+    from safetensors.torch import save_file
+    m = tiny()
+    targets = ["blocks.0.attn1.to_q", "blocks.1.attn2.to_out.0", "blocks.1.ffn.net.0.proj", "blocks.0.ffn.net.2"]
+    sd = _lora(m, targets, r=4, prefix=prefix, style=style, alpha=alpha)
+    before = {t: dict(m.named_modules())[t].weight.detach().clone() for t in targets}
+    untouched = m.blocks[0].attn1.to_k.weight.detach().clone()
+    m.engine  # noqa: B018  (attribute exists; fuse must drop any packed engine)
+    m._engine = object()
+    f = tmp_path / "distill.safetensors"
+    save_file(sd, str(f))
+    m.load_lora_weights(str(f), adapter_name="distill")
+    m.fuse_lora(adapter_names=["distill"], lora_scale=0.7)
+    assert m._engine is None
+    for t in targets:
+        a, b = sd[f"{prefix}{t}.{style[0]}.weight"], sd[f"{prefix}{t}.{style[1]}.weight"]
+        s = 0.7 * ((alpha / 4) if alpha is not None else 1.0)
+        want = (before[t].float() + s * (b @ a)).to(torch.bfloat16)
+        assert torch.equal(dict(m.named_modules())[t].weight, want), t
+    assert torch.equal(m.blocks[0].attn1.to_k.weight, untouched)
+    with pytest.raises(ValueError, match="already fused"):
+        m.fuse_lora(adapter_names=["distill"])
+
+
+def test_two_adapters_and_errors():
+    m = tiny()
+    a1 = _lora(m, ["blocks.0.attn1.to_q"], seed=1)
+    a2 = _lora(m, ["blocks.0.attn1.to_q", "blocks.0.attn1.to_v"], seed=2)
+    w0 = m.blocks[0].attn1.to_q.weight.detach().clone()
+    m.load_lora_weights(a1, adapter_name="a").load_lora_weights(a2, adapter_name="b")
+    with pytest.raises(ValueError, match="already loaded"):
+        m.load_lora_weights(a1, adapter_name="a")
+    m.fuse_lora(lora_scale=1.0)  # both, in load order; each rounds into bf16 once
+    k = "transformer.blocks.0.attn1.to_q."
+    step1 = (w0.float() + a1[k + "lora_B.weight"] @ a1[k + "lora_A.weight"]).to(torch.bfloat16)
+    step2 = (step1.float() + a2[k + "lora_B.weight"] @ a2[k + "lora_A.weight"]).to(torch.bfloat16)
+    assert torch.equal(m.blocks[0].attn1.to_q.weight, step2)
+    with pytest.raises(KeyError, match="not a Linear"):
+        tiny().load_lora_weights({"transformer.blocks.0.norm2.lora_A.weight": torch.zeros(2, 256),
+                                  "transformer.blocks.0.norm2.lora_B.weight": torch.zeros(256, 2)})
+    with pytest.raises(ValueError, match="LoRA maps"):
+        tiny().load_lora_weights({"transformer.blocks.0.attn1.to_q.lora_A.weight": torch.zeros(2, 100),
+                                  "transformer.blocks.0.attn1.to_q.lora_B.weight": torch.zeros(256, 2)})
+    with pytest.raises(KeyError, match="pair up"):
+        weights.parse_lora({"transformer.blocks.0.attn1.to_q.lora_A.weight": torch.zeros(2, 256)})
+    with pytest.raises(KeyError, match="unrecognised"):
+        weights.parse_lora({"transformer.blocks.0.attn1.to_q.weight": torch.zeros(2, 256)})
+    with pytest.raises(KeyError, match="no adapter"):
+        tiny().fuse_lora(adapter_names=["zzz"])
+
+
+def test_pipeline_delegates_lora():
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    m = tiny()
+    pipe = ChronoEditPipeline(vae=None, transformer=m, scheduler=None)
+    a = _lora(m, ["blocks.1.attn1.to_k"])
+    w0 = m.blocks[1].attn1.to_k.weight.detach().clone()
+    pipe.load_lora_weights(a, adapter_name="x")
+    pipe.fuse_lora(adapter_names=["x"], lora_scale=0.5)
+    assert not torch.equal(m.blocks[1].attn1.to_k.weight, w0)
