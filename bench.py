@@ -101,6 +101,21 @@ def cpu_baseline(N: int, steps_fwd: int):
             "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, {dt:.2f} s measured; x40 blocks x{steps_fwd} forwards/step"}
 
 
+def _pmc_traffic(kernel_label: str):
+    """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
+    are collected in their own runs, tools/gpu_pmc.sh; they cannot be read live from inside this process).  None when the
+    shape of this run has no committed measurement."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(kernel_label)
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None, None
+    return rec["fetch_bytes"] + rec["write_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+
+
 def _baseline_config_name(a, T) -> str:
     """Which BASELINE.json configuration the chosen shape corresponds to (label only)."""
     if (a.width, a.height) == (1280, 720) and T == 2:
@@ -205,8 +220,9 @@ def main():
                      for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
         dom = max((k for k in summ if k.startswith(("gemm", "attention"))), key=lambda k: summ[k]["total_ms"])
         ach = summ[dom]["work"] / (summ[dom]["avg_ms"] * 1e-3) / 1e12
+        traffic, traffic_src = _pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches": summ[dom]["n"], "avg_ms": round(summ[dom]["avg_ms"], 4)}
 
     # ---- VAE encode + decode at the same resolution (once per edit) -> composed sec/edit for the 50-step schedule
