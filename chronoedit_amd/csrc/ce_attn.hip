@@ -1310,8 +1310,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 constexpr int w4_start(int u) { return u <= 2 ? 0 : (u >= 16 ? 32 : ((u - 2) * 32) / 14); }  // softmax elements done before unit u
 constexpr float W4_RESCALE_THR = 8.0f;
 
+#ifdef CE_W4_NO_SOFTMAX  // timing experiment: the K.Q^T sections without their softmax filler
+#define W4_SM(x)
+#else
+#define W4_SM(x) x
+#endif
+#ifdef CE_W4_S_IN_AGPR
+#define W4_MFMA_QK0(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "a"(b) : "memory")
+#define W4_MFMA_QK(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "a"(b) : "memory")
+#else
 #define W4_MFMA_QK0(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b) : "memory")
 #define W4_MFMA_QK(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b) : "memory")
+#endif
 #define W4_MFMA_PV(acc, a, b) \
   asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b) : "memory")
 
@@ -1560,14 +1570,14 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const bf16* __restrict
     // ================= section 1: S_A(t) | softmax_B(t-1)
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      if (u == 2) sm_update_max(1);
+      if (u == 2) W4_SM(sm_update_max(1));
       if (u < 2) W4_MFMA_QK0(st[0][u & 1], kf[u % RING], qf[0][u >> 1]);
       else W4_MFMA_QK(st[0][u & 1], kf[u % RING], qf[0][u >> 1]);
       if (u + RING < 16) kf[u % RING] = W4_LDK(kb, u + RING);
       else vf[u + RING - 16] = W4_LDV(vb_p, u + RING - 16);
-      sm_slice(1, u);
+      W4_SM(sm_slice(1, u));
     }
-    sm_finish(1);
+    W4_SM(sm_finish(1));
     if ((t + 1) * KVB > sg.len) mask_tail(0, t);
 
     W4_STAMP(ts1);
@@ -1586,15 +1596,15 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const bf16* __restrict
     // ================= section 3: S_B(t) | softmax_A(t), fetch V(t+2)
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-      if (u == 2) sm_update_max(0);
+      if (u == 2) W4_SM(sm_update_max(0));
       if (u < 2) W4_MFMA_QK0(st[1][u & 1], kf[u % RING], qf[1][u >> 1]);
       else W4_MFMA_QK(st[1][u & 1], kf[u % RING], qf[1][u >> 1]);
       if (u + RING < 16) kf[u % RING] = W4_LDK(kb, u + RING);
       else vf[u + RING - 16] = W4_LDV(vb_c, u + RING - 16);
-      sm_slice(0, u);
+      W4_SM(sm_slice(0, u));
       if (u < 8) load_v_part(t + 2, u >> 2, u & 3);
     }
-    sm_finish(0);
+    W4_SM(sm_finish(0));
     if ((t + 1) * KVB > sg.len) mask_tail(1, t);
     W4_STAMP(ts3);
     CE_EPOCH_BARRIER();  // tile t+1 visible to every wave; K(t-1) / V(t-2) buffers free for the stores of the next iteration

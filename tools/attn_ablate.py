@@ -20,7 +20,8 @@ if os.environ.get("ATTN_KERNEL") == "64":
 
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCE_ATTN_ABLATE", "-I", CSRC,
+    extra = os.environ.get("ATTN_DEFS", "").split()
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCE_ATTN_ABLATE", *extra, "-I", CSRC,
            os.path.join(CSRC, "ce_attn.hip"), "-o", LIB]
     subprocess.check_call(cmd)
     print("built", LIB)
