@@ -983,6 +983,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
   }
+  // Q is scaled ONCE by softmax_scale * log2(e) (fp32 multiply, rounded back to bf16): S comes out of the matrix pipe in
+  // the exp2 domain and, with the running max folded into the accumulator init below, P is a bare v_exp_f32 per element.
+  // (Plain VALU ops beside MFMAs are not hidden on this chip - probe in tools/probes - and the fma per element was a
+  // quarter of them.  torch's math SDPA also scales q and k in bf16 before the product.)
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const u32x4 w = __builtin_bit_cast(u32x4, qf[ks]);
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = pack_bf16(bf16lo(w[i]) * scale_log2e, bf16hi(w[i]) * scale_log2e);
+    qf[ks] = __builtin_bit_cast(bf16x8, o);
+  }
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));  // retire the Q loads before the loop (see ping-pong)
 
@@ -1013,7 +1025,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f, alpha_prev = 1.0f, mc = NEG_BIG * scale_log2e;
+    // mc: offset in use (exp2 domain); the K.Q^T accumulators start at -mc (cinit), so S arrives as "score - mc"
+    float l_run = 0.f, alpha_prev = 1.0f, mc = 0.f;
+    f32x16 cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
     bf16x8 ppk[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
@@ -1110,7 +1126,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
             if (i < 2) st[i & 1] = zero16;
             asm volatile("" ::"v"(kf[i % RING]));
           } else {
-            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], i < 2 ? zero16 : st[i & 1], 0, 0, 0);
+            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], i < 2 ? cinit : st[i & 1], 0, 0, 0);
           }
           if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
           if (ABL != 4 && ABL != 8) {
@@ -1158,15 +1174,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[f][r]);
       if (ABL != 6) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // Lazy running max: the max in use (m_run, mc) moves only when some row's tile max exceeds it by more than 2^8 in the
-      // exp2 domain; then the whole wave rescales.  P may reach 2^8 instead of 1 - harmless in fp32 / bf16 - and on random
-      // scores the exact form rescaled O (64 accumulator registers) in about every second tile (any of 32 rows).
+      // Lazy running max, in offset coordinates (mx is relative to mc): the offset moves only when some row's tile max
+      // exceeds it by more than 2^8 - then the whole wave re-bases S(t), O and l - and always on the first tile.  P may
+      // reach 2^8 instead of 1, harmless in fp32 / bf16; on random scores the exact form rescaled O (64 accumulator
+      // registers) in about every second tile (any of 32 rows).
       float alpha = 1.0f;
-      if (__any((mx - m_run) * scale_log2e > SP_RESCALE_THR)) {
-        const float m_new = fmaxf(m_run, mx);
-        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
-        mc = m_new * scale_log2e;
-        m_run = m_new;
+      if (t == 0 || __any(mx > SP_RESCALE_THR)) {
+        const float shift = t == 0 ? mx : fmaxf(mx, 0.f);
+        alpha = __builtin_amdgcn_exp2f(-shift);
+        mc += shift;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[f][r] -= shift;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[r] = -mc;
       }
       if (ABL == 10) asm volatile("" ::"v"(mc));
       CE_SPSTAMP(2);
@@ -1200,8 +1222,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           if (u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
 #pragma unroll
           for (int e = 2 * u; e < 2 * u + 2; ++e)
-            st[e >> 4][e & 15] = ABL == 1 ? fmaf(st[e >> 4][e & 15], scale_log2e, -mc)
-                                          : __builtin_amdgcn_exp2f(fmaf(st[e >> 4][e & 15], scale_log2e, -mc));
+            st[e >> 4][e & 15] = ABL == 1 ? st[e >> 4][e & 15] * 0.5f : __builtin_amdgcn_exp2f(st[e >> 4][e & 15]);
           if (u > 0) {
 #pragma unroll
             for (int e = 2 * u - 2; e < 2 * u; ++e) psum += st[e >> 4][e & 15];
