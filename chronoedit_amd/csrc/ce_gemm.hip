@@ -26,6 +26,7 @@
 #define EPI_GATE_RES 2
 #define EPI_BIAS_GELU_ERF 3
 #define EPI_F32 4  // C is float*: raw fp32 accumulators (attention scores of the VAE mid block)
+#define EPI_MUL 5  // C = bf16(bf16(acc + bias) * res): the gated activation of the UMT5 feed-forward (wi_1(x) * gelu(wi_0(x)))
 
 namespace {
 
@@ -40,8 +41,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
                                                      bf16* __restrict__ C, const float* __restrict__ bias,
                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
                                                      int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                                     int tiles_m, int tiles_n) {
+                                                     int tiles_m, int tiles_n, int batch0, long long sA0, long long sA1,
+                                                     long long sW0, long long sW1, long long sC0, long long sC1) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];  // [buf][A|W]
+  if (gridDim.y > 1) {  // strided batch (two levels, e.g. head within sample): element strides, C in units of its own type
+    const int z0 = blockIdx.y % batch0, z1 = blockIdx.y / batch0;
+    A += z0 * sA0 + z1 * sA1;
+    W += z0 * sW0 + z1 * sW1;
+    const long long oc = z0 * sC0 + z1 * sC1;
+    C = EPI == EPI_F32 ? reinterpret_cast<bf16*>(reinterpret_cast<float*>(C) + oc) : C + oc;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 
@@ -177,6 +186,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
       } else if (EPI == EPI_BIAS_GELU_ERF) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_erf(bf16lo(v[q])), gelu_erf(bf16hi(v[q])));
+      } else if (EPI == EPI_MUL) {
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = pack_bf16(bf16lo(rv[q]) * bf16lo(v[q]), bf16hi(rv[q]) * bf16hi(v[q]));
       } else if (EPI == EPI_GATE_RES) {
         const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
         float g[8];
@@ -227,9 +240,9 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
   if (!A || !W || !C) return CE_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7)) return CE_ERR_SHAPE;
   if ((lda & 7) || (ldw & 7) || (ldc & 7)) return CE_ERR_ALIGN;
-  if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
-  if (epilogue < 0 || epilogue > 4) return CE_ERR_ARG;
-  if (epilogue != EPI_F32) {
+  if ((epilogue == EPI_GATE_RES || epilogue == EPI_MUL) && (!res || (ldres & 7))) return CE_ERR_ARG;
+  if (epilogue < 0 || epilogue > 5) return CE_ERR_ARG;
+  if (epilogue != EPI_F32 && epilogue != EPI_MUL) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant >= 1 || (g_gemm_variant == -1 && big);
     if (want && ce_gemm256_supported(M, N, K, lda, ldw))
@@ -239,15 +252,38 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
   dim3 grid(tiles_m * tiles_n), block(256);
 #define CE_LAUNCH(E)                                                                                              \
   hipLaunchKernelGGL(gemm_bf16_128<E>, grid, block, 0, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
-                     (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n)
+                     (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, 1, 0ll, 0ll, 0ll, 0ll, 0ll, 0ll)
   switch (epilogue) {
     case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;
     case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;
     case EPI_GATE_RES: CE_LAUNCH(EPI_GATE_RES); break;
     case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
     case EPI_F32: CE_LAUNCH(EPI_F32); break;
+    case EPI_MUL: CE_LAUNCH(EPI_MUL); break;
     default: return CE_ERR_ARG;
   }
+#undef CE_LAUNCH
+  return (int)hipGetLastError();
+}
+
+// batch0 x batch1 independent products with two-level element strides (e.g. head within sample): operand z = (z0, z1) is
+// A + z0 sA0 + z1 sA1, W + z0 sW0 + z1 sW1, C + z0 sC0 + z1 sC1 (C strides in elements of C's type).  Epilogues EPI_BIAS
+// and EPI_F32 only; always the 128-tile kernel (these are the per-head attention products of the encoders).
+extern "C" int ce_gemm_batched_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, int M, int N, int K,
+                                    int lda, int ldw, int ldc, int batch0, int batch1, long long sA0, long long sA1, long long sW0,
+                                    long long sW1, long long sC0, long long sC1, hipStream_t stream) {
+  if (!A || !W || !C) return CE_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7) || batch0 <= 0 || batch1 <= 0 || (long long)batch0 * batch1 > 65535)
+    return CE_ERR_SHAPE;
+  if ((lda & 7) || (ldw & 7) || (ldc & 7) || (sA0 & 7) || (sA1 & 7) || (sW0 & 7) || (sW1 & 7) || (sC0 & 7) || (sC1 & 7))
+    return CE_ERR_ALIGN;
+  if (epilogue != EPI_BIAS && epilogue != EPI_F32) return CE_ERR_ARG;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  dim3 grid(tiles_m * tiles_n, batch0 * batch1), block(256);
+#define CE_LAUNCH(E)                                                                                                 \
+  hipLaunchKernelGGL(gemm_bf16_128<E>, grid, block, 0, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, nullptr, \
+                     nullptr, M, N, K, lda, ldw, ldc, 0, 0, tiles_m, tiles_n, batch0, sA0, sA1, sW0, sW1, sC0, sC1)
+  if (epilogue == EPI_BIAS) CE_LAUNCH(EPI_BIAS); else CE_LAUNCH(EPI_F32);
 #undef CE_LAUNCH
   return (int)hipGetLastError();
 }

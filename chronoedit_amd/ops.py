@@ -14,6 +14,7 @@ import torch
 from . import hiplib
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_GATE_RES, EPI_BIAS_GELU_ERF = 0, 1, 2, 3
+EPI_F32, EPI_MUL = 4, 5
 
 _lib = None
 
@@ -155,9 +156,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Op
     Mo, No, ldc = _rows(out, "out")
     assert (Mo, No) == (M, N), ((Mo, No), (M, N))
     ldres = 0
-    if epilogue == EPI_GATE_RES:
+    if epilogue in (EPI_GATE_RES, EPI_MUL):
         if res is None:
-            raise ValueError("EPI_GATE_RES needs res")
+            raise ValueError("EPI_GATE_RES / EPI_MUL need res")
         _dev(res, torch.bfloat16, "res")
         _, _, ldres = _rows(res, "res")
         if gate is not None:
@@ -376,3 +377,80 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = Non
     _check(lib().ce_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(None), 4, _ptr(None), _ptr(None), M, N, K, lda, ldw, ldc, 0, 0,
                               _stream()), "ce_gemm_bf16(f32)")
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# conditioning encoders (once per edit)
+# ------------------------------------------------------------------------------------------
+def gemm_batched(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int, ldw: int, ldc: int,
+                 batch: tuple, stride_a: tuple, stride_w: tuple, stride_c: tuple, f32_out: bool = False,
+                 bias: Optional[torch.Tensor] = None):
+    """batch[0] x batch[1] products out_z[M,N] = a_z[M,K] @ w_z[N,K]^T; operand z = (z0, z1) starts stride[0]*z0 + stride[1]*z1
+    elements into its tensor (flat storage offsets; see ce_gemm_batched_bf16).  Raw-pointer form: the caller states the geometry."""
+    _dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w")
+    _dev(out, torch.float32 if f32_out else torch.bfloat16, "out")
+    if bias is not None:
+        _dev(bias, torch.float32, "bias")
+    st = _prof_begin()
+    _check(lib().ce_gemm_batched_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), EPI_F32 if f32_out else EPI_BIAS, M, N, K, lda, ldw, ldc,
+                                      batch[0], batch[1], stride_a[0], stride_a[1], stride_w[0], stride_w[1], stride_c[0], stride_c[1],
+                                      _stream()), "ce_gemm_batched_bf16")
+    _prof_end(st, f"gemm_batched_{batch[0] * batch[1]}x{M}x{N}x{K}", 2.0 * M * N * K * batch[0] * batch[1])
+    return out
+
+
+def im2col_patch2d(img: torch.Tensor, patch: int, kpad: int, out: Optional[torch.Tensor] = None):
+    """img [B,C,H,W] bf16 contiguous -> cols [B*(H/P)*(W/P), kpad] (column = c*P*P + y*P + x, zero padded)."""
+    _dev(img, torch.bfloat16, "img")
+    if img.dim() != 4 or not img.is_contiguous():
+        raise ValueError("im2col_patch2d: need a contiguous [B,C,H,W] tensor")
+    B, C, H, W = img.shape
+    if out is None:
+        out = torch.empty((B * (H // patch) * (W // patch), kpad), dtype=torch.bfloat16, device=img.device)
+    _check(lib().ce_im2col_patch2d_bf16(_ptr(img), _ptr(out), B, C, H, W, patch, kpad, _stream()), "ce_im2col_patch2d_bf16")
+    return out
+
+
+def gather_rows(table: torch.Tensor, ids: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """out[i] = table[ids[i]] (bf16 rows, int64 ids)."""
+    _dev(table, torch.bfloat16, "table"), _dev(ids, torch.int64, "ids")
+    V, D, ldt = _rows(table, "table")
+    ids = ids.reshape(-1).contiguous()
+    if out is None:
+        out = torch.empty((ids.numel(), D), dtype=torch.bfloat16, device=table.device)
+    _, _, ldo = _rows(out, "out")
+    _check(lib().ce_gather_rows_bf16(_ptr(table), _ptr(ids), _ptr(out), ids.numel(), D, ldt, ldo, V, _stream()), "ce_gather_rows_bf16")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None):
+    """T5LayerNorm: out = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w); x, w, out bf16."""
+    _dev(x, torch.bfloat16, "x"), _dev(w, torch.bfloat16, "w")
+    M, D, ldx = _rows(x, "x")
+    assert w.numel() == D and w.is_contiguous()
+    if out is None:
+        out = torch.empty((M, D), dtype=torch.bfloat16, device=x.device)
+    _, _, ldy = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_rmsnorm_bf16(_ptr(x), _ptr(out), _ptr(w), M, D, ldx, ldy, float(eps), _stream()), "ce_rmsnorm_bf16")
+    _prof_end(st, f"rmsnorm_{M}x{D}", 4.0 * M * D)
+    return out
+
+
+def softmax_t5(scores: torch.Tensor, probs: torch.Tensor, batch: int, heads: int, Lq: int, Lk: int,
+               bucket_lut: Optional[torch.Tensor] = None, table: Optional[torch.Tensor] = None,
+               valid_len: Optional[torch.Tensor] = None):
+    """probs = softmax(scores + relative-position bias) over the valid keys; scores [batch*heads*Lq, ld] fp32, probs [.., ldp] bf16."""
+    _dev(scores, torch.float32, "scores"), _dev(probs, torch.bfloat16, "probs")
+    rows, _, ld = _rows(scores, "scores")
+    rows_p, _, ldp = _rows(probs, "probs")
+    assert rows == rows_p == batch * heads * Lq
+    for t, dt, n in ((bucket_lut, torch.int32, "bucket_lut"), (valid_len, torch.int32, "valid_len"), (table, torch.float32, "table")):
+        if t is not None:
+            _dev(t, dt, n)
+            assert t.is_contiguous()
+    if table is not None:
+        assert bucket_lut.numel() == Lq + Lk - 1 and table.shape[-1] == heads
+    _check(lib().ce_softmax_t5_bf16(_ptr(scores), _ptr(probs), batch, heads, Lq, Lk, ld, ldp, _ptr(bucket_lut), _ptr(table),
+                                    _ptr(valid_len), _stream()), "ce_softmax_t5_bf16")
+    return probs

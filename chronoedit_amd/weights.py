@@ -35,18 +35,20 @@ def read_config(path: str, subfolder: Optional[str] = None) -> Dict:
     return {k: v for k, v in cfg.items() if not k.startswith("_")}
 
 
-def shard_files(path: str, subfolder: Optional[str] = None) -> List[str]:
-    """The safetensors files that make up the checkpoint (single file, or the shards listed by the index)."""
+def shard_files(path: str, subfolder: Optional[str] = None, names: Iterable[str] = (WEIGHTS_NAME,)) -> List[str]:
+    """The safetensors files that make up the checkpoint: ``<name>`` or the shards listed by ``<name>.index.json``, for the
+    first of ``names`` that exists (diffusers models: diffusion_pytorch_model.safetensors; transformers: model.safetensors)."""
     d = _resolve(path, subfolder)
-    index = os.path.join(d, INDEX_NAME)
-    if os.path.exists(index):
-        with open(index) as f:
-            names = sorted(set(json.load(f)["weight_map"].values()))
-        return [os.path.join(d, n) for n in names]
-    single = os.path.join(d, WEIGHTS_NAME)
-    if os.path.exists(single):
-        return [single]
-    raise FileNotFoundError(f"neither {INDEX_NAME} nor {WEIGHTS_NAME} under {d}")
+    for name in names:
+        index = os.path.join(d, name + ".index.json")
+        if os.path.exists(index):
+            with open(index) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+            return [os.path.join(d, n) for n in shards]
+        single = os.path.join(d, name)
+        if os.path.exists(single):
+            return [single]
+    raise FileNotFoundError(f"none of {[n for n in names]} (or their .index.json) under {d}")
 
 
 def load_state_dict_files(files: Iterable[str], device: str = "cpu") -> Dict[str, torch.Tensor]:

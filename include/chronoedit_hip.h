@@ -151,6 +151,32 @@ int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipSt
 int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int npad, int ld, int ldp, float scale,
                              hipStream_t stream);
 
+/* ---- conditioning encoders (run once per edit, outside the loop: pipeline_chronoedit.py:205-254; the arithmetic is
+ * transformers==4.57.1 CLIPVisionModel / UMT5EncoderModel, restated in oracle/clip_oracle.py, oracle/umt5_oracle.py) ---- */
+
+/* batch0 x batch1 independent C = A W^T products with two-level element strides (head within sample); epilogue 0 (bias,
+ * bf16 C) or 4 (fp32 C, no bias).  The per-head Q K^T and P V products of the encoders' attention. */
+int ce_gemm_batched_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, int M, int N, int K, int lda,
+                         int ldw, int ldc, int batch0, int batch1, long long sA0, long long sA1, long long sW0, long long sW1,
+                         long long sC0, long long sC1, hipStream_t stream);
+
+/* cols[(b gh + py) gw + px][c P P + y P + x] = img[b][c][py P + y][px P + x], zero padded to Kpad columns: the im2col of
+ * CLIPVisionEmbeddings.patch_embedding (Conv2d, kernel = stride = P, no bias). */
+int ce_im2col_patch2d_bf16(const void* img, void* cols, int B, int C, int H, int W, int P, int Kpad, hipStream_t stream);
+
+/* out[i][:] = table[ids[i]][:] (ids int64, clamped to [0, vocab)): UMT5Stack.embed_tokens. */
+int ce_gather_rows_bf16(const void* table, const long long* ids, void* out, int n, int D, int ldt, int ldo, int vocab,
+                        hipStream_t stream);
+
+/* y = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w), statistics in fp32, w bf16: UMT5LayerNorm.forward. */
+int ce_rmsnorm_bf16(const void* x, void* y, const void* w, int M, int D, int ldx, int ldy, float eps, hipStream_t stream);
+
+/* probs[b][h][q][:] = softmax_k(scores[b][h][q][k] + table[bucket_lut[k - q + Lq - 1]][h]) over keys k < valid_len[b]
+ * (fp32 in, bf16 out, columns [Lk, ldp) written as zeros); table / bucket_lut may both be NULL (no bias), valid_len may be
+ * NULL (no padding mask).  UMT5Attention: position bias + extended attention mask + softmax in fp32. */
+int ce_softmax_t5_bf16(const float* scores, void* probs, int batch, int heads, int Lq, int Lk, int ld, int ldp,
+                       const int* bucket_lut, const float* table, const int* valid_len, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
