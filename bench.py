@@ -52,6 +52,7 @@ def parse():
                          "over the GPUs (Ulysses all-to-all over RCCL/xGMI, strong scaling)")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
+    ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--attn-kernel", type=int, default=0,
@@ -245,6 +246,31 @@ def main():
         torch.cuda.synchronize()
         vae_s = {"encode_s": round(te, 4), "decode_s": round(time.perf_counter() - tv, 4)}
 
+    # ---- conditioning encoders (once per edit): UMT5-XXL on the positive + negative prompt padded to 512 tokens, CLIP ViT-H/14
+    enc_s = None
+    if not a.no_encoders and rank == 0:
+        from chronoedit_amd.clip_vision import CLIPVisionModel
+        from chronoedit_amd.umt5 import UMT5EncoderModel, t5_prompt_embeds
+        torch.manual_seed(0)
+        te_model = UMT5EncoderModel(device=dev)   # architecture defaults = google/umt5-xxl encoder; random-init weights
+        ie_model = CLIPVisionModel(device=dev)    # ViT-H/14 defaults
+        ids = torch.randint(2, 256384, (2, 512), device=dev)
+        am = torch.zeros((2, 512), dtype=torch.long, device=dev)
+        am[0, :64], am[1, :20] = 1, 1
+        px = torch.randn(1, 3, 224, 224, device=dev)
+        t5_prompt_embeds(te_model, ids, am), ie_model(pixel_values=px, output_hidden_states=True)  # warm-up (packs weights)
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        pe = t5_prompt_embeds(te_model, ids, am)
+        torch.cuda.synchronize()
+        tt_ = time.perf_counter() - tv
+        tv = time.perf_counter()
+        ie = ie_model(pixel_values=px, output_hidden_states=True).hidden_states[-2]
+        torch.cuda.synchronize()
+        enc_s = {"text_s": round(tt_, 4), "image_s": round(time.perf_counter() - tv, 4),
+                 "finite": bool(torch.isfinite(pe.float()).all().item() and torch.isfinite(ie.float()).all().item())}
+        del te_model, ie_model
+
     if rank == 0:
         steps_per_s = a.steps / dt * (1 if ulysses else world)
         fl = flops_per_forward(DiTConfig(num_layers=a.layers), N) * fwd_per_step
@@ -264,7 +290,9 @@ def main():
             "finite": finite,
             "launch": "hipGraph replay" if a.graph else "eager",
             "vae": vae_s,
-            "sec_per_edit_50_steps": None if vae_s is None else round(50 * dt / a.steps + vae_s["encode_s"] + vae_s["decode_s"], 2),
+            "encoders": enc_s,
+            "sec_per_edit_50_steps": None if vae_s is None else round(
+                50 * dt / a.steps + vae_s["encode_s"] + vae_s["decode_s"] + (0.0 if enc_s is None else enc_s["text_s"] + enc_s["image_s"]), 2),
             "roofline": roofline,
             "kernel_breakdown": breakdown,
         }

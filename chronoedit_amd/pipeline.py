@@ -200,8 +200,28 @@ class ChronoEditPipeline:
     """The denoising part of the reference pipeline behind the same call (text / CLIP encoders and guardrails are out of
     scope: pass `prompt_embeds`, `negative_prompt_embeds`, `image_embeds` as the reference's encoders produce them)."""
 
-    def __init__(self, vae, transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPCMultistepScheduler):
+    def __init__(self, vae, transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPCMultistepScheduler,
+                 text_encoder=None, image_encoder=None):
         self.vae, self.transformer, self.scheduler = vae, transformer, scheduler
+        self.text_encoder, self.image_encoder = text_encoder, image_encoder  # chronoedit_amd.umt5 / .clip_vision drop-ins
+
+    def encode_prompt(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                      negative_input_ids: Optional[torch.Tensor] = None, negative_attention_mask: Optional[torch.Tensor] = None):
+        """``encode_prompt`` / ``_get_t5_prompt_embeds`` after the tokenizer (pipeline_chronoedit.py:205-243,258-330): token ids
+        padded to ``max_sequence_length`` and their masks in, ``(prompt_embeds, negative_prompt_embeds)`` out.  Tokenising
+        (``prompt_clean`` + the UMT5 sentencepiece tokenizer) stays the reference's host code."""
+        from .umt5 import t5_prompt_embeds
+        if self.text_encoder is None:
+            raise ValueError("this pipeline was built without a text_encoder: pass prompt_embeds instead")
+        pos = t5_prompt_embeds(self.text_encoder, input_ids, attention_mask)
+        neg = None if negative_input_ids is None else t5_prompt_embeds(self.text_encoder, negative_input_ids, negative_attention_mask)
+        return pos, neg
+
+    def encode_image(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """``encode_image`` after the CLIP image processor (pipeline_chronoedit.py:247-256): penultimate hidden state."""
+        if self.image_encoder is None:
+            raise ValueError("this pipeline was built without an image_encoder: pass image_embeds instead")
+        return self.image_encoder(pixel_values=pixel_values, output_hidden_states=True).hidden_states[-2]
 
     # LoRA entry points of the reference runner (run_inference_diffusers.py:370-374); the adapters target the transformer
     def load_lora_weights(self, path_or_state, adapter_name: str = "default"):

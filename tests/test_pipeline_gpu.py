@@ -77,3 +77,28 @@ def test_hipgraph_replay_equals_eager_loop():
                             num_temporal_reasoning_steps=3, use_graph=use_graph).clone())
     assert outs[0].shape == (1, 16, 2, 8, 12)
     assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max()
+
+
+def test_pipeline_encoders_feed_the_edit():
+    """encode_prompt / encode_image (HIP UMT5 + CLIP drop-ins) produce the conditioning tensors the edit consumes: shapes and
+    zero padding as pipeline_chronoedit.py:231-256, and a 2-step edit on them runs finite."""
+    from chronoedit_amd.clip_vision import CLIPVisionModel
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.umt5 import UMT5EncoderModel
+    torch.manual_seed(0)
+    te = UMT5EncoderModel(vocab_size=300, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2, device="cuda:0")
+    ie = CLIPVisionModel(hidden_size=320, intermediate_size=640, num_hidden_layers=3, num_attention_heads=4, image_size=56, patch_size=14,
+                         device="cuda:0")
+    pipe = ChronoEditPipeline(vae=None, transformer=None, scheduler=None, text_encoder=te, image_encoder=ie)
+    ids = torch.randint(2, 300, (1, 64), device="cuda:0")
+    am = torch.zeros((1, 64), dtype=torch.long, device="cuda:0")
+    am[0, :11] = 1
+    nids, nam = torch.randint(2, 300, (1, 64), device="cuda:0"), torch.zeros((1, 64), dtype=torch.long, device="cuda:0")
+    nam[0, :5] = 1
+    pos, neg = pipe.encode_prompt(ids, am, nids, nam)
+    assert pos.shape == neg.shape == (1, 64, 128) and pos.dtype == torch.bfloat16
+    assert pos[0, 11:].abs().max().item() == 0 and neg[0, 5:].abs().max().item() == 0 and pos[0, :11].abs().max().item() > 0
+    img = pipe.encode_image(torch.randn(1, 3, 56, 56, device="cuda:0"))
+    assert img.shape == (1, 17, 320) and torch.isfinite(img.float()).all()
+    with pytest.raises(ValueError):
+        ChronoEditPipeline(None, None, None).encode_image(torch.zeros(1, 3, 56, 56, device="cuda:0"))

@@ -8,7 +8,7 @@ tail -4 gpurun_out/pytest_gpu.log
 if [ "$1" != "tests" ]; then
 timeout 600 python tools/microbench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/microbench.log
 timeout 900 python bench.py --steps 4 --warmup 1 2>/dev/null | tail -1 > gpurun_out/bench.log
-timeout 900 python bench.py --steps 4 --warmup 1 --graph --no-cpu-baseline --no-vae 2>/dev/null | tail -1 > gpurun_out/bench_graph.log
+timeout 900 python bench.py --steps 4 --warmup 1 --graph --no-cpu-baseline --no-vae --no-encoders 2>/dev/null | tail -1 > gpurun_out/bench_graph.log
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-vae > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1)
 ls -R gpurun_out/prof | head -20 >> gpurun_out/rocprof.log
 cat gpurun_out/microbench.log
