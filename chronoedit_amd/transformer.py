@@ -213,6 +213,18 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         model.invalidate()
         return model
 
+    def load_wan_native_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Load a checkpoint in the original Wan naming used by the reference's two sibling stacks (diffsynth ``WanModel``,
+        ``_src`` ``wan2pt1``; correspondence: wan_video_dit_chronoedit.py:434-505)."""
+        renamed = weights.wan_native_to_diffusers(sd, [k for k, _ in self.named_parameters()])
+        weights.assign_state_dict(self, renamed, ignore_unexpected=self._keys_to_ignore_on_load_unexpected)
+        self.invalidate()
+        return self
+
+    def wan_native_state_dict(self) -> Dict[str, torch.Tensor]:
+        """The parameters under their Wan-native names (e.g. to hand LoRA-fused weights to the sibling stacks)."""
+        return {weights.diffusers_to_wan_native_key(k): p.detach() for k, p in self.named_parameters()}
+
     def save_pretrained(self, path: str, max_shard_bytes: int = 5 << 30):
         """config.json + safetensors shard(s) in the layout from_pretrained reads."""
         return weights.save_pretrained(self, path, dict(vars(self.config)), max_shard_bytes, "ChronoEditTransformer3DModel")

@@ -115,6 +115,64 @@ def save_pretrained(model: torch.nn.Module, path: str, config: Dict, max_shard_b
 
 
 # ------------------------------------------------------------------------------------------
+# Wan-native checkpoint names (the two sibling stacks of the reference)
+# ------------------------------------------------------------------------------------------
+# chronoedit_diffsynth.WanModel and chronoedit/_src wan2pt1 keep the original Wan names; the reference converts diffusers ->
+# native in WanModelStateDictConverter.from_diffusers (wan_video_dit_chronoedit.py:434-505).  This is the same correspondence
+# written from the module structure (attn1 = self_attn, attn2 = cross_attn with k_img / v_img for the image tokens, FeedForward
+# = ffn.0 / ffn.2, norm2 = norm3, scale_shift_table = modulation, condition embedder = text_embedding / time_embedding /
+# time_projection / img_emb.proj, proj_out + scale_shift_table = head), usable in both directions so that a native
+# checkpoint loads into the drop-in transformer and a fused one can be written back for those stacks.
+_BLOCK_RULES = [
+    (r"attn1\.to_(q|k|v)\.", r"self_attn.\1."), (r"attn1\.to_out\.0\.", "self_attn.o."), (r"attn1\.norm_(q|k)\.", r"self_attn.norm_\1."),
+    (r"attn2\.to_(q|k|v)\.", r"cross_attn.\1."), (r"attn2\.to_out\.0\.", "cross_attn.o."), (r"attn2\.norm_(q|k)\.", r"cross_attn.norm_\1."),
+    (r"attn2\.add_(k|v)_proj\.", r"cross_attn.\1_img."), (r"attn2\.norm_added_k\.", "cross_attn.norm_k_img."),
+    (r"ffn\.net\.0\.proj\.", "ffn.0."), (r"ffn\.net\.2\.", "ffn.2."), (r"norm2\.", "norm3."), (r"scale_shift_table$", "modulation"),
+]
+_TOP_RULES = [
+    (r"^condition_embedder\.text_embedder\.linear_1\.", "text_embedding.0."), (r"^condition_embedder\.text_embedder\.linear_2\.", "text_embedding.2."),
+    (r"^condition_embedder\.time_embedder\.linear_1\.", "time_embedding.0."), (r"^condition_embedder\.time_embedder\.linear_2\.", "time_embedding.2."),
+    (r"^condition_embedder\.time_proj\.", "time_projection.1."),
+    (r"^condition_embedder\.image_embedder\.norm1\.", "img_emb.proj.0."), (r"^condition_embedder\.image_embedder\.ff\.net\.0\.proj\.", "img_emb.proj.1."),
+    (r"^condition_embedder\.image_embedder\.ff\.net\.2\.", "img_emb.proj.3."), (r"^condition_embedder\.image_embedder\.norm2\.", "img_emb.proj.4."),
+    (r"^scale_shift_table$", "head.modulation"), (r"^proj_out\.", "head.head."), (r"^patch_embedding\.", "patch_embedding."),
+]
+
+
+def diffusers_to_wan_native_key(key: str) -> str:
+    m = re.match(r"^blocks\.(\d+)\.(.*)$", key)
+    if m:
+        rest = m.group(2)
+        for pat, rep in _BLOCK_RULES:
+            new, n = re.subn("^" + pat, rep, rest)
+            if n:
+                return f"blocks.{m.group(1)}.{new}"
+        raise KeyError(f"no Wan-native name for {key}")
+    for pat, rep in _TOP_RULES:
+        new, n = re.subn(pat, rep, key)
+        if n:
+            return new
+    raise KeyError(f"no Wan-native name for {key}")
+
+
+def wan_native_to_diffusers(sd: Dict[str, torch.Tensor], diffusers_keys: Iterable[str]) -> Dict[str, torch.Tensor]:
+    """Rename a Wan-native state dict (diffsynth ``WanModel`` / ``wan2pt1`` names) to the diffusers names of the drop-in
+    transformer.  ``diffusers_keys`` = the model's parameter names (the map is built from them, so nothing is guessed)."""
+    back = {diffusers_to_wan_native_key(k): k for k in diffusers_keys}
+    out, unknown = {}, []
+    for k, v in sd.items():
+        if k in back:
+            out[back[k]] = v
+        elif k in back.values():  # already a diffusers name
+            out[k] = v
+        else:
+            unknown.append(k)
+    if unknown:
+        raise KeyError(f"keys that are neither Wan-native nor diffusers names of this model: {sorted(unknown)[:5]}")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
 # LoRA
 # ------------------------------------------------------------------------------------------
 _PREFIXES = ("transformer.", "diffusion_model.", "model.diffusion_model.", "base_model.model.")

@@ -138,3 +138,29 @@ def test_pipeline_delegates_lora():
     pipe.load_lora_weights(a, adapter_name="x")
     pipe.fuse_lora(adapter_names=["x"], lora_scale=0.5)
     assert not torch.equal(m.blocks[1].attn1.to_k.weight, w0)
+
+
+def test_wan_native_names_match_the_reference_converter(golden_dir):
+    """diffusers <-> Wan-native key map == what the reference's own WanModelStateDictConverter.from_diffusers produces
+    (tests/golden/wan_native_keymap.json, generated by oracle/gen_golden_keymap.py from wan_video_dit_chronoedit.py:434-505)."""
+    fx = json.load(open(os.path.join(golden_dir, "wan_native_keymap.json")))
+    assert not fx["dropped_by_reference_converter"]
+    for d, n in fx["pairs"]:
+        assert weights.diffusers_to_wan_native_key(d) == n, (d, n)
+    with pytest.raises(KeyError):
+        weights.diffusers_to_wan_native_key("blocks.0.attn9.to_q.weight")
+
+
+def test_wan_native_checkpoint_roundtrip():
+    m = tiny(seed=3)
+    native = m.wan_native_state_dict()
+    assert "blocks.1.cross_attn.k_img.weight" in native and "head.modulation" in native and "blocks.0.modulation" in native
+    assert not any(k.startswith(("condition_embedder", "proj_out")) or ".attn1." in k for k in native)
+    m2 = tiny(seed=4)
+    m2._engine = object()
+    m2.load_wan_native_state_dict({k: v.clone() for k, v in native.items()})
+    assert m2._engine is None
+    for (k, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k
+    with pytest.raises(KeyError):
+        m2.load_wan_native_state_dict({**native, "blocks.0.bogus.weight": torch.zeros(1)})
