@@ -210,6 +210,8 @@ def main():
     # ---- per-kernel HIP-event profile of ONE more step (outside the timed region) -> roofline of the dominant kernel
     roofline = None
     breakdown = None
+    if not a.no_profile and ulysses and rank != 0:
+        (eager_step if a.graph else one_step)(a.warmup + a.steps)  # the step has collectives: every rank must take part
     if not a.no_profile and rank == 0:
         with ops.profile() as prof:
             (eager_step if a.graph else one_step)(a.warmup + a.steps)
@@ -243,7 +245,7 @@ def main():
 
     # ---- VAE encode + decode at the same resolution (once per edit) -> composed sec/edit for the 50-step schedule
     vae_s = None
-    if not a.no_vae and rank == 0:
+    if not a.no_vae and rank == 0 and world == 1:
         from chronoedit_amd.vae import AutoencoderKLWan
         from oracle import vae_oracle as V
         vae = AutoencoderKLWan({k: v.to(dev) for k, v in V.make_synthetic_params(V.VAEConfig()).items()})
@@ -263,7 +265,7 @@ def main():
 
     # ---- conditioning encoders (once per edit): UMT5-XXL on the positive + negative prompt padded to 512 tokens, CLIP ViT-H/14
     enc_s = None
-    if not a.no_encoders and rank == 0:
+    if not a.no_encoders and rank == 0 and world == 1:
         from chronoedit_amd.clip_vision import CLIPVisionModel
         from chronoedit_amd.umt5 import UMT5EncoderModel, t5_prompt_embeds
         torch.manual_seed(0)
