@@ -21,6 +21,8 @@
 //    buffer afterwards (one barrier per tile).
 //  * Output rows are staged through LDS and stored as whole 256-B rows (16 B per lane).
 //  * blockIdx -> (head, q-block) keeps all q-blocks of a head on one XCD (K/V stay in that L2).
+#include <cstdlib>
+
 #include "ce_common.h"
 
 namespace {
@@ -947,35 +949,60 @@ constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 *
 template <bool TWO_SEG, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
                                                               KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
-                                                              float scale_log2e) {
+                                                              float scale_log2e, int batch, int order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  {  // stacked samples: sample b = blockIdx.y owns rows [b Nq, (b+1) Nq) of Q/O and [b len, (b+1) len) of each K/V segment
-    const size_t bz = blockIdx.y;
-    Q += bz * Nq * ldq;
-    O += bz * Nq * ldo;
-    seg0.k += bz * seg0.len * seg0.ldk;
-    seg0.v += bz * seg0.len * seg0.ldv;
-    if (TWO_SEG) {
-      seg1.k += bz * seg1.len * seg1.ldk;
-      seg1.v += bz * seg1.len * seg1.ldv;
-    }
-  }
   constexpr int NWAVE = 8, QB = QW * NWAVE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
 
-  int head, qb;
-  if ((H & 7) == 0) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    head = xcd + 8 * (local / nqb);
-    qb = local % nqb;
-  } else {
-    head = blockIdx.x / nqb;
-    qb = blockIdx.x % nqb;
+  // Work order (batch folded into blockIdx.x): every XCD takes its heads' FULL 256-row query blocks first, sample by sample,
+  // and the remainder blocks (Nq % 256 rows; only their first waves have work and the others merely stage, so they run
+  // ~2.5x faster) last - they fill the partially occupied final round of workgroups instead of heading it.  At
+  // Nq = 7200, H = 40, two samples: 2320 workgroups = 9.06 rounds of 256 CUs used to cost ten.
+  int head, qb, bz;
+  {
+    const int nqb_full = Nq / QB;
+    if ((H & 7) == 0 && order == 1) {
+      const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, hx_n = H >> 3;
+      const int full = batch * hx_n * nqb_full;
+      if (local < full) {
+        bz = local / (hx_n * nqb_full);
+        const int r = local % (hx_n * nqb_full);
+        head = xcd + 8 * (r / nqb_full);
+        qb = r % nqb_full;
+      } else {
+        const int l2 = local - full;
+        bz = l2 / hx_n;
+        head = xcd + 8 * (l2 % hx_n);
+        qb = nqb_full;
+      }
+    } else if ((H & 7) == 0) {  // plain order: sample, then head (XCD-contiguous), then query block
+      bz = blockIdx.x / (nqb * H);
+      const int r = blockIdx.x % (nqb * H);
+      const int xcd = r & 7, local = r >> 3;
+      head = xcd + 8 * (local / nqb);
+      qb = local % nqb;
+    } else {
+      bz = blockIdx.x / (nqb * H);
+      const int r = blockIdx.x % (nqb * H);
+      head = r / nqb;
+      qb = r % nqb;
+    }
+  }
+  {  // stacked samples: sample bz owns rows [bz Nq, (bz+1) Nq) of Q/O and [bz len, (bz+1) len) of each K/V segment
+    Q += (size_t)bz * Nq * ldq;
+    O += (size_t)bz * Nq * ldo;
+    seg0.k += (size_t)bz * seg0.len * seg0.ldk;
+    seg0.v += (size_t)bz * seg0.len * seg0.ldv;
+    if (TWO_SEG) {
+      seg1.k += (size_t)bz * seg1.len * seg1.ldk;
+      seg1.v += (size_t)bz * seg1.len * seg1.ldv;
+    }
   }
   const int q0 = qb * QB + wave * QW;
   const int hoff = head * HD;
+  const bool active = q0 < Nq || order == 0;  // wave-uniform: a wave past the last query row only helps staging the K / V tiles
 
   bf16x8 qf[8];
   {
@@ -1103,6 +1130,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       CE_EPOCH_BARRIER();  // K(t), V(t) visible; K(t-1) and V(t-2) no longer read by anyone
       CE_SPSTAMP(0);
       const int vb_next = 3 - vb_prev - vb_cur;
+      if (!active) {  // staging only, same barriers
+        store_k((t + 1) & 1);
+        store_v(vb_next);
+        load_k(t + 2);
+        load_v(t + 2);
+        vb_prev = vb_cur;
+        vb_cur = vb_next;
+        continue;
+      }
       const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
       const unsigned char* vb = v_rd + vb_prev * PV_TILE;
 
@@ -1252,13 +1288,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       vb_cur = vb_next;
     }
     // ---- drain: P(ntiles-1).V(ntiles-1); its V buffer (now vb_prev) became visible at the last barrier
-    if (__any(alpha_prev != 1.0f)) {
+    if (active && __any(alpha_prev != 1.0f)) {
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
     }
-    {
+    if (active) {
       const unsigned char* vb = v_rd + vb_prev * PV_TILE;
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -1713,6 +1749,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const bf16* __restrict
 // running max ("sp"; in the batched-CFG step 0.89-0.91 PFLOP/s self-attention and 0.66 cross-attention, vs 0.89 / 0.62 for
 // ping-pong + plain); 128 = one wave per SIMD, 64 query rows per wave ("w4", single-segment only; 0.84-0.85 in the step).
 static int g_attn_nwave = 0;
+static int g_attn_order = getenv("CE_ATTN_ORDER") ? atoi(getenv("CE_ATTN_ORDER")) : 1;  // experiment switch: 0 plain work order
 #ifdef CE_ATTN_ABLATE
 static int g_attn_ablate = 0;
 extern "C" void ce_attn_set_ablation(int a) { g_attn_ablate = a; }
@@ -1782,16 +1819,16 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
                                 sp_smem_bytes(TWO));                                                                 \
       done = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((attn_fwd_sp_kernel<TWO>), grid, block, sp_smem_bytes(TWO), stream, (const bf16*)Q, (bf16*)O, s0, \
-                       s1, Nq, H, ldq, ldo, nqb, sl2);                                                               \
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<TWO>), dim3(nqb * H * batch), block, sp_smem_bytes(TWO), stream, (const bf16*)Q, \
+                       (bf16*)O, s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, g_attn_order);                            \
   } while (0)
 #ifdef CE_ATTN_ABLATE
 #define CE_SP_ABL(A)                                                                                                   \
   case A:                                                                                                              \
     (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<false, A>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                               sp_smem_bytes(false));                                                                   \
-    hipLaunchKernelGGL((attn_fwd_sp_kernel<false, A>), grid, block, sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O, \
-                       s0, s1, Nq, H, ldq, ldo, nqb, sl2);                                                             \
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<false, A>), dim3(nqb * H * batch), block, sp_smem_bytes(false), stream,         \
+                       (const bf16*)Q, (bf16*)O, s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, g_attn_order);              \
     return (int)hipGetLastError();
     if (!two) switch (g_attn_ablate) {
         CE_SP_ABL(1) CE_SP_ABL(2) CE_SP_ABL(3) CE_SP_ABL(4) CE_SP_ABL(6) CE_SP_ABL(7) CE_SP_ABL(8) CE_SP_ABL(10)
