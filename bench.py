@@ -145,7 +145,7 @@ def main():
     from chronoedit_amd import ops
     from chronoedit_amd.pipeline import GraphedDenoiser, denoise_step, make_cfg_inputs
     from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
-    from oracle.dit_oracle import DiTConfig, flops_per_forward
+    from chronoedit_amd.flops import dit_flops_per_forward
 
     ops.lib()  # fail loudly if the HIP library is missing
     if a.attn_kernel:
@@ -247,8 +247,7 @@ def main():
     vae_s = None
     if not a.no_vae and rank == 0 and world == 1:
         from chronoedit_amd.vae import AutoencoderKLWan
-        from oracle import vae_oracle as V
-        vae = AutoencoderKLWan({k: v.to(dev) for k, v in V.make_synthetic_params(V.VAEConfig()).items()})
+        vae = AutoencoderKLWan.random_init(dev, seed=4321)
         nf = 4 * (T - 1) + 1
         vid = (torch.rand(1, 3, nf, a.height, a.width, device=dev) * 2 - 1).to(torch.bfloat16)
         zl = torch.randn(1, 16, T, h, w, device=dev).to(torch.bfloat16)
@@ -290,7 +289,7 @@ def main():
 
     if rank == 0:
         steps_per_s = a.steps / dt * (1 if ulysses else world)
-        fl = flops_per_forward(DiTConfig(num_layers=a.layers), N) * fwd_per_step
+        fl = dit_flops_per_forward(N, num_layers=a.layers) * fwd_per_step
         out = {
             "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),

@@ -330,8 +330,80 @@ class WanVAEEngine:
         return v.permute(3, 0, 1, 2).contiguous()
 
 
+def wan_vae_param_shapes(dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True)):
+    """{state-dict key: shape} of the Wan 2.1 VAE in the reference's own naming (_src/tokenizers/wan2pt1.py:283-305,384-415,
+    492-493): what a checkpoint for `AutoencoderKLWan(params)` must contain."""
+    eng = WanVAEEngine.__new__(WanVAEEngine)
+    eng.cfg = SimpleNamespace(dim=dim, z_dim=z_dim, dim_mult=tuple(dim_mult), num_res_blocks=num_res_blocks,
+                              temperal_downsample=tuple(temperal_downsample), temporal_window=4)
+    eng._layers()
+    s: Dict[str, tuple] = {}
+
+    def conv(name, cin, cout, k):
+        s[name + ".weight"] = (cout, cin) + tuple(k)
+        s[name + ".bias"] = (cout,)
+
+    def block(l):
+        kind, name = l[0], l[1]
+        if kind == "res":
+            cin, cout = l[2], l[3]
+            s[name + ".residual.0.gamma"] = (cin, 1, 1, 1)
+            conv(name + ".residual.2", cin, cout, (3, 3, 3))
+            s[name + ".residual.3.gamma"] = (cout, 1, 1, 1)
+            conv(name + ".residual.6", cout, cout, (3, 3, 3))
+            if cin != cout:
+                conv(name + ".shortcut", cin, cout, (1, 1, 1))
+        elif kind == "attn":
+            c = l[2]
+            s[name + ".norm.gamma"] = (c, 1, 1)
+            conv(name + ".to_qkv", c, 3 * c, (1, 1))
+            conv(name + ".proj", c, c, (1, 1))
+        elif kind in ("down2d", "down3d"):
+            c = l[2]
+            conv(name + ".resample.1", c, c, (3, 3))
+            if kind == "down3d":
+                conv(name + ".time_conv", c, c, (3, 1, 1))
+        else:  # up2d / up3d
+            c = l[2]
+            conv(name + ".resample.1", c, c // 2, (3, 3))
+            if kind == "up3d":
+                conv(name + ".time_conv", c, 2 * c, (3, 1, 1))
+
+    conv("encoder.conv1", 3, dim, (3, 3, 3))
+    for l in eng.enc:
+        block(l)
+    ec = dim * dim_mult[-1]
+    s["encoder.head.0.gamma"] = (ec, 1, 1, 1)
+    conv("encoder.head.2", ec, 2 * z_dim, (3, 3, 3))
+    conv("conv1", 2 * z_dim, 2 * z_dim, (1, 1, 1))
+    conv("conv2", z_dim, z_dim, (1, 1, 1))
+    conv("decoder.conv1", z_dim, ec, (3, 3, 3))
+    for l in eng.dec:
+        block(l)
+    s["decoder.head.0.gamma"] = (dim, 1, 1, 1)
+    conv("decoder.head.2", dim, 3, (3, 3, 3))
+    return s
+
+
 class AutoencoderKLWan(torch.nn.Module):
     """`pipe.vae`-compatible wrapper around WanVAEEngine (parameters held as a flat buffer dict)."""
+
+    @classmethod
+    def random_init(cls, device, seed: int = 0, **arch):
+        """The architecture with seeded random weights (convs ~ N(0, 1/fan_in), gammas 1): for benchmarks without a checkpoint."""
+        g = torch.Generator(device=device).manual_seed(seed)
+        params = {}
+        for k, shp in wan_vae_param_shapes(**arch).items():
+            if k.endswith("gamma"):
+                params[k] = torch.ones(shp, device=device)
+            elif k.endswith(".bias"):
+                params[k] = torch.zeros(shp, device=device)
+            else:
+                fan_in = 1
+                for d in shp[1:]:
+                    fan_in *= d
+                params[k] = torch.randn(shp, generator=g, device=device) / fan_in ** 0.5
+        return cls(params, **arch)
 
     def __init__(self, params: Dict[str, torch.Tensor], dim=96, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2,
                  temperal_downsample=(False, True, True)):

@@ -58,3 +58,18 @@ def test_cpu_call_fails_loudly():
     from chronoedit_amd import ops
     with pytest.raises(ops.HipKernelError):
         ops.ln_affine(torch.zeros(4, 64, dtype=torch.bfloat16), torch.ones(64), torch.zeros(64), 1e-6)
+
+
+def test_product_side_shape_helpers_match_the_oracles():
+    """bench.py / tools use product-side helpers (they must not import oracle/ outside the cpu_baseline leg):
+    the flop count and the VAE parameter table agree with the oracle's."""
+    from chronoedit_amd.flops import dit_flops_per_forward
+    from chronoedit_amd.vae import wan_vae_param_shapes
+    from oracle import dit_oracle as O
+    from oracle import vae_oracle as V
+    for n in (512, 7200, 13068, 28800):
+        assert dit_flops_per_forward(n) == float(O.flops_per_forward(O.DiTConfig(), n))
+    assert abs(dit_flops_per_forward(7200) / 1e12 - 222.38) < 0.01  # SURVEY 8d
+    assert dit_flops_per_forward(7200, num_layers=2) == float(O.flops_per_forward(O.DiTConfig(num_layers=2), 7200))
+    a, b = wan_vae_param_shapes(), V.param_shapes(V.VAEConfig())
+    assert set(a) == set(b) and all(tuple(a[k]) == tuple(b[k]) for k in a)

@@ -31,11 +31,10 @@ def main():
     from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
     from chronoedit_amd.umt5 import UMT5EncoderModel
     from chronoedit_amd.vae import AutoencoderKLWan
-    from oracle import vae_oracle as V  # synthetic VAE parameters only (seeded shapes); no oracle arithmetic is run
 
     t_build = time.perf_counter()
     torch.manual_seed(0)
-    pipe = ChronoEditPipeline(vae=AutoencoderKLWan({k: v.to(dev) for k, v in V.make_synthetic_params(V.VAEConfig()).items()}),
+    pipe = ChronoEditPipeline(vae=AutoencoderKLWan.random_init(dev, seed=4321),
                               transformer=bench.build_model(40, dev), scheduler=FlowUniPCMultistepScheduler(flow_shift=a.flow_shift),
                               text_encoder=UMT5EncoderModel(device=dev), image_encoder=CLIPVisionModel(device=dev))
     torch.cuda.synchronize()

@@ -9,12 +9,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chronoedit_amd import ops  # noqa: E402
 from chronoedit_amd.vae import AutoencoderKLWan  # noqa: E402
-from oracle import vae_oracle as V  # noqa: E402
 
 H, W, T = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (720, 1280, 5)))
-cfg = V.VAEConfig()
-p = {k: v.cuda() for k, v in V.make_synthetic_params(cfg).items()}
-vae = AutoencoderKLWan(p)
+vae = AutoencoderKLWan.random_init(torch.device("cuda:0"), seed=4321)
 x = (torch.rand(1, 3, T, H, W, device="cuda") * 2 - 1).to(torch.bfloat16)
 res = {}
 for name, fn in (("encode", lambda: vae.encode(x).latent_dist.mode()),):
