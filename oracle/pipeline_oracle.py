@@ -26,11 +26,18 @@ def prepare_latents(vp, vcfg, image, num_frames, latents):
 
 
 def edit(dp, dcfg, vp, vcfg, image, prompt, negative, image_embeds, latents, num_frames=5, steps=4, guidance=5.0, shift=5.0,
-         decode=True):
+         decode=True, enable_temporal_reasoning=False, num_temporal_reasoning_steps=0):
     latents, cond = prepare_latents(vp, vcfg, image, num_frames, latents)
     sch = UniPCOracle()
     sch.set_timesteps(steps, shift=shift)
     for i, t in enumerate(sch.timesteps):
+        if enable_temporal_reasoning and i == num_temporal_reasoning_steps:  # pipeline_chronoedit.py:700-709
+            latents = latents[:, :, [0, -1]]
+            cond = cond[:, :, [0, -1]]
+            sch.model_outputs = [None if m is None else (m[:, :, [0, -1]] if m.shape[-3] != latents.shape[-3] else m)
+                                 for m in sch.model_outputs]
+            if sch.last_sample is not None:
+                sch.last_sample = sch.last_sample[:, :, [0, -1]] if sch.last_sample.shape[-3] != latents.shape[-3] else sch.last_sample
         inp = torch.cat([latents, cond], dim=1).to(prompt.dtype)
         ts = t.expand(latents.shape[0])
         c = D.dit_forward(dp, dcfg, inp, ts, prompt, image_embeds)
@@ -42,5 +49,11 @@ def edit(dp, dcfg, vp, vcfg, image, prompt, negative, image_embeds, latents, num
         return latents, None
     mean = torch.tensor(V.LATENTS_MEAN[: vcfg.z_dim], dtype=latents.dtype).view(1, -1, 1, 1, 1)
     inv_std = (1.0 / torch.tensor(V.LATENTS_STD[: vcfg.z_dim])).to(latents.dtype).view(1, -1, 1, 1, 1)
-    video = V.decode(vp, vcfg, latents / inv_std + mean)
+    z = latents / inv_std + mean
+    if enable_temporal_reasoning and num_temporal_reasoning_steps > 0:  # pipeline_chronoedit.py:776-779
+        video_edit = V.decode(vp, vcfg, z[:, :, [0, -1]])
+        video_reason = V.decode(vp, vcfg, z[:, :, :-1])
+        video = torch.cat([video_reason, video_edit[:, :, 1:]], dim=2)
+    else:
+        video = V.decode(vp, vcfg, z)
     return latents, video

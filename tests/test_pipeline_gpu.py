@@ -102,3 +102,51 @@ def test_pipeline_encoders_feed_the_edit():
     assert img.shape == (1, 17, 320) and torch.isfinite(img.float()).all()
     with pytest.raises(ValueError):
         ChronoEditPipeline(None, None, None).encode_image(torch.zeros(1, 3, 56, 56, device="cuda:0"))
+
+
+def test_temporal_reasoning_edit_vs_oracle():
+    """The reasoning mode of the reference (pipeline_chronoedit.py:700-709, 776-779): 29 pixel frames = 8 latent frames for the first
+    steps, truncated to the first and last latent frame (with the scheduler history) afterwards, decoded as reasoning video +
+    edited frame.  HIP pipeline vs the fp32 oracle."""
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from chronoedit_amd.vae import AutoencoderKLWan
+    dcfg = D.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    vcfg = V.VAEConfig(dim=32, z_dim=16)
+    dp = D.make_synthetic_params(dcfg, dtype=torch.bfloat16)
+    vp = V.make_synthetic_params(vcfg)
+    g = torch.Generator().manual_seed(1)
+    H, W, F = 64, 96, 29
+    image = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    prompt = torch.randn(1, 40, 128, generator=g)
+    negative = torch.randn(1, 40, 128, generator=g)
+    img_emb = torch.randn(1, 257, 64, generator=g)
+    lat0 = torch.randn(1, 16, 8, H // 8, W // 8, generator=g)
+    bf = torch.bfloat16
+    dp32 = {k: v.float() for k, v in dp.items()}
+    kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)
+    with torch.no_grad():
+        lat_ref, vid_ref = P.edit(dp32, dcfg, vp, vcfg, image.to(bf).float(), prompt.to(bf).float(), negative.to(bf).float(),
+                                  img_emb.to(bf).float(), lat0.clone(), num_frames=F, steps=4, **kw)
+    assert lat_ref.shape[2] == 2 and vid_ref.shape[2] == 5
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
+    vae = AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16)
+    pipe = ChronoEditPipeline(vae, m, FlowUniPCMultistepScheduler(flow_shift=5.0))
+    args = (image.cuda().to(bf), prompt.cuda().to(bf), negative.cuda().to(bf), img_emb.cuda().to(bf))
+    lat = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent", **kw)
+    vid = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), **kw)
+    e_lat, e_vid = rel_l2(lat, lat_ref), rel_l2(vid, vid_ref)
+    print(f"reasoning edit: latents rel-L2 {e_lat:.3e}, video rel-L2 {e_vid:.3e}")
+    assert lat.shape == lat_ref.shape and vid.shape == vid_ref.shape
+    assert e_lat < 6e-2 and e_vid < 8e-2
+    # never truncated (k >= steps): 8 latent frames to the end, reasoning video (all but the last latent frame) + edited frame
+    kw2 = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=50)
+    with torch.no_grad():
+        lat_ref2, vid_ref2 = P.edit(dp32, dcfg, vp, vcfg, image.to(bf).float(), prompt.to(bf).float(), negative.to(bf).float(),
+                                    img_emb.to(bf).float(), lat0.clone(), num_frames=F, steps=3, **kw2)
+    vid2 = pipe(*args, num_frames=F, num_inference_steps=3, guidance_scale=5.0, latents=lat0.cuda(), **kw2)
+    print(f"reasoning (no truncation): video rel-L2 {rel_l2(vid2, vid_ref2):.3e}  shape {tuple(vid2.shape)}")
+    assert vid2.shape == vid_ref2.shape and rel_l2(vid2, vid_ref2) < 8e-2
