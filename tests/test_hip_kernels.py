@@ -215,6 +215,23 @@ def test_attention_batched_equals_per_sample(two_seg, attn_waves):
         ops.attention(q[:-1], kv1[:, :D], kv1[:, D:], H, batch=B)
 
 
+@pytest.mark.parametrize("Nq,Nkv,H,B", [(256, 256, 8, 1), (512, 100, 8, 2), (290, 64, 5, 3), (31, 700, 16, 2), (1056, 1056, 5, 2),
+                                         (769, 769, 24, 1)])
+def test_attention_work_order_shapes(Nq, Nkv, H, B):
+    """Default kernel over the corner cases of its workgroup order: no remainder block, only a remainder block, head counts that
+    are / are not multiples of 8 (XCD-aware vs plain mapping), several stacked samples."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    D = H * 128
+    q = torch.randn(B * Nq, D, generator=g).to(BF).to(dev)
+    kv = torch.randn(B * Nkv, 2 * D, generator=g).to(BF).to(dev)
+    out = ops.attention(q, kv[:, :D], kv[:, D:], H, batch=B)
+    for b in range(B):
+        ref = _sdpa_ref(q[b * Nq:(b + 1) * Nq], kv[b * Nkv:(b + 1) * Nkv, :D], kv[b * Nkv:(b + 1) * Nkv, D:], H)
+        assert rel_l2(out[b * Nq:(b + 1) * Nq], ref) < 1e-2, (b, rel_l2(out[b * Nq:(b + 1) * Nq], ref))
+
+
 @pytest.mark.parametrize("Nq,Nkv,H", [(64, 64, 2), (300, 257, 2), (1000, 1000, 8), (7200, 7200, 8), (33, 512, 3)])
 def test_attention_single_segment(Nq, Nkv, H, attn_waves):
     from chronoedit_amd import ops
