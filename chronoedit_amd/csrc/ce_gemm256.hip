@@ -59,6 +59,9 @@ struct Stager {
   const char* w_base;
   int wave;              // wave-uniform
   int kt_last;
+#ifdef CE_GEMM_BUFFER_DMA  // experiment: buffer_load ... lds (32-bit per-lane offsets + SRD) instead of global_load_lds
+  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
+#endif
 };
 
 template <int SLOT_ID>
@@ -66,6 +69,14 @@ __device__ __forceinline__ void stage_half(unsigned char* smem, const Stager& s,
   constexpr int half = SLOT_ID & 1;
   constexpr bool isB = (SLOT_ID & 2) != 0;
   const int t = tile < s.kt_last ? tile : s.kt_last;  // clamp: surplus prefetches re-read the last K-tile
+#ifdef CE_GEMM_BUFFER_DMA
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint32_t off = isB ? s.w_off[half][r] : s.a_off[half][r];
+    unsigned char* dst = smem + SLOT_ID * SLOT + (r * 8 + s.wave) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? s.w_rsrc : s.a_rsrc, (lds_void*)dst, 16, off, t * (BK * 2), 0, 0);
+  }
+#else
   const char* base = (isB ? s.w_base : s.a_base) + (size_t)t * (BK * 2);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -73,6 +84,7 @@ __device__ __forceinline__ void stage_half(unsigned char* smem, const Stager& s,
     unsigned char* dst = smem + SLOT_ID * SLOT + (r * 8 + s.wave) * 1024;  // wave-uniform; lane l lands at +16 l
     __builtin_amdgcn_global_load_lds((gbl_void*)(base + off), (lds_void*)dst, 16, 0, 0);
   }
+#endif
 }
 
 // fragment reads of one k-step (32 deep): 64 rows of an A half-tile -> 4 fragments, 32 rows of a W half-tile -> 2
@@ -220,6 +232,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   Stager st;
   st.a_base = reinterpret_cast<const char*>(A) + (size_t)kt0 * (BK * 2);
   st.w_base = reinterpret_cast<const char*>(W) + (size_t)kt0 * (BK * 2);
+#ifdef CE_GEMM_BUFFER_DMA
+  st.a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.a_base, 0, 0x7fffffff, 0x00020000);
+  st.w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.w_base, 0, 0x7fffffff, 0x00020000);
+#endif
   st.wave = wave;
   st.kt_last = ktn - 1;
 #pragma unroll

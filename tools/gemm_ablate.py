@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "chronoedit_amd", "csrc")
 NAMES = {0: "full kernel", 1: "no barriers in the loop", 2: "no LDS-DMA staging in the loop", 3: "no fragment reads in the loop",
          4: "no MFMAs", 5: "LDS-DMA stream only (no barriers / reads / MFMAs)",
-         6: "LDS-DMA stream only, no vmcnt waits"}
+         6: "LDS-DMA stream only, no vmcnt waits", 7: "full kernel, buffer_load..lds instead of global_load_lds"}
 
 
 def lib_path(a):
@@ -18,7 +18,8 @@ def lib_path(a):
 
 def build():
     for a in NAMES:
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DCE_GEMM_ABL={a}", "-I", CSRC,
+        defs = ["-DCE_GEMM_ABL=0", "-DCE_GEMM_BUFFER_DMA"] if a == 7 else [f"-DCE_GEMM_ABL={a}"]
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *defs, "-I", CSRC,
                os.path.join(CSRC, "ce_gemm256.hip"), "-o", lib_path(a)]
         subprocess.check_call(cmd)
         print("built", lib_path(a))
