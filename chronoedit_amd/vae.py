@@ -389,6 +389,27 @@ class AutoencoderKLWan(torch.nn.Module):
     """`pipe.vae`-compatible wrapper around WanVAEEngine (parameters held as a flat buffer dict)."""
 
     @classmethod
+    def from_pretrained(cls, path: str, subfolder: Optional[str] = None, torch_dtype: torch.dtype = torch.bfloat16, device="cuda:0",
+                        **unused):
+        """``AutoencoderKLWan.from_pretrained(model_path, subfolder="vae", torch_dtype=bf16)`` (run_inference_diffusers.py:341-345):
+        config.json (base_dim, z_dim, dim_mult, num_res_blocks, temperal_downsample) + safetensors in the diffusers or the native
+        Wan naming; the key set and every shape are checked against the architecture."""
+        from . import weights
+        cfg = weights.read_config(path, subfolder)
+        arch = dict(dim=cfg.get("base_dim", 96), z_dim=cfg.get("z_dim", 16), dim_mult=tuple(cfg.get("dim_mult", (1, 2, 4, 4))),
+                    num_res_blocks=cfg.get("num_res_blocks", 2), temperal_downsample=tuple(cfg.get("temperal_downsample", (False, True, True))))
+        sd = weights.load_state_dict_files(weights.shard_files(path, subfolder))
+        sd = weights.wan_vae_diffusers_to_native(sd, arch["num_res_blocks"], len(arch["dim_mult"]))
+        want = wan_vae_param_shapes(**arch)
+        if set(sd) != set(want):
+            odd = sorted(set(sd) ^ set(want))
+            raise KeyError(f"VAE checkpoint does not match the architecture: {odd[:6]}")
+        for k, shp in want.items():
+            if tuple(sd[k].shape) != tuple(shp) and sd[k].numel() != int(torch.tensor(shp).prod()):
+                raise ValueError(f"{k}: checkpoint shape {tuple(sd[k].shape)} != {tuple(shp)}")
+        return cls({k: sd[k].reshape(want[k]).to(device) for k in want}, **arch)
+
+    @classmethod
     def random_init(cls, device, seed: int = 0, **arch):
         """The architecture with seeded random weights (convs ~ N(0, 1/fan_in), gammas 1): for benchmarks without a checkpoint."""
         g = torch.Generator(device=device).manual_seed(seed)

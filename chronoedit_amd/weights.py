@@ -173,6 +173,71 @@ def wan_native_to_diffusers(sd: Dict[str, torch.Tensor], diffusers_keys: Iterabl
 
 
 # ------------------------------------------------------------------------------------------
+# Wan VAE: diffusers AutoencoderKLWan names -> the native names of _src/tokenizers/wan2pt1.py that chronoedit_amd.vae uses
+# ------------------------------------------------------------------------------------------
+def wan_vae_diffusers_to_native(sd: Dict[str, torch.Tensor], num_res_blocks: int = 2, num_stages: int = 4) -> Dict[str, torch.Tensor]:
+    """Rename a diffusers ``AutoencoderKLWan`` state dict (what ``from_pretrained(subfolder="vae")`` reads,
+    run_inference_diffusers.py:341-345) to the native Wan names.  diffusers is NOT installed in this environment, so the
+    diffusers side of this table is written from its published layout (conv_in / down_blocks (flat) / mid_block.{resnets,
+    attentions} / norm_out / conv_out, decoder up_blocks.{i}.{resnets.{j}, upsamplers.0}, quant_conv / post_quant_conv,
+    residual blocks as norm1 / conv1 / norm2 / conv2 / conv_shortcut) and is pinned only structurally: the caller checks that
+    the result has exactly the native key set with matching shapes.  Native-named dicts pass through unchanged."""
+    if "encoder.conv1.weight" in sd:
+        return dict(sd)
+    res_map = {"norm1.gamma": "residual.0.gamma", "conv1.": "residual.2.", "norm2.gamma": "residual.3.gamma", "conv2.": "residual.6.",
+               "conv_shortcut.": "shortcut."}
+
+    def res(rest: str) -> str:
+        for a, b in res_map.items():
+            if rest.startswith(a):
+                return b + rest[len(a):]
+        return rest  # resample.1.* / time_conv.* / norm.gamma / to_qkv.* / proj.* keep their names
+
+    out = {}
+    for k, v in sd.items():
+        m = re.match(r"^(encoder|decoder)\.(.*)$", k)
+        if not m:
+            top = {"quant_conv.": "conv1.", "post_quant_conv.": "conv2."}
+            for a, b in top.items():
+                if k.startswith(a):
+                    out[b + k[len(a):]] = v
+                    break
+            else:
+                raise KeyError(f"unrecognised VAE key {k}")
+            continue
+        side, rest = m.group(1), m.group(2)
+        if rest.startswith("conv_in."):
+            new = "conv1." + rest[len("conv_in."):]
+        elif rest.startswith("conv_out."):
+            new = "head.2." + rest[len("conv_out."):]
+        elif rest == "norm_out.gamma":
+            new = "head.0.gamma"
+        elif rest.startswith("mid_block.resnets."):
+            j, tail = rest[len("mid_block.resnets."):].split(".", 1)
+            new = f"middle.{0 if j == '0' else 2}." + res(tail)
+        elif rest.startswith("mid_block.attentions.0."):
+            new = "middle.1." + rest[len("mid_block.attentions.0."):]
+        elif rest.startswith("down_blocks."):
+            j, tail = rest[len("down_blocks."):].split(".", 1)
+            new = f"downsamples.{j}." + res(tail)
+        elif rest.startswith("up_blocks."):
+            i, kind, tail = rest[len("up_blocks."):].split(".", 2)
+            base = int(i) * (num_res_blocks + 2)  # num_res_blocks + 1 residual blocks and one upsampler per stage
+            if kind == "resnets":
+                j, tail2 = tail.split(".", 1)
+                new = f"upsamples.{base + int(j)}." + res(tail2)
+            elif kind == "upsamplers":
+                _, tail2 = tail.split(".", 1)
+                new = f"upsamples.{base + num_res_blocks + 1}." + tail2
+            else:
+                raise KeyError(f"unrecognised VAE key {k}")
+        else:
+            raise KeyError(f"unrecognised VAE key {k}")
+        out[f"{side}.{new}"] = v
+    return out
+
+
+# ------------------------------------------------------------------------------------------
 # LoRA
 # ------------------------------------------------------------------------------------------
 _PREFIXES = ("transformer.", "diffusion_model.", "model.diffusion_model.", "base_model.model.")

@@ -164,3 +164,67 @@ def test_wan_native_checkpoint_roundtrip():
         assert torch.equal(a, b), k
     with pytest.raises(KeyError):
         m2.load_wan_native_state_dict({**native, "blocks.0.bogus.weight": torch.zeros(1)})
+
+
+def _diffusers_vae_names(native_keys, num_res_blocks=2):
+    """Independent forward map native -> diffusers layout (test-side), to exercise the product's inverse."""
+    res = {"residual.0.gamma": "norm1.gamma", "residual.2.": "conv1.", "residual.3.gamma": "norm2.gamma", "residual.6.": "conv2.",
+           "shortcut.": "conv_shortcut."}
+    out = {}
+    for k in native_keys:
+        side, rest = (k.split(".", 1) + [""])[:2] if k.split(".")[0] in ("encoder", "decoder") else (None, k)
+        if side is None:
+            out[k] = ("quant_conv." if k.startswith("conv1.") else "post_quant_conv.") + k.split(".", 1)[1]
+            continue
+        def r(t):
+            for a, b in res.items():
+                if t.startswith(a):
+                    return b + t[len(a):]
+            return t
+        if rest.startswith("conv1."):
+            new = "conv_in." + rest[6:]
+        elif rest.startswith("head.2."):
+            new = "conv_out." + rest[7:]
+        elif rest == "head.0.gamma":
+            new = "norm_out.gamma"
+        elif rest.startswith("middle."):
+            j, t = rest[7:].split(".", 1)
+            new = f"mid_block.attentions.0.{t}" if j == "1" else f"mid_block.resnets.{0 if j == '0' else 1}.{r(t)}"
+        elif rest.startswith("downsamples."):
+            j, t = rest[12:].split(".", 1)
+            new = f"down_blocks.{j}.{r(t)}"
+        else:
+            j, t = rest[len("upsamples."):].split(".", 1)
+            i, jj = divmod(int(j), num_res_blocks + 2)
+            new = f"up_blocks.{i}.upsamplers.0.{t}" if jj == num_res_blocks + 1 else f"up_blocks.{i}.resnets.{jj}.{r(t)}"
+        out[k] = f"{side}.{new}"
+    return out
+
+
+def test_vae_checkpoint_naming_roundtrip(tmp_path):
+    """AutoencoderKLWan.from_pretrained accepts the native Wan names and the diffusers layout (structural check only: diffusers is
+    not installed here, see wan_vae_diffusers_to_native)."""
+    from safetensors.torch import save_file
+    from chronoedit_amd.vae import wan_vae_param_shapes
+    arch = dict(dim=32, z_dim=16)
+    shapes = wan_vae_param_shapes(**arch)
+    g = torch.Generator().manual_seed(0)
+    native = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
+    fwd = _diffusers_vae_names(shapes)
+    assert len(set(fwd.values())) == len(fwd)
+    assert "decoder.up_blocks.3.resnets.2.conv2.weight" in fwd.values() and "encoder.mid_block.attentions.0.to_qkv.weight" in fwd.values()
+    diff = {fwd[k]: v for k, v in native.items()}
+    back = weights.wan_vae_diffusers_to_native(diff)
+    assert set(back) == set(native) and all(torch.equal(back[k], native[k]) for k in native)
+    assert weights.wan_vae_diffusers_to_native(native).keys() == native.keys()  # native passes through
+    with pytest.raises(KeyError):
+        weights.wan_vae_diffusers_to_native({**diff, "encoder.bogus.weight": torch.zeros(1)})
+    # from_pretrained end to end on CPU tensors (device="cpu": only the loader is exercised, no kernels run)
+    from chronoedit_amd.vae import AutoencoderKLWan
+    d = tmp_path / "vae"
+    d.mkdir()
+    json.dump({"base_dim": 32, "z_dim": 16, "dim_mult": [1, 2, 4, 4], "num_res_blocks": 2, "temperal_downsample": [False, True, True],
+               "_class_name": "AutoencoderKLWan"}, open(d / "config.json", "w"))
+    save_file({k: v.contiguous() for k, v in diff.items()}, str(d / weights.WEIGHTS_NAME))
+    vae = AutoencoderKLWan.from_pretrained(str(tmp_path), subfolder="vae", device="cpu")
+    assert vae.config.z_dim == 16 and torch.equal(vae._params["decoder.head.2.weight"], native["decoder.head.2.weight"])
