@@ -205,6 +205,38 @@ class ChronoEditPipeline:
         self.vae, self.transformer, self.scheduler = vae, transformer, scheduler
         self.text_encoder, self.image_encoder = text_encoder, image_encoder  # chronoedit_amd.umt5 / .clip_vision drop-ins
 
+    @classmethod
+    def from_pretrained(cls, path: str, transformer=None, vae=None, text_encoder=None, image_encoder=None, scheduler=None,
+                        torch_dtype: torch.dtype = torch.bfloat16, device="cuda:0", load_encoders: bool = True, **unused):
+        """``ChronoEditPipeline.from_pretrained(model_path, image_encoder=..., transformer=..., vae=..., torch_dtype=bf16)``
+        (run_inference_diffusers.py:357-364): components handed in are used as they are, the others are read from the
+        diffusers directory layout (``transformer/``, ``vae/``, ``text_encoder/``, ``image_encoder/``,
+        ``scheduler/scheduler_config.json``).  The tokenizer and the CLIP image processor are host-side transformers objects and
+        stay with the caller."""
+        import json
+        import os
+
+        from .vae import AutoencoderKLWan
+        if transformer is None:
+            transformer = ChronoEditTransformer3DModel.from_pretrained(path, subfolder="transformer", torch_dtype=torch_dtype, device=device)
+        if vae is None:
+            vae = AutoencoderKLWan.from_pretrained(path, subfolder="vae", torch_dtype=torch_dtype, device=device)
+        if scheduler is None:
+            cfg_file = os.path.join(path, "scheduler", "scheduler_config.json")
+            cfg = {}
+            if os.path.exists(cfg_file):
+                with open(cfg_file) as f:
+                    cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+            scheduler = FlowUniPCMultistepScheduler.from_config(cfg)
+        if load_encoders:
+            if text_encoder is None and os.path.isdir(os.path.join(path, "text_encoder")):
+                from .umt5 import UMT5EncoderModel
+                text_encoder = UMT5EncoderModel.from_pretrained(path, subfolder="text_encoder", torch_dtype=torch_dtype, device=device)
+            if image_encoder is None and os.path.isdir(os.path.join(path, "image_encoder")):
+                from .clip_vision import CLIPVisionModel
+                image_encoder = CLIPVisionModel.from_pretrained(path, subfolder="image_encoder", torch_dtype=torch_dtype, device=device)
+        return cls(vae, transformer, scheduler, text_encoder=text_encoder, image_encoder=image_encoder)
+
     def encode_prompt(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
                       negative_input_ids: Optional[torch.Tensor] = None, negative_attention_mask: Optional[torch.Tensor] = None):
         """``encode_prompt`` / ``_get_t5_prompt_embeds`` after the tokenizer (pipeline_chronoedit.py:205-243,258-330): token ids

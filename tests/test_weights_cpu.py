@@ -228,3 +228,42 @@ def test_vae_checkpoint_naming_roundtrip(tmp_path):
     save_file({k: v.contiguous() for k, v in diff.items()}, str(d / weights.WEIGHTS_NAME))
     vae = AutoencoderKLWan.from_pretrained(str(tmp_path), subfolder="vae", device="cpu")
     assert vae.config.z_dim == 16 and torch.equal(vae._params["decoder.head.2.weight"], native["decoder.head.2.weight"])
+
+
+def test_pipeline_from_pretrained_directory_layout(tmp_path):
+    """The diffusers model-directory layout the reference's runner points at: transformer/, vae/, text_encoder/, image_encoder/,
+    scheduler/ - every drop-in loads itself from its subfolder (CPU tensors here: loaders only, no kernels)."""
+    from safetensors.torch import save_file
+    from chronoedit_amd.clip_vision import CLIPVisionModel
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.umt5 import UMT5EncoderModel
+    from chronoedit_amd.vae import wan_vae_param_shapes
+    root = tmp_path / "ChronoEdit-tiny"
+    t = tiny(seed=5)
+    t.save_pretrained(str(root / "transformer"))
+    (root / "vae").mkdir()
+    json.dump({"base_dim": 32, "z_dim": 16}, open(root / "vae" / "config.json", "w"))
+    g = torch.Generator().manual_seed(1)
+    save_file({k: torch.randn(s, generator=g) for k, s in wan_vae_param_shapes(dim=32, z_dim=16).items()}, str(root / "vae" / weights.WEIGHTS_NAME))
+    te = UMT5EncoderModel(vocab_size=50, d_model=128, d_kv=64, d_ff=256, num_layers=1, num_heads=2, device="cpu")
+    (root / "text_encoder").mkdir()
+    json.dump({**vars(te.config), "model_type": "umt5"}, open(root / "text_encoder" / "config.json", "w"))
+    sd = {k: v.detach().clone() for k, v in te.state_dict().items()}
+    save_file(sd, str(root / "text_encoder" / "model.safetensors"))
+    ie = CLIPVisionModel(hidden_size=320, intermediate_size=640, num_hidden_layers=1, num_attention_heads=4, image_size=28, patch_size=14, device="cpu")
+    (root / "image_encoder").mkdir()
+    json.dump(vars(ie.config), open(root / "image_encoder" / "config.json", "w"))
+    save_file({k: v.detach().clone() for k, v in ie.state_dict().items()}, str(root / "image_encoder" / "model.safetensors"))
+    (root / "scheduler").mkdir()
+    json.dump({"_class_name": "UniPCMultistepScheduler", "flow_shift": 3.0, "solver_order": 2, "use_flow_sigmas": True,
+               "prediction_type": "flow_prediction"}, open(root / "scheduler" / "scheduler_config.json", "w"))
+    pipe = ChronoEditPipeline.from_pretrained(str(root), device="cpu")
+    assert pipe.scheduler.config.shift == 3.0
+    for (k, a), (_, b) in zip(t.named_parameters(), pipe.transformer.named_parameters()):
+        assert torch.equal(a, b), k
+    assert torch.equal(pipe.text_encoder.shared.weight, te.shared.weight)
+    assert pipe.text_encoder.encoder.embed_tokens.weight is pipe.text_encoder.shared.weight  # tied, as in transformers
+    assert torch.equal(pipe.image_encoder.vision_model.embeddings.class_embedding, ie.vision_model.embeddings.class_embedding)
+    assert pipe.vae.config.z_dim == 16
+    pipe2 = ChronoEditPipeline.from_pretrained(str(root), transformer=t, device="cpu", load_encoders=False)
+    assert pipe2.transformer is t and pipe2.text_encoder is None
