@@ -408,6 +408,19 @@ class DiTEngine:
             p.w_f2, p.b_f2 = blk.ffn.net[2].weight.detach().contiguous(), f32(blk.ffn.net[2].bias)
             tables.append(f32(blk.scale_shift_table).reshape(6, self.D))
             self.blk.append(p)
+        # K13 for ALL layers as one GEMM per context stream: the per-layer [k | v] weights are re-homed, layer after layer, in
+        # one [L*2D, D] buffer (the step-invariant projections of 769 context rows are 40 small GEMMs otherwise: 0.5-1.0 PFLOP/s
+        # at M = 514 / 1024 against 1.35 for one [M, L*2D] product); p.w_kv_* stay views of their layer's rows.
+        self.w_kv_t_all = self._fuse([lin for blk in model.blocks for lin in (blk.attn2.to_k, blk.attn2.to_v)])
+        self.b_kv_t_all = torch.cat([p.b_kv_t for p in self.blk])
+        self.all_img = all(p.has_img for p in self.blk)
+        if self.all_img:
+            self.w_kv_i_all = self._fuse([lin for blk in model.blocks for lin in (blk.attn2.add_k_proj, blk.attn2.add_v_proj)])
+            self.b_kv_i_all = torch.cat([p.b_kv_i for p in self.blk])
+        for li, p in enumerate(self.blk):
+            p.w_kv_t = self.w_kv_t_all[li * 2 * self.D:(li + 1) * 2 * self.D]
+            if self.all_img:
+                p.w_kv_i = self.w_kv_i_all[li * 2 * self.D:(li + 1) * 2 * self.D]
         self.tables = torch.stack(tables, 0).contiguous()  # [L, 6, D]
         self.table_out = f32(model.scale_shift_table).reshape(1, 2, self.D)
         self.w_out, self.b_out = _pad_n(model.proj_out.weight.detach().contiguous(), f32(model.proj_out.bias))
@@ -489,11 +502,18 @@ class DiTEngine:
         kv = []
         eps = self.cfg.eps
         hd = self.cfg.attention_head_dim
-        for p in self.blk:
-            kv_t = ops.gemm(enc_t, p.w_kv_t, p.b_kv_t)  # [B*Tt, 2D] = [k | v]
+        kv_t_all = ops.gemm(enc_t, self.w_kv_t_all, self.b_kv_t_all)  # [B*Tt, L*2D] = per layer [k | v]
+        kv_i_all = None
+        if enc_i is not None and self.all_img:
+            kv_i_all = ops.gemm(enc_i, self.w_kv_i_all, self.b_kv_i_all)
+        for li, p in enumerate(self.blk):
+            kv_t = kv_t_all[:, li * 2 * D:(li + 1) * 2 * D]
             ops.rmsnorm_rope_(kv_t[:, :D], p.nk2, None, hd, eps)
             kv_i = None
-            if enc_i is not None and p.has_img:
+            if kv_i_all is not None:
+                kv_i = kv_i_all[:, li * 2 * D:(li + 1) * 2 * D]
+                ops.rmsnorm_rope_(kv_i[:, :D], p.nk_i, None, hd, eps)
+            elif enc_i is not None and p.has_img:
                 kv_i = ops.gemm(enc_i, p.w_kv_i, p.b_kv_i)
                 ops.rmsnorm_rope_(kv_i[:, :D], p.nk_i, None, hd, eps)
             kv.append((kv_t, kv_i))
