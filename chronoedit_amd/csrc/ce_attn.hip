@@ -1204,12 +1204,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
             if (kv >= sg.len) st[f][r] = NEG_BIG;
           }
       }
-      float mx = st[0][0];
+      // row max: four independent chains (a single 16-deep v_max3 chain is ~130 cycles of dependent latency in front of the
+      // softmax), then the other half of the row from lane ^ 32 through v_permlane32_swap (no LDS round trip)
+      float mx;
+      {
+        float m0 = fmaxf(st[0][0], st[0][1]), m1 = fmaxf(st[0][8], st[0][9]), m2 = fmaxf(st[1][0], st[1][1]), m3 = fmaxf(st[1][8], st[1][9]);
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[f][r]);
-      if (ABL != 6) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        for (int r = 2; r < 8; ++r) {
+          m0 = fmaxf(m0, st[0][r]);
+          m1 = fmaxf(m1, st[0][8 + r]);
+          m2 = fmaxf(m2, st[1][r]);
+          m3 = fmaxf(m3, st[1][8 + r]);
+        }
+        mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      }
+      if (ABL != 6) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
       // Lazy running max, in offset coordinates (mx is relative to mc): the offset moves only when some row's tile max
       // exceeds it by more than 2^8 - then the whole wave re-bases S(t), O and l - and always on the first tile.  P may
       // reach 2^8 instead of 1, harmless in fp32 / bf16; on random scores the exact form rescaled O (64 accumulator
