@@ -206,7 +206,8 @@ def set_gemm_variant(v: int) -> int:
 
 
 def set_attention_waves(n: int) -> int:
-    """8 (256 query rows / workgroup) or 4 (128 rows, two workgroups per CU); returns the previous value."""
+    """Attention loop body: 0 auto (= 64), 4 / 8 plain, 16 first pipelined, 32 ping-pong, 64 software-pipelined (default),
+    128 one wave per SIMD; returns the previous value (see include/chronoedit_hip.h)."""
     return lib().ce_set_attention_waves(int(n))
 
 
