@@ -455,3 +455,52 @@ def softmax_t5(scores: torch.Tensor, probs: torch.Tensor, batch: int, heads: int
     _check(lib().ce_softmax_t5_bf16(_ptr(scores), _ptr(probs), batch, heads, Lq, Lk, ld, ldp, _ptr(bucket_lut), _ptr(table),
                                     _ptr(valid_len), _stream()), "ce_softmax_t5_bf16")
     return probs
+
+
+# ------------------------------------------------------------------------------------------
+# fp8 (OCP e4m3) GEMM path
+# ------------------------------------------------------------------------------------------
+def quant_rows_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """x [M,K] bf16 -> (q [M,K] uint8 holding fp8 e4m3, s [M] fp32) with x ~= q * s[:, None] and max |q| = 448 per row."""
+    _dev(x, torch.bfloat16, "x")
+    M, K, ldx = _rows(x, "x")
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty((M,), dtype=torch.float32, device=x.device)
+    _dev(out, torch.uint8, "out"), _dev(scale, torch.float32, "scale")
+    _, _, ldq = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_quant_rows_fp8(_ptr(x), _ptr(out), _ptr(scale), M, K, ldx, ldq, _stream()), "ce_quant_rows_fp8")
+    _prof_end(st, f"quant_fp8_{M}x{K}", 3.0 * M * K)
+    return out, scale
+
+
+def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor],
+             out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None,
+             res: Optional[torch.Tensor] = None, gate_rows: int = 0):
+    """out[M,N] (bf16) = epilogue(sa[:,None] * sw[None,:] * (aq @ wq^T) + bias); aq [M,K], wq [N,K] uint8 (fp8 e4m3)."""
+    _dev(aq, torch.uint8, "aq"), _dev(wq, torch.uint8, "wq"), _dev(sa, torch.float32, "sa"), _dev(sw, torch.float32, "sw")
+    M, K, lda = _rows(aq, "aq")
+    N, K2, ldw = _rows(wq, "wq")
+    if K != K2 or sa.numel() != M or sw.numel() != N:
+        raise ValueError("gemm_fp8: operand / scale shapes do not match")
+    if bias is not None:
+        _dev(bias, torch.float32, "bias")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=aq.device)
+    _dev(out, torch.bfloat16, "out")
+    _, _, ldc = _rows(out, "out")
+    ldres = 0
+    if epilogue == EPI_GATE_RES:
+        if res is None:
+            raise ValueError("EPI_GATE_RES needs res")
+        _dev(res, torch.bfloat16, "res")
+        _, _, ldres = _rows(res, "res")
+        if gate is not None:
+            _dev(gate, torch.float32, "gate")
+    st = _prof_begin()
+    _check(lib().ce_gemm_fp8(_ptr(aq), _ptr(wq), _ptr(out), _ptr(sa), _ptr(sw), _ptr(bias), epilogue, _ptr(gate), _ptr(res), M, N, K,
+                             lda, ldw, ldc, ldres, int(gate_rows), _stream()), "ce_gemm_fp8")
+    _prof_end(st, f"gemm_fp8_{M}x{N}x{K}_epi{epilogue}", 2.0 * M * N * K)
+    return out

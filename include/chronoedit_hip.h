@@ -155,6 +155,19 @@ int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipSt
 int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int npad, int ld, int ldp, float scale,
                              hipStream_t stream);
 
+/* ---- fp8 (OCP e4m3) path of BASELINE.json configs[4].  The reference has no fp8 inference code: the contract is defined
+ * here (per-row activation scales, per-output-channel weight scales, fp32 accumulation on the MX matrix instruction) ---- */
+
+/* q[m][k] = fp8_e4m3(x[m][k] / s[m]), s[m] = max_k |x[m][k]| / 448 (1 for an all-zero row); x bf16 [M][ldx], q bytes [M][ldq].
+ * Used for activations (per token row) and, once at load time, for nn.Linear weights (per output channel). */
+int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, int K, int ldx, int ldq, hipStream_t stream);
+
+/* C = epilogue(sa[m] * sw[n] * (Aq Wq^T)[m][n] + bias[n]); Aq [M][lda], Wq [N][ldw] fp8 e4m3 bytes, C bf16; K % 256 == 0.
+ * Epilogues 0 (bias), 1 (bias + tanh GELU), 2 (gated residual) as ce_gemm_bf16. */
+int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias, int epilogue,
+                const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                hipStream_t stream);
+
 /* ---- conditioning encoders (run once per edit, outside the loop: pipeline_chronoedit.py:205-254; the arithmetic is
  * transformers==4.57.1 CLIPVisionModel / UMT5EncoderModel, restated in oracle/clip_oracle.py, oracle/umt5_oracle.py) ---- */
 

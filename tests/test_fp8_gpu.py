@@ -1,0 +1,75 @@
+"""fp8 (OCP e4m3) GEMM path (BASELINE.json configs[4]): the row quantiser against torch's float8_e4m3fn cast, the MX-instruction
+GEMM against fp32 math on the dequantised operands (what the kernel is defined to compute), and the end-to-end quantisation
+error of an fp8 Linear against the bf16 one (reported)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _deq(q, s):
+    return q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
+
+
+@pytest.mark.parametrize("M,K", [(7, 256), (300, 5120), (1000, 13824)])
+def test_quant_rows_fp8_matches_torch_cast(M, K):
+    from chronoedit_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3).to(BF)
+    x[min(2, M - 1)] = 0  # an all-zero row
+    q, s = ops.quant_rows_fp8(x.cuda())
+    amax = x.float().abs().amax(dim=1)
+    want_s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(s.cpu(), want_s, rtol=1e-6, atol=0)
+    want_q = (x.float() / want_s[:, None]).to(torch.float8_e4m3fn)
+    got = q.cpu().view(torch.float8_e4m3fn)
+    same = (got.view(torch.uint8) == want_q.view(torch.uint8)).float().mean().item()
+    assert same > 0.999, same  # RNE on both sides; the division by the scale may differ in the last fp32 bit at exact ties
+    assert (got.float() - want_q.float()).abs().max().item() <= 32.0  # never more than one fp8 step (32 at the top binade)
+    assert got.float().abs().max().item() <= 448.0
+    assert rel_l2(_deq(q, s), x) < 4e-2  # e4m3: 3 mantissa bits
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, "bias"), (300, 520, 512, "bias"), (1000, 1280, 5120, "gelu"),
+                                       (7200, 5120, 13824, "gate"), (14400, 15360, 5120, "bias")])
+def test_gemm_fp8_matches_fp32_on_dequantised_operands(M, N, K, epi):
+    from chronoedit_amd import ops
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(M, K, generator=g).to(BF).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).to(BF).cuda()
+    w[: min(N, 5)] *= 4  # asymmetric rows: a transposed operand would show
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(BF).cuda()
+    gate = torch.randn(N, generator=g).cuda()
+    aq, sa = ops.quant_rows_fp8(a)
+    wq, sw = ops.quant_rows_fp8(w)
+    kw = {"bias": dict(), "gelu": dict(epilogue=ops.EPI_BIAS_GELU), "gate": dict(epilogue=ops.EPI_GATE_RES, gate=gate, res=res)}[epi]
+    out = ops.gemm_fp8(aq, sa, wq, sw, bias, **kw)
+    # what the kernel is defined to compute, in fp32 on the GPU (large shapes) from the dequantised fp8 operands
+    ad = aq.view(torch.float8_e4m3fn).float() * sa[:, None]
+    wd = wq.view(torch.float8_e4m3fn).float() * sw[:, None]
+    lin = ad @ wd.t() + bias
+    ref = {"bias": lin, "gelu": torch.nn.functional.gelu(lin.to(BF).float(), approximate="tanh"),
+           "gate": res.float() + lin.to(BF).float() * gate}[epi]
+    e = rel_l2(out, ref)
+    assert e < 4e-3, e  # bf16 rounding of the output only
+    # and the price of fp8 itself against the bf16 Linear (informational bound)
+    full = a.float() @ w.float().t() + bias
+    e8 = rel_l2(lin, full)
+    print(f"fp8 GEMM {M}x{N}x{K} {epi}: kernel-vs-definition {e:.2e}; fp8 quantisation error vs bf16 operands {e8:.2e}")
+    assert e8 < 6e-2
+
+
+def test_gemm_fp8_rejects_bad_shapes():
+    from chronoedit_amd import ops
+    aq = torch.zeros(8, 128, dtype=torch.uint8, device="cuda")
+    wq = torch.zeros(16, 128, dtype=torch.uint8, device="cuda")
+    s = torch.ones(8, device="cuda")
+    with pytest.raises(ops.HipKernelError):
+        ops.gemm_fp8(aq, s, wq, torch.ones(16, device="cuda"), None)  # K % 256 != 0
