@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE.json configs[4] arithmetic: the six large Linears of every block in fp8 e4m3 (MX matrix instruction); "
+                         "reported with dtype fp8, never the headline bf16 number")
     ap.add_argument("--attn-kernel", type=int, default=0,
                     help="(tuning) self-attention kernel knob of ce_set_attention_waves: 0 auto, 32 ping-pong, 64 sw-pipelined, 128 w4")
     return ap.parse_args()
@@ -152,6 +155,8 @@ def main():
         ops.set_attention_waves(a.attn_kernel)
     model = build_model(a.layers, dev)
     model.cache_context = a.cache_context
+    if a.fp8:
+        model.enable_fp8_gemms()
     ulysses = world > 1 and a.parallel == "ulysses"
     if ulysses:
         model.enable_sequence_parallel()
@@ -293,7 +298,8 @@ def main():
         out = {
             "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None,
+            "dtype": "fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
                                    f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
                                    + _baseline_config_name(a, T),

@@ -188,6 +188,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.scale_shift_table = nn.Parameter(torch.randn(1, 2, inner, device=device, dtype=torch.float32) / inner**0.5)
         self._engine: Optional["DiTEngine"] = None
         self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
+        self.gemm_dtype = "bf16"    # "fp8": the six large Linears of every block on the OCP-e4m3 MX matrix path
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
 
     # -- reference-compatible helpers --------------------------------------------------
@@ -254,6 +255,15 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
     def invalidate(self):
         """Call after changing parameters in place (LoRA fuse, load_state_dict): re-packs on next forward."""
         self._engine = None
+
+    def enable_fp8_gemms(self, on: bool = True):
+        """BASELINE.json configs[4]: run the six large Linears of every block (fused q|k|v, the two output projections, the
+        cross-attention query, FFN up / down) in fp8 - weights quantised once per output channel to OCP e4m3, activations per
+        token row on the fly, fp32 accumulation on the MX matrix instruction (`ce_gemm_fp8`).  Attention, norms, the residual
+        stream, the conditioning projections and the head stay bf16 / fp32 as before.  The bf16 parameters are kept."""
+        self.gemm_dtype = "fp8" if on else "bf16"
+        self._engine = None
+        return self
 
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() / .cpu() re-create storages
         self._engine = None
@@ -408,6 +418,13 @@ class DiTEngine:
             p.w_f2, p.b_f2 = blk.ffn.net[2].weight.detach().contiguous(), f32(blk.ffn.net[2].bias)
             tables.append(f32(blk.scale_shift_table).reshape(6, self.D))
             self.blk.append(p)
+        self.fp8 = model.gemm_dtype == "fp8"
+        if self.fp8:
+            if self.D % 256 or self.F % 256:
+                raise NotImplementedError("fp8 GEMMs need inner and ffn dims that are multiples of 256")
+            for p in self.blk:  # per-output-channel e4m3 copies of the six large weights (the bf16 originals stay)
+                for name in ("qkv", "o1", "q2", "o2", "f1", "f2"):
+                    setattr(p, "q_" + name, ops.quant_rows_fp8(getattr(p, "w_" + name)))
         # K13 for ALL layers as one GEMM per context stream: the per-layer [k | v] weights are re-homed, layer after layer, in
         # one [L*2D, D] buffer (the step-invariant projections of 769 context rows are 40 small GEMMs otherwise: 0.5-1.0 PFLOP/s
         # at M = 514 / 1024 against 1.35 for one [M, L*2D] product); p.w_kv_* stay views of their layer's rows.
@@ -441,6 +458,17 @@ class DiTEngine:
             o += n
         return w
 
+    def _linear(self, ws, a: torch.Tensor, p, name: str, out: torch.Tensor, **kw):
+        """One of the six large projections of a block: bf16 GEMM, or (fp8 mode) row-quantise the activations and run the MX GEMM."""
+        w, b = getattr(p, "w_" + name), getattr(p, "b_" + name)
+        if not self.fp8:
+            return ops.gemm(a, w, b, out=out, **kw)
+        K = a.shape[1]
+        aq = ws.a8[:, :K]
+        ops.quant_rows_fp8(a, out=aq, scale=ws.s8)
+        wq, sw = getattr(p, "q_" + name)
+        return ops.gemm_fp8(aq, ws.s8, wq, sw, b, out=out, **kw)
+
     # -- workspaces --------------------------------------------------------------------
     def _workspace(self, N: int):
         ws = self._ws.get(N)
@@ -449,6 +477,9 @@ class DiTEngine:
             e = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)
             ws = SimpleNamespace(x=e(N, D), h=e(N, D), qkv=e(N, 3 * D), att=e(N, D), q2=e(N, D), ffn=e(N, F),
                                  cols=e(N, self.kpatch), head=e(N, self.w_out.shape[0]))
+            if self.fp8:  # activation rows as fp8 + one scale per row
+                ws.a8 = torch.empty((N, max(D, F)), dtype=torch.uint8, device=dev)
+                ws.s8 = torch.empty((N,), dtype=torch.float32, device=dev)
             self._ws = {N: ws}  # keep one shape resident
         return ws
 
@@ -588,7 +619,7 @@ class DiTEngine:
         for li, p in enumerate(self.blk):
             # 1. self-attention
             ops.ln_affine(x, mod[li, 0, 1], mod[li, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
-            ops.gemm(ws.h, p.w_qkv, p.b_qkv, out=ws.qkv)
+            self._linear(ws, ws.h, p, "qkv", ws.qkv)
             ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)  # q and k, all samples
             if sp is None:  # all samples in one launch (stacked rows)
                 ops.attention(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :], H, out=ws.att, batch=B)
@@ -599,27 +630,27 @@ class DiTEngine:
                     g = sp.scatter_heads(qkv, H, hd)  # [W*Nl, 3*Dl]
                     og = ops.attention(g[:, :Dl], g[:N, Dl : 2 * Dl], g[:N, 2 * Dl :], H // sp.world)
                     ws.att[rows[b]].copy_(sp.gather_heads(og, H, hd))
-            ops.gemm(ws.att, p.w_o1, p.b_o1, out=x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
-                     res=x, gate_rows=grow)
+            self._linear(ws, ws.att, p, "o1", x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
+                         res=x, gate_rows=grow)
             # 2. cross-attention (text + image segments)
             if p.n2w is not None:
                 ops.ln_affine(x, p.n2w, p.n2b, eps, out=ws.h)
                 hq = ws.h
             else:
                 hq = x
-            ops.gemm(hq, p.w_q2, p.b_q2, out=ws.q2)
+            self._linear(ws, hq, p, "q2", ws.q2)
             ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
             kv_t, kv_i = ctx.kv[li]
             if kv_i is not None:
                 ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, k2=kv_i[:, :D], v2=kv_i[:, D:], batch=B)
             else:
                 ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, batch=B)
-            ops.gemm(ws.att, p.w_o2, p.b_o2, out=x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
+            self._linear(ws, ws.att, p, "o2", x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
             ops.ln_affine(x, mod[li, 0, 4], mod[li, 0, 3], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
-            ops.gemm(ws.h, p.w_f1, p.b_f1, out=ws.ffn, epilogue=ops.EPI_BIAS_GELU)
-            ops.gemm(ws.ffn, p.w_f2, p.b_f2, out=x, epilogue=ops.EPI_GATE_RES, gate=gate_ffn[li] if B > 1 else mods[0][li, 5],
-                     res=x, gate_rows=grow)
+            self._linear(ws, ws.h, p, "f1", ws.ffn, epilogue=ops.EPI_BIAS_GELU)
+            self._linear(ws, ws.ffn, p, "f2", x, epilogue=ops.EPI_GATE_RES, gate=gate_ffn[li] if B > 1 else mods[0][li, 5],
+                         res=x, gate_rows=grow)
 
         # K18
         ops.ln_affine(x, mod_out[0, 0, 1], mod_out[0, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=2 * D)

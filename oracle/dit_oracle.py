@@ -234,23 +234,40 @@ def linear(x, p, name):
     return F.linear(x, p[name + ".weight"], p[name + ".bias"])
 
 
+def fake_quant_rows_fp8(x: torch.Tensor) -> torch.Tensor:
+    """The fp8 contract of chronoedit_amd (include/chronoedit_hip.h, ce_quant_rows_fp8): per row s = amax / 448 (1 for a zero row),
+    values rounded to OCP e4m3 (torch.float8_e4m3fn, round to nearest even), returned de-quantised in x's dtype."""
+    amax = x.float().abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return ((x.float() / s).to(torch.float8_e4m3fn).float() * s).to(x.dtype)
+
+
+def linear_fp8(x, p, name):
+    """A Linear under the fp8 contract: activations quantised per token row, weights per output channel, exact products, bias
+    added afterwards (BASELINE.json configs[4]; the reference has no fp8 path of its own)."""
+    return F.linear(fake_quant_rows_fp8(x), fake_quant_rows_fp8(p[name + ".weight"]), p[name + ".bias"])
+
+
 # --------------------------------------------------------------------------------------
 # the modules of transformer_chronoedit.py
 # --------------------------------------------------------------------------------------
 
 
-def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=None):
-    """ChronoEditAttnProcessor2_0.__call__ (transformer_chronoedit.py:43-108)."""
+def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=None, fp8=False):
+    """ChronoEditAttnProcessor2_0.__call__ (transformer_chronoedit.py:43-108).  fp8: the projections that chronoedit_amd runs on
+    the fp8 path (q, the self-attention k / v, the output projection) follow linear_fp8; the context k / v stay as they are."""
     H = cfg.num_attention_heads
+    lin_q = linear_fp8 if fp8 else linear
+    lin_kv = linear_fp8 if (fp8 and encoder is None) else linear
     enc_img = None
     has_added = (pre + ".add_k_proj.weight") in p
     if has_added and encoder is not None:
         enc_img, encoder = encoder[:, :257], encoder[:, 257:]
     if encoder is None:
         encoder = hidden
-    q = linear(hidden, p, pre + ".to_q")
-    k = linear(encoder, p, pre + ".to_k")
-    v = linear(encoder, p, pre + ".to_v")
+    q = lin_q(hidden, p, pre + ".to_q")
+    k = lin_kv(encoder, p, pre + ".to_k")
+    v = lin_kv(encoder, p, pre + ".to_v")
     q = rms_norm(q, p[pre + ".norm_q.weight"], cfg.eps)
     k = rms_norm(k, p[pre + ".norm_k.weight"], cfg.eps)
     q = q.unflatten(2, (H, -1)).transpose(1, 2)
@@ -276,25 +293,26 @@ def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=No
         out = out + out_img
     if taps is not None:
         taps[pre + ".sdpa"] = out
-    return linear(out, p, pre + ".to_out.0")
+    return lin_q(out, p, pre + ".to_out.0")
 
 
-def feed_forward(p, pre, x, approximate: str):
+def feed_forward(p, pre, x, approximate: str, fp8=False):
     """diffusers FeedForward: net.0 = GELU(proj + gelu), net.1 = Dropout(0), net.2 = Linear.
     "gelu-approximate" -> tanh (block FFN, transformer_chronoedit.py:262);
     "gelu" -> erf (image MLP, :116).  Sibling: wan_video_dit_chronoedit.py:224-225,251-257."""
-    h = F.gelu(linear(x, p, pre + ".net.0.proj"), approximate=approximate)
-    return linear(h, p, pre + ".net.2")
+    lin = linear_fp8 if fp8 else linear
+    h = F.gelu(lin(x, p, pre + ".net.0.proj"), approximate=approximate)
+    return lin(h, p, pre + ".net.2")
 
 
-def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=None):
+def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=None, fp8=False):
     """ChronoEditTransformerBlock.forward (transformer_chronoedit.py:267-295)."""
     b = f"blocks.{i}"
     shift, scale, gate, c_shift, c_scale, c_gate = (p[b + ".scale_shift_table"] + temb6.float()).chunk(6, dim=1)
     h = (fp32_layer_norm(x.float(), None, None, cfg.eps) * (1 + scale) + shift).type_as(x)
     if taps is not None:
         taps[b + ".ln1"] = h
-    a = attention(p, b + ".attn1", cfg, h, None, rotary, taps)
+    a = attention(p, b + ".attn1", cfg, h, None, rotary, taps, fp8=fp8)
     x = (x.float() + a * gate).type_as(x)
     if taps is not None:
         taps[b + ".x_after_attn1"] = x
@@ -302,12 +320,12 @@ def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=Non
         h = fp32_layer_norm(x.float(), p[b + ".norm2.weight"], p[b + ".norm2.bias"], cfg.eps).type_as(x)
     else:
         h = x
-    a = attention(p, b + ".attn2", cfg, h, encoder, None, taps)
+    a = attention(p, b + ".attn2", cfg, h, encoder, None, taps, fp8=fp8)
     x = x + a
     if taps is not None:
         taps[b + ".x_after_attn2"] = x
     h = (fp32_layer_norm(x.float(), None, None, cfg.eps) * (1 + c_scale) + c_shift).type_as(x)
-    f = feed_forward(p, b + ".ffn", h, "tanh")
+    f = feed_forward(p, b + ".ffn", h, "tanh", fp8=fp8)
     x = (x.float() + f.float() * c_gate).type_as(x)
     return x
 
@@ -340,8 +358,10 @@ def dit_forward(
     encoder_hidden_states: torch.Tensor,
     encoder_hidden_states_image: Optional[torch.Tensor] = None,
     taps: Optional[dict] = None,
+    fp8: bool = False,
 ) -> torch.Tensor:
-    """ChronoEditTransformer3DModel.forward (transformer_chronoedit.py:397-476)."""
+    """ChronoEditTransformer3DModel.forward (transformer_chronoedit.py:397-476).  fp8=True restates chronoedit_amd's fp8 GEMM mode
+    (the six large Linears of every block under linear_fp8; everything else unchanged)."""
     B, C, T, Hh, Ww = hidden_states.shape
     pt, ph, pw = cfg.patch_size
     ppf, pph, ppw = T // pt, Hh // ph, Ww // pw
@@ -359,7 +379,7 @@ def dit_forward(
     if taps is not None:
         taps["temb"], taps["tproj"], taps["enc"] = temb, tproj, enc
     for i in range(cfg.num_layers):
-        x = block_forward(p, i, cfg, x, enc, tproj, rotary, taps)
+        x = block_forward(p, i, cfg, x, enc, tproj, rotary, taps, fp8=fp8)
         if taps is not None:
             taps[f"blocks.{i}.out"] = x
     shift, scale = (p["scale_shift_table"] + temb.unsqueeze(1)).chunk(2, dim=1)

@@ -73,3 +73,32 @@ def test_gemm_fp8_rejects_bad_shapes():
     s = torch.ones(8, device="cuda")
     with pytest.raises(ops.HipKernelError):
         ops.gemm_fp8(aq, s, wq, torch.ones(16, device="cuda"), None)  # K % 256 != 0
+
+
+def test_dit_forward_fp8_mode_vs_fp8_contract_oracle():
+    """enable_fp8_gemms(): the HIP forward against the fp32 oracle that restates the same fp8 contract (fake-quantised operands of
+    the six large Linears per block), and - reported - against the un-quantised fp32 oracle (the price of fp8 itself)."""
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from oracle import dit_oracle as O
+    cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=4, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    p_bf = O.make_synthetic_params(cfg, seed=3, dtype=BF)
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 16, 24, dtype=BF)
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=4, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in p_bf.items()})
+    ts = torch.tensor([400], device="cuda:0")
+    args = (lat.cuda(), ts, text.cuda(), image.cuda())
+    out16 = m(*args, return_dict=False)[0].clone()
+    m.enable_fp8_gemms()
+    out8 = m(*args, return_dict=False)[0].clone()
+    m.enable_fp8_gemms(False)
+    assert torch.equal(m(*args, return_dict=False)[0], out16)  # switching back restores the bf16 path bit for bit
+    p32 = {k: v.float() for k, v in p_bf.items()}
+    with torch.no_grad():
+        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([400]), text.float(), image.float())
+        ref8 = O.dit_forward(p32, cfg, lat.float(), torch.tensor([400]), text.float(), image.float(), fp8=True)
+    e_contract, e_price, e_bf16 = rel_l2(out8, ref8), rel_l2(ref8, ref), rel_l2(out16, ref)
+    print(f"fp8 mode: hip-vs-fp8-contract-oracle {e_contract:.3e}; fp8 contract vs exact fp32 {e_price:.3e}; bf16 path vs fp32 {e_bf16:.3e}")
+    assert e_contract <= 2.5e-2      # bf16-level agreement with the contract (rounding boundaries of fp8 add a little)
+    assert rel_l2(out8, ref) <= 0.12  # the whole fp8 forward stays close to the exact one
+    assert rel_l2(out8, out16) > 1e-3

@@ -77,6 +77,28 @@ def main():
             res[f"split_{M}x{N}x{K}_epi{epi}"] = {"whole_ms": t0 * 1e3, "split_ms": t1 * 1e3, "tiles": tiles}
             print(f"gemm {M}x{N}x{K} epi{epi}: tiles {tiles} (tail {tiles % 256}) whole {t0*1e3:.3f} ms {fl/t0/1e12:.1f} TF | split {t1*1e3:.3f} ms {fl/t1/1e12:.1f} TF", flush=True)
             del a, w, out
+    if "fp8" in only:
+        for (M, N, K, epi) in [(14400, 15360, 5120, 0), (14400, 5120, 5120, 2), (14400, 13824, 5120, 1), (14400, 5120, 13824, 2),
+                               (7200, 15360, 5120, 0), (28800, 13824, 5120, 1)]:
+            a = torch.randn(M, K, generator=g).to(BF).to(dev)
+            w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
+            b = torch.zeros(N, device=dev)
+            out = torch.empty(M, N, dtype=BF, device=dev)
+            gate = torch.ones(N, device=dev)
+            aq, sa = ops.quant_rows_fp8(a)
+            wq, sw = ops.quant_rows_fp8(w)
+            fl = 2.0 * M * N * K
+            run8 = lambda: ops.gemm_fp8(aq, sa, wq, sw, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+            run16 = lambda: ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+            tq = timeit(lambda: ops.quant_rows_fp8(a, out=aq, scale=sa), iters=20)
+            t8 = t16 = 1e9
+            for _ in range(2):
+                t16 = min(t16, timeit(run16, iters=10))
+                t8 = min(t8, timeit(run8, iters=10))
+            res[f"fp8_{M}x{N}x{K}_epi{epi}"] = {"fp8_ms": t8 * 1e3, "fp8_tflops": fl / t8 / 1e12, "bf16_ms": t16 * 1e3, "quant_a_ms": tq * 1e3}
+            print(f"gemm {M}x{N}x{K} epi{epi}: fp8 {t8*1e3:.3f} ms {fl/t8/1e12:.1f} TF | bf16 {t16*1e3:.3f} ms {fl/t16/1e12:.1f} TF | "
+                  f"activation quant pass {tq*1e3:.3f} ms ({3.0*M*K/tq/1e9:.0f} GB/s)", flush=True)
+            del a, w, out, aq, wq
     if "attn" in only:
         for (Nq, Nkv, H) in [(7200, 7200, 40), (28800, 28800, 40), (7200, 512, 40)]:
             D = H * 128
