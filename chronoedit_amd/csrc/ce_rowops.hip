@@ -12,9 +12,13 @@
 // ------------------------------------------------------------------------------------
 // LN * a + b
 // ------------------------------------------------------------------------------------
+// FP8: the bf16-rounded result is not written; it is quantised in registers to OCP e4m3 with one scale per row (the contract of
+// ce_quant_rows_fp8 applied to the row this kernel would have written) - the A operand of ce_gemm_fp8 without the extra pass.
+template <bool FP8>
 __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                         const float* __restrict__ a, const float* __restrict__ b,
-                                                        int M, int D, int ldx, int ldy, float eps, int ab_rows, int ab_stride) {
+                                                        int M, int D, int ldx, int ldy, float eps, int ab_rows, int ab_stride,
+                                                        unsigned char* __restrict__ q8, float* __restrict__ qscale, int ldq) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -49,7 +53,8 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__
     }
   }
   const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
-  bf16* yr = y + (size_t)row * ldy;
+  bf16* yr = FP8 ? nullptr : y + (size_t)row * ldy;
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < ROW_MAXC; ++i) {
     const int c = lane + 64 * i;
@@ -63,8 +68,31 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__
         const float bb0 = j < 2 ? b0[2 * j] : b1[2 * j - 4], bb1 = j < 2 ? b0[2 * j + 1] : b1[2 * j - 3];
         const float n0 = (bf16lo(raw[i][j]) - mean) * rstd, n1 = (bf16hi(raw[i][j]) - mean) * rstd;
         o[j] = pack_bf16(n0 * aa0 + bb0, n1 * aa1 + bb1);
+        if (FP8) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(o[j])), fabsf(bf16hi(o[j]))));
       }
-      *reinterpret_cast<u32x4*>(yr + c * 8) = o;
+      if (FP8) raw[i] = o;
+      else *reinterpret_cast<u32x4*>(yr + c * 8) = o;
+    }
+  }
+  if (FP8) {
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) qscale[row] = sc;
+    unsigned char* qr = q8 + (size_t)row * ldq;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const u32x4 v = raw[i];
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[0]) * inv, bf16hi(v[0]) * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[1]) * inv, bf16hi(v[1]) * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[2]) * inv, bf16hi(v[2]) * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[3]) * inv, bf16hi(v[3]) * inv, w1, true);
+        u32x2 o = {(uint32_t)w0, (uint32_t)w1};
+        *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+      }
     }
   }
 }
@@ -227,8 +255,17 @@ extern "C" int ce_ln_affine_bf16(const void* x, void* y, const float* a, const f
                                  float eps, int ab_rows, int ab_stride, hipStream_t stream) {
   if (!x || !y || !a || !b) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldy & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
-  hipLaunchKernelGGL(ln_affine_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M, D, ldx,
-                     ldy, eps, ab_rows, ab_stride);
+  hipLaunchKernelGGL(ln_affine_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M, D, ldx,
+                     ldy, eps, ab_rows, ab_stride, nullptr, nullptr, 0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_ln_affine_fp8(const void* x, void* q, float* scale, const float* a, const float* b, int M, int D, int ldx, int ldq,
+                                float eps, int ab_rows, int ab_stride, hipStream_t stream) {
+  if (!x || !q || !scale || !a || !b) return CE_ERR_ARG;
+  if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
+  hipLaunchKernelGGL(ln_affine_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D, ldx, 0, eps,
+                     ab_rows, ab_stride, (unsigned char*)q, scale, ldq);
   return (int)hipGetLastError();
 }
 

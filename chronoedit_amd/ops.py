@@ -476,6 +476,20 @@ def quant_rows_fp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: O
     return out, scale
 
 
+def ln_affine_fp8(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: float, out: torch.Tensor, scale: torch.Tensor,
+                  ab_rows: int = 0, ab_stride: int = 0):
+    """ln_affine + quant_rows_fp8 in one pass: out (uint8 fp8 e4m3) and scale (fp32 per row) of LN(x) * a + b rounded to bf16."""
+    _dev(x, torch.bfloat16, "x"), _dev(a, torch.float32, "a"), _dev(b, torch.float32, "b")
+    _dev(out, torch.uint8, "out"), _dev(scale, torch.float32, "scale")
+    M, D, ldx = _rows(x, "x")
+    _, _, ldq = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_ln_affine_fp8(_ptr(x), _ptr(out), _ptr(scale), _ptr(a), _ptr(b), M, D, ldx, ldq, float(eps), int(ab_rows),
+                                  int(ab_stride), _stream()), "ce_ln_affine_fp8")
+    _prof_end(st, f"ln_affine_fp8_{M}x{D}", 3.0 * M * D)
+    return out, scale
+
+
 def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor],
              out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None,
              res: Optional[torch.Tensor] = None, gate_rows: int = 0):

@@ -458,6 +458,18 @@ class DiTEngine:
             o += n
         return w
 
+    def _ln_linear(self, ws, x: torch.Tensor, a_row, b_row, p, name: str, out: torch.Tensor, ab_rows: int = 0, ab_stride: int = 0, **kw):
+        """LayerNorm (+ affine / AdaLN rows) followed by one of the large projections.  fp8 mode: the LN kernel emits the fp8
+        operand and its row scales directly (no bf16 round trip through HBM, no separate quantisation pass)."""
+        eps = self.cfg.eps
+        if not self.fp8:
+            ops.ln_affine(x, a_row, b_row, eps, out=ws.h, ab_rows=ab_rows, ab_stride=ab_stride)
+            return ops.gemm(ws.h, getattr(p, "w_" + name), getattr(p, "b_" + name), out=out, **kw)
+        aq = ws.a8[:, : x.shape[1]]
+        ops.ln_affine_fp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=ab_rows, ab_stride=ab_stride)
+        wq, sw = getattr(p, "q_" + name)
+        return ops.gemm_fp8(aq, ws.s8, wq, sw, getattr(p, "b_" + name), out=out, **kw)
+
     def _linear(self, ws, a: torch.Tensor, p, name: str, out: torch.Tensor, **kw):
         """One of the six large projections of a block: bf16 GEMM, or (fp8 mode) row-quantise the activations and run the MX GEMM."""
         w, b = getattr(p, "w_" + name), getattr(p, "b_" + name)
@@ -618,8 +630,7 @@ class DiTEngine:
         x = ws.x
         for li, p in enumerate(self.blk):
             # 1. self-attention
-            ops.ln_affine(x, mod[li, 0, 1], mod[li, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
-            self._linear(ws, ws.h, p, "qkv", ws.qkv)
+            self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)
             ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)  # q and k, all samples
             if sp is None:  # all samples in one launch (stacked rows)
                 ops.attention(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :], H, out=ws.att, batch=B)
@@ -634,11 +645,9 @@ class DiTEngine:
                          res=x, gate_rows=grow)
             # 2. cross-attention (text + image segments)
             if p.n2w is not None:
-                ops.ln_affine(x, p.n2w, p.n2b, eps, out=ws.h)
-                hq = ws.h
+                self._ln_linear(ws, x, p.n2w, p.n2b, p, "q2", ws.q2)
             else:
-                hq = x
-            self._linear(ws, hq, p, "q2", ws.q2)
+                self._linear(ws, x, p, "q2", ws.q2)
             ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
             kv_t, kv_i = ctx.kv[li]
             if kv_i is not None:
@@ -647,8 +656,7 @@ class DiTEngine:
                 ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, batch=B)
             self._linear(ws, ws.att, p, "o2", x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
-            ops.ln_affine(x, mod[li, 0, 4], mod[li, 0, 3], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
-            self._linear(ws, ws.h, p, "f1", ws.ffn, epilogue=ops.EPI_BIAS_GELU)
+            self._ln_linear(ws, x, mod[li, 0, 4], mod[li, 0, 3], p, "f1", ws.ffn, ab_rows=Nl, ab_stride=6 * D, epilogue=ops.EPI_BIAS_GELU)
             self._linear(ws, ws.ffn, p, "f2", x, epilogue=ops.EPI_GATE_RES, gate=gate_ffn[li] if B > 1 else mods[0][li, 5],
                          res=x, gate_rows=grow)
 

@@ -162,6 +162,11 @@ int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int
  * Used for activations (per token row) and, once at load time, for nn.Linear weights (per output channel). */
 int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, int K, int ldx, int ldq, hipStream_t stream);
 
+/* ce_ln_affine_bf16 followed by ce_quant_rows_fp8 in one pass: q / scale are the quantisation of the bf16 row that
+ * ce_ln_affine_bf16 would have written (bit-identical to the two-launch form). */
+int ce_ln_affine_fp8(const void* x, void* q, float* scale, const float* a, const float* b, int M, int D, int ldx, int ldq, float eps,
+                     int ab_rows, int ab_stride, hipStream_t stream);
+
 /* C = epilogue(sa[m] * sw[n] * (Aq Wq^T)[m][n] + bias[n]); Aq [M][lda], Wq [N][ldw] fp8 e4m3 bytes, C bf16; K % 256 == 0.
  * Epilogues 0 (bias), 1 (bias + tanh GELU), 2 (gated residual) as ce_gemm_bf16. */
 int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias, int epilogue,

@@ -102,3 +102,21 @@ def test_dit_forward_fp8_mode_vs_fp8_contract_oracle():
     assert e_contract <= 2.5e-2      # bf16-level agreement with the contract (rounding boundaries of fp8 add a little)
     assert rel_l2(out8, ref) <= 0.12  # the whole fp8 forward stays close to the exact one
     assert rel_l2(out8, out16) > 1e-3
+
+
+def test_ln_affine_fp8_equals_two_launch_form():
+    """The fused LayerNorm -> fp8 kernel == ln_affine followed by quant_rows_fp8, bit for bit (bytes and scales)."""
+    from chronoedit_amd import ops
+    g = torch.Generator().manual_seed(4)
+    M, D = 1003, 5120
+    x = (torch.randn(M, D, generator=g) * 2 + 0.3).to(BF).cuda()
+    a = (1 + 0.2 * torch.randn(2, D, generator=g)).cuda()
+    b = (0.1 * torch.randn(2, D, generator=g)).cuda()
+    for kw in (dict(), dict(ab_rows=600, ab_stride=D)):
+        aa, bb = (a, b) if kw else (a[0], b[0])
+        h = ops.ln_affine(x, aa, bb, 1e-6, **kw)
+        q_ref, s_ref = ops.quant_rows_fp8(h)
+        q = torch.empty((M, D), dtype=torch.uint8, device="cuda")
+        s = torch.empty((M,), dtype=torch.float32, device="cuda")
+        ops.ln_affine_fp8(x, aa, bb, 1e-6, out=q, scale=s, **kw)
+        assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
