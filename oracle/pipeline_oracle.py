@@ -26,7 +26,7 @@ def prepare_latents(vp, vcfg, image, num_frames, latents):
 
 
 def edit(dp, dcfg, vp, vcfg, image, prompt, negative, image_embeds, latents, num_frames=5, steps=4, guidance=5.0, shift=5.0,
-         decode=True, enable_temporal_reasoning=False, num_temporal_reasoning_steps=0):
+         decode=True, enable_temporal_reasoning=False, num_temporal_reasoning_steps=0, fp8=False):
     latents, cond = prepare_latents(vp, vcfg, image, num_frames, latents)
     sch = UniPCOracle()
     sch.set_timesteps(steps, shift=shift)
@@ -40,9 +40,9 @@ def edit(dp, dcfg, vp, vcfg, image, prompt, negative, image_embeds, latents, num
                 sch.last_sample = sch.last_sample[:, :, [0, -1]] if sch.last_sample.shape[-3] != latents.shape[-3] else sch.last_sample
         inp = torch.cat([latents, cond], dim=1).to(prompt.dtype)
         ts = t.expand(latents.shape[0])
-        c = D.dit_forward(dp, dcfg, inp, ts, prompt, image_embeds)
+        c = D.dit_forward(dp, dcfg, inp, ts, prompt, image_embeds, fp8=fp8)
         if guidance > 1.0:
-            u = D.dit_forward(dp, dcfg, inp, ts, negative, image_embeds)
+            u = D.dit_forward(dp, dcfg, inp, ts, negative, image_embeds, fp8=fp8)
             c = u + guidance * (c - u)
         latents = sch.step(c.to(latents.dtype), latents)
     if not decode:

@@ -120,3 +120,42 @@ def test_ln_affine_fp8_equals_two_launch_form():
         s = torch.empty((M,), dtype=torch.float32, device="cuda")
         ops.ln_affine_fp8(x, aa, bb, 1e-6, out=q, scale=s, **kw)
         assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
+
+
+def test_edit_end_to_end_fp8_mode_vs_fp8_contract_oracle():
+    """A whole 4-step CFG edit (prepare_latents -> loop -> decode) with the transformer in fp8 GEMM mode, against the oracle edit
+    whose DiT follows the same fp8 contract; and how far that is from the exact-arithmetic edit (reported)."""
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from chronoedit_amd.vae import AutoencoderKLWan
+    from oracle import dit_oracle as D
+    from oracle import pipeline_oracle as P
+    from oracle import vae_oracle as V
+    dcfg = D.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    vcfg = V.VAEConfig(dim=32, z_dim=16)
+    dp = D.make_synthetic_params(dcfg, dtype=BF)
+    vp = V.make_synthetic_params(vcfg)
+    g = torch.Generator().manual_seed(0)
+    H, W, F = 64, 96, 5
+    image = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    prompt, negative = torch.randn(1, 40, 128, generator=g), torch.randn(1, 40, 128, generator=g)
+    img_emb = torch.randn(1, 257, 64, generator=g)
+    lat0 = torch.randn(1, 16, 2, H // 8, W // 8, generator=g)
+    dp32 = {k: v.float() for k, v in dp.items()}
+    cpu_args = (image.to(BF).float(), prompt.to(BF).float(), negative.to(BF).float(), img_emb.to(BF).float())
+    with torch.no_grad():
+        lat8, vid8 = P.edit(dp32, dcfg, vp, vcfg, *cpu_args, lat0.clone(), num_frames=F, steps=4, fp8=True)
+        lat_x, _ = P.edit(dp32, dcfg, vp, vcfg, *cpu_args, lat0.clone(), num_frames=F, steps=4, decode=False)
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
+    m.enable_fp8_gemms()
+    pipe = ChronoEditPipeline(AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16), m, FlowUniPCMultistepScheduler(flow_shift=5.0))
+    args = (image.cuda().to(BF), prompt.cuda().to(BF), negative.cuda().to(BF), img_emb.cuda().to(BF))
+    lat = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent")
+    vid = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda())
+    print(f"fp8 edit: latents vs fp8-contract oracle {rel_l2(lat, lat8):.3e}, video {rel_l2(vid, vid8):.3e}; "
+          f"contract vs exact edit (latents) {rel_l2(lat8, lat_x):.3e}")
+    assert rel_l2(lat, lat8) < 8e-2 and rel_l2(vid, vid8) < 1e-1
+    assert rel_l2(lat, lat_x) < 0.2
