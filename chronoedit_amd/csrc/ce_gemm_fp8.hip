@@ -214,12 +214,18 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const unsigned char* __restr
         const float swv = n < N ? sw[n] : 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const int mrow = m0 + i * 128 + wm * 64 + f * 16 + fg * 4;
+          const int mrow = m0 + i * 128 + wm * 64 + f * 16 + fg * 4;  // 4 consecutive rows: one 16-B load of their scales
+          f32x4 sav;
+          if (mrow + 3 < M) {
+            sav = *reinterpret_cast<const f32x4*>(sa + mrow);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sav[r] = sa[min(mrow + r, M - 1)];
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rl = wm * 64 + f * 16 + fg * 4 + r;
-            const float sav = sa[min(mrow + r, M - 1)];
-            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] * (sav * swv) + bv);
+            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] * (sav[r] * swv) + bv);
           }
         }
       }
