@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
+    ap.add_argument("--no-fp8-leg", action="store_true", help="skip the secondary fp8-GEMM-mode timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--fp8", action="store_true",
@@ -248,6 +249,21 @@ def main():
         cached_rate = round(2 / (time.perf_counter() - tc), 4)
         model.cache_context = False
 
+    # ---- secondary figure, outside the timed region: the same step in the fp8 GEMM mode (BASELINE.json configs[4] arithmetic,
+    # DESIGN.md section 9) - a different precision, reported beside the bf16 `value`, never as it
+    fp8_rate = None
+    if rank == 0 and not a.fp8 and not a.graph and world == 1 and not a.no_fp8_leg:
+        model.enable_fp8_gemms()
+        base = a.warmup + a.steps + 4
+        one_step(base)  # packs the e4m3 weights
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for i in range(2):
+            one_step(base + 1 + i)
+        torch.cuda.synchronize()
+        fp8_rate = round(2 / (time.perf_counter() - tc), 4)
+        model.enable_fp8_gemms(False)
+
     # ---- VAE encode + decode at the same resolution (once per edit) -> composed sec/edit for the 50-step schedule
     vae_s = None
     if not a.no_vae and rank == 0 and world == 1:
@@ -312,6 +328,7 @@ def main():
             "finite": finite,
             "launch": "hipGraph replay" if a.graph else "eager",
             "steps_per_sec_with_context_kv_cache": cached_rate,
+            "steps_per_sec_fp8_gemm_mode": fp8_rate,
             "vae": vae_s,
             "encoders": enc_s,
             "sec_per_edit_50_steps": None if vae_s is None else round(
