@@ -941,7 +941,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 //                   | 16 MFMA of O += V^T(t-1).P^T(t-1), each followed by 2 v_exp + 2 fma + 2 add of P(t) | pack P(t)
 // LDS: K double-buffered, V^T triple-buffered (V(t-1) is read while V(t+1) is written): one barrier per tile.
 // ------------------------------------------------------------------------------------------------
-constexpr float SP_RESCALE_THR = 8.0f;
+constexpr float SP_SPEC_THR = 1024.0f;  // a lane's partial row sum above this sends the tile through the exact route
 constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow the two K buffers
 constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
 constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 * QW * OST_ROW : SP_TILE_BYTES; }
@@ -1057,11 +1057,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     f32x16 cinit;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
-    bf16x8 ppk[4];
+    u32x4 ppk[4];  // P(t-1) as bf16 pairs: word w of ppk[s] = elements 8 s + 2 w, + 1 of the lane's 32 scores
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ppk[s4][i] = (bf16)0.f;
+    for (int s4 = 0; s4 < 4; ++s4) ppk[s4] = u32x4{0u, 0u, 0u, 0u};
 
     pp_u4 kreg[2];
     pp_u2 vreg[4];
@@ -1125,20 +1123,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     }
     int vb_prev = 2, vb_cur = 0;  // V^T buffer of tile t-1 / tile t
 
-    for (int t = 0; t < ntiles; ++t) {
+    // A wave without query rows only stages, behind the same barriers - in a loop of its own: as a `continue` path inside
+    // the main loop its fetches joined the main path's in phi nodes that hipcc resolved with six v_mov_b64 (behind a
+    // vmcnt(0)) in the loop latch of every wave.
+    for (int t = 0; !active && t < ntiles; ++t) {
+      CE_EPOCH_BARRIER();
+      const int vb_next = 3 - vb_prev - vb_cur;
+      store_k((t + 1) & 1);
+      store_v(vb_next);
+      load_k(t + 2);
+      load_v(t + 2);
+      vb_prev = vb_cur;
+      vb_cur = vb_next;
+    }
+    for (int t = 0; active && t < ntiles; ++t) {
       CE_SPSTAMP(5);
       CE_EPOCH_BARRIER();  // K(t), V(t) visible; K(t-1) and V(t-2) no longer read by anyone
       CE_SPSTAMP(0);
       const int vb_next = 3 - vb_prev - vb_cur;
-      if (!active) {  // staging only, same barriers
-        store_k((t + 1) & 1);
-        store_v(vb_next);
-        load_k(t + 2);
-        load_v(t + 2);
-        vb_prev = vb_cur;
-        vb_cur = vb_next;
-        continue;
-      }
       const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
       const unsigned char* vb = v_rd + vb_prev * PV_TILE;
 
@@ -1148,6 +1150,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       // -> LDS after MFMAs 1, 3, 5..8, fetch of K(t+2) / V(t+2) after MFMAs 10 and 12.  Unconditional: past the last
       // tile the stores fill buffers nobody reads and the fetches are out of range of the buffer descriptor (zeros).
       CE_SPSTAMP(1);
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16 st[2];
       {
         constexpr int RING = 6;
@@ -1155,14 +1158,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + ((i) & 1) * 32 * PK_ROW + ((i) >> 1) * 32))
 #pragma unroll
         for (int i = 0; i < RING; ++i) kf[i] = CE_LDK(i);
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           if (ABL == 3) {
             if (i < 2) st[i & 1] = zero16;
             asm volatile("" ::"v"(kf[i % RING]));
+          } else if (i < 2) {
+            // untied form spelled out (D != C, both chains start from the same cinit registers): left to itself hipcc
+            // tied D to C for one of the two and copied cinit first, 8 v_mov_b64 per tile
+            asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(st[i & 1]) : "v"(kf[i % RING]), "v"(qf[i >> 1]), "v"(cinit));
           } else {
-            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], i < 2 ? cinit : st[i & 1], 0, 0, 0);
+            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], st[i & 1], 0, 0, 0);
           }
           if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
           if (ABL != 4 && ABL != 8) {
@@ -1194,41 +1200,44 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           if (i == 12) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
         }
       }
-      if ((t + 1) * KVB > sg.len) {
-        const int base = t * KVB + 4 * hh;
+      // ---- softmax of tile t, SPECULATIVE on the offset mc in use: P(t) = exp2(S(t)) is formed straight away (S arrives as
+      // "score - mc" from the accumulator init) beside the P(t-1).V(t-1) MFMAs, with no row max in front of it - the 23
+      // v_max of a tile were a quarter of the VALU work that nothing hides on this chip (probe in tools/probes).  Only the
+      // row sums, which are needed anyway, are checked afterwards: a partial sum above 2^10 (or inf) in any lane means some
+      // row's scores climbed more than ~10 octaves over its offset; that wave then recomputes S(t) from the K tile still
+      // in LDS, moves the offset to the true max and redoes the tile's softmax (exact_tile below).  Nothing of a failed
+      // attempt survives: P(t) meets V(t) only in the next iteration and l is updated after the check.  The first tile
+      // always takes the exact route (offset = its row max, P <= 1); afterwards P <= 2^10, harmless in fp32 / bf16.
+      float alpha = 1.0f;
+      f32x2 ps2 = {0.f, 0.f};
+      auto mask_tail = [&]() {
+        if ((t + 1) * KVB > sg.len) {
+          const int base = t * KVB + 4 * hh;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+          for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
-            if (kv >= sg.len) st[f][r] = NEG_BIG;
-          }
-      }
-      // row max: four independent chains (a single 16-deep v_max3 chain is ~130 cycles of dependent latency in front of the
-      // softmax), then the other half of the row from lane ^ 32 through v_permlane32_swap (no LDS round trip)
-      float mx;
-      {
-        float m0 = fmaxf(st[0][0], st[0][1]), m1 = fmaxf(st[0][8], st[0][9]), m2 = fmaxf(st[1][0], st[1][1]), m3 = fmaxf(st[1][8], st[1][9]);
-#pragma unroll
-        for (int r = 2; r < 8; ++r) {
-          m0 = fmaxf(m0, st[0][r]);
-          m1 = fmaxf(m1, st[0][8 + r]);
-          m2 = fmaxf(m2, st[1][r]);
-          m3 = fmaxf(m3, st[1][8 + r]);
+            for (int r = 0; r < 16; ++r) {
+              const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
+              if (kv >= sg.len) st[f][r] = NEG_BIG;
+            }
         }
-        mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-      }
-      if (ABL != 6) {
+      };
+      auto rebase = [&]() {  // exact tile max of both halves of the row (lane ^ 32 holds the other half): move the offset
+        float mx;
+        {
+          float m0 = fmaxf(st[0][0], st[0][1]), m1 = fmaxf(st[0][8], st[0][9]), m2 = fmaxf(st[1][0], st[1][1]), m3 = fmaxf(st[1][8], st[1][9]);
+#pragma unroll
+          for (int r = 2; r < 8; ++r) {
+            m0 = fmaxf(m0, st[0][r]);
+            m1 = fmaxf(m1, st[0][8 + r]);
+            m2 = fmaxf(m2, st[1][r]);
+            m3 = fmaxf(m3, st[1][8 + r]);
+          }
+          mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        }
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
         mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      // Lazy running max, in offset coordinates (mx is relative to mc): the offset moves only when some row's tile max
-      // exceeds it by more than 2^8 - then the whole wave re-bases S(t), O and l - and always on the first tile.  P may
-      // reach 2^8 instead of 1, harmless in fp32 / bf16; on random scores the exact form rescaled O (64 accumulator
-      // registers) in about every second tile (any of 32 rows).
-      float alpha = 1.0f;
-      if (t == 0 || __any(mx > SP_RESCALE_THR)) {
-        const float shift = t == 0 ? mx : fmaxf(mx, 0.f);
+        const float shift = t == 0 ? mx : fmaxf(mx, 0.f);  // the offset only ever rises after the first tile
         alpha = __builtin_amdgcn_exp2f(-shift);
         mc += shift;
 #pragma unroll
@@ -1237,7 +1246,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           for (int r = 0; r < 16; ++r) st[f][r] -= shift;
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[r] = -mc;
-      }
+      };
+      auto pack_pair = [&](int j) {  // elements 2j, 2j+1 of P(t) -> word j & 3 of the P fragment of k-step j >> 2
+        const f32x2 pr = {st[j >> 3][(2 * j) & 15], st[j >> 3][(2 * j + 1) & 15]};
+        ppk[j >> 2][j & 3] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
+      };
+      mask_tail();
+      if (t == 0) rebase();
       if (ABL == 10) asm volatile("" ::"v"(mc));
       CE_SPSTAMP(2);
       // O at the scale of m(t-1) before P(t-1).V(t-1) is added (rare after the first tiles)
@@ -1247,53 +1262,69 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
       }
-      // ---- O^T += V^T(t-1).P^T(t-1) on the matrix pipe, P(t) = exp2(S(t) scale - mc) on the VALU, one stream:
-      // unit u = (k-step s4 = u >> 2, dv fragment m = u & 3) is one MFMA followed by two elements of the softmax
-      float psum = 0.f;
+      // ---- O^T += V^T(t-1).P^T(t-1) on the matrix pipe, P(t) on the VALU, one stream: unit u = (k-step u >> 2, dv
+      // fragment u & 3) is one MFMA, the v_exp of elements 2u, 2u+1, one packed add into the row sums (one unit behind, for
+      // the transcendental result latency) and one packed bf16 conversion (four units behind: pair j lands in the word of
+      // the P fragment that MFMA j + 3 was the last to read, so P(t) replaces P(t-1) in place, without copies).
       {
 #define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vb + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
         constexpr int VRING = 6;
         bf16x8 vf[VRING];
 #pragma unroll
         for (int u = 0; u < VRING; ++u) vf[u] = CE_LDV(u);
-        // One scheduling region per unit (sched_barrier(0) after each): hipcc may order the seven instructions of a unit
-        // as it likes but cannot pull the exp2 work of several units together (with sched_group_barrier alone it issued
-        // six MFMAs back to back and then bursts of eight or nine v_exp, longer than an MFMA's 32-cycle shadow).
-        // The row-sum add of an element runs one unit behind its v_exp (transcendental result latency).
+        // One scheduling region per unit (sched_barrier(0) after each): hipcc may order the instructions of a unit as it
+        // likes but cannot pull the exp2 work of several units together (with sched_group_barrier alone it issued six
+        // MFMAs back to back and then bursts of eight or nine v_exp, longer than an MFMA's 32-cycle shadow).
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           if (ABL == 2) {
             asm volatile("" ::"v"(vf[u % VRING]), "v"(ppk[u >> 2]));
           } else {
-            oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+            oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], __builtin_bit_cast(bf16x8, ppk[u >> 2]), oacc[u & 3], 0, 0, 0);
           }
           if (u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
 #pragma unroll
           for (int e = 2 * u; e < 2 * u + 2; ++e)
             st[e >> 4][e & 15] = ABL == 1 ? st[e >> 4][e & 15] * 0.5f : __builtin_amdgcn_exp2f(st[e >> 4][e & 15]);
           if (u > 0) {
-#pragma unroll
-            for (int e = 2 * u - 2; e < 2 * u; ++e) psum += st[e >> 4][e & 15];
+            ps2 += f32x2{st[(u - 1) >> 3][(2 * u - 2) & 15], st[(u - 1) >> 3][(2 * u - 1) & 15]};
           }
+          if (u >= 4) pack_pair(u - 4);
           __builtin_amdgcn_sched_barrier(0);
         }
-        psum += st[1][14];
-        psum += st[1][15];
+        ps2 += f32x2{st[1][14], st[1][15]};
+#pragma unroll
+        for (int j = 12; j < 16; ++j) pack_pair(j);
 #undef CE_LDV
+      }
+      float psum = ps2[0] + ps2[1];
+      if (__builtin_expect(t > 0 && ABL == 0 && __any(psum > SP_SPEC_THR), 0)) {
+        // exact_tile: S(t) again (K(t) is untouched until the next barrier), true row max, plain softmax
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb + (i & 1) * 32 * PK_ROW + (i >> 1) * 32);
+          st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[i >> 1], i < 2 ? zero16 : st[i & 1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)  // (zero init and an explicit "- mc": a second live copy of cinit cost the common path 8 v_mov)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[f][r] -= mc;
+        mask_tail();
+        rebase();
+        ps2 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          st[j >> 3][(2 * j) & 15] = __builtin_amdgcn_exp2f(st[j >> 3][(2 * j) & 15]);
+          st[j >> 3][(2 * j + 1) & 15] = __builtin_amdgcn_exp2f(st[j >> 3][(2 * j + 1) & 15]);
+          ps2 += f32x2{st[j >> 3][(2 * j) & 15], st[j >> 3][(2 * j + 1) & 15]};
+          pack_pair(j);
+        }
+        psum = ps2[0] + ps2[1];
       }
       l_run = l_run * alpha + psum;
       alpha_prev = alpha;
       if (ABL == 10) asm volatile("" ::"v"(l_run), "v"(oacc[3]));
       CE_SPSTAMP(3);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int f = s4 >> 1, rb = 8 * (s4 & 1);
-        f32x2 t0 = {st[f][rb + 0], st[f][rb + 1]}, t1 = {st[f][rb + 2], st[f][rb + 3]};
-        f32x2 t2 = {st[f][rb + 4], st[f][rb + 5]}, t3 = {st[f][rb + 6], st[f][rb + 7]};
-        const bf16x2 p0 = __builtin_convertvector(t0, bf16x2), p1 = __builtin_convertvector(t1, bf16x2);
-        const bf16x2 p2 = __builtin_convertvector(t2, bf16x2), p3 = __builtin_convertvector(t3, bf16x2);
-        ppk[s4] = bf16x8{p0[0], p0[1], p1[0], p1[1], p2[0], p2[1], p3[0], p3[1]};
-      }
       if (ABL == 10) asm volatile("" ::"v"(ppk[3]));
       CE_SPSTAMP(4);
       vb_prev = vb_cur;
@@ -1311,7 +1342,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const bf16x8 vfd = *reinterpret_cast<const bf16x8*>(vb + (u & 3) * 32 * PV_ROW + (u >> 2) * 32);
-        oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfd, ppk[u >> 2], oacc[u & 3], 0, 0, 0);
+        oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfd, __builtin_bit_cast(bf16x8, ppk[u >> 2]), oacc[u & 3], 0, 0, 0);
       }
     }
     CE_EPOCH_BARRIER();  // every wave is done with the tile buffers (the O staging overlays them when !TWO_SEG)

@@ -248,9 +248,12 @@ def test_attention_single_segment(Nq, Nkv, H, attn_waves):
     assert (out.float() - ref).abs().max().item() < 3e-2
 
 
-def test_attention_spiked_scores_force_rescale(attn_waves):
+@pytest.mark.parametrize("slope", [0.5, 10.0])
+def test_attention_spiked_scores_force_rescale(attn_waves, slope):
     """One key per tile has a much larger score than everything before it: exercises the online-softmax
-    rescale path on every tile (cdna guide rule 26)."""
+    rescale path on every tile (cdna guide rule 26).  slope 0.5: +8 octaves per tile (the default kernel's speculative
+    softmax takes its exact route every second tile, and runs with P up to 2^8 in between); slope 10: +160 octaves per
+    tile, exp2 overflows to inf before the row-sum check sends the tile through the exact route."""
     from chronoedit_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(5)
@@ -259,7 +262,7 @@ def test_attention_spiked_scores_force_rescale(attn_waves):
     k = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
     v = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
     for t in range(N // 64):
-        k[t * 64 + 5] = q[7] * (0.5 + 0.5 * t)
+        k[t * 64 + 5] = q[7] * (0.5 + slope * t)
     out = ops.attention(q, k, v, H)
     ref = _sdpa_ref(q, k, v, H)
     assert rel_l2(out, ref) < 1e-2
