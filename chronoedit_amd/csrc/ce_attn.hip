@@ -941,6 +941,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 //                   | 16 MFMA of O += V^T(t-1).P^T(t-1), each followed by 2 v_exp + 2 fma + 2 add of P(t) | pack P(t)
 // LDS: K double-buffered, V^T triple-buffered (V(t-1) is read while V(t+1) is written): one barrier per tile.
 // ------------------------------------------------------------------------------------------------
+#ifdef CE_SP_PRIO  // experiment: fillers at raised priority so that the OTHER wave's next MFMA does not take the issue port first
+#define CE_SP_PRIO_QK(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define CE_SP_PRIO_QK(x)
+#endif
 constexpr float SP_SPEC_THR = 1024.0f;  // a lane's partial row sum above this sends the tile through the exact route
 constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow the two K buffers
 constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
@@ -1144,7 +1149,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
       const unsigned char* vb = v_rd + vb_prev * PV_TILE;
 
-      // ---- S^T(t) = K(t).Q^T: MFMA i works on kv fragment f = i & 1, k-step ks = i >> 1 (alternating accumulators).
+      // ---- S^T(t) = K(t).Q^T: MFMA i works on kv fragment f = i & 1, k-step ks = i >> 1 (alternating accumulators; every
+      // unit - MFMA, ring refill, its piece of staging - is its own scheduling region: with sched_group_barrier alone hipcc
+      // re-linearised the MFMAs accumulator by accumulator, and a filler between two MFMAs on the SAME accumulator costs
+      // ~40 cycles (MI355X guide, latency table) - pinning the alternating order was worth 4 % of the kernel).
       // The staging of the NEXT tiles rides inside this MFMA stream instead of in front of it (stamps: with all eight
       // waves storing right after the barrier the matrix pipe idled ~600 cycles per tile): K(t+1) / V(t+1) registers
       // -> LDS after MFMAs 1, 3, 5..8, fetch of K(t+2) / V(t+2) after MFMAs 10 and 12.  Unconditional: past the last
@@ -1170,6 +1178,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           } else {
             st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], st[i & 1], 0, 0, 0);
           }
+          CE_SP_PRIO_QK(1);
           if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
           if (ABL != 4 && ABL != 8) {
             if (i == 1) *reinterpret_cast<pp_u4*>(k_wr + ((t + 1) & 1) * PK_TILE) = kreg[0];
@@ -1184,21 +1193,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
             if (i == 10) load_k(t + 2);
             if (i == 12) load_v(t + 2);
           }
+          CE_SP_PRIO_QK(0);
+          __builtin_amdgcn_sched_barrier(0);
         }
 #undef CE_LDK
-        __builtin_amdgcn_sched_group_barrier(0x100, RING, 0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (i < 16 - RING) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          if (i == 1 || i == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          if (i >= 5 && i < 9) {
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-          }
-          if (i == 10) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-          if (i == 12) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-        }
       }
       // ---- softmax of tile t, SPECULATIVE on the offset mc in use: P(t) = exp2(S(t)) is formed straight away (S arrives as
       // "score - mc" from the accumulator init) beside the P(t-1).V(t-1) MFMAs, with no row max in front of it - the 23
@@ -1209,7 +1207,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       // attempt survives: P(t) meets V(t) only in the next iteration and l is updated after the check.  The first tile
       // always takes the exact route (offset = its row max, P <= 1); afterwards P <= 2^10, harmless in fp32 / bf16.
       float alpha = 1.0f;
-      f32x2 ps2 = {0.f, 0.f};
+      float psum = 0.f;
       auto mask_tail = [&]() {
         if ((t + 1) * KVB > sg.len) {
           const int base = t * KVB + 4 * hh;
@@ -1263,7 +1261,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
       }
       // ---- O^T += V^T(t-1).P^T(t-1) on the matrix pipe, P(t) on the VALU, one stream: unit u = (k-step u >> 2, dv
-      // fragment u & 3) is one MFMA, the v_exp of elements 2u, 2u+1, one packed add into the row sums (one unit behind, for
+      // fragment u & 3) is one MFMA, the v_exp of elements 2u, 2u+1, two adds into the row sum (one unit behind, for
       // the transcendental result latency) and one packed bf16 conversion (four units behind: pair j lands in the word of
       // the P fragment that MFMA j + 3 was the last to read, so P(t) replaces P(t-1) in place, without copies).
       {
@@ -1282,22 +1280,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           } else {
             oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], __builtin_bit_cast(bf16x8, ppk[u >> 2]), oacc[u & 3], 0, 0, 0);
           }
+          CE_SP_PRIO_QK(1);
           if (u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
 #pragma unroll
           for (int e = 2 * u; e < 2 * u + 2; ++e)
             st[e >> 4][e & 15] = ABL == 1 ? st[e >> 4][e & 15] * 0.5f : __builtin_amdgcn_exp2f(st[e >> 4][e & 15]);
-          if (u > 0) {
-            ps2 += f32x2{st[(u - 1) >> 3][(2 * u - 2) & 15], st[(u - 1) >> 3][(2 * u - 1) & 15]};
+          if (u > 0) {  // (scalar adds: v_pk_add_f32 beside MFMAs is slower than the two adds it replaces; measured +1.6 %)
+            psum += st[(u - 1) >> 3][(2 * u - 2) & 15];
+            psum += st[(u - 1) >> 3][(2 * u - 1) & 15];
           }
           if (u >= 4) pack_pair(u - 4);
+          CE_SP_PRIO_QK(0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        ps2 += f32x2{st[1][14], st[1][15]};
+        psum += st[1][14];
+        psum += st[1][15];
 #pragma unroll
         for (int j = 12; j < 16; ++j) pack_pair(j);
 #undef CE_LDV
       }
-      float psum = ps2[0] + ps2[1];
       if (__builtin_expect(t > 0 && ABL == 0 && __any(psum > SP_SPEC_THR), 0)) {
         // exact_tile: S(t) again (K(t) is untouched until the next barrier), true row max, plain softmax
 #pragma unroll
@@ -1311,15 +1312,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           for (int r = 0; r < 16; ++r) st[f][r] -= mc;
         mask_tail();
         rebase();
-        ps2 = f32x2{0.f, 0.f};
+        psum = 0.f;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           st[j >> 3][(2 * j) & 15] = __builtin_amdgcn_exp2f(st[j >> 3][(2 * j) & 15]);
           st[j >> 3][(2 * j + 1) & 15] = __builtin_amdgcn_exp2f(st[j >> 3][(2 * j + 1) & 15]);
-          ps2 += f32x2{st[j >> 3][(2 * j) & 15], st[j >> 3][(2 * j + 1) & 15]};
+          psum += st[j >> 3][(2 * j) & 15] + st[j >> 3][(2 * j + 1) & 15];
           pack_pair(j);
         }
-        psum = ps2[0] + ps2[1];
       }
       l_run = l_run * alpha + psum;
       alpha_prev = alpha;

@@ -1,5 +1,5 @@
 """A/B timing of two builds of the attention kernel in ONE process (box-to-box and thermal drift exceed the effects being
-measured): usage  python tools/attn_ab.py <base.so> [<new.so>]   (new defaults to the in-tree library).
+measured): usage  python tools/attn_ab.py <base.so> [<variant.so> ...]   (the in-tree library is always the last entry).
 The base library is built from an older ce_attn.hip with the same hipcc line as hiplib.build(); both are called through
 the C ABI on the same tensors, interleaved A/B/A/B, best of each."""
 import ctypes
@@ -23,15 +23,16 @@ def bind(path):
 
 
 def main():
-    base = bind(sys.argv[1])
-    new = bind(sys.argv[2] if len(sys.argv) > 2 else hiplib.LIB_PATH)
+    paths = sys.argv[1:] + [hiplib.LIB_PATH]
+    fns = [bind(p) for p in paths]
+    names = [p.split("/")[-1].replace("lib", "").replace(".so", "") for p in paths]
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     for (Nq, Nkv, H, B) in [(7200, 7200, 40, 2), (7200, 7200, 40, 1), (7200, 512, 40, 2), (17424, 17424, 40, 1)]:
         D = H * 128
         qkv = torch.randn(B * max(Nq, Nkv), 3 * D, generator=g).to(BF).to(dev)
         q, k, v = qkv[:B * Nq, :D], qkv[:B * Nkv, D:2 * D], qkv[:B * Nkv, 2 * D:]
-        outs = [torch.empty(B * Nq, D, dtype=BF, device=dev) for _ in range(2)]
+        outs = [torch.empty(B * Nq, D, dtype=BF, device=dev) for _ in fns]
         st = torch.cuda.current_stream().cuda_stream
 
         def run(f, o):
@@ -50,14 +51,16 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / iters
 
-        ta = tb = 1e9
+        best = [1e9] * len(fns)
         for _ in range(4):
-            ta = min(ta, timeit(base, outs[0]))
-            tb = min(tb, timeit(new, outs[1]))
+            for i, f in enumerate(fns):
+                best[i] = min(best[i], timeit(f, outs[i]))
         fl = 4.0 * Nq * Nkv * 128 * H * B
-        d = (outs[0].float() - outs[1].float()).abs().max().item()
-        print(f"attn {Nq}x{Nkv} H{H} B{B}: base {ta:.3f} ms {fl/ta/1e9:.1f} TF | new {tb:.3f} ms {fl/tb/1e9:.1f} TF | "
-              f"{(ta/tb-1)*100:+.1f} % | max |base - new| {d:.2e}", flush=True)
+        line = f"attn {Nq}x{Nkv} H{H} B{B}:"
+        for i, n in enumerate(names):
+            d = (outs[0].float() - outs[i].float()).abs().max().item()
+            line += f" | {n} {best[i]:.3f} ms {fl/best[i]/1e9:.0f} TF ({(best[0]/best[i]-1)*100:+.1f} %, d {d:.1e})"
+        print(line, flush=True)
         del qkv, outs
 
 
