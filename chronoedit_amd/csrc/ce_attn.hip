@@ -941,11 +941,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 //                   | 16 MFMA of O += V^T(t-1).P^T(t-1), each followed by 2 v_exp + 2 fma + 2 add of P(t) | pack P(t)
 // LDS: K double-buffered, V^T triple-buffered (V(t-1) is read while V(t+1) is written): one barrier per tile.
 // ------------------------------------------------------------------------------------------------
-#ifdef CE_SP_PRIO  // experiment: fillers at raised priority so that the OTHER wave's next MFMA does not take the issue port first
-#define CE_SP_PRIO_QK(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define CE_SP_PRIO_QK(x)
-#endif
+constexpr int K_GRP = 1088;  // LDS-DMA K image: 4 rows (1 KiB) + 64 B pad per group; 16 groups = PK_TILE
+typedef __attribute__((address_space(3))) void lds_void;
 constexpr float SP_SPEC_THR = 1024.0f;  // a lane's partial row sum above this sends the tile through the exact route
 constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow the two K buffers
 constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
@@ -1030,14 +1027,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));  // retire the Q loads before the loop (see ping-pong)
 
-  // staging shares and LDS bases: as in the ping-pong kernel (K rows 272 B, V^T rows 144 B, (h, b) chunk order)
-  const int k_ck = tid & 15, k_row0 = tid >> 4;
+  // staging shares and LDS bases: V^T as in the ping-pong kernel (rows 144 B, (h, b) chunk order), K by LDS-DMA (below)
   const int v_dvq = (tid & 1) | (((tid >> 4) & 15) << 1), v_kvq = ((tid >> 1) & 7) | (((tid >> 8) & 1) << 3);
   const int v_chunk = (v_kvq & ~3) | ((v_kvq & 1) << 1) | ((v_kvq >> 1) & 1);
   unsigned char* ost = smem + (TWO_SEG ? SP_TILE_BYTES : 0) + (size_t)(wave * QW + l31) * OST_ROW;
-  const unsigned char* k_rd = smem + l31 * PK_ROW + hh * 16;            // + buf*PK_TILE + f*32*PK_ROW + ks*32
+  // K image filled by LDS-DMA (no VGPR round trip, no ds_write): 16 groups of 4 kv rows, one 1 KiB wave-instruction each,
+  // 1088 B apart; in a group, row w = r & 3 keeps its 16-B chunk c in slot c ^ w.  A b128 read group covers 4 groups
+  // (x 64 B pad = slots +0, +4, +8, +12) times 4 rows (low slot bits ^ w): 16 distinct slots, conflict-free.  With
+  // c = 2 ks + h the slot is 4 (ks >> 1) + 2 ((ks & 1) ^ (w >> 1)) + (h ^ (w & 1)): two per-lane bases (even / odd ks) +
+  // immediates.
+  const int k_w = l31 & 3;
+  const unsigned char* k_rd = smem + (l31 >> 2) * K_GRP + k_w * 256 + ((hh ^ (k_w & 1)) << 4);  // + buf*PK_TILE + f*8*K_GRP
+  const int k_eo[2] = {(k_w >> 1) << 5, ((k_w >> 1) ^ 1) << 5};                                    // + k_eo[ks & 1] + (ks >> 1)*64
   const unsigned char* v_rd = smem + SP_V0 + l31 * PV_ROW + hh * 16;    // + buf*PV_TILE + m*32*PV_ROW + s*32
-  unsigned char* k_wr = smem + k_row0 * PK_ROW + k_ck * 16;             // + buf*PK_TILE + i*32*PK_ROW
   unsigned char* v_wr = smem + SP_V0 + (4 * v_dvq) * PV_ROW + v_chunk * 8;  // + buf*PV_TILE + j*PV_ROW
 
 #pragma unroll
@@ -1046,7 +1048,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     const int ntiles = (sg.len + KVB - 1) / KVB;
     const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (sg.len - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
     const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + hoff), 0, (sg.len - 1) * sg.ldv * 2 + HD * 2, 0x00020000);
-    const int k_voff0 = k_row0 * sg.ldk * 2 + k_ck * 16, k_voff1 = k_voff0 + 32 * sg.ldk * 2;
     int v_voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v_voff[i] = (4 * v_kvq + i) * sg.ldv * 2 + v_dvq * 8;
@@ -1066,21 +1067,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) ppk[s4] = u32x4{0u, 0u, 0u, 0u};
 
-    pp_u4 kreg[2];
     pp_u2 vreg[4];
-    auto load_k = [&](int t) {
-      const int so = t * k_tile_bytes;
-      kreg[0] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff0, so, 0);
-      kreg[1] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff1, so, 0);
+    // wave-instruction j fills group wave + 8 j of the image: lane -> row 4 (wave + 8 j) + (lane >> 4), chunk (lane & 15) ^ (lane >> 4)
+    const int kd_voff0 = (4 * wave + (lane >> 4)) * sg.ldk * 2 + (((lane & 15) ^ (lane >> 4)) << 4), kd_voff1 = kd_voff0 + 32 * sg.ldk * 2;
+    auto dma_k = [&](int t, int buf, int j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + buf * PK_TILE + (wave + 8 * j) * K_GRP), 16,
+                                               j ? kd_voff1 : kd_voff0, t * k_tile_bytes, 0, 0);
     };
     auto load_v = [&](int t) {
       const int so = t * v_tile_bytes;
 #pragma unroll
       for (int i = 0; i < 4; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b64(v_rsrc, v_voff[i], so, 0);
-    };
-    auto store_k = [&](int buf) {
-      *reinterpret_cast<pp_u4*>(k_wr + buf * PK_TILE) = kreg[0];
-      *reinterpret_cast<pp_u4*>(k_wr + buf * PK_TILE + 32 * PK_ROW) = kreg[1];
     };
     auto store_v_part = [&](int buf, int j) {  // row j of this thread's transposed 4x4 patch
       const int w = j >> 1;
@@ -1114,35 +1111,40 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 
     // ---- prologue: tile 0 -> K buffer 0 / V buffer 0; V buffer 2 plays "V(-1)" (zeros: P(-1) = 0 must not meet NaNs)
     if (TWO_SEG && sidx == 1) { CE_EPOCH_BARRIER(); }  // segment 0's drain still read the V buffers
-    load_k(0);
+    dma_k(0, 0, 0);
+    dma_k(0, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
     load_v(0);
     {
       const pp_u4 z = {0u, 0u, 0u, 0u};
       for (int i = tid; i < PV_TILE / 16; i += NWAVE * 64) *reinterpret_cast<pp_u4*>(smem + SP_V0 + 2 * PV_TILE + i * 16) = z;
     }
-    store_k(0);
     store_v(0);
-    if (ntiles > 1) {
-      load_k(1);
-      load_v(1);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K(0) has landed (its DMA precedes the V(0) fetch just consumed)
+    load_v(1);
+    // From here on the vector-memory queue of a wave holds, in order: K(t) DMA x2 (tile t-1, units 1 and 3), V(t+1) x4
+    // (tile t-1, unit 12): "vmcnt(4)" in front of the barrier of tile t = K(t) is in LDS.
+#define CE_SP_KWAIT() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
     int vb_prev = 2, vb_cur = 0;  // V^T buffer of tile t-1 / tile t
 
     // A wave without query rows only stages, behind the same barriers - in a loop of its own: as a `continue` path inside
     // the main loop its fetches joined the main path's in phi nodes that hipcc resolved with six v_mov_b64 (behind a
     // vmcnt(0)) in the loop latch of every wave.
     for (int t = 0; !active && t < ntiles; ++t) {
+      CE_SP_KWAIT();
       CE_EPOCH_BARRIER();
       const int vb_next = 3 - vb_prev - vb_cur;
-      store_k((t + 1) & 1);
+      dma_k(t + 1, (t + 1) & 1, 0);
+      dma_k(t + 1, (t + 1) & 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
       store_v(vb_next);
-      load_k(t + 2);
       load_v(t + 2);
       vb_prev = vb_cur;
       vb_cur = vb_next;
     }
     for (int t = 0; active && t < ntiles; ++t) {
       CE_SPSTAMP(5);
+      CE_SP_KWAIT();
       CE_EPOCH_BARRIER();  // K(t), V(t) visible; K(t-1) and V(t-2) no longer read by anyone
       CE_SPSTAMP(0);
       const int vb_next = 3 - vb_prev - vb_cur;
@@ -1163,7 +1165,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       {
         constexpr int RING = 6;
         bf16x8 kf[RING];
-#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + ((i) & 1) * 32 * PK_ROW + ((i) >> 1) * 32))
+#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + k_eo[((i) >> 1) & 1] + ((i) & 1) * 8 * K_GRP + ((i) >> 2) * 64))
 #pragma unroll
         for (int i = 0; i < RING; ++i) kf[i] = CE_LDK(i);
 #pragma unroll
@@ -1178,22 +1180,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           } else {
             st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], st[i & 1], 0, 0, 0);
           }
-          CE_SP_PRIO_QK(1);
           if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
-          if (ABL != 4 && ABL != 8) {
-            if (i == 1) *reinterpret_cast<pp_u4*>(k_wr + ((t + 1) & 1) * PK_TILE) = kreg[0];
-            if (i == 3) *reinterpret_cast<pp_u4*>(k_wr + ((t + 1) & 1) * PK_TILE + 32 * PK_ROW) = kreg[1];
-            if (i >= 5 && i < 9) store_v_part(vb_next, i - 5);
-          }
-          if (ABL == 8) {  // keep the fetched registers (and their vmcnt waits) alive without the LDS stores
-            if (i == 1) asm volatile("" ::"v"(kreg[0]), "v"(kreg[1]));
-            if (i == 5) asm volatile("" ::"v"(vreg[0]), "v"(vreg[1]), "v"(vreg[2]), "v"(vreg[3]));
-          }
           if (ABL != 4 && ABL != 7) {
-            if (i == 10) load_k(t + 2);
+            if (i == 1) dma_k(t + 1, (t + 1) & 1, 0);
+            if (i == 3) dma_k(t + 1, (t + 1) & 1, 1);
             if (i == 12) load_v(t + 2);
           }
-          CE_SP_PRIO_QK(0);
+          if (ABL != 4 && ABL != 8) {
+            if (i >= 5 && i < 9) store_v_part(vb_next, i - 5);
+          }
+          if (ABL == 8 && i == 5) asm volatile("" ::"v"(vreg[0]), "v"(vreg[1]), "v"(vreg[2]), "v"(vreg[3]));
           __builtin_amdgcn_sched_barrier(0);
         }
 #undef CE_LDK
@@ -1280,7 +1276,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           } else {
             oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u % VRING], __builtin_bit_cast(bf16x8, ppk[u >> 2]), oacc[u & 3], 0, 0, 0);
           }
-          CE_SP_PRIO_QK(1);
           if (u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
 #pragma unroll
           for (int e = 2 * u; e < 2 * u + 2; ++e)
@@ -1290,7 +1285,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
             psum += st[(u - 1) >> 3][(2 * u - 1) & 15];
           }
           if (u >= 4) pack_pair(u - 4);
-          CE_SP_PRIO_QK(0);
           __builtin_amdgcn_sched_barrier(0);
         }
         psum += st[1][14];
@@ -1303,7 +1297,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
         // exact_tile: S(t) again (K(t) is untouched until the next barrier), true row max, plain softmax
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb + (i & 1) * 32 * PK_ROW + (i >> 1) * 32);
+          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb + k_eo[(i >> 1) & 1] + (i & 1) * 8 * K_GRP + (i >> 2) * 64);
           st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[i >> 1], i < 2 ? zero16 : st[i & 1], 0, 0, 0);
         }
 #pragma unroll
