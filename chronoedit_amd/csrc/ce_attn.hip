@@ -1181,9 +1181,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
             st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i % RING], qf[i >> 1], st[i & 1], 0, 0, 0);
           }
           if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
-          if (ABL != 4 && ABL != 7) {
+          if (ABL != 4 && ABL != 7 && ABL != 11) {
             if (i == 1) dma_k(t + 1, (t + 1) & 1, 0);
             if (i == 3) dma_k(t + 1, (t + 1) & 1, 1);
+          }
+          if (ABL != 4 && ABL != 7 && ABL != 12) {
             if (i == 12) load_v(t + 2);
           }
           if (ABL != 4 && ABL != 8) {
@@ -1868,7 +1870,7 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
                        (const bf16*)Q, (bf16*)O, s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, g_attn_order);              \
     return (int)hipGetLastError();
     if (!two) switch (g_attn_ablate) {
-        CE_SP_ABL(1) CE_SP_ABL(2) CE_SP_ABL(3) CE_SP_ABL(4) CE_SP_ABL(6) CE_SP_ABL(7) CE_SP_ABL(8) CE_SP_ABL(10)
+        CE_SP_ABL(1) CE_SP_ABL(2) CE_SP_ABL(3) CE_SP_ABL(4) CE_SP_ABL(7) CE_SP_ABL(8) CE_SP_ABL(10) CE_SP_ABL(11) CE_SP_ABL(12)
         default: break;
       }
 #undef CE_SP_ABL

@@ -15,7 +15,8 @@ NAMES = {0: "full kernel", 1: "no exp2 (fma only)", 2: "no P.V MFMAs", 3: "no K.
          8: "static prio 1 for group 1", 9: "prio 3 on P.V MFMAs, 0 on exp"}
 if os.environ.get("ATTN_KERNEL") == "64":
     NAMES = {0: "full kernel", 1: "no exp2 (fma only)", 2: "no P.V MFMAs", 3: "no K.Q^T MFMAs", 4: "no staging (stores + fetches)",
-             6: "no cross-lane row-max exchange", 7: "no global fetches (stores kept)", 8: "no LDS stores (fetches kept)"}
+             7: "no global fetches (stores kept)", 8: "no LDS stores (fetches kept)",
+             11: "no K LDS-DMA (V fetches kept)", 12: "no V fetches (K DMA kept)"}
 
 
 def build():
