@@ -105,13 +105,15 @@ __device__ __forceinline__ void read_b(const unsigned char* smem, int wn, int fr
   }
 }
 
-// 8 MFMAs: one k-step of a 64x32 quadrant
+// 8 MFMAs: one k-step of a 64x32 quadrant.  The W fragment is the MFMA's first operand, so the accumulator holds C^T: lane
+// (fr, fg) of acc[f][g] owns row f*16 + fr and the FOUR CONSECUTIVE columns g*16 + fg*4 + [0,4) - one 8-byte store per
+// accumulator in the epilogue instead of four 2-byte ones (the LDS store issue of the epilogue was ~5 % of a K = 5120 GEMM).
 __device__ __forceinline__ void mma_half(f32x4 (&acc)[4][2], const bf16x8 (&a)[4], const bf16x8 (&b)[2]) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[f], b[g], acc[f][g], 0, 0, 0);
+    for (int g = 0; g < 2; ++g) acc[f][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[g], a[f], acc[f][g], 0, 0, 0);
   __builtin_amdgcn_s_setprio(0);
 }
 
@@ -150,16 +152,18 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2][2][4][2], unsi
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int cl = j * 128 + wn * 32 + g * 16 + fr;
+        const int cl = j * 128 + wn * 32 + g * 16 + fg * 4;
         const int n = n0 + cl;
-        const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+        float bv[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int r = 0; r < 4; ++r) bv[r] = (bias != nullptr && n + r < N) ? bias[n + r] : 0.f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rl = wm * 64 + f * 16 + fg * 4 + r;
-            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] + bv);
-          }
+        for (int f = 0; f < 4; ++f) {
+          const int rl = wm * 64 + f * 16 + fr;
+          const f32x4 v = acc[i][j][f][g];
+          const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
+          *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
+        }
       }
     __syncthreads();
 #pragma unroll
