@@ -14,7 +14,12 @@ BF = torch.bfloat16
 
 
 def bind(path):
+    knob = None
+    if "@" in path:  # <lib.so>@<knob>: select a loop body through ce_set_attention_waves
+        path, knob = path.split("@")
     lib = ctypes.CDLL(path)
+    if knob is not None:
+        lib.ce_set_attention_waves(int(knob))
     f = lib.ce_attention_batched_bf16
     f.restype = ctypes.c_int
     f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] + \
@@ -26,6 +31,7 @@ def main():
     paths = sys.argv[1:] + [hiplib.LIB_PATH]
     fns = [bind(p) for p in paths]
     names = [p.split("/")[-1].replace("lib", "").replace(".so", "") for p in paths]
+    paths = [p.split("@")[0] for p in paths]
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     for (Nq, Nkv, H, B) in [(7200, 7200, 40, 2), (7200, 7200, 40, 1), (7200, 512, 40, 2), (17424, 17424, 40, 1)]:
