@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x0
 // K2: timestep sinusoid + small GEMV chain (one wave per output feature)
 // ------------------------------------------------------------------------------------
 // out[i] = cos(t * f_i) for i < half, sin(t * f_i) otherwise;  f_i = exp(-ln(1e4) * i / half)
-__global__ void timestep_sinusoid_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int dim) {
+template <typename TT>
+__global__ void timestep_sinusoid_kernel(const TT* __restrict__ t, float* __restrict__ out, int dim) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int half = dim >> 1;
   if (i >= dim) return;
@@ -280,7 +281,13 @@ extern "C" int ce_rmsnorm_rope_bf16(void* x, const float* w, void* x2, const flo
 
 extern "C" int ce_timestep_sinusoid(const int64_t* t, float* out, int dim, hipStream_t stream) {
   if (!t || !out || dim <= 0 || (dim & 1)) return CE_ERR_ARG;
-  hipLaunchKernelGGL(timestep_sinusoid_kernel, dim3((dim + 255) / 256), dim3(256), 0, stream, t, out, dim);
+  hipLaunchKernelGGL(timestep_sinusoid_kernel<int64_t>, dim3((dim + 255) / 256), dim3(256), 0, stream, t, out, dim);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_timestep_sinusoid_f32(const float* t, float* out, int dim, hipStream_t stream) {
+  if (!t || !out || dim <= 0 || (dim & 1)) return CE_ERR_ARG;
+  hipLaunchKernelGGL(timestep_sinusoid_kernel<float>, dim3((dim + 255) / 256), dim3(256), 0, stream, t, out, dim);
   return (int)hipGetLastError();
 }
 

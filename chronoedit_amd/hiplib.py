@@ -43,6 +43,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_attention_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "ce_attention_batched_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_timestep_sinusoid": [_P, _P, _I, _P],
+    "ce_timestep_sinusoid_f32": [_P, _P, _I, _P],
     "ce_gemv": [_P, _I, _P, _P, _P, _I, _I, _I, _P],
     "ce_modulation": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "ce_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -245,10 +245,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out
 
 
 def timestep_sinusoid(t: torch.Tensor, dim: int, out: Optional[torch.Tensor] = None):
-    _dev(t, torch.int64, "timestep")
+    """[cos, sin] table of one timestep: int64 (diffusers path) or float32 (the sibling stacks' float timesteps)."""
+    if t.dtype == torch.float32:
+        _dev(t, torch.float32, "timestep")
+    else:
+        _dev(t, torch.int64, "timestep")
     if out is None:
         out = torch.empty((dim,), dtype=torch.float32, device=t.device)
-    _check(lib().ce_timestep_sinusoid(_ptr(t), _ptr(out), dim, _stream()), "ce_timestep_sinusoid")
+    if t.dtype == torch.float32:
+        _check(lib().ce_timestep_sinusoid_f32(_ptr(t), _ptr(out), dim, _stream()), "ce_timestep_sinusoid_f32")
+    else:
+        _check(lib().ce_timestep_sinusoid(_ptr(t), _ptr(out), dim, _stream()), "ce_timestep_sinusoid")
     return out
 
 

@@ -302,11 +302,13 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
 
 
 # ------------------------------------------------------------------------------------------
-def rope_cos_sin(head_dim: int, max_len: int, skip_len: int, T: int, Hp: int, Wp: int, theta: float = 10000.0) -> torch.Tensor:
+def rope_cos_sin(head_dim: int, max_len: int, skip_len: int, T: int, Hp: int, Wp: int, theta: float = 10000.0,
+                 plain_temporal: bool = False) -> torch.Tensor:
     """[T*Hp*Wp, head_dim/2, 2] fp32 (cos, sin) of ChronoEditRotaryPosEmbed
     (transformer_chronoedit.py:168-213): per-axis dims (t, h, w) = (hd - 4*(hd//6), 2*(hd//6), 2*(hd//6)),
-    angles in fp64; temporal indices {0, skip_len-1} when T == 2 (:205-207)."""
-    assert T == 2 or T == skip_len, f"num_frames must be 2 or {skip_len}, but got {T}"
+    angles in fp64; temporal indices {0, skip_len-1} when T == 2 (:205-207).  plain_temporal: indices 0..T-1 for any T,
+    what the diffsynth call path uses (wan_video_new_chronoedit.py:1428-1432)."""
+    assert plain_temporal or T == 2 or T == skip_len, f"num_frames must be 2 or {skip_len}, but got {T}"
     h_dim = w_dim = 2 * (head_dim // 6)
     t_dim = head_dim - h_dim - w_dim
 
@@ -314,7 +316,7 @@ def rope_cos_sin(head_dim: int, max_len: int, skip_len: int, T: int, Hp: int, Wp
         f = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64)[: dim // 2] / dim))
         return torch.outer(idx.to(torch.float64), f)
 
-    t_idx = torch.tensor([0, skip_len - 1]) if T == 2 else torch.arange(T)
+    t_idx = torch.tensor([0, skip_len - 1]) if (T == 2 and not plain_temporal) else torch.arange(T)
     assert max(T, Hp, Wp, skip_len) <= max_len
     a_t = ang(t_dim, t_idx).view(T, 1, 1, -1).expand(T, Hp, Wp, -1)
     a_h = ang(h_dim, torch.arange(Hp)).view(1, Hp, 1, -1).expand(T, Hp, Wp, -1)
@@ -496,10 +498,12 @@ class DiTEngine:
         return ws
 
     def _rope_table(self, T, Hp, Wp):
-        key = (T, Hp, Wp)
+        plain = bool(getattr(self.model, "rope_plain_temporal", False))
+        key = (T, Hp, Wp, plain)
         if key not in self._rope:
             c = self.cfg
-            self._rope = {key: rope_cos_sin(c.attention_head_dim, c.rope_max_seq_len, c.rope_temporal_skip_len, T, Hp, Wp).to(self.dev)}
+            self._rope = {key: rope_cos_sin(c.attention_head_dim, c.rope_max_seq_len, c.rope_temporal_skip_len, T, Hp, Wp,
+                                            plain_temporal=plain).to(self.dev)}
         return self._rope[key]
 
     # -- K3 + K13: conditioning-side work (step-invariant) -------------------------------
@@ -595,7 +599,8 @@ class DiTEngine:
             Nl = N
         ws = self._workspace(B * Nl)
         hidden = hidden.to(torch.bfloat16).contiguous()
-        timestep = timestep.to(device=self.dev, dtype=torch.int64).contiguous()
+        # integer timesteps as in the diffusers pipeline; floating-point ones (sibling stacks) keep their fraction
+        timestep = timestep.to(device=self.dev, dtype=torch.float32 if timestep.is_floating_point() else torch.int64).contiguous()
         rows = [slice(b * Nl, (b + 1) * Nl) for b in range(B)]
 
         # K1

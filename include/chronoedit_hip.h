@@ -97,6 +97,11 @@ int ce_set_attention_waves(int nwave);
  * (transformer_chronoedit.py:137,153). */
 int ce_timestep_sinusoid(const int64_t* t, float* out, int dim, hipStream_t stream);
 
+/* Same table from a FLOATING-POINT timestep (device fp32): the reference's two sibling stacks hand the scheduler's float
+ * timesteps to sinusoidal_embedding_1d (wan_video_dit_chronoedit.py:83-87, wan2pt1.py:191-200; call sites
+ * wan_video_new_chronoedit.py:1383, wan2pt1.py:812). */
+int ce_timestep_sinusoid_f32(const float* t, float* out, int dim, hipStream_t stream);
+
 /* y[N] = post(W[N,K] . pre(x[K]) + bias); W fp32 (w_is_bf16 = 0) or bf16.
  * flags: 1 = pre: x <- bf16(silu(x)); 2 = post: silu; 4 = post: round result to bf16 (still stored fp32).
  * Replaces TimestepEmbedding + act_fn + time_proj (transformer_chronoedit.py:153-159). */

@@ -56,6 +56,7 @@ class DiTConfig:
     added_kv_proj_dim: Optional[int] = 5120
     rope_max_seq_len: int = 1024
     rope_temporal_skip_len: int = 8
+    rope_plain_temporal: bool = False  # temporal positions 0..T-1 for any T: the diffsynth call path (wan_video_new_chronoedit.py:1428-1432)
 
     @property
     def inner_dim(self) -> int:
@@ -211,10 +212,10 @@ def rope_table(cfg: DiTConfig, num_frames: int, height: int, width: int) -> torc
     ft, fh, fw = (rope_freqs_1d(d, cfg.rope_max_seq_len) for d in (t_dim, h_dim, w_dim))
     pt, ph, pw = cfg.patch_size
     ppf, pph, ppw = num_frames // pt, height // ph, width // pw
-    assert num_frames == 2 or num_frames == cfg.rope_temporal_skip_len, (
+    assert cfg.rope_plain_temporal or num_frames == 2 or num_frames == cfg.rope_temporal_skip_len, (
         f"num_frames must be 2 or {cfg.rope_temporal_skip_len}, but got {num_frames}"
     )
-    if num_frames == 2:
+    if num_frames == 2 and not cfg.rope_plain_temporal:
         f_t = ft[: cfg.rope_temporal_skip_len][[0, -1]]
     else:
         f_t = ft[:ppf]
