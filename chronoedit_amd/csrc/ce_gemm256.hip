@@ -137,6 +137,39 @@ __device__ __forceinline__ void tile_origin(int wg, int tiles_m, int tiles_n, in
   n0 = tn * BN;
 }
 
+// One 16-byte chunk (8 bf16 of row m starting at column n, already "acc + bias" rounded to bf16): activation / gated residual,
+// then the global store.  Shared by the GEMM kernel's epilogue and the split-K reduce kernel.
+template <int EPI>
+__device__ __forceinline__ void epi_chunk(u32x4 v, int m, int n, bf16* __restrict__ C, const float* __restrict__ gate,
+                                          const bf16* __restrict__ res, int N, int ldc, int ldres, int gate_rows) {
+    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_tanh(bf16lo(v[q])), gelu_tanh(bf16hi(v[q])));
+    } else if (EPI == EPI_BIAS_GELU_ERF) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_erf(bf16lo(v[q])), gelu_erf(bf16hi(v[q])));
+    } else if (EPI == EPI_GATE_RES) {
+      const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
+      float gt[8];
+      if (gate != nullptr) {
+        const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;  // per-sample gate rows
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gt[q] = g0[q];
+          gt[4 + q] = g1[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gt[q] = 1.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * gt[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * gt[2 * q + 1]);
+    }
+    *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
+}
+
 // Epilogue shared by the GEMM kernel and the split-K reduce kernel: the accumulators go through LDS in two passes
 // of 128 tile rows so that the global stores (and the residual reads) are 16-byte row-contiguous.
 template <int EPI>
@@ -172,33 +205,7 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2][2][4][2], unsi
       const int rl = c >> 5, cc = c & 31;
       const int m = m0 + i * 128 + rl, n = n0 + cc * 8;
       if (m < M && n < N) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16);
-        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_tanh(bf16lo(v[q])), gelu_tanh(bf16hi(v[q])));
-        } else if (EPI == EPI_BIAS_GELU_ERF) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_erf(bf16lo(v[q])), gelu_erf(bf16hi(v[q])));
-        } else if (EPI == EPI_GATE_RES) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
-          float gt[8];
-          if (gate != nullptr) {
-            const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;  // per-sample gate rows
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              gt[q] = g0[q];
-              gt[4 + q] = g1[q];
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) gt[q] = 1.0f;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * gt[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * gt[2 * q + 1]);
-        }
-        *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
+        epi_chunk<EPI>(*reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16), m, n, C, gate, res, N, ldc, ldres, gate_rows);
       }
     }
   }
@@ -438,8 +445,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   epilogue256<EPI>(acc, smem, tid, wm, wn, fr, fg, m0, n0, C, bias, gate, res, M, N, ldc, ldres, gate_rows);
 }
 
-// Sums the `split` fp32 slabs of one tail tile (same thread <-> accumulator mapping as the GEMM kernel) and runs the
-// common epilogue.  grid = number of tail tiles.
+// Sums the `split` fp32 slabs of one QUADRANT (128 x 128) of a tail tile - same thread <-> accumulator mapping as the GEMM
+// kernel - and applies the epilogue.  grid = 4 x the number of tail tiles: with one block per tile the reduce ran on as
+// few as six CUs (FFN-up: six tail tiles, eight slabs each, 68 us) and added up to 2.3 % of a denoising step.
+constexpr int QROW = 128 * 2 + 16;  // padded staging row of a quadrant (272 B)
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm256_reduce(bf16* __restrict__ C, const float* __restrict__ bias,
                                                       const float* __restrict__ gate, const bf16* __restrict__ res, int M,
@@ -450,24 +459,38 @@ __global__ __launch_bounds__(512) void gemm256_reduce(bf16* __restrict__ C, cons
   const int wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
   const int fr = lane & 15, fg = lane >> 4;
+  const int tile = blockIdx.x >> 2, qi = (blockIdx.x >> 1) & 1, qj = blockIdx.x & 1;
   int m0, n0;
-  tile_origin(t_full + blockIdx.x, tiles_m, tiles_n, m0, n0);
-  f32x4 acc[2][2][4][2];
-  const float* slab = ws + (size_t)blockIdx.x * split * (BM * BN);
+  tile_origin(t_full + tile, tiles_m, tiles_n, m0, n0);
+  m0 += qi * 128;
+  n0 += qj * 128;
+  const float* slab = ws + (size_t)tile * split * (BM * BN);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int g = 0; g < 2; ++g) {
+    const int cl = wn * 32 + g * 16 + fg * 4;
+    const int n = n0 + cl;
+    float bv[4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < 4; ++r) bv[r] = (bias != nullptr && n + r < N) ? bias[n + r] : 0.f;
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+    for (int f = 0; f < 4; ++f) {
+      const int e = (((((qi * 2 + qj) * 4 + f) * 2 + g) * 512) + tid) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
+      for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
+      const int rl = wm * 64 + f * 16 + fr;
+      const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
+      *reinterpret_cast<u32x2*>(smem + rl * QROW + cl * 2) = pk;
+    }
+  }
+  __syncthreads();
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          const int e = ((((i * 2 + j) * 4 + f) * 2 + g) * 512 + tid) * 4;
-          f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
-          for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
-          acc[i][j][f][g] = v;
-        }
-  epilogue256<EPI>(acc, smem, tid, wm, wn, fr, fg, m0, n0, C, bias, gate, res, M, N, ldc, ldres, gate_rows);
+  for (int tt = 0; tt < 4; ++tt) {
+    const int c = tid + 512 * tt;
+    const int rl = c >> 4, cc = c & 15;
+    const int m = m0 + rl, n = n0 + cc * 8;
+    if (m < M && n < N)
+      epi_chunk<EPI>(*reinterpret_cast<const u32x4*>(smem + rl * QROW + cc * 16), m, n, C, gate, res, N, ldc, ldres, gate_rows);
+  }
 }
 
 }  // namespace
@@ -519,7 +542,7 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
     if (!attr_done[E]) {                                                                                              \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_256<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);  \
-      (void)hipFuncSetAttribute((const void*)gemm256_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * CROW);     \
+      (void)hipFuncSetAttribute((const void*)gemm256_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * QROW);     \
       attr_done[E] = true;                                                                                            \
     }                                                                                                                 \
     if (staggered)                                                                                                    \
@@ -531,7 +554,7 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
                          bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n,    \
                          t_full2, split, g_ws);                                                                       \
     if (tail)                                                                                                         \
-      hipLaunchKernelGGL((gemm256_reduce<E>), dim3(tail), block, 128 * CROW, stream, (bf16*)C, bias, gate,            \
+      hipLaunchKernelGGL((gemm256_reduce<E>), dim3(4 * tail), block, 128 * QROW, stream, (bf16*)C, bias, gate,        \
                          (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);      \
   } while (0)
   switch (epilogue) {
