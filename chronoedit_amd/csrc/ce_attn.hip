@@ -936,10 +936,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(const bf16* __restr
 // instruction stream cost the MFMA time alone (5.6 ms; two such waves per SIMD: 10.1 ms = the matrix pipe saturated).
 // The ping-pong kernel above relied on the cross-wave overlap and its s_memtime stamps showed epochs of ~1900 cycles
 // for 1024 cycles of MFMA per SIMD.  Here every wave runs the same program and hides its own VALU:
-//     iteration t:  barrier | store K(t+1), V(t+1) (fetched one iteration ago) | fetch K(t+2), V(t+2)
-//                   | S(t) = K(t).Q^T (16 MFMA) | row max, alpha | O *= alpha(t-1) (rare)
-//                   | 16 MFMA of O += V^T(t-1).P^T(t-1), each followed by 2 v_exp + 2 fma + 2 add of P(t) | pack P(t)
-// LDS: K double-buffered, V^T triple-buffered (V(t-1) is read while V(t+1) is written): one barrier per tile.
+//     iteration t:  vmcnt(4) (this wave's pieces of K(t) have landed), barrier
+//                   | S(t) = K(t).Q^T: 16 MFMA, alternating accumulators, one scheduling region each; in their gaps the
+//                     LDS-DMA of K(t+1), V(t+1) registers -> LDS (transposed 4x4 patches), the fetch of V(t+2)
+//                   | tail mask (last tile), exact offset (first tile only), O *= alpha(t-1) (rare)
+//                   | O += V^T(t-1).P^T(t-1): 16 MFMA, each followed by 2 v_exp + 2 adds of P(t) and one packed bf16
+//                     conversion that replaces a word of P(t-1) in place
+//                   | row-sum check of the speculative softmax; exact route (S(t) again, true max, offset moved) if it fails
+// LDS: K double-buffered (LDS-DMA image, swizzled on the source side), V^T triple-buffered (V(t-1) is read while V(t+1) is
+// written): one barrier per tile.  History and A/B numbers of each step: DESIGN.md section 4.2.
 // ------------------------------------------------------------------------------------------------
 constexpr int K_GRP = 1088;  // LDS-DMA K image: 4 rows (1 KiB) + 64 B pad per group; 16 groups = PK_TILE
 typedef __attribute__((address_space(3))) void lds_void;
