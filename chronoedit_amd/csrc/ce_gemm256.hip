@@ -137,37 +137,66 @@ __device__ __forceinline__ void tile_origin(int wg, int tiles_m, int tiles_n, in
   n0 = tn * BN;
 }
 
-// One 16-byte chunk (8 bf16 of row m starting at column n, already "acc + bias" rounded to bf16): activation / gated residual,
-// then the global store.  Shared by the GEMM kernel's epilogue and the split-K reduce kernel.
-template <int EPI>
-__device__ __forceinline__ void epi_chunk(u32x4 v, int m, int n, bf16* __restrict__ C, const float* __restrict__ gate,
-                                          const bf16* __restrict__ res, int N, int ldc, int ldres, int gate_rows) {
+// The second half of an epilogue pass for NCH 16-byte chunks per thread (8 bf16 of one row each, already "acc + bias" rounded
+// to bf16, staged row-contiguous in LDS): activation or gated residual, then the global store.  The residual and gate loads
+// of ALL the thread's chunks are issued first, unconditionally, on clamped addresses, and only the stores are predicated:
+// written chunk by chunk under `if (m < M && n < N)` hipcc gave every chunk its own exec-mask branch with a load and an
+// `s_waitcnt vmcnt(0)` inside - sixteen serial memory round trips per thread and tile in the gated-residual GEMMs.
+template <int EPI, int NCH, bool HAS_GATE, typename RowCol>
+__device__ __forceinline__ void epi_chunks_impl(const unsigned char* smem, int row_bytes, RowCol rowcol, int m0, int n0,
+                                                bf16* __restrict__ C, const float* __restrict__ gate, const bf16* __restrict__ res,
+                                                int M, int N, int ldc, int ldres, int gate_rows) {
+  u32x4 v[NCH], rv[NCH];
+  f32x4 g0[NCH], g1[NCH];
+  int ms[NCH], ns[NCH];
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    int rl, cc;
+    rowcol(t, rl, cc);
+    ms[t] = m0 + rl;
+    ns[t] = n0 + cc * 8;
+    v[t] = *reinterpret_cast<const u32x4*>(smem + rl * row_bytes + cc * 16);
+    if (EPI == EPI_GATE_RES) {
+      const int mc = min(ms[t], M - 1), nc = min(ns[t], N - 8);
+      rv[t] = *reinterpret_cast<const u32x4*>(res + (size_t)mc * ldres + nc);
+      if (HAS_GATE) {
+        const float* gp = gate + (gate_rows > 0 ? (size_t)(mc / gate_rows) * N : 0) + nc;  // per-sample gate rows
+        g0[t] = *reinterpret_cast<const f32x4*>(gp);
+        g1[t] = *reinterpret_cast<const f32x4*>(gp + 4);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NCH; ++t) {
+    u32x4 o = v[t];
     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_tanh(bf16lo(v[q])), gelu_tanh(bf16hi(v[q])));
+      for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_tanh(bf16lo(o[q])), gelu_tanh(bf16hi(o[q])));
     } else if (EPI == EPI_BIAS_GELU_ERF) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_erf(bf16lo(v[q])), gelu_erf(bf16hi(v[q])));
+      for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_erf(bf16lo(o[q])), gelu_erf(bf16hi(o[q])));
     } else if (EPI == EPI_GATE_RES) {
-      const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
-      float gt[8];
-      if (gate != nullptr) {
-        const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;  // per-sample gate rows
-      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          gt[q] = g0[q];
-          gt[4 + q] = g1[q];
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) gt[q] = 1.0f;
+      for (int q = 0; q < 4; ++q) {
+        const float ga = !HAS_GATE ? 1.0f : q < 2 ? g0[t][2 * q] : g1[t][2 * q - 4];
+        const float gb = !HAS_GATE ? 1.0f : q < 2 ? g0[t][2 * q + 1] : g1[t][2 * q - 3];
+        // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
+        o[q] = pack_bf16(__fadd_rn(bf16lo(rv[t][q]), __fmul_rn(bf16lo(o[q]), ga)), __fadd_rn(bf16hi(rv[t][q]), __fmul_rn(bf16hi(o[q]), gb)));
       }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * gt[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * gt[2 * q + 1]);
     }
-    *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
+    if (ms[t] < M && ns[t] < N) *reinterpret_cast<u32x4*>(C + (size_t)ms[t] * ldc + ns[t]) = o;
+  }
+}
+// (the gate pointer is tested once, around everything: as a per-chunk `gate != nullptr ? loaded : 1` it became a select right
+// behind every load, i.e. a wait per chunk again)
+template <int EPI, int NCH, typename RowCol>
+__device__ __forceinline__ void epi_chunks(const unsigned char* smem, int row_bytes, RowCol rowcol, int m0, int n0,
+                                           bf16* __restrict__ C, const float* __restrict__ gate, const bf16* __restrict__ res,
+                                           int M, int N, int ldc, int ldres, int gate_rows) {
+  if (EPI == EPI_GATE_RES && gate != nullptr)
+    epi_chunks_impl<EPI, NCH, true>(smem, row_bytes, rowcol, m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+  else
+    epi_chunks_impl<EPI, NCH, false>(smem, row_bytes, rowcol, m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
 }
 
 // Epilogue shared by the GEMM kernel and the split-K reduce kernel: the accumulators go through LDS in two passes
@@ -199,15 +228,8 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2][2][4][2], unsi
         }
       }
     __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
-      const int c = tid + 512 * tt;
-      const int rl = c >> 5, cc = c & 31;
-      const int m = m0 + i * 128 + rl, n = n0 + cc * 8;
-      if (m < M && n < N) {
-        epi_chunk<EPI>(*reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16), m, n, C, gate, res, N, ldc, ldres, gate_rows);
-      }
-    }
+    epi_chunks<EPI, 8>(smem, CROW, [&](int tt, int& rl, int& cc) { const int c = tid + 512 * tt; rl = c >> 5; cc = c & 31; },
+                       m0 + i * 128, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
   }
 }
 
@@ -483,14 +505,8 @@ __global__ __launch_bounds__(512) void gemm256_reduce(bf16* __restrict__ C, cons
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt) {
-    const int c = tid + 512 * tt;
-    const int rl = c >> 4, cc = c & 15;
-    const int m = m0 + rl, n = n0 + cc * 8;
-    if (m < M && n < N)
-      epi_chunk<EPI>(*reinterpret_cast<const u32x4*>(smem + rl * QROW + cc * 16), m, n, C, gate, res, N, ldc, ldres, gate_rows);
-  }
+  epi_chunks<EPI, 4>(smem, QROW, [&](int tt, int& rl, int& cc) { const int c = tid + 512 * tt; rl = c >> 4; cc = c & 15; }, m0, n0, C,
+                     gate, res, M, N, ldc, ldres, gate_rows);
 }
 
 }  // namespace
