@@ -10,10 +10,7 @@
 // Operand packing: lane (r = lane & 15, g = lane >> 4) feeds row r with the 32 bytes k = 32 g + [0, 32) of the k-step - the
 // two 16-B chunks 2g and 2g + 1 of the LDS row.  Any packing that is the same for A and W is correct (sum over k).
 #include "ce_common.h"
-
-#define EPI_BIAS 0
-#define EPI_BIAS_GELU 1
-#define EPI_GATE_RES 2
+#include "ce_gemm_epi.h"
 
 namespace {
 
@@ -230,38 +227,8 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const unsigned char* __restr
         }
       }
     __syncthreads();
-#pragma unroll
-    for (int tt = 0; tt < 8; ++tt) {
-      const int c = tid + 512 * tt;
-      const int rl = c >> 5, cc = c & 31;
-      const int m = m0 + i * 128 + rl, n = n0 + cc * 8;
-      if (m < M && n < N) {
-        u32x4 v = *reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16);
-        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = pack_bf16(gelu_tanh(bf16lo(v[q])), gelu_tanh(bf16hi(v[q])));
-        } else if (EPI == EPI_GATE_RES) {
-          const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + n);
-          float gt[8];
-          if (gate != nullptr) {
-            const float* gp = gate + (gate_rows > 0 ? (size_t)(m / gate_rows) * N : 0) + n;
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              gt[q] = g0[q];
-              gt[4 + q] = g1[q];
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) gt[q] = 1.0f;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * gt[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * gt[2 * q + 1]);
-        }
-        *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
-      }
-    }
+    epi_chunks<EPI, 8>(smem, CROW, [&](int tt, int& rl, int& cc) { const int c = tid + 512 * tt; rl = c >> 5; cc = c & 31; },
+                       m0 + i * 128, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
   }
 }
 
