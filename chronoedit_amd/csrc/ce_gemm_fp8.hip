@@ -233,6 +233,9 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const unsigned char* __restr
 }
 
 // one wave per row: amax -> scale -> fp8 (v_cvt_pk_fp8_f32, OCP e4m3 on gfx950, round to nearest even)
+// NCHL > 0: K == 64 * 8 * NCHL, the row sits in registers (one HBM read, all loads issued back to back - a load inside a
+// run-time loop or a per-chunk guard is waited for before the next one is issued); NCHL == 0: any K, two passes over the row.
+template <int NCHL>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restrict__ x, unsigned char* __restrict__ q,
                                                              float* __restrict__ scale, int M, int K, int ldx, int ldq) {
   const int lane = threadIdx.x & 63;
@@ -240,19 +243,29 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restr
   if (row >= M) return;
   const int nch = K >> 3;
   const bf16* xr = x + (size_t)row * ldx;
+  constexpr int NR = NCHL > 0 ? NCHL : 1;
+  u32x4 raw[NR];
   float amax = 0.f;
-  for (int c = lane; c < nch; c += 64) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+  if (NCHL > 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(v[j])), fabsf(bf16hi(v[j]))));
+    for (int i = 0; i < NR; ++i) raw[i] = *reinterpret_cast<const u32x4*>(xr + (lane + 64 * i) * 8);
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(raw[i][j])), fabsf(bf16hi(raw[i][j]))));
+  } else {
+    for (int c = lane; c < nch; c += 64) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(v[j])), fabsf(bf16hi(v[j]))));
+    }
   }
   amax = wave_max(amax);
   const float s = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
   const float inv = 1.0f / s;
   if (lane == 0) scale[row] = s;
   unsigned char* qr = q + (size_t)row * ldq;
-  for (int c = lane; c < nch; c += 64) {  // second read of the row: L2-resident
-    const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+  auto put = [&](int c, u32x4 v) {
     int w0 = 0, w1 = 0;
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[0]) * inv, bf16hi(v[0]) * inv, w0, false);
     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[1]) * inv, bf16hi(v[1]) * inv, w0, true);
@@ -260,6 +273,12 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restr
     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[3]) * inv, bf16hi(v[3]) * inv, w1, true);
     u32x2 o = {(uint32_t)w0, (uint32_t)w1};
     *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+  };
+  if (NCHL > 0) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) put(lane + 64 * i, raw[i]);
+  } else {
+    for (int c = lane; c < nch; c += 64) put(c, *reinterpret_cast<const u32x4*>(xr + c * 8));  // second read: L2-resident
   }
 }
 
@@ -269,7 +288,12 @@ extern "C" int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, in
   if (!x || !q || !scale) return CE_ERR_ARG;
   if (M <= 0 || K <= 0) return CE_ERR_SHAPE;
   if ((K & 7) || (ldx & 7) || (ldq & 7)) return CE_ERR_ALIGN;
-  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (unsigned char*)q, scale, M, K, ldx, ldq);
+#define F8_QUANT(NC) \
+  hipLaunchKernelGGL(quant_rows_fp8_kernel<NC>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (unsigned char*)q, scale, M, K, ldx, ldq)
+  if (K == 64 * 8 * 10) F8_QUANT(10);       // 5120
+  else if (K == 64 * 8 * 27) F8_QUANT(27);  // 13824
+  else F8_QUANT(0);
+#undef F8_QUANT
   return (int)hipGetLastError();
 }
 
