@@ -86,8 +86,8 @@ int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int
 
 /* Loop body behind ce_attention_bf16 / ce_attention_batched_bf16 (returns the previous value; all are tested against the
  * same reference): 0 automatic (= 64); 4 / 8 the plain kernel with 4 / 8 waves per workgroup; 16 first software-pipelined
- * kernel; 32 ping-pong (two wave groups one barrier apart); 64 software-pipelined on the padded LDS images with the
- * pre-scaled Q / lazy running max (default); 128 one wave per SIMD, 64 query rows per wave (single KV segment only; two
+ * kernel; 32 ping-pong (two wave groups one barrier apart); 64 software-pipelined, K by LDS-DMA, pre-scaled Q, speculative
+ * softmax with an exact fall-back route per tile (default); 128 one wave per SIMD, 64 query rows per wave (single KV segment only; two
  * segments fall back to 8).  Host-side tuning knob; the environment variable CE_ATTN_ORDER=0 (read once at load) switches
  * kernel 64 back to the plain workgroup order for A/B measurements. */
 int ce_set_attention_waves(int nwave);
