@@ -128,7 +128,8 @@ def _baseline_config_name(a, T) -> str:
     if (a.width, a.height) == (1280, 720) and T == 8:
         return "BASELINE.json configs[3] shape (temporal reasoning, 8 latent frames)"
     if (a.width, a.height) == (1584, 1056):
-        return "BASELINE.json configs[4] shape, run in bf16 (the fp8 variant is not built)"
+        return ("BASELINE.json configs[4] (fp8 GEMM mode: fp8 weights / activations in the six large Linears, attention in bf16)"
+                if a.fp8 else "BASELINE.json configs[4] shape, run in bf16")
     return "non-BASELINE shape"
 
 
