@@ -201,28 +201,39 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const unsigned char* __restr
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (i == 1) __syncthreads();
+    // row scales of this pass (4 consecutive rows per f: one 16-byte load each, clamped, issued together - per (j, g, f) and
+    // guarded they were 16 serial round trips per pass), then the column scale / bias of each (j, g)
+    f32x4 sav[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int mrow = m0 + i * 128 + wm * 64 + f * 16 + fg * 4;
+      if (mrow + 3 < M) {
+        sav[f] = *reinterpret_cast<const f32x4*>(sa + mrow);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sav[f][r] = sa[min(mrow + r, M - 1)];
+      }
+    }
+    float swv[2][2], bvv[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int nc = min(n0 + j * 128 + wn * 32 + g * 16 + fr, N - 1);
+        swv[j][g] = sw[nc];
+        bvv[j][g] = bias != nullptr ? bias[nc] : 0.f;
+      }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int cl = j * 128 + wn * 32 + g * 16 + fr;
-        const int n = n0 + cl;
-        const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
-        const float swv = n < N ? sw[n] : 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const int mrow = m0 + i * 128 + wm * 64 + f * 16 + fg * 4;  // 4 consecutive rows: one 16-B load of their scales
-          f32x4 sav;
-          if (mrow + 3 < M) {
-            sav = *reinterpret_cast<const f32x4*>(sa + mrow);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sav[r] = sa[min(mrow + r, M - 1)];
-          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int rl = wm * 64 + f * 16 + fg * 4 + r;
-            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] * (sav[r] * swv) + bv);
+            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] * (sav[f][r] * swv[j][g]) + bvv[j][g]);
           }
         }
       }
