@@ -1,0 +1,57 @@
+"""Static checks on the gfx950 code hipcc generates for the hot kernels (no GPU needed; hipcc cross-compiles).  A spill or a
+register count past the occupancy the kernel was designed for does not break parity - it silently costs tens of percent - so
+it is pinned here, together with the "load inside a bounds guard" trap (tools/isa_lint.py)."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "chronoedit_amd", "csrc")
+spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(ROOT, "tools", "isa_lint.py"))
+isa_lint = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(isa_lint)
+
+HIPCC = "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _rows(name):
+    # (kernel, insts, regs, scratch, mfma, serialised loads, s_nop, v_mov)
+    return isa_lint.lint(os.path.join(CSRC, name), 60)
+
+
+def _pick(rows, *needles):
+    hit = [r for r in rows if all(n in r[0] for n in needles)]
+    assert hit, (needles, [r[0] for r in rows])
+    return hit
+
+
+def test_attention_kernels_fit_two_waves_per_simd_without_spills():
+    rows = _rows("ce_attn.hip")
+    for r in _pick(rows, "attn_fwd_sp_kernel"):  # the default loop body, one and two KV segments
+        assert r[3] == 0, f"{r[0]}: {r[3]} bytes of scratch"
+        assert r[2] <= 256, f"{r[0]}: {r[2]} registers (512 threads per workgroup = two waves per SIMD)"
+        assert r[5] == 0, f"{r[0]}: a load is waited for right where it is issued"
+    for r in rows:
+        assert r[3] == 0, f"{r[0]}: scratch"
+
+
+def test_gemm_kernels_have_no_spills_and_a_batched_epilogue():
+    for f in ("ce_gemm256.hip", "ce_gemm_fp8.hip"):
+        rows = _rows(f)
+        for r in rows:
+            assert r[3] == 0, f"{r[0]}: scratch"
+            if "gemm_bf16_256" in r[0] or "gemm_fp8_256" in r[0]:
+                assert r[2] <= 256, (r[0], r[2])
+                # bias / scale loads of the first epilogue half only; the residual / gate loads are batched (ce_gemm_epi.h)
+                assert r[5] <= 8, f"{r[0]}: {r[5]} serialised loads"
+
+
+def test_row_kernels_issue_their_row_loads_back_to_back():
+    rows = _rows("ce_rowops.hip")
+    (rr,) = _pick(rows, "rmsnorm_rope_kernel", "ILb1E")  # FULL variant (D = 5120)
+    assert rr[5] == 0 and rr[3] == 0 and rr[2] <= 168, rr  # three waves per SIMD
+    for r in _pick(rows, "ln_affine_kernel", "ELb1EE"):  # FULL variants (bf16 and fp8 output)
+        assert r[3] == 0 and r[2] <= 168, r
+        assert r[5] <= 20, r  # the (a, b) table reads of the third pass (L2 hits); the ten row loads are not among them
