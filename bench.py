@@ -233,7 +233,11 @@ def main():
         traffic, traffic_src = _pmc_traffic(dom)
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "launches": summ[dom]["n"], "avg_ms": round(summ[dom]["avg_ms"], 4)}
+                    "launches": summ[dom]["n"], "avg_ms": round(summ[dom]["avg_ms"], 4),
+                    # context, not the denominator: what a loop of nothing but MFMAs sustains on this chip when the operands
+                    # toggle (power-limited clock; tools/probes/mfma_rate_probe.hip, profiles/r01_mfma_rate_probe.txt)
+                    "sustained_mfma_only_random_operands": {"32x32x16": 2030.0, "16x16x32": 2160.0, "unit": "TFLOP/s",
+                                                            "source": "profiles/r01_mfma_rate_probe.txt"}}
 
     # ---- secondary figure, outside the timed region: the same step with the step-invariant text / image K/V projections
     # computed once and reused (identical results, 1.4 % fewer flops) - reported beside `value`, never as it
