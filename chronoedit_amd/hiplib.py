@@ -65,7 +65,8 @@ def header_symbols() -> List[str]:
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into lib/libchronoedit_hip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    deps = srcs + [os.path.join(CSRC, "ce_common.h")]
+    import glob
+    deps = srcs + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [HEADER]  # every header a source may include
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH

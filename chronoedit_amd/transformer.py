@@ -449,6 +449,7 @@ class DiTEngine:
         self._ws = {}
         self._ctx_key = None
         self._ctx = None
+        self._ctx_refs = None
 
     def _fuse(self, linears) -> torch.Tensor:
         """cat the [out,in] weights into one buffer and re-point the module parameters at its rows."""
@@ -511,10 +512,13 @@ class DiTEngine:
         """text [B, Tt, text_dim], image [B, Ti, image_dim] -> per-layer cross-attention K/V, samples stacked along rows."""
         key = None
         if self.model.cache_context:
-            key = (text.data_ptr(), text._version, tuple(text.shape),
-                   None if image is None else (image.data_ptr(), image._version, tuple(image.shape)))
+            # The entry keeps the keyed tensors alive (self._ctx_refs): an address can then not be handed out again for another
+            # edit's conditioning while the entry exists, so (data_ptr, _version, shape) identifies the CONTENT, not just a slot.
+            key = (text.data_ptr(), text._version, tuple(text.shape), text.dtype,
+                   None if image is None else (image.data_ptr(), image._version, tuple(image.shape), image.dtype))
             if key == self._ctx_key:
                 return self._ctx
+        keyed = (text, image)
         D = self.D
         B, Tt = text.shape[0], text.shape[1]
         text = text.to(torch.bfloat16).reshape(B * Tt, -1)
@@ -566,8 +570,12 @@ class DiTEngine:
             kv.append((kv_t, kv_i))
         ctx = SimpleNamespace(kv=kv, Tt=Tt, Ti=Ti)
         if key is not None:
-            self._ctx_key, self._ctx = key, ctx
+            self._ctx_key, self._ctx, self._ctx_refs = key, ctx, keyed
         return ctx
+
+    def clear_context_cache(self):
+        """Drop the cached conditioning-side results (called by the pipeline at the start of every edit)."""
+        self._ctx_key = self._ctx = self._ctx_refs = None
 
     # -- the forward (transformer_chronoedit.py:397-476) ---------------------------------
     def forward(self, hidden: torch.Tensor, timestep: torch.Tensor, text: torch.Tensor, image: Optional[torch.Tensor]):

@@ -23,7 +23,9 @@ def test_clip_oracle_matches_transformers_golden(golden_dir):
     assert rel_l2(hs[-2], fx["penultimate_fp32"]) < 1e-6
     hb = C.clip_vision_hidden_states({k: v.to(torch.bfloat16) for k, v in p.items()}, cfg, px)
     assert hb[-2].dtype == torch.bfloat16
-    assert rel_l2(hb[-2], fx["penultimate_bf16"]) < 2e-3  # same op sequence in bf16; bit-equal on this torch build
+    # same op sequence in bf16, but bf16 CPU GEMMs round host-dependently (oneDNN blocking follows the ISA): measured 0 on the
+    # generating host, 2.8e-3 on another Xeon -> stated tolerance 1e-2 (one bf16 ulp is 7.8e-3 of the value)
+    assert rel_l2(hb[-2], fx["penultimate_bf16"]) < 1e-2
 
 
 def test_umt5_oracle_matches_transformers_golden(golden_dir):
