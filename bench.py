@@ -4,26 +4,34 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one iteration of ChronoEditPipeline.__call__'s loop
-(/root/reference/chronoedit_diffusers/pipeline_chronoedit.py:695-756) at BASELINE.json configs[1]:
-ChronoEdit-14B bf16, 1280x720, 5 pixel frames -> latents [1,16,2,90,160] -> N = 7200 tokens,
-guidance 5.0 -> TWO DiT forwards + CFG + flow-UniPC update.  Synthetic (seeded) weights of the real
-architecture and synthetic inputs — there are no checkpoints offline.  Inputs are resident in HBM
-before the timed region; nothing is cached across steps unless --cache-context is given (then the
+(/root/reference/chronoedit_diffusers/pipeline_chronoedit.py:695-756): guidance 5.0 -> TWO DiT forwards + CFG + flow-UniPC
+update.  Synthetic (seeded) weights of the real 14B architecture and synthetic inputs — there are no checkpoints offline.
+Inputs are resident in HBM before the timed region; nothing is cached across steps unless --cache-context is given (then the
 step-invariant text/image K/V are reused, and the JSON says so).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): each rank denoises its own
-edit (independent replicas, no data-path collective; "scaling": "weak").  Timing: barrier +
-synchronize on both sides, MAX over ranks.
+N = 1: BASELINE.json configs[1] — bf16, 1280x720, 5 pixel frames -> latents [1,16,2,90,160] -> 7200 tokens.
+N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): BASELINE.json configs[3] — the temporal-reasoning shape,
+8 latent frames = 28 800 tokens, ONE edit with the token axis sharded over the N GPUs (Ulysses: three all-to-all per self-attention
+over xGMI, chronoedit_amd/parallel.py), "scaling": "strong".  The line also carries, measured in the same run outside the timed
+region: the same workload on ONE GPU (rank 0, so that the strong-scaling speed-up can be read off the line itself) and the
+replica figure (N independent configs[1] edits, weak scaling).  `--parallel replica` makes the replica mode the headline instead;
+`--cfg-parallel` runs the two guidance passes as two (N/2)-way Ulysses groups side by side.
+Timing: barrier + synchronize on both sides, MAX over ranks.
 
 The JSON line carries:
-  roofline      dominant kernel (FFN-up GEMM) algorithmic FLOPs / mean launch duration measured with HIP events
-                on the launch stream in one extra profiled step after the timed region, vs 2.5 PFLOP/s dense bf16;
-  cpu_baseline  the CPU oracle (oracle/dit_oracle.py, "port") timed on this host's cores on ONE transformer block
-                at the same N (rank 0, N=1 only), extrapolated to steps/sec.
+  roofline         the single largest kernel launch shape (the batched self-attention at 7200 tokens), algorithmic FLOPs / mean
+                   launch duration measured with HIP events on the launch stream in one extra profiled step after the timed
+                   region, vs 2.5 PFLOP/s dense bf16; `traffic` from the committed rocprofv3 --pmc passes under profiles/;
+  roofline_family  the same accounting for ALL launches of the 256x256x64 GEMM kernel together (68 % of a step);
+  cpu_baseline     the CPU oracle (oracle/dit_oracle.py, "port") timed on this host's cores on ONE transformer block at the
+                   same token count (rank 0, N=1 only; one warm-up + median of three), extrapolated to steps/sec;
+  sec_per_edit     MEASURED end to end through ChronoEditPipeline for configs[2] (8-step distilled schedule, guidance 1) and,
+                   with --full-edit, configs[1] (50 steps); the composed 50-step figure is labelled as composed.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -41,26 +49,31 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--layers", type=int, default=40, help="(debug only) fewer blocks => result marked invalid")
-    ap.add_argument("--frames", type=int, default=2, help="latent frames: 2 (edit) or 8 (temporal reasoning)")
+    ap.add_argument("--frames", type=int, default=None, help="latent frames: 2 (edit; default on one GPU / replicas) or 8 "
+                                                             "(temporal reasoning; default for the Ulysses mode)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--guidance", type=float, default=5.0)
     ap.add_argument("--cache-context", action="store_true", help="reuse step-invariant text/image K/V across steps")
     ap.add_argument("--sequential-cfg", action="store_true", help="two B=1 forwards per step instead of one batched B=2 forward")
-    ap.add_argument("--parallel", choices=["replica", "ulysses"], default="replica",
-                    help="N>1: independent edits per GPU (weak scaling, default) or ONE edit with the token axis sharded "
-                         "over the GPUs (Ulysses all-to-all over RCCL/xGMI, strong scaling)")
+    ap.add_argument("--parallel", choices=["auto", "replica", "ulysses"], default="auto",
+                    help="N>1: 'ulysses' (default via auto) = ONE edit with the token axis sharded over the GPUs (all-to-all over "
+                         "RCCL/xGMI, strong scaling); 'replica' = independent edits per GPU (weak scaling)")
+    ap.add_argument("--cfg-parallel", action="store_true", help="Ulysses mode: the cond / uncond passes on two (N/2)-way groups")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
+    ap.add_argument("--no-edit", action="store_true", help="skip the measured 8-step end-to-end edit")
+    ap.add_argument("--full-edit", action="store_true", help="also MEASURE the 50-step configs[1] edit end to end (~20 s)")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the secondary fp8-GEMM-mode timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the single-GPU / replica legs beside the Ulysses line")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE.json configs[4] arithmetic: the six large Linears of every block in fp8 e4m3 (MX matrix instruction); "
                          "reported with dtype fp8, never the headline bf16 number")
     ap.add_argument("--attn-kernel", type=int, default=0,
-                    help="(tuning) self-attention kernel knob of ce_set_attention_waves: 0 auto, 32 ping-pong, 64 sw-pipelined, 128 w4")
+                    help="(tuning) self-attention kernel knob of ce_set_attention_waves: 0 auto, 8 plain, 64 sw-pipelined")
     return ap.parse_args()
 
 
@@ -85,7 +98,8 @@ def build_model(layers: int, dev):
 
 
 def cpu_baseline(N: int, steps_fwd: int):
-    """Oracle ("port") on the host cores: one full-width transformer block at N tokens, fp32."""
+    """Oracle ("port") on the host cores: one full-width transformer block at N tokens, fp32; one warm-up run, then the
+    median of three."""
     from oracle import dit_oracle as O
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
@@ -97,28 +111,34 @@ def cpu_baseline(N: int, steps_fwd: int):
     temb6 = torch.randn(1, 6, cfg.inner_dim, generator=g) * 0.1
     T, hp, wp = 2, 45, N // 90
     rot = O.rope_table(cfg, T, 2 * hp, 2 * wp) if T * hp * wp == N else None
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        O.block_forward(p, 0, cfg, x, enc, temb6, rot)
-        dt = time.perf_counter() - t0
+        for i in range(4):
+            t0 = time.perf_counter()
+            O.block_forward(p, 0, cfg, x, enc, temb6, rot)
+            if i:
+                times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     per_step = dt * 40 * steps_fwd
     return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
-            "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, {dt:.2f} s measured; x40 blocks x{steps_fwd} forwards/step"}
+            "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, median of 3 after 1 warm-up = {dt:.2f} s "
+                      f"(runs {', '.join(f'{t:.2f}' for t in times)}); x40 blocks x{steps_fwd} forwards/step"}
 
 
 def _pmc_traffic(kernel_label: str):
     """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
     are collected in their own runs, tools/gpu_pmc.sh; they cannot be read live from inside this process).  None when the
     shape of this run has no committed measurement."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f).get(kernel_label)
-    except (OSError, ValueError):
-        rec = None
-    if not rec:
-        return None, None
-    return rec["fetch_bytes"] + rec["write_bytes"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(kernel_label)
+        except (OSError, ValueError):
+            rec = None
+        if rec:
+            return rec["fetch_bytes"] + rec["write_bytes"], f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+    return None, None
 
 
 def _baseline_config_name(a, T) -> str:
@@ -126,11 +146,28 @@ def _baseline_config_name(a, T) -> str:
     if (a.width, a.height) == (1280, 720) and T == 2:
         return "BASELINE.json configs[1]" if a.guidance > 1 else "BASELINE.json configs[2] (distilled: 1 forward/step)"
     if (a.width, a.height) == (1280, 720) and T == 8:
-        return "BASELINE.json configs[3] shape (temporal reasoning, 8 latent frames)"
+        return "BASELINE.json configs[3] (temporal reasoning, 8 latent frames)"
     if (a.width, a.height) == (1584, 1056):
         return ("BASELINE.json configs[4] (fp8 GEMM mode: fp8 weights / activations in the six large Linears, attention in bf16)"
                 if a.fp8 else "BASELINE.json configs[4] shape, run in bf16")
     return "non-BASELINE shape"
+
+
+class Workload:
+    """Resident inputs of one edit at a given latent shape (seeded)."""
+
+    def __init__(self, dev, T, h, w, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.T, self.h, self.w = T, h, w
+        self.N = T * (h // 2) * (w // 2)
+        self.latents = torch.randn((1, 16, T, h, w), generator=g, device=dev, dtype=torch.float32)
+        self.condition = torch.randn((1, 20, T, h, w), generator=g, device=dev).to(torch.bfloat16)
+        prompt = torch.randn((1, 512, 4096), generator=g, device=dev)
+        prompt[:, 64:] = 0
+        negative = torch.randn((1, 512, 4096), generator=g, device=dev)
+        negative[:, 64:] = 0
+        self.prompt, self.negative = prompt.to(torch.bfloat16), negative.to(torch.bfloat16)
+        self.image = torch.randn((1, 257, 1280), generator=g, device=dev).to(torch.bfloat16)
 
 
 def main():
@@ -138,19 +175,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        dist.init_process_group("nccl")  # == RCCL on ROCm
+        if dist.get_world_size() != world or dist.get_backend() != "nccl":
+            raise RuntimeError(f"RCCL group came up with {dist.get_world_size()} ranks on backend {dist.get_backend()}, expected {world} on nccl")
+        if a.gpus != world:
+            raise RuntimeError(f"--gpus {a.gpus} but the launcher started {world} ranks")
+    elif a.gpus != 1:
+        raise RuntimeError(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` (one rank per GPU)")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
 
     from chronoedit_amd import ops
+    from chronoedit_amd.flops import dit_flops_per_forward
     from chronoedit_amd.pipeline import GraphedDenoiser, denoise_step, make_cfg_inputs
     from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
-    from chronoedit_amd.flops import dit_flops_per_forward
 
     ops.lib()  # fail loudly if the HIP library is missing
     if a.attn_kernel:
@@ -159,74 +203,89 @@ def main():
     model.cache_context = a.cache_context
     if a.fp8:
         model.enable_fp8_gemms()
-    ulysses = world > 1 and a.parallel == "ulysses"
+    mode = a.parallel
+    if mode == "auto":
+        mode = "ulysses" if world > 1 else "replica"
+    ulysses = world > 1 and mode == "ulysses"
+    if a.cfg_parallel and not (ulysses and world % 2 == 0 and a.guidance > 1):
+        raise RuntimeError("--cfg-parallel needs the Ulysses mode on an even number of GPUs with guidance > 1")
+    T = a.frames if a.frames is not None else (8 if ulysses else 2)
+    h, w = a.height // 8, a.width // 8
     if ulysses:
-        model.enable_sequence_parallel()
-        a.sequential_cfg = True  # the token shard is per sample
-    T, h, w = a.frames, a.height // 8, a.width // 8
-    N = T * (h // 2) * (w // 2)
-    g = torch.Generator(device=dev).manual_seed(42 + (0 if ulysses else rank))  # Ulysses: replicated inputs
-    latents = torch.randn((1, 16, T, h, w), generator=g, device=dev, dtype=torch.float32)
-    condition = torch.randn((1, 20, T, h, w), generator=g, device=dev).to(torch.bfloat16)
-    prompt = torch.randn((1, 512, 4096), generator=g, device=dev)
-    prompt[:, 64:] = 0
-    negative = torch.randn((1, 512, 4096), generator=g, device=dev)
-    negative[:, 64:] = 0
-    prompt, negative = prompt.to(torch.bfloat16), negative.to(torch.bfloat16)
-    image = torch.randn((1, 257, 1280), generator=g, device=dev).to(torch.bfloat16)
-    sched = FlowUniPCMultistepScheduler(flow_shift=5.0)
-    total = a.warmup + a.steps + (0 if a.no_profile else 1)
-    sched.set_timesteps(max(50, total), device=dev)
+        if a.cfg_parallel:
+            model.enable_cfg_parallel()
+        else:
+            model.enable_sequence_parallel()
+    wl = Workload(dev, T, h, w, 42 + (0 if ulysses else rank))  # Ulysses: replicated inputs
+    N = wl.N
     fwd_per_step = 2 if a.guidance > 1.0 else 1
 
-    cfg_inputs = make_cfg_inputs(prompt, negative, image)  # resident before the timed region, like every other input
+    def make_stepper(wl_, sched_, graph=False, sequential=False):
+        cfg_inputs = make_cfg_inputs(wl_.prompt, wl_.negative, wl_.image)  # resident before the timed region, like every input
+        if graph:
+            sched_._step_index = 0
+            gd = GraphedDenoiser(model, sched_, wl_.latents, wl_.condition, wl_.prompt, wl_.negative, wl_.image, a.guidance,
+                                 batch_cfg=not sequential)
+            return lambda i: gd.step(i)
+        return lambda i: denoise_step(model, sched_, wl_.latents, wl_.condition, sched_.timesteps[i], wl_.prompt, wl_.negative,
+                                      wl_.image, a.guidance, batch_cfg=not sequential, cfg_inputs=cfg_inputs)
 
-    def one_step(i):
-        denoise_step(model, sched, latents, condition, sched.timesteps[i], prompt, negative, image, a.guidance,
-                     batch_cfg=not a.sequential_cfg, cfg_inputs=cfg_inputs)
-
-    graphed = None
-    if a.graph:
-        sched._step_index = 0
-        graphed = GraphedDenoiser(model, sched, latents, condition, prompt, negative, image, a.guidance, batch_cfg=not a.sequential_cfg)
-        eager_step = one_step
-
-        def one_step(i):  # noqa: F811
-            graphed.step(i)
+    def new_sched(n):
+        s = FlowUniPCMultistepScheduler(flow_shift=5.0)
+        s.set_timesteps(max(50, n), device=dev)
+        return s
 
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        one_step(i)
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        one_step(a.warmup + i)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    finite = bool(torch.isfinite(latents).all().item())
+    def timed(step_fn, warm, steps, first=0):
+        for i in range(warm):
+            step_fn(first + i)
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_fn(first + warm + i)
+        sync_all()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_
+
+    total = a.warmup + a.steps + (0 if a.no_profile else 1)
+    sched = new_sched(total)
+    one_step = make_stepper(wl, sched, graph=a.graph, sequential=a.sequential_cfg)
+    eager_step = one_step if not a.graph else make_stepper(wl, sched, graph=False, sequential=a.sequential_cfg)
+    if ulysses:
+        model._sp.stats.update(all_to_all_calls=0, all_to_all_bytes_sent_off_rank=0)
+    dt = timed(one_step, a.warmup, a.steps)
+    finite = bool(torch.isfinite(wl.latents).all().item())
+    rccl = None
+    if ulysses:
+        st = model._sp.stats
+        n_fwd = (a.warmup + a.steps) * (1 if a.cfg_parallel else fwd_per_step)
+        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ulysses_group": model._sp.world,
+                "cfg_parallel_groups": 2 if a.cfg_parallel else 1,
+                "all_to_all_per_layer_per_forward": st["all_to_all_calls"] / max(1, n_fwd * a.layers),
+                "bytes_sent_off_rank_per_layer_per_forward": st["all_to_all_bytes_sent_off_rank"] // max(1, n_fwd * a.layers),
+                "exchange": "k|v all-to-all overlapped with the q projection; q; attention output (K-segmented operand of the out-projection)"}
 
     # ---- per-kernel HIP-event profile of ONE more step (outside the timed region) -> roofline of the dominant kernel
-    roofline = None
-    breakdown = None
+    roofline = roofline_family = breakdown = None
     if not a.no_profile and ulysses and rank != 0:
-        (eager_step if a.graph else one_step)(a.warmup + a.steps)  # the step has collectives: every rank must take part
+        eager_step(a.warmup + a.steps)  # the step has collectives: every rank must take part
     if not a.no_profile and rank == 0:
         with ops.profile() as prof:
-            (eager_step if a.graph else one_step)(a.warmup + a.steps)
+            eager_step(a.warmup + a.steps)
         summ = prof.summary()
         tot = sum(d["total_ms"] for d in summ.values())
         breakdown = {k: {"n": d["n"], "avg_ms": round(d["avg_ms"], 4), "share": round(d["total_ms"] / tot, 4),
                          "tflops": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e12, 1) if k.startswith(("gemm", "attention")) else None,
-                         "GBps": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e9, 1) if k.startswith(("ln_", "rmsnorm")) else None}
+                         "GBps": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e9, 1) if k.startswith(("ln_", "rmsnorm", "rope_")) else None}
                      for k, d in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])}
         dom = max((k for k in summ if k.startswith(("gemm", "attention"))), key=lambda k: summ[k]["total_ms"])
         ach = summ[dom]["work"] / (summ[dom]["avg_ms"] * 1e-3) / 1e12
@@ -238,40 +297,126 @@ def main():
                     # toggle (power-limited clock; tools/probes/mfma_rate_probe.hip, profiles/r01_mfma_rate_probe.txt)
                     "sustained_mfma_only_random_operands": {"32x32x16": 2030.0, "16x16x32": 2160.0, "unit": "TFLOP/s",
                                                             "source": "profiles/r01_mfma_rate_probe.txt"}}
+        big = {k: d for k, d in summ.items() if k.startswith("gemm_") and d["work"] >= 2.0 * 256 * 256 * 128 * 64}  # the 256-tile kernel's launches
+        if big:
+            fam_ms = sum(d["total_ms"] for d in big.values())
+            fam_fl = sum(d["work"] * d["n"] for d in big.values())
+            fam = fam_fl / (fam_ms * 1e-3) / 1e12
+            roofline_family = {"kernel": "gemm_bf16_256 (every launch of the 256x256x64 LDS-DMA GEMM in the step, all epilogues)", "bound": "mfma",
+                               "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
+                               "launches": sum(d["n"] for d in big.values()), "total_ms": round(fam_ms, 3), "share_of_step": round(fam_ms / tot, 4)}
 
-    # ---- secondary figure, outside the timed region: the same step with the step-invariant text / image K/V projections
-    # computed once and reused (identical results, 1.4 % fewer flops) - reported beside `value`, never as it
-    cached_rate = None
-    if rank == 0 and not a.cache_context and not a.graph and world == 1:
+    single = dict(cached_rate=None, fp8_rate=None, vae_s=None, enc_s=None, edit8=None, edit50=None)
+    if world == 1 and rank == 0:
+        _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w, single)
+
+    # ---- N > 1, Ulysses headline: the same workload on ONE GPU (rank 0) and the replica (weak-scaling) figure, both outside
+    # the timed region, so the line is self-contained
+    single_same = replica = None
+    if ulysses and not a.no_secondary:
+        sp, cfgp = model._sp, model._cfgp
+        model._sp = model._cfgp = None
+        model.engine()._ws = {}
+        if rank == 0:
+            s1 = new_sched(3)
+            st1 = make_stepper(wl, s1)
+            st1(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st1(1)
+            torch.cuda.synchronize()
+            single_same = round(1.0 / (time.perf_counter() - t0), 4)
+        wl2 = Workload(dev, 2, h, w, 42 + rank)
+        s2 = new_sched(4)
+        dt2 = timed(make_stepper(wl2, s2), 1, 2)
+        replica = {"value": round(2 / dt2 * world, 4), "unit": "denoising-steps/sec, aggregate of independent configs[1] edits (one per GPU)",
+                   "scaling": "weak", "ms_per_step": round(dt2 / 2 * 1e3, 2)}
+        model._sp, model._cfgp = sp, cfgp
+        model.engine()._ws = {}
+
+    if rank == 0:
+        vae_s, enc_s = single["vae_s"], single["enc_s"]
+        steps_per_s = a.steps / dt * (1 if ulysses else world)
+        fl = dit_flops_per_forward(N, num_layers=a.layers) * fwd_per_step
+        per_gpu = fl * a.steps / dt / 1e12 / (world if ulysses else 1)
+        out = {
+            "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None,
+            "dtype": "fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if a.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
+                                   f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
+                                   + _baseline_config_name(a, T),
+                       "tokens": N, "forwards_per_step": fwd_per_step,
+                       "parallelism": (f"ulysses sp{model._sp.world}" + (" x cfg2" if a.cfg_parallel else "")) if ulysses else f"replica x{world}",
+                       "cfg": ("parallel (two Ulysses groups)" if a.cfg_parallel else "sequential (2 x B=1)") if ulysses
+                              else ("sequential (2 x B=1)" if a.sequential_cfg else "batched (1 x B=2)"),
+                       "context_cache": bool(a.cache_context)},
+            "model_tflops_per_step": round(fl / 1e12, 2),
+            "achieved_tflops_per_gpu": round(per_gpu, 1),
+            "mfma_roofline_frac_whole_step": round(per_gpu / PEAK_BF16_TFLOPS, 4),
+            "finite": finite,
+            "launch": "hipGraph replay" if a.graph else "eager",
+            "rccl": rccl,
+            "single_gpu_same_workload_steps_per_sec": single_same,
+            "strong_scaling_speedup_vs_one_gpu": None if not single_same else round(steps_per_s / single_same, 3),
+            "replica_mode": replica,
+            "steps_per_sec_with_context_kv_cache": single["cached_rate"],
+            "steps_per_sec_fp8_gemm_mode": single["fp8_rate"],
+            "vae": vae_s,
+            "encoders": enc_s,
+            "sec_per_edit": {"configs[2] 8-step distilled schedule, guidance 1 (measured end to end)": single["edit8"],
+                             "configs[1] 50 steps, guidance 5 (measured end to end)": single["edit50"],
+                             "configs[1] 50 steps, composed = 50 x ms_per_step + VAE + encoders": None if vae_s is None else round(
+                                 50 * dt / a.steps + vae_s["encode_s"] + vae_s["decode_s"] + (0.0 if enc_s is None else enc_s["text_s"] + enc_s["image_s"]), 2)},
+            "roofline": roofline,
+            "roofline_family": roofline_family,
+            "kernel_breakdown": breakdown,
+        }
+        if a.layers != 40:
+            out["invalid"] = "reduced depth (debug run)"
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, fwd_per_step)
+            except Exception as e:  # the baseline must never take the bench line down
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w, out):
+    """Secondary figures of the one-GPU run, all outside the timed region."""
+    base_sched = new_sched(12)
+    step = make_stepper(wl, base_sched, sequential=a.sequential_cfg)
+    # the same step with the step-invariant text / image K/V projections computed once and reused (SURVEY K13; identical
+    # results, 1.4 % fewer flops) - reported beside `value`, never as it
+    if not a.cache_context and not a.graph:
         model.cache_context = True
-        base = a.warmup + a.steps + (0 if a.no_profile else 1)
-        one_step(base)  # fills the cache
+        step(0)  # fills the cache
         torch.cuda.synchronize()
         tc = time.perf_counter()
         for i in range(2):
-            one_step(base + 1 + i)
+            step(1 + i)
         torch.cuda.synchronize()
-        cached_rate = round(2 / (time.perf_counter() - tc), 4)
+        out["cached_rate"] = round(2 / (time.perf_counter() - tc), 4)
         model.cache_context = False
-
-    # ---- secondary figure, outside the timed region: the same step in the fp8 GEMM mode (BASELINE.json configs[4] arithmetic,
-    # DESIGN.md section 9) - a different precision, reported beside the bf16 `value`, never as it
-    fp8_rate = None
-    if rank == 0 and not a.fp8 and not a.graph and world == 1 and not a.no_fp8_leg:
+        model.clear_context_cache()
+    # the same step in the fp8 GEMM mode (BASELINE.json configs[4] arithmetic, DESIGN.md section 9) - a different precision,
+    # reported beside the bf16 `value`, never as it
+    if not a.fp8 and not a.graph and not a.no_fp8_leg:
         model.enable_fp8_gemms()
-        base = a.warmup + a.steps + 4
-        one_step(base)  # packs the e4m3 weights
+        step(4)  # packs the e4m3 weights
         torch.cuda.synchronize()
         tc = time.perf_counter()
         for i in range(2):
-            one_step(base + 1 + i)
+            step(5 + i)
         torch.cuda.synchronize()
-        fp8_rate = round(2 / (time.perf_counter() - tc), 4)
+        out["fp8_rate"] = round(2 / (time.perf_counter() - tc), 4)
         model.enable_fp8_gemms(False)
-
-    # ---- VAE encode + decode at the same resolution (once per edit) -> composed sec/edit for the 50-step schedule
-    vae_s = None
-    if not a.no_vae and rank == 0 and world == 1:
+    # VAE encode + decode at the same resolution (once per edit)
+    vae = None
+    if not a.no_vae:
         from chronoedit_amd.vae import AutoencoderKLWan
         vae = AutoencoderKLWan.random_init(dev, seed=4321)
         nf = 4 * (T - 1) + 1
@@ -286,11 +431,10 @@ def main():
         tv = time.perf_counter()
         vae.decode(zl, return_dict=False)
         torch.cuda.synchronize()
-        vae_s = {"encode_s": round(te, 4), "decode_s": round(time.perf_counter() - tv, 4)}
-
-    # ---- conditioning encoders (once per edit): UMT5-XXL on the positive + negative prompt padded to 512 tokens, CLIP ViT-H/14
-    enc_s = None
-    if not a.no_encoders and rank == 0 and world == 1:
+        out["vae_s"] = {"encode_s": round(te, 4), "decode_s": round(time.perf_counter() - tv, 4)}
+    # conditioning encoders (once per edit): UMT5-XXL on the positive + negative prompt padded to 512 tokens, CLIP ViT-H/14
+    te_model = ie_model = None
+    if not a.no_encoders:
         from chronoedit_amd.clip_vision import CLIPVisionModel
         from chronoedit_amd.umt5 import UMT5EncoderModel, t5_prompt_embeds
         torch.manual_seed(0)
@@ -309,48 +453,40 @@ def main():
         tv = time.perf_counter()
         ie = ie_model(pixel_values=px, output_hidden_states=True).hidden_states[-2]
         torch.cuda.synchronize()
-        enc_s = {"text_s": round(tt_, 4), "image_s": round(time.perf_counter() - tv, 4),
-                 "finite": bool(torch.isfinite(pe.float()).all().item() and torch.isfinite(ie.float()).all().item())}
-        del te_model, ie_model
+        out["enc_s"] = {"text_s": round(tt_, 4), "image_s": round(time.perf_counter() - tv, 4),
+                        "finite": bool(torch.isfinite(pe.float()).all().item() and torch.isfinite(ie.float()).all().item())}
+    # MEASURED sec/edit through ChronoEditPipeline: token ids + pixel values + image in, video out
+    if vae is not None and te_model is not None and not a.no_edit and (a.width, a.height, T) == (1280, 720, 2):
+        from chronoedit_amd.pipeline import ChronoEditPipeline
+        from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+        g = torch.Generator(device=dev).manual_seed(43)
+        image = torch.rand((1, 3, a.height, a.width), generator=g, device=dev) * 2 - 1
+        ids = torch.randint(2, 256384, (1, 512), generator=g, device=dev)
+        am = torch.zeros((1, 512), dtype=torch.long, device=dev)
+        am[0, :64] = 1
+        nids = torch.randint(2, 256384, (1, 512), generator=g, device=dev)
+        nam = torch.zeros((1, 512), dtype=torch.long, device=dev)
+        nam[0, :20] = 1
+        px = torch.randn((1, 3, 224, 224), generator=g, device=dev)
 
-    if rank == 0:
-        steps_per_s = a.steps / dt * (1 if ulysses else world)
-        fl = dit_flops_per_forward(N, num_layers=a.layers) * fwd_per_step
-        out = {
-            "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None,
-            "dtype": "fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if a.fp8 else "bf16", "data": "synthetic",
-            "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
-                                   f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
-                                   + _baseline_config_name(a, T),
-                       "tokens": N, "forwards_per_step": fwd_per_step, "parallelism": f"ulysses sp{world}" if ulysses else f"replica x{world}",
-                       "cfg": "sequential (2 x B=1)" if a.sequential_cfg else "batched (1 x B=2)",
-                       "context_cache": bool(a.cache_context)},
-            "model_tflops_per_step": round(fl / 1e12, 2),
-            "achieved_tflops_per_gpu": round(fl * a.steps / dt / 1e12 / (world if ulysses else 1), 1),
-            "mfma_roofline_frac_whole_step": round(fl * a.steps / dt / 1e12 / (world if ulysses else 1) / PEAK_BF16_TFLOPS, 4),
-            "finite": finite,
-            "launch": "hipGraph replay" if a.graph else "eager",
-            "steps_per_sec_with_context_kv_cache": cached_rate,
-            "steps_per_sec_fp8_gemm_mode": fp8_rate,
-            "vae": vae_s,
-            "encoders": enc_s,
-            "sec_per_edit_50_steps": None if vae_s is None else round(
-                50 * dt / a.steps + vae_s["encode_s"] + vae_s["decode_s"] + (0.0 if enc_s is None else enc_s["text_s"] + enc_s["image_s"]), 2),
-            "roofline": roofline,
-            "kernel_breakdown": breakdown,
-        }
-        if a.layers != 40:
-            out["invalid"] = "reduced depth (debug run)"
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(N, fwd_per_step)
-            except Exception as e:  # the baseline must never take the bench line down
-                out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+        def edit(steps, guidance, shift):
+            pipe = ChronoEditPipeline(text_encoder=te_model, image_encoder=ie_model, transformer=model, vae=vae,
+                                      scheduler=FlowUniPCMultistepScheduler(flow_shift=shift))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pos, neg = pipe.encode_prompt(input_ids=ids, attention_mask=am, negative_input_ids=nids if guidance > 1 else None,
+                                          negative_attention_mask=nam if guidance > 1 else None)
+            img = pipe.encode_image(px)
+            video = pipe.edit_tensors(image, pos, neg, img, num_frames=5, num_inference_steps=steps, guidance_scale=guidance)
+            torch.cuda.synchronize()
+            return round(time.perf_counter() - t0, 3), bool(torch.isfinite(video.float()).all().item())
+
+        edit(2, 1.0, 2.0)  # warm-up of the B = 1 shapes
+        s8, ok8 = edit(8, 1.0, 2.0)
+        out["edit8"] = {"seconds": s8, "finite": ok8, "includes": "UMT5 (1 prompt) + CLIP + VAE encode + 8 steps x 1 forward + VAE decode"}
+        if a.full_edit:
+            s50, ok50 = edit(50, 5.0, 5.0)
+            out["edit50"] = {"seconds": s50, "finite": ok50, "includes": "UMT5 (2 prompts) + CLIP + VAE encode + 50 steps x 2 forwards + VAE decode"}
 
 
 if __name__ == "__main__":

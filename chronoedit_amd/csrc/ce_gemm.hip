@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
                                                      int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                                      int tiles_m, int tiles_n, int batch0, long long sA0, long long sA1,
-                                                     long long sW0, long long sW1, long long sC0, long long sC1) {
+                                                     long long sW0, long long sW1, long long sC0, long long sC1,
+                                                     int a_seg_tiles, long long a_seg_extra) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];  // [buf][A|W]
   if (gridDim.y > 1) {  // strided batch (two levels, e.g. head within sample): element strides, C in units of its own type
     const int z0 = blockIdx.y % batch0, z1 = blockIdx.y / batch0;
@@ -105,9 +106,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
     const int cur = kt & 1;
     if (kt + 1 < KT) {
       const int koff = (kt + 1) * BK;
+      // segmented A (ce_gemm_aseg_bf16): every a_seg_tiles K-tiles the source jumps a_seg_extra elements further
+      const long long koff_a = koff + (a_seg_tiles > 0 ? ((kt + 1) / a_seg_tiles) * a_seg_extra : 0ll);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff);
+        ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + koff_a);
         rw[i] = *reinterpret_cast<const u32x4*>(w_src[i] + koff);
       }
     }
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
 extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw);
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                 hipStream_t stream);
+                                 int a_seg_k, long long a_seg_stride, hipStream_t stream);
 
 extern "C" void ce_gemm256_set_staggered(int on);
 
@@ -234,10 +237,15 @@ extern "C" int ce_set_gemm_variant(int v) {
   return old;
 }
 
-extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
-                            const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                            hipStream_t stream) {
+// Column k of A lives at A + (k / a_seg_k) * a_seg_stride + m * lda + k % a_seg_k: the layout an all-to-all leaves the
+// attention output in ([source rank][local row][D / W], chronoedit_amd/parallel.py), consumed by the out-projection
+// without a gather pass.  a_seg_k == 0 (or >= K): plain row-major A.
+extern "C" int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, hipStream_t stream) {
   if (!A || !W || !C) return CE_ERR_ARG;
+  if (a_seg_k < 0 || (a_seg_k > 0 && a_seg_k < K && ((a_seg_k % BK) || (K % a_seg_k) || (a_seg_stride & 7)))) return CE_ERR_SHAPE;
+  if (a_seg_k >= K) a_seg_k = 0;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7)) return CE_ERR_SHAPE;
   if ((lda & 7) || (ldw & 7) || (ldc & 7)) return CE_ERR_ALIGN;
   if ((epilogue == EPI_GATE_RES || epilogue == EPI_MUL) && (!res || (ldres & 7))) return CE_ERR_ARG;
@@ -245,14 +253,19 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
   if (epilogue != EPI_F32 && epilogue != EPI_MUL) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant >= 1 || (g_gemm_variant == -1 && big);
-    if (want && ce_gemm256_supported(M, N, K, lda, ldw))
-      return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, stream);
+    if (want && ce_gemm256_supported(M, N, K, lda, ldw) &&
+        (a_seg_k == 0 || ((long long)(K / a_seg_k - 1) * a_seg_stride + (long long)M * lda) * 2 < (1ll << 32)))
+      return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
+                               stream);
   }
+  const int a_seg_tiles = a_seg_k > 0 ? a_seg_k / BK : 0;
+  const long long a_seg_extra = a_seg_k > 0 ? a_seg_stride - a_seg_k : 0;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(256);
 #define CE_LAUNCH(E)                                                                                              \
   hipLaunchKernelGGL(gemm_bf16_128<E>, grid, block, 0, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
-                     (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, 1, 0ll, 0ll, 0ll, 0ll, 0ll, 0ll)
+                     (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, 1, 0ll, 0ll, 0ll, 0ll, 0ll, 0ll, \
+                     a_seg_tiles, a_seg_extra)
   switch (epilogue) {
     case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;
     case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;
@@ -264,6 +277,12 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
   }
 #undef CE_LAUNCH
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                            const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                            hipStream_t stream) {
+  return ce_gemm_aseg_bf16(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, 0, 0, stream);
 }
 
 // batch0 x batch1 independent products with two-level element strides (e.g. head within sample): operand z = (z0, z1) is
@@ -282,7 +301,7 @@ extern "C" int ce_gemm_batched_bf16(const void* A, const void* W, void* C, const
   dim3 grid(tiles_m * tiles_n, batch0 * batch1), block(256);
 #define CE_LAUNCH(E)                                                                                                 \
   hipLaunchKernelGGL(gemm_bf16_128<E>, grid, block, 0, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, nullptr, \
-                     nullptr, M, N, K, lda, ldw, ldc, 0, 0, tiles_m, tiles_n, batch0, sA0, sA1, sW0, sW1, sC0, sC1)
+                     nullptr, M, N, K, lda, ldw, ldc, 0, 0, tiles_m, tiles_n, batch0, sA0, sA1, sW0, sW1, sC0, sC1, 0, 0ll)
   if (epilogue == EPI_BIAS) CE_LAUNCH(EPI_BIAS); else CE_LAUNCH(EPI_F32);
 #undef CE_LAUNCH
   return (int)hipGetLastError();

@@ -55,9 +55,12 @@ struct Stager {
   const char* w_base;
   int wave;              // wave-uniform
   int kt_last;
-#ifdef CE_GEMM_BUFFER_DMA  // experiment: buffer_load ... lds (32-bit per-lane offsets + SRD) instead of global_load_lds
-  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
-#endif
+  // Segmented A (Ulysses receive layout, ce_gemm_aseg_bf16): K-tile t of A starts a_seg_extra bytes further for every
+  // a_seg_tiles tiles passed, i.e. at t*128 + (t / a_seg_tiles) * a_seg_extra; t / a_seg_tiles = (t * a_seg_magic) >> 16
+  // (checked on the host for every tile index of the launch).  a_seg_extra == 0: plain row-major A.
+  int kt0;               // first K-tile of this block (split-K tail pieces start past 0)
+  uint32_t a_seg_magic;
+  uint32_t a_seg_extra;  // bytes
 };
 
 template <int SLOT_ID>
@@ -65,22 +68,14 @@ __device__ __forceinline__ void stage_half(unsigned char* smem, const Stager& s,
   constexpr int half = SLOT_ID & 1;
   constexpr bool isB = (SLOT_ID & 2) != 0;
   const int t = tile < s.kt_last ? tile : s.kt_last;  // clamp: surplus prefetches re-read the last K-tile
-#ifdef CE_GEMM_BUFFER_DMA
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const uint32_t off = isB ? s.w_off[half][r] : s.a_off[half][r];
-    unsigned char* dst = smem + SLOT_ID * SLOT + (r * 8 + s.wave) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? s.w_rsrc : s.a_rsrc, (lds_void*)dst, 16, off, t * (BK * 2), 0, 0);
-  }
-#else
-  const char* base = (isB ? s.w_base : s.a_base) + (size_t)t * (BK * 2);
+  const int ta = s.kt0 + t;  // absolute K-tile
+  const char* base = (isB ? s.w_base : s.a_base + (size_t)(((uint32_t)(ta * s.a_seg_magic) >> 16) * s.a_seg_extra)) + (size_t)ta * (BK * 2);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const uint32_t off = isB ? s.w_off[half][r] : s.a_off[half][r];
     unsigned char* dst = smem + SLOT_ID * SLOT + (r * 8 + s.wave) * 1024;  // wave-uniform; lane l lands at +16 l
     __builtin_amdgcn_global_load_lds((gbl_void*)(base + off), (lds_void*)dst, 16, 0, 0);
   }
-#endif
 }
 
 // fragment reads of one k-step (32 deep): 64 rows of an A half-tile -> 4 fragments, 32 rows of a W half-tile -> 2
@@ -173,7 +168,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
                                                      int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                                      int tiles_m, int tiles_n, int t_full, int split,
-                                                     float* __restrict__ ws) {
+                                                     float* __restrict__ ws, uint32_t a_seg_magic, uint32_t a_seg_extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -197,12 +192,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   tile_origin(wg, tiles_m, tiles_n, m0, n0);
 
   Stager st;
-  st.a_base = reinterpret_cast<const char*>(A) + (size_t)kt0 * (BK * 2);
-  st.w_base = reinterpret_cast<const char*>(W) + (size_t)kt0 * (BK * 2);
-#ifdef CE_GEMM_BUFFER_DMA
-  st.a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.a_base, 0, 0x7fffffff, 0x00020000);
-  st.w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)st.w_base, 0, 0x7fffffff, 0x00020000);
-#endif
+  st.a_base = reinterpret_cast<const char*>(A);
+  st.w_base = reinterpret_cast<const char*>(W);
+  st.kt0 = kt0;
+  st.a_seg_magic = a_seg_magic;
+  st.a_seg_extra = a_seg_extra;
   st.wave = wave;
   st.kt_last = ktn - 1;
 #pragma unroll
@@ -471,9 +465,21 @@ extern "C" int ce_set_gemm_workspace(void* ptr, size_t bytes) {
 
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                 hipStream_t stream) {
+                                 int a_seg_k, long long a_seg_stride, hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n, kt = K / BK;
+  // segmented A: column k of A lives at A + (k / a_seg_k) * a_seg_stride + m * lda + k % a_seg_k (elements)
+  uint32_t a_seg_magic = 0, a_seg_extra = 0;
+  if (a_seg_k > 0 && a_seg_k < K) {
+    if (a_seg_k % BK) return CE_ERR_SHAPE;
+    const int tps = a_seg_k / BK;
+    a_seg_magic = 65536u / (uint32_t)tps + 1u;
+    for (int t = 0; t < kt; ++t)
+      if ((int)(((uint32_t)t * a_seg_magic) >> 16) != t / tps) return CE_ERR_SHAPE;
+    const long long extra = (a_seg_stride - a_seg_k) * 2;  // bytes on top of the contiguous advance
+    if (extra < 0 || extra * (K / a_seg_k) >= (1ll << 32)) return CE_ERR_SHAPE;
+    a_seg_extra = (uint32_t)extra;
+  }
   // split-K only for the tail of the last, partially filled round of workgroups
   int tail = nwg % g_cus, split = 1;
   if (tail > 0 && g_ws != nullptr) {
@@ -498,11 +504,11 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
     if (staggered)                                                                                                    \
       hipLaunchKernelGGL((gemm_bf16_256<E, true>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
                          bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n,    \
-                         t_full2, split, g_ws);                                                                       \
+                         t_full2, split, g_ws, a_seg_magic, a_seg_extra);                                             \
     else                                                                                                              \
       hipLaunchKernelGGL((gemm_bf16_256<E, false>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
                          bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n,    \
-                         t_full2, split, g_ws);                                                                       \
+                         t_full2, split, g_ws, a_seg_magic, a_seg_extra);                                             \
     if (tail)                                                                                                         \
       hipLaunchKernelGGL((gemm256_reduce<E>), dim3(4 * tail), block, 128 * QROW, stream, (bf16*)C, bias, gate,        \
                          (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);      \

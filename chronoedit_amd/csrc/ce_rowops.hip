@@ -167,6 +167,82 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x0
 }
 
 // ------------------------------------------------------------------------------------
+// Ulysses send-side layout transform fused into the RMSNorm(+RoPE) pass (reference design
+// chronoedit_diffsynth/wan_video_new_chronoedit.py:330-355,1448-1453: q/k are normalised across ALL heads and rotated
+// BEFORE the head split, so both are token-local).  For each of `nt` column blocks of x ([M][ldx], block i starts at
+// column col_i and is D wide): RMSNorm * w_i (+ RoPE) when w_i != NULL, a plain copy otherwise (v), written straight into
+// the all-to-all SEND buffer
+//     send[dst rank r][row m][block i][Dl],   Dl = D / W,   column n of block i goes to r = n / Dl, offset n % Dl
+// so that the chunk for rank r is contiguous (what all_to_all_single wants) and no permute().contiguous() pass exists.
+// W == 1 degenerates to a packed [M][nt][D] copy.  Same rounding points as rmsnorm_rope_kernel.
+// ------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ __launch_bounds__(256) void rope_scatter_kernel(const bf16* __restrict__ x, int ldx, bf16* __restrict__ send,
+                                                           int M, int D, int W, int nt, int col0, const float* __restrict__ w0,
+                                                           int col1, const float* __restrict__ w1, int col2,
+                                                           const float* __restrict__ w2, const float* __restrict__ cs,
+                                                           int head_dim, float eps, int rope_rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int ti = blockIdx.y;
+  const int col = ti == 0 ? col0 : ti == 1 ? col1 : col2;
+  const float* __restrict__ w = ti == 0 ? w0 : ti == 1 ? w1 : w2;
+  const int cs_row = rope_rows > 0 ? row % rope_rows : row;
+  const int nch = D >> 3;
+  const int Dl = D / W;
+  const bf16* xr = x + (size_t)row * ldx + col;
+  u32x4 raw[ROW_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (FULL || c < nch) {
+      raw[i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = bf16lo(raw[i][j]), v1 = bf16hi(raw[i][j]);
+        s += v0 * v0 + v1 * v1;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(s) / (float)D + eps);
+  const int half = head_dim >> 1;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (FULL || c < nch) {
+      u32x4 o = raw[i];
+      if (w != nullptr) {
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(w + c * 8), wb = *reinterpret_cast<const f32x4*>(w + c * 8 + 4);
+        f32x4 cs0, cs1;
+        if (cs != nullptr) {
+          const int pair0 = ((c * 8) % head_dim) >> 1;
+          const float* p = cs + ((size_t)cs_row * half + pair0) * 2;
+          cs0 = *reinterpret_cast<const f32x4*>(p);
+          cs1 = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float ww0 = j < 2 ? wa[2 * j] : wb[2 * j - 4], ww1 = j < 2 ? wa[2 * j + 1] : wb[2 * j - 3];
+          float v0 = round_bf16(round_bf16(bf16lo(raw[i][j]) * rstd) * ww0);
+          float v1 = round_bf16(round_bf16(bf16hi(raw[i][j]) * rstd) * ww1);
+          if (cs != nullptr) {
+            const float co = j < 2 ? cs0[2 * j] : cs1[2 * j - 4], si = j < 2 ? cs0[2 * j + 1] : cs1[2 * j - 3];
+            const float r0 = v0 * co - v1 * si, r1 = v0 * si + v1 * co;
+            v0 = r0;
+            v1 = r1;
+          }
+          o[j] = pack_bf16(v0, v1);
+        }
+      }
+      const int n = c * 8, r = n / Dl, cc = n - r * Dl;
+      *reinterpret_cast<u32x4*>(send + (((size_t)r * M + row) * nt + ti) * Dl + cc) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // K2: timestep sinusoid + small GEMV chain (one wave per output feature)
 // ------------------------------------------------------------------------------------
 // out[i] = cos(t * f_i) for i < half, sin(t * f_i) otherwise;  f_i = exp(-ln(1e4) * i / half)
@@ -254,15 +330,19 @@ __global__ void modulation_kernel(const float* __restrict__ table, const float* 
 // K1 patchify (im2col of the k=s=(1,2,2) Conv3d) and K18 unpatchify
 // x [C][T][H][W] bf16 -> cols [N = T*(H/2)*(W/2)][Kpad], k = c*4 + dh*2 + dw, zero padded
 // ------------------------------------------------------------------------------------
-__global__ void patchify_kernel(const bf16* __restrict__ x, bf16* __restrict__ cols, int C, int T, int H, int W, int Kpad) {
+// row0 / nrows: only token rows [row0, row0 + nrows) are produced (cols has nrows rows; rows past the last token are zero):
+// the local shard of a sequence-parallel rank.
+__global__ void patchify_kernel(const bf16* __restrict__ x, bf16* __restrict__ cols, int C, int T, int H, int W, int Kpad,
+                                int row0, int nrows) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int h2 = H >> 1, w2 = W >> 1;
-  const size_t total = (size_t)T * h2 * w2 * Kpad;
+  const size_t ntok = (size_t)T * h2 * w2;
+  const size_t total = (size_t)nrows * Kpad;
   if (idx >= total) return;
   const int k = idx % Kpad;
-  const size_t tok = idx / Kpad;
+  const size_t tok = idx / Kpad + row0;
   bf16 v = (bf16)0.f;
-  if (k < C * 4) {
+  if (k < C * 4 && tok < ntok) {
     const int c = k >> 2, dh = (k >> 1) & 1, dw = k & 1;
     const int wq = tok % w2, hq = (tok / w2) % h2, t = tok / ((size_t)w2 * h2);
     v = x[(((size_t)c * T + t) * H + (hq * 2 + dh)) * W + wq * 2 + dw];
@@ -358,11 +438,33 @@ extern "C" int ce_modulation(const float* table, const float* v, float* mod, int
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_patchify_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, hipStream_t stream) {
-  if (!x || !cols || (H & 1) || (W & 1) || Kpad < C * 4) return CE_ERR_ARG;
-  const size_t total = (size_t)T * (H / 2) * (W / 2) * Kpad;
+extern "C" int ce_patchify_rows_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, int row0, int nrows,
+                                     hipStream_t stream) {
+  if (!x || !cols || (H & 1) || (W & 1) || Kpad < C * 4 || row0 < 0 || nrows <= 0) return CE_ERR_ARG;
+  const size_t total = (size_t)nrows * Kpad;
   hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)x, (bf16*)cols,
-                     C, T, H, W, Kpad);
+                     C, T, H, W, Kpad, row0, nrows);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_patchify_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, hipStream_t stream) {
+  if ((H & 1) || (W & 1)) return CE_ERR_ARG;
+  return ce_patchify_rows_bf16(x, cols, C, T, H, W, Kpad, 0, T * (H / 2) * (W / 2), stream);
+}
+
+extern "C" int ce_rope_scatter_bf16(const void* x, int ldx, void* send, int M, int D, int W, int nt, int col0, const float* w0,
+                                    int col1, const float* w1, int col2, const float* w2, const float* cos_sin, int head_dim,
+                                    float eps, int rope_rows, hipStream_t stream) {
+  if (!x || !send || nt < 1 || nt > 3 || W < 1) return CE_ERR_ARG;
+  if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (head_dim & 7) || D % head_dim || D % W ||
+      ((D / W) & 7) || (col0 & 7) || (col1 & 7) || (col2 & 7))
+    return CE_ERR_SHAPE;
+  if (D == 64 * 8 * ROW_MAXC)
+    hipLaunchKernelGGL(rope_scatter_kernel<true>, dim3((M + 3) / 4, nt), dim3(256), 0, stream, (const bf16*)x, ldx, (bf16*)send, M,
+                       D, W, nt, col0, w0, col1, w1, col2, w2, cos_sin, head_dim, eps, rope_rows);
+  else
+    hipLaunchKernelGGL(rope_scatter_kernel<false>, dim3((M + 3) / 4, nt), dim3(256), 0, stream, (const bf16*)x, ldx, (bf16*)send, M,
+                       D, W, nt, col0, w0, col1, w1, col2, w2, cos_sin, head_dim, eps, rope_rows);
   return (int)hipGetLastError();
 }
 

@@ -39,11 +39,17 @@ __global__ __launch_bounds__(256) void cfg_unipc_kernel(const bf16* __restrict__
     const float m0o = m0[i], m1o = m1[i];
     float xc = xs;
     if (use_corr) xc = a0 * x_last[i] + a1 * m0o + a2 * m1o + a3 * x0;
-    const float xn = p0 * xc + p1 * x0 + p2 * m0o;
+    float xn = p0 * xc + p1 * x0 + p2 * m0o;
+    float x0s = x0;
+    if (flags & 2) {  // reference-precision trajectory: latents and the scheduler history are bf16 tensors in the reference
+      xn = round_bf16(xn);  // (pipeline_chronoedit.py:681 passes torch.bfloat16 to prepare_latents); keep fp32 storage, bf16 values
+      xc = round_bf16(xc);
+      x0s = round_bf16(x0);
+    }
     x[i] = xn;
     x_last[i] = xc;
     m1[i] = m0o;
-    m0[i] = x0;
+    m0[i] = x0s;
     if (x0_out != nullptr) x0_out[i] = x0;
   }
 }

@@ -29,6 +29,9 @@ SIGNATURES: Dict[str, List] = {
     "ce_ln_affine_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "ce_rmsnorm_rope_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_gemm_aseg_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _P],
+    "ce_rope_scatter_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _I, _P],
+    "ce_patchify_rows_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_gemm_variant": [_I],
     "ce_set_gemm_workspace": [_P, ctypes.c_size_t],
     "ce_ln_affine_fp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],

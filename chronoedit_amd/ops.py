@@ -141,9 +141,17 @@ def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tens
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
          epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, gate_rows: int = 0):
-    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias).  gate [N] or, with gate_rows > 0, [M/gate_rows, N] (one per sample)."""
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias).  gate [N] or, with gate_rows > 0, [M/gate_rows, N] (one per sample).
+    a may be a 3-D [S, M, K/S] tensor (contiguous): the K-segmented operand an all-to-all leaves behind (ce_gemm_aseg_bf16)."""
     _dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w")
-    M, K, lda = _rows(a, "a")
+    a_seg_k, a_seg_stride = 0, 0
+    if a.dim() == 3:
+        S, M, Ks = a.shape
+        if a.stride(2) != 1 or a.stride(1) < Ks:
+            raise ValueError(f"gemm: segmented a needs unit inner stride, got {a.stride()}")
+        K, lda, a_seg_k, a_seg_stride = S * Ks, a.stride(1), Ks, a.stride(0)
+    else:
+        M, K, lda = _rows(a, "a")
     N, K2, ldw = _rows(w, "w")
     if K != K2:
         raise ValueError(f"gemm: K mismatch {K} vs {K2}")
@@ -166,9 +174,39 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Op
             assert gate.is_contiguous() and gate.numel() == (N if gate_rows <= 0 else (M + gate_rows - 1) // gate_rows * N)
     ensure_gemm_workspace(a.device)
     st = _prof_begin()
-    _check(lib().ce_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), epilogue, _ptr(gate), _ptr(res), M, N, K, lda, ldw, ldc,
-                              ldres, int(gate_rows), _stream()), "ce_gemm_bf16")
+    _check(lib().ce_gemm_aseg_bf16(_ptr(a), _ptr(w), _ptr(out), _ptr(bias), epilogue, _ptr(gate), _ptr(res), M, N, K, lda, ldw, ldc,
+                                   ldres, int(gate_rows), int(a_seg_k), int(a_seg_stride), _stream()), "ce_gemm_bf16")
     _prof_end(st, f"gemm_{M}x{N}x{K}_epi{epilogue}", 2.0 * M * N * K)
+    return out
+
+
+def rope_scatter(x: torch.Tensor, cols, weights, D: int, world: int, cos_sin: Optional[torch.Tensor], head_dim: int, eps: float,
+                 out: Optional[torch.Tensor] = None):
+    """Ulysses send buffer [world, M, len(cols), D/world] from column blocks `cols` (start columns, each D wide) of x [M, ld]:
+    RMSNorm * weights[i] (+ RoPE with cos_sin) where weights[i] is given, plain copy where it is None (ce_rope_scatter_bf16)."""
+    _dev(x, torch.bfloat16, "x")
+    M, _, ldx = _rows(x, "x")
+    nt = len(cols)
+    assert 1 <= nt <= 3 and len(weights) == nt
+    for w in weights:
+        if w is not None:
+            _dev(w, torch.float32, "w")
+            assert w.is_contiguous() and w.numel() == D
+    rope_rows = 0
+    if cos_sin is not None:
+        _dev(cos_sin, torch.float32, "cos_sin")
+        assert cos_sin.is_contiguous() and cos_sin.shape[1:] == (head_dim // 2, 2) and M % cos_sin.shape[0] == 0
+        rope_rows = cos_sin.shape[0]
+    if out is None:
+        out = torch.empty((world, M, nt, D // world), dtype=torch.bfloat16, device=x.device)
+    _dev(out, torch.bfloat16, "out")
+    assert out.is_contiguous() and out.numel() == M * nt * D
+    c = list(cols) + [0] * (3 - nt)
+    w = list(weights) + [None] * (3 - nt)
+    st = _prof_begin()
+    _check(lib().ce_rope_scatter_bf16(_ptr(x), ldx, _ptr(out), M, D, world, nt, c[0], _ptr(w[0]), c[1], _ptr(w[1]), c[2], _ptr(w[2]),
+                                      _ptr(cos_sin), head_dim, float(eps), rope_rows, _stream()), "ce_rope_scatter_bf16")
+    _prof_end(st, f"rope_scatter_{M}x{D}x{nt}", 4.0 * M * D * nt)
     return out
 
 
@@ -285,15 +323,16 @@ def modulation(table: torch.Tensor, v: torch.Tensor, one_mask: int, out: Optiona
     return out
 
 
-def patchify(x: torch.Tensor, kpad: int, out: Optional[torch.Tensor] = None):
-    """x [C,T,H,W] bf16 -> [T*(H/2)*(W/2), kpad]."""
+def patchify(x: torch.Tensor, kpad: int, out: Optional[torch.Tensor] = None, row0: int = 0, nrows: Optional[int] = None):
+    """x [C,T,H,W] bf16 -> [T*(H/2)*(W/2), kpad]; (row0, nrows): only that range of token rows (zero rows past the last token)."""
     _dev(x, torch.bfloat16, "x")
     assert x.is_contiguous() and x.dim() == 4
     C, T, H, W = x.shape
-    n = T * (H // 2) * (W // 2)
+    n = T * (H // 2) * (W // 2) if nrows is None else int(nrows)
     if out is None:
         out = torch.empty((n, kpad), dtype=torch.bfloat16, device=x.device)
-    _check(lib().ce_patchify_bf16(_ptr(x), _ptr(out), C, T, H, W, kpad, _stream()), "ce_patchify_bf16")
+    assert out.is_contiguous() and out.shape == (n, kpad)
+    _check(lib().ce_patchify_rows_bf16(_ptr(x), _ptr(out), C, T, H, W, kpad, int(row0), n, _stream()), "ce_patchify_rows_bf16")
     return out
 
 
@@ -307,8 +346,10 @@ def unpatchify(y: torch.Tensor, cout: int, T: int, H: int, W: int, out: Optional
 
 
 def cfg_unipc_step(v_cond: torch.Tensor, v_uncond: Optional[torch.Tensor], x: torch.Tensor, x_last: torch.Tensor, m0: torch.Tensor,
-                   m1: torch.Tensor, coef: torch.Tensor, x0_out: Optional[torch.Tensor] = None, round_sigma_v: bool = True):
-    """Fused CFG + flow-UniPC update, in place on (x, x_last, m0, m1).  coef = device float[10]."""
+                   m1: torch.Tensor, coef: torch.Tensor, x0_out: Optional[torch.Tensor] = None, round_sigma_v: bool = True,
+                   bf16_state: bool = False):
+    """Fused CFG + flow-UniPC update, in place on (x, x_last, m0, m1).  coef = device float[10].  bf16_state: the stored
+    latents / history carry bf16 values like the reference's bf16 tensors (fp32 storage)."""
     _dev(v_cond, torch.bfloat16, "v_cond")
     for n, t in (("x", x), ("x_last", x_last), ("m0", m0), ("m1", m1), ("coef", coef)):
         _dev(t, torch.float32, n)
@@ -320,7 +361,7 @@ def cfg_unipc_step(v_cond: torch.Tensor, v_uncond: Optional[torch.Tensor], x: to
     n = x.numel()
     assert v_cond.numel() == n == x_last.numel() == m0.numel() == m1.numel()
     _check(lib().ce_cfg_unipc_step(_ptr(v_cond), _ptr(v_uncond), _ptr(x), _ptr(x_last), _ptr(m0), _ptr(m1), _ptr(x0_out), _ptr(coef),
-                                   _ptr(None), n, int(round_sigma_v), _stream()), "ce_cfg_unipc_step")
+                                   _ptr(None), n, int(round_sigma_v) | (2 if bf16_state else 0), _stream()), "ce_cfg_unipc_step")
     return x
 
 

@@ -1,24 +1,42 @@
-"""Ulysses sequence parallelism for the DiT forward: one exchange step per self-attention.
+"""Ulysses sequence parallelism (+ CFG parallelism) for the DiT forward: one exchange step per self-attention.
 
 Reference design (DiffSynth/xfuser path, not the diffusers path we sit behind):
 chronoedit_diffsynth/wan_video_new_chronoedit.py:330-355 (USP enablement), :1448-1453 (token chunk + zero pad),
-:1495-1498 (final all_gather).  Everything in a block is token-wise except self-attention, so tokens are sharded
-contiguously (N/W per rank, last shard zero-padded), weights replicated, and around the attention kernel q/k/v go
-from [N/W tokens, all 40 heads] to [all N tokens, 40/W heads] with ONE `all_to_all_single` (q, k, v fused in one
-message) and the attention output comes back with a second one.  RMSNorm-across-heads and RoPE are applied BEFORE the
+:1495-1498 (final all_gather); truncation re-shard: chronoedit/_src/models/chronoedit_14b_edit_model.py:168-186.
+Everything in a block is token-wise except self-attention, so tokens are sharded contiguously (N/W per rank, last shard
+zero-padded), weights replicated, and around the attention kernel q/k/v go from [N/W tokens, all 40 heads] to
+[all N tokens, 40/W heads] and the attention output comes back.  RMSNorm-across-heads and RoPE are applied BEFORE the
 exchange (they need all heads of a token / the token's position, both local).
 
-MI355X: xGMI is point-to-point, 7 links per GPU; an all-to-all drives all links at once (each peer gets 1/W of the
-payload) — per layer and GPU at W = 8, N = 28 800: 3 x 36.9 MB out + 36.9 MB back.  `torch.distributed` owns the
-communicator (backend "nccl" == RCCL); with the gloo backend (CPU tests, or two ranks sharing one GPU) tensors are
-staged through host memory.
+MI355X layout (no permute().contiguous() passes anywhere on the path):
+  * send side: `ce_rope_scatter_bf16` writes q | k | v of the local rows straight into the all-to-all SEND layout
+    [dst rank][local row][tensor][D/W] while it normalises / rotates them (the pass that touched q and k anyway);
+  * receive side: the buffer [src rank][row][tensor][D/W] IS [global token][tensor][D/W] (token shards are contiguous and
+    rank-ordered), so the attention kernel reads q / k / v as strided views of it;
+  * the attention output [global token][D/W] is already the send buffer of the second exchange (chunk t = rows of rank t);
+  * its receive buffer [src rank = head group][local row][D/W] is consumed in place by the out-projection GEMM as a
+    K-segmented A operand (`ce_gemm_aseg_bf16`).
+The k|v exchange is issued asynchronously as soon as the k|v projection is done and overlaps the q projection GEMM
+(SURVEY.md section 5.8); `torch.distributed` owns the communicator (backend "nccl" == RCCL over xGMI: an all-to-all drives
+all 7 links of a GPU at once, each peer gets 1/W of the payload).  With the gloo backend (CPU tests, or several ranks sharing
+one GPU in the GPU tests) CUDA tensors are staged through host memory.
+
+CFG parallelism (SURVEY.md section 8e "additional free 2x"): the conditional and unconditional forwards of a guidance step are
+independent, so a world of W ranks can run them as two Ulysses groups of W/2 ranks side by side (`CFGParallel`), then exchange
+the two noise predictions (3.7 MB at N = 28 800) - half the exchange volume per rank and twice the rows per GEMM compared
+with W-way Ulysses over sequential passes.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 class Ulysses:
@@ -28,10 +46,12 @@ class Ulysses:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self._host_staged = dist.get_backend(group) == "gloo"
+        self.backend = dist.get_backend(group)
+        self._host_staged = self.backend == "gloo"
+        self.stats = {"all_to_all_calls": 0, "all_to_all_bytes_sent_off_rank": 0, "all_gather_calls": 0}
 
     # -- token sharding ----------------------------------------------------------------
-    def shard(self, n_tokens: int):
+    def shard(self, n_tokens: int) -> Tuple[int, int, int]:
         """(n_local, start, n_valid): every rank holds n_local = ceil(N / W) rows, rows past N are zero padding."""
         n_local = (n_tokens + self.world - 1) // self.world
         start = self.rank * n_local
@@ -47,39 +67,31 @@ class Ulysses:
         return out
 
     # -- collectives -------------------------------------------------------------------
-    def _a2a(self, x: torch.Tensor) -> torch.Tensor:
+    def all_to_all(self, send: torch.Tensor, recv: Optional[torch.Tensor] = None, async_op: bool = False):
+        """send / recv: contiguous, leading axis = peer rank.  Returns (recv, work); work.wait() orders the current stream
+        behind the exchange (RCCL runs it on the process group's own stream, so kernels launched between the call and
+        the wait overlap it)."""
+        assert send.is_contiguous() and send.shape[0] == self.world
+        if recv is None:
+            recv = torch.empty_like(send)
+        assert recv.is_contiguous() and recv.shape == send.shape
+        self.stats["all_to_all_calls"] += 1
+        self.stats["all_to_all_bytes_sent_off_rank"] += send.numel() * send.element_size() * (self.world - 1) // self.world
         if self.world == 1:
-            return x
-        if self._host_staged and x.is_cuda:
-            xc = x.cpu()
-            yc = torch.empty_like(xc)
-            dist.all_to_all_single(yc, xc, group=self.group)
-            return yc.to(x.device)
-        y = torch.empty_like(x)
-        dist.all_to_all_single(y, x, group=self.group)
-        return y
-
-    def scatter_heads(self, qkv_local: torch.Tensor, heads: int, head_dim: int) -> torch.Tensor:
-        """[n_local, 3*H*hd] (q|k|v, all heads) -> [W*n_local, 3*(H/W)*hd] (q|k|v of this rank's heads, all tokens)."""
-        W = self.world
-        n_local = qkv_local.shape[0]
-        assert heads % W == 0, f"{heads} heads do not divide over {W} ranks"
-        hl = heads // W
-        x = qkv_local.view(n_local, 3, W, hl * head_dim).permute(2, 0, 1, 3).contiguous()  # [W(dst), n_local, 3, hl*hd]
-        y = self._a2a(x)                                                                   # [W(src), n_local, 3, hl*hd]
-        return y.view(W * n_local, 3 * hl * head_dim)
-
-    def gather_heads(self, out_g: torch.Tensor, heads: int, head_dim: int) -> torch.Tensor:
-        """[W*n_local, (H/W)*hd] (this rank's heads, all tokens) -> [n_local, H*hd] (all heads, local tokens)."""
-        W = self.world
-        hl = heads // W
-        n_local = out_g.shape[0] // W
-        x = out_g.view(W, n_local, hl * head_dim).contiguous()  # [W(dst token shard), n_local, hl*hd]
-        y = self._a2a(x)                                        # [W(src head group), n_local, hl*hd]
-        return y.permute(1, 0, 2).reshape(n_local, heads * head_dim).contiguous()
+            recv.copy_(send)
+            return recv, _Done()
+        if self._host_staged and send.is_cuda:
+            sc = send.cpu()
+            rc = torch.empty_like(sc)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            recv.copy_(rc)
+            return recv, _Done()
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        return recv, (work if async_op else _Done())
 
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n_local, C] -> [W*n_local, C] in rank order."""
+        self.stats["all_gather_calls"] += 1
         if self.world == 1:
             return x_local
         x_local = x_local.contiguous()
@@ -91,3 +103,59 @@ class Ulysses:
         out = torch.empty((self.world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
         dist.all_gather_into_tensor(out, x_local, group=self.group)
         return out
+
+    # -- layout contracts (plain-torch statements of what the HIP kernels produce / consume; used by the CPU tests and as
+    #    the fp8-mode fallback, never on the bf16 hot path) --------------------------------------------------------------
+    def send_layout_reference(self, blocks: List[torch.Tensor]) -> torch.Tensor:
+        """What ce_rope_scatter_bf16 writes for already normalised / rotated column blocks [n_local, D] each:
+        [W(dst), n_local, len(blocks), D/W]."""
+        W = self.world
+        n_local, D = blocks[0].shape
+        x = torch.stack([b.reshape(n_local, W, D // W) for b in blocks], dim=2)  # [n_local, W, nt, Dl]
+        return x.permute(1, 0, 2, 3).contiguous()
+
+    @staticmethod
+    def gathered_view(recv: torch.Tensor) -> torch.Tensor:
+        """[W(src), n_local, nt, Dl] -> [W*n_local (global token), nt*Dl] without a copy."""
+        W, n_local, nt, Dl = recv.shape
+        return recv.view(W * n_local, nt * Dl)
+
+    @staticmethod
+    def merge_heads_reference(y: torch.Tensor) -> torch.Tensor:
+        """What the K-segmented GEMM operand means: [W(head group), n_local, Dl] -> [n_local, W*Dl]."""
+        W, n_local, Dl = y.shape
+        return y.permute(1, 0, 2).reshape(n_local, W * Dl)
+
+
+class CFGParallel:
+    """World of W = 2 * S ranks: ranks [0, S) run the conditional forward, ranks [S, W) the unconditional one, each as an
+    S-way Ulysses group; `exchange` hands every rank both predictions.  Every rank must construct this (new_group is collective)."""
+
+    def __init__(self):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised before enabling CFG parallelism")
+        W, r = dist.get_world_size(), dist.get_rank()
+        if W % 2:
+            raise ValueError(f"CFG parallelism needs an even world size, got {W}")
+        S = W // 2
+        self.world, self.rank, self.branch = W, r, r // S  # branch 0 = conditional, 1 = unconditional
+        groups = [dist.new_group(list(range(b * S, (b + 1) * S))) for b in range(2)]
+        self.sp_group = groups[self.branch]
+        self.pairs = [dist.new_group([i, i + S]) for i in range(S)]
+        self.pair_group = self.pairs[r % S]
+        self._host_staged = dist.get_backend() == "gloo"
+
+    def exchange(self, pred: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """pred = this rank's branch prediction (replicated inside its Ulysses group) -> (cond, uncond) on every rank."""
+        x = pred.contiguous()
+        n = x.shape[0]
+        shape = (2 * n,) + tuple(x.shape[1:])  # concatenated along dim 0 (the form every backend accepts)
+        if self._host_staged and x.is_cuda:
+            xc = x.cpu()
+            out = torch.empty(shape, dtype=xc.dtype)
+            dist.all_gather_into_tensor(out, xc, group=self.pair_group)
+            out = out.to(x.device)
+        else:
+            out = torch.empty(shape, dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(out, x, group=self.pair_group)
+        return out[:n], out[n:]

@@ -7,12 +7,35 @@ on the device for the whole trajectory; the CFG combine and the UniPC update are
 """
 from __future__ import annotations
 
-from typing import Optional
+import html
+import re
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 
 import torch
 
 from .scheduler import FlowUniPCMultistepScheduler
 from .transformer import ChronoEditTransformer3DModel
+
+
+def _is_pil(x) -> bool:
+    try:
+        from PIL import Image
+    except ImportError:  # pragma: no cover
+        return False
+    return isinstance(x, Image.Image)
+
+
+def prompt_clean(text: str) -> str:
+    """pipeline_chronoedit.py:98-112: ftfy.fix_text (when ftfy is installed, as in the reference), double html.unescape,
+    whitespace collapse."""
+    try:
+        import ftfy
+        text = ftfy.fix_text(text)
+    except ImportError:
+        pass
+    text = html.unescape(html.unescape(text)).strip()
+    return re.sub(r"\s+", " ", text).strip()
 
 
 def make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds):
@@ -21,6 +44,11 @@ def make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds):
     text2 = torch.cat([prompt_embeds, negative_prompt_embeds], 0)
     image2 = None if image_embeds is None else torch.cat([image_embeds, image_embeds], 0)
     return text2, image2
+
+
+def _token_sharded(transformer) -> bool:
+    sp = getattr(transformer, "_sp", None)
+    return sp is not None and sp.world > 1
 
 
 @torch.no_grad()
@@ -32,8 +60,15 @@ def denoise_step(transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPC
     latent_model_input = torch.cat([latents.to(torch.bfloat16), condition], dim=1)
     B = latents.shape[0]
     timestep = t.expand(B)
+    batch_cfg = batch_cfg and not _token_sharded(transformer)  # Ulysses shards the tokens of ONE sample per forward
+    cfgp = getattr(transformer, "_cfgp", None)
     if guidance_scale > 1.0 and negative_prompt_embeds is not None:  # do_classifier_free_guidance
-        if batch_cfg:
+        if cfgp is not None:
+            # CFG parallelism: this rank's Ulysses group runs ONE of the two passes, the predictions are exchanged pairwise
+            text = prompt_embeds if cfgp.branch == 0 else negative_prompt_embeds
+            mine = transformer(latent_model_input, timestep, text, image_embeds, return_dict=False)[0]
+            noise_pred, noise_uncond = cfgp.exchange(mine)
+        elif batch_cfg:
             # the conditional and unconditional passes (pipeline_chronoedit.py:715-735) as ONE forward over 2B samples:
             # identical per-sample arithmetic, but every weight streams from HBM once and the GEMM grids fill the chip
             text2, image2 = cfg_inputs if cfg_inputs is not None else make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)
@@ -59,6 +94,8 @@ class GraphedDenoiser:
     def __init__(self, transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
                  guidance_scale: float, batch_cfg: bool = True):
         assert latents.dtype == torch.float32 and latents.is_contiguous()
+        if _token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None:
+            raise NotImplementedError("hipGraph capture of a step with RCCL exchanges is not built: run the sharded loop eagerly")
         self.tr, self.sch, self.latents, self.condition = transformer, scheduler, latents, condition
         self.prompt, self.negative, self.image, self.g, self.batch_cfg = prompt_embeds, negative_prompt_embeds, image_embeds, guidance_scale, batch_cfg
         dev = latents.device
@@ -118,15 +155,25 @@ class GraphedDenoiser:
 @torch.no_grad()
 def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
             num_inference_steps: int, guidance_scale: float = 5.0, enable_temporal_reasoning: bool = False,
-            num_temporal_reasoning_steps: int = 0, use_graph: bool = False):
-    """The whole loop, including the temporal-reasoning truncation 8 -> 2 latent frames (pipeline_chronoedit.py:700-709)."""
+            num_temporal_reasoning_steps: int = 0, use_graph: bool = False, on_step_end=None, interrupted=None):
+    """The whole loop, including the temporal-reasoning truncation 8 -> 2 latent frames (pipeline_chronoedit.py:700-709).
+    on_step_end(i, t, latents) -> replacement latents or None (the reference's callback_on_step_end hook, :741-749);
+    interrupted() -> True skips the remaining steps (`self.interrupt`, :697-698).  With the tokens sharded over ranks
+    (Ulysses) every rank holds the replicated latents and scheduler history, so the truncation is a local slice on every
+    rank (the reference all-gathers and re-shards: chronoedit_14b_edit_model.py:168-186) and the next forward simply shards
+    the shorter sequence."""
     scheduler.set_timesteps(num_inference_steps, device=latents.device)
     latents = latents.to(torch.float32).contiguous()
+    sharded = _token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None
     cfg_inputs = None
-    if guidance_scale > 1.0 and negative_prompt_embeds is not None:
+    if guidance_scale > 1.0 and negative_prompt_embeds is not None and not sharded:
         cfg_inputs = make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)
+    if hasattr(transformer, "clear_context_cache"):
+        transformer.clear_context_cache()  # a new edit: nothing of the previous edit's conditioning may be reused
     graphed = None
     for i, t in enumerate(scheduler.timesteps):
+        if interrupted is not None and interrupted():
+            continue
         if enable_temporal_reasoning and i == num_temporal_reasoning_steps:
             graphed = None  # new latent shape -> new graph
             latents = latents[:, :, [0, -1]].contiguous()
@@ -146,7 +193,12 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
             latents = graphed.step(i)
         else:
             latents = denoise_step(transformer, scheduler, latents, condition, t, prompt_embeds, negative_prompt_embeds,
-                                   image_embeds, guidance_scale, cfg_inputs=cfg_inputs)
+                                   image_embeds, guidance_scale, batch_cfg=not sharded, cfg_inputs=cfg_inputs)
+        if on_step_end is not None:
+            new = on_step_end(i, t, latents)
+            if new is not None and new is not latents:
+                graphed = None  # the graph is tied to the latents' storage
+                latents = new.to(torch.float32).contiguous()
     return latents
 
 
@@ -196,23 +248,109 @@ def decode_latents(vae, latents: torch.Tensor, enable_temporal_reasoning: bool =
     return vae.decode(latents, return_dict=False)[0]
 
 
-class ChronoEditPipeline:
-    """The denoising part of the reference pipeline behind the same call (text / CLIP encoders and guardrails are out of
-    scope: pass `prompt_embeds`, `negative_prompt_embeds`, `image_embeds` as the reference's encoders produce them)."""
+@dataclass
+class WanPipelineOutput:
+    """diffusers.pipelines.wan.pipeline_output.WanPipelineOutput: `.frames` is what callers index
+    (run_inference_diffusers.py:441 `.frames[0]`)."""
+    frames: Any
 
-    def __init__(self, vae, transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPCMultistepScheduler,
-                 text_encoder=None, image_encoder=None):
-        self.vae, self.transformer, self.scheduler = vae, transformer, scheduler
-        self.text_encoder, self.image_encoder = text_encoder, image_encoder  # chronoedit_amd.umt5 / .clip_vision drop-ins
+
+def _randn_tensor(shape, generator, device, dtype):
+    """diffusers.utils.torch_utils.randn_tensor semantics (pipeline_chronoedit.py:418): the noise is drawn on the GENERATOR's
+    device (a CPU generator gives CPU-reproducible noise that is then moved), one generator per sample when a list is given."""
+    device = torch.device(device)
+    gens = generator if isinstance(generator, (list, tuple)) else [generator] * 1
+    if isinstance(generator, (list, tuple)):
+        shape1 = (1,) + tuple(shape[1:])
+        return torch.cat([_randn_tensor(shape1, g, device, dtype) for g in generator], dim=0)
+    g = gens[0]
+    gdev = device if g is None else torch.device(g.device)
+    if gdev.type != device.type:
+        if gdev.type == "cpu":
+            return torch.randn(shape, generator=g, device="cpu", dtype=dtype).to(device)
+        raise ValueError(f"Cannot generate a {device.type} tensor from a generator of type {gdev.type}.")
+    return torch.randn(shape, generator=g, device=device, dtype=dtype)
+
+
+class ChronoEditPipeline:
+    """MI355X drop-in for the reference pipeline of the same name (chronoedit_diffusers/pipeline_chronoedit.py:124-812): the same
+    constructor components, `from_pretrained`, `encode_prompt` / `encode_image`, `check_inputs`, `prepare_latents`, LoRA entry
+    points and `__call__(image=, prompt=, negative_prompt=, height=, width=, num_frames=, num_inference_steps=, guidance_scale=,
+    ..., offload_model=) -> WanPipelineOutput(frames=...)`, so `scripts/run_inference_diffusers.py:428-441` drives it unchanged.
+    Every tensor op behind it runs on the HIP kernels (DiT, UniPC+CFG, VAE, UMT5, CLIP drop-ins); the tokenizer and the CLIP
+    image processor are the reference's host-side transformers objects and are injected (`tokenizer=`, `image_processor=`).
+    Guardrails are out of scope: `text_guardrail_runner` / `video_guardrail_runner` stay None unless the
+    caller installs callables, which are then honoured with the reference's error behaviour (:621-629, :784-799)."""
+
+    model_cpu_offload_seq = "text_encoder->image_encoder->transformer->vae"
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]
+
+    def __init__(self, tokenizer=None, text_encoder=None, image_encoder=None, image_processor=None,
+                 transformer: Optional[ChronoEditTransformer3DModel] = None, vae=None,
+                 scheduler: Optional[FlowUniPCMultistepScheduler] = None, disable_guardrails: bool = True):
+        self.tokenizer, self.text_encoder, self.image_encoder, self.image_processor = tokenizer, text_encoder, image_encoder, image_processor
+        self.vae, self.transformer, self.scheduler = vae, transformer, scheduler  # chronoedit_amd drop-ins
+        tds = getattr(vae, "temperal_downsample", None)
+        self.vae_scale_factor_temporal = 2 ** sum(tds) if tds is not None else 4      # :185
+        self.vae_scale_factor_spatial = 2 ** len(tds) if tds is not None else 8       # :186
+        self.guardrail_enabled = not disable_guardrails
+        self.text_guardrail_runner = None
+        self.video_guardrail_runner = None
+        self.use_graph = False  # replay one hipGraph-captured step per iteration (GraphedDenoiser)
+        self._guidance_scale, self._attention_kwargs, self._current_timestep, self._interrupt, self._num_timesteps = 1.0, None, None, False, 0
+
+    # -- properties of the reference pipeline (:458-478) ---------------------------------------------------------------
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._guidance_scale > 1
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    @property
+    def current_timestep(self):
+        return self._current_timestep
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    @property
+    def attention_kwargs(self):
+        return self._attention_kwargs
+
+    @property
+    def _execution_device(self) -> torch.device:
+        for m in (self.transformer, self.vae, self.text_encoder, self.image_encoder):
+            d = getattr(m, "device", None)
+            if d is not None:
+                return torch.device(d)
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    def to(self, device=None, dtype=None):
+        """`pipe.to(device)` (run_inference_diffusers.py:386): moves every nn.Module component."""
+        for m in (self.text_encoder, self.image_encoder, self.transformer, self.vae):
+            if m is not None and hasattr(m, "to") and device is not None:
+                m.to(device)
+        return self
+
+    def maybe_free_model_hooks(self):
+        return None
 
     @classmethod
     def from_pretrained(cls, path: str, transformer=None, vae=None, text_encoder=None, image_encoder=None, scheduler=None,
-                        torch_dtype: torch.dtype = torch.bfloat16, device="cuda:0", load_encoders: bool = True, **unused):
-        """``ChronoEditPipeline.from_pretrained(model_path, image_encoder=..., transformer=..., vae=..., torch_dtype=bf16)``
-        (run_inference_diffusers.py:357-364): components handed in are used as they are, the others are read from the
-        diffusers directory layout (``transformer/``, ``vae/``, ``text_encoder/``, ``image_encoder/``,
-        ``scheduler/scheduler_config.json``).  The tokenizer and the CLIP image processor are host-side transformers objects and
-        stay with the caller."""
+                        tokenizer=None, image_processor=None, torch_dtype: torch.dtype = torch.bfloat16, device="cuda:0",
+                        load_encoders: bool = True, disable_guardrails: bool = True):
+        """``ChronoEditPipeline.from_pretrained(model_path, image_encoder=..., transformer=..., vae=..., torch_dtype=bf16,
+        disable_guardrails=...)`` (run_inference_diffusers.py:357-364): components handed in are used as they are, the others
+        are read from the diffusers directory layout (``transformer/``, ``vae/``, ``text_encoder/``, ``image_encoder/``,
+        ``scheduler/scheduler_config.json``; ``tokenizer/`` and ``image_processor/`` through transformers when present).
+        The scheduler defaults to the diffusers sigma grid - the class the reference runner installs (:379-382)."""
         import json
         import os
 
@@ -227,6 +365,7 @@ class ChronoEditPipeline:
             if os.path.exists(cfg_file):
                 with open(cfg_file) as f:
                     cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+            cfg.setdefault("sigma_grid", "diffusers")
             scheduler = FlowUniPCMultistepScheduler.from_config(cfg)
         if load_encoders:
             if text_encoder is None and os.path.isdir(os.path.join(path, "text_encoder")):
@@ -235,25 +374,125 @@ class ChronoEditPipeline:
             if image_encoder is None and os.path.isdir(os.path.join(path, "image_encoder")):
                 from .clip_vision import CLIPVisionModel
                 image_encoder = CLIPVisionModel.from_pretrained(path, subfolder="image_encoder", torch_dtype=torch_dtype, device=device)
-        return cls(vae, transformer, scheduler, text_encoder=text_encoder, image_encoder=image_encoder)
+            if tokenizer is None and os.path.isdir(os.path.join(path, "tokenizer")):
+                from transformers import AutoTokenizer
+                tokenizer = AutoTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+            if image_processor is None and os.path.isdir(os.path.join(path, "image_processor")):
+                from transformers import CLIPImageProcessor
+                image_processor = CLIPImageProcessor.from_pretrained(os.path.join(path, "image_processor"))
+        return cls(tokenizer=tokenizer, text_encoder=text_encoder, image_encoder=image_encoder, image_processor=image_processor,
+                   transformer=transformer, vae=vae, scheduler=scheduler, disable_guardrails=disable_guardrails)
 
-    def encode_prompt(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
-                      negative_input_ids: Optional[torch.Tensor] = None, negative_attention_mask: Optional[torch.Tensor] = None):
-        """``encode_prompt`` / ``_get_t5_prompt_embeds`` after the tokenizer (pipeline_chronoedit.py:205-243,258-330): token ids
-        padded to ``max_sequence_length`` and their masks in, ``(prompt_embeds, negative_prompt_embeds)`` out.  Tokenising
-        (``prompt_clean`` + the UMT5 sentencepiece tokenizer) stays the reference's host code."""
+    # -- conditioning (pipeline_chronoedit.py:205-330) -------------------------------------------------------------------
+    def _get_t5_prompt_embeds(self, prompt=None, num_videos_per_prompt: int = 1, max_sequence_length: int = 512, device=None, dtype=None):
+        """:205-243: clean, tokenise to max_length, encode, zero the padding rows, repeat per video."""
+        if self.tokenizer is None or self.text_encoder is None:
+            raise ValueError("`prompt` strings need the pipeline's tokenizer and text_encoder; pass `prompt_embeds` instead")
         from .umt5 import t5_prompt_embeds
-        if self.text_encoder is None:
-            raise ValueError("this pipeline was built without a text_encoder: pass prompt_embeds instead")
-        pos = t5_prompt_embeds(self.text_encoder, input_ids, attention_mask)
-        neg = None if negative_input_ids is None else t5_prompt_embeds(self.text_encoder, negative_input_ids, negative_attention_mask)
-        return pos, neg
+        device = device or self._execution_device
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        prompt = [prompt_clean(u) for u in prompt]
+        batch_size = len(prompt)
+        text_inputs = self.tokenizer(prompt, padding="max_length", max_length=max_sequence_length, truncation=True,
+                                     add_special_tokens=True, return_attention_mask=True, return_tensors="pt")
+        ids, mask = text_inputs.input_ids, text_inputs.attention_mask
+        prompt_embeds = t5_prompt_embeds(self.text_encoder, ids.to(device), mask.to(device))
+        if dtype is not None:
+            prompt_embeds = prompt_embeds.to(dtype)
+        _, seq_len, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_videos_per_prompt, 1)
+        return prompt_embeds.view(batch_size * num_videos_per_prompt, seq_len, -1)
 
-    def encode_image(self, pixel_values: torch.Tensor) -> torch.Tensor:
-        """``encode_image`` after the CLIP image processor (pipeline_chronoedit.py:247-256): penultimate hidden state."""
+    def encode_prompt(self, prompt=None, negative_prompt=None, do_classifier_free_guidance: bool = True, num_videos_per_prompt: int = 1,
+                      prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                      max_sequence_length: int = 226, device=None, dtype=None, *, input_ids: Optional[torch.Tensor] = None,
+                      attention_mask: Optional[torch.Tensor] = None, negative_input_ids: Optional[torch.Tensor] = None,
+                      negative_attention_mask: Optional[torch.Tensor] = None):
+        """:258-330 (strings through the injected tokenizer).  Tokenizer-free form for callers that tokenise themselves:
+        `encode_prompt(input_ids=, attention_mask=, negative_input_ids=, negative_attention_mask=)` (ids padded to max length)."""
+        if input_ids is not None:
+            from .umt5 import t5_prompt_embeds
+            if self.text_encoder is None:
+                raise ValueError("this pipeline was built without a text_encoder: pass prompt_embeds instead")
+            pos = t5_prompt_embeds(self.text_encoder, input_ids, attention_mask)
+            neg = None if negative_input_ids is None else t5_prompt_embeds(self.text_encoder, negative_input_ids, negative_attention_mask)
+            return pos, neg
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        batch_size = len(prompt) if prompt is not None else prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds = self._get_t5_prompt_embeds(prompt, num_videos_per_prompt, max_sequence_length, device, dtype)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt = negative_prompt or ""
+            negative_prompt = batch_size * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            if prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} != {type(prompt)}.")
+            elif batch_size != len(negative_prompt):
+                raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`: {prompt} has "
+                                 f"batch size {batch_size}. Please make sure that passed `negative_prompt` matches the batch size of `prompt`.")
+            negative_prompt_embeds = self._get_t5_prompt_embeds(negative_prompt, num_videos_per_prompt, max_sequence_length, device, dtype)
+        return prompt_embeds, negative_prompt_embeds
+
+    def encode_image(self, image, device=None) -> torch.Tensor:
+        """:247-256: CLIP penultimate hidden state.  `image`: whatever the injected CLIPImageProcessor accepts, or - without a
+        processor - the pixel_values tensor [B,3,224,224] it would have produced."""
         if self.image_encoder is None:
             raise ValueError("this pipeline was built without an image_encoder: pass image_embeds instead")
-        return self.image_encoder(pixel_values=pixel_values, output_hidden_states=True).hidden_states[-2]
+        device = device or self._execution_device
+        if self.image_processor is not None and not (isinstance(image, torch.Tensor) and image.dim() == 4 and image.is_floating_point()
+                                                     and image.shape[1] == 3 and image.min() < 0):
+            pixel_values = self.image_processor(images=image, return_tensors="pt")["pixel_values"]
+        elif isinstance(image, torch.Tensor):
+            pixel_values = image
+        else:
+            raise ValueError("encode_image needs the pipeline's image_processor for non-tensor images")
+        return self.image_encoder(pixel_values=pixel_values.to(device), output_hidden_states=True).hidden_states[-2]
+
+    def check_inputs(self, prompt, negative_prompt, image, height, width, prompt_embeds=None, negative_prompt_embeds=None,
+                     image_embeds=None, callback_on_step_end_tensor_inputs=None):
+        """:332-390, message for message - with ONE rule relaxed: the reference rejects `image` together with `image_embeds`
+        although its own `__call__` needs `image` for `prepare_latents`, which makes `image_embeds` unusable there; here
+        both may be given (the embeds then skip the CLIP encoder)."""
+        if image is None and image_embeds is None:
+            raise ValueError("Provide either `image` or `prompt_embeds`. Cannot leave both `image` and `image_embeds` undefined.")
+        if image is not None and not isinstance(image, torch.Tensor) and not _is_pil(image):
+            raise ValueError(f"`image` has to be of type `torch.Tensor` or `PIL.Image.Image` but is {type(image)}")
+        if height % 16 != 0 or width % 16 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 16 but are {height} and {width}.")
+        if callback_on_step_end_tensor_inputs is not None and not all(k in self._callback_tensor_inputs for k in callback_on_step_end_tensor_inputs):
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found "
+                             f"{[k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]}")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `prompt`: {prompt} and `prompt_embeds`: {prompt_embeds}. Please make sure to only forward one of the two.")
+        elif negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError(f"Cannot forward both `negative_prompt`: {negative_prompt} and `negative_prompt_embeds`: {negative_prompt_embeds}. "
+                             "Please make sure to only forward one of the two.")
+        elif prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+        elif prompt is not None and (not isinstance(prompt, str) and not isinstance(prompt, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        elif negative_prompt is not None and (not isinstance(negative_prompt, str) and not isinstance(negative_prompt, list)):
+            raise ValueError(f"`negative_prompt` has to be of type `str` or `list` but is {type(negative_prompt)}")
+
+    def prepare_latents(self, image: torch.Tensor, batch_size: int, num_channels_latents: int = 16, height: int = 480, width: int = 832,
+                        num_frames: int = 81, dtype: Optional[torch.dtype] = None, device=None, generator=None,
+                        latents: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """:392-456 with the reference's argument list: returns (latents in `dtype`, condition [B,20,T,h,w])."""
+        device = device or self._execution_device
+        T = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        shape = (batch_size, num_channels_latents, T, height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = _randn_tensor(shape, generator, device, dtype or torch.bfloat16)
+        else:
+            latents = latents.to(device=device, dtype=dtype or latents.dtype)
+        if image.shape[-2:] != (height, width):
+            raise ValueError(f"image is {tuple(image.shape[-2:])}, expected ({height}, {width}) after preprocessing")
+        _, condition = prepare_latents(self.vae, image.to(device), num_frames, latents=latents)
+        if condition.shape[0] != batch_size:
+            condition = condition.repeat(batch_size, 1, 1, 1, 1)
+        return latents, condition
 
     # LoRA entry points of the reference runner (run_inference_diffusers.py:370-374); the adapters target the transformer
     def load_lora_weights(self, path_or_state, adapter_name: str = "default"):
@@ -264,11 +503,143 @@ class ChronoEditPipeline:
         self.transformer.fuse_lora(adapter_names=adapter_names, lora_scale=lora_scale)
         return self
 
+    # -- image pre / post processing (diffusers VideoProcessor, pipeline_chronoedit.py:673,801) ---------------------------
+    @staticmethod
+    def preprocess_image(image, height: int, width: int) -> torch.Tensor:
+        """VideoProcessor.preprocess(image, height=, width=): PIL / array / tensor -> [B,3,height,width] in [-1, 1] (fp32, CPU or
+        the tensor's device).  PIL images are resized with Lanczos, arrays / tensors are taken as [0, 1] unless they already
+        carry negative values (diffusers' own rule)."""
+        import numpy as np
+        if _is_pil(image) or (isinstance(image, (list, tuple)) and all(_is_pil(i) for i in image)):
+            from PIL import Image
+            imgs = list(image) if isinstance(image, (list, tuple)) else [image]
+            arr = np.stack([np.asarray(i.convert("RGB").resize((width, height), Image.LANCZOS), dtype=np.float32) / 255.0 for i in imgs])
+            x = torch.from_numpy(arr).permute(0, 3, 1, 2)
+        elif isinstance(image, np.ndarray):
+            x = torch.from_numpy(image.astype(np.float32))
+            x = x[None] if x.dim() == 3 else x
+            x = x.permute(0, 3, 1, 2)
+        elif isinstance(image, torch.Tensor):
+            x = image.float()
+            x = x[None] if x.dim() == 3 else x
+        else:
+            raise ValueError(f"`image` has to be of type `torch.Tensor` or `PIL.Image.Image` but is {type(image)}")
+        if x.shape[-2:] != (height, width):
+            x = torch.nn.functional.interpolate(x, size=(height, width), mode="bilinear", align_corners=False)
+        if x.min() >= 0:
+            x = 2.0 * x - 1.0
+        return x.contiguous()
+
+    @staticmethod
+    def postprocess_video(video: torch.Tensor, output_type: str = "np"):
+        """VideoProcessor.postprocess_video: [B,3,F,H,W] in [-1,1] -> per sample F frames in [0,1]: "np" [B,F,H,W,3] float32,
+        "pt" [B,F,3,H,W], "pil" list of lists of PIL images."""
+        v = (video.float() / 2 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4)  # [B,F,3,H,W]
+        if output_type == "pt":
+            return v
+        arr = v.permute(0, 1, 3, 4, 2).cpu().numpy()
+        if output_type == "np":
+            return arr
+        if output_type == "pil":
+            from PIL import Image
+            return [[Image.fromarray((f * 255).round().astype("uint8")) for f in sample] for sample in arr]
+        raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt', 'pil']")
+
+    # -- the call (pipeline_chronoedit.py:484-812) -----------------------------------------------------------------------
     @torch.no_grad()
-    def __call__(self, image: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor],
-                 image_embeds: Optional[torch.Tensor], num_frames: int = 5, num_inference_steps: int = 50, guidance_scale: float = 5.0,
-                 enable_temporal_reasoning: bool = False, num_temporal_reasoning_steps: int = 0, generator=None,
-                 latents: Optional[torch.Tensor] = None, output_type: str = "pt"):
+    def __call__(self, image=None, prompt: Union[str, List[str], None] = None, negative_prompt: Union[str, List[str], None] = None,
+                 height: int = 480, width: int = 832, num_frames: int = 81, num_inference_steps: int = 50, guidance_scale: float = 5.0,
+                 num_videos_per_prompt: Optional[int] = 1, generator=None, latents: Optional[torch.Tensor] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                 image_embeds: Optional[torch.Tensor] = None, output_type: Optional[str] = "np", return_dict: bool = True,
+                 attention_kwargs: Optional[Dict[str, Any]] = None, callback_on_step_end: Optional[Callable] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], max_sequence_length: int = 512,
+                 enable_temporal_reasoning: bool = False, num_temporal_reasoning_steps: int = 0, offload_model: bool = False):
+        """Same arguments, defaults, checks and return value as the reference's `__call__`.  What differs is underneath: the two
+        guidance passes run as ONE batched forward, CFG + flow-UniPC are one fused launch, the latents stay fp32 on the device
+        (`scheduler.trajectory_dtype = torch.bfloat16` restores the reference's bf16 rounding of latents and history)."""
+        if hasattr(callback_on_step_end, "tensor_inputs"):
+            callback_on_step_end_tensor_inputs = callback_on_step_end.tensor_inputs
+        self.check_inputs(prompt, negative_prompt, image, height, width, prompt_embeds, negative_prompt_embeds, image_embeds,
+                          callback_on_step_end_tensor_inputs)
+        if num_frames % self.vae_scale_factor_temporal != 1:  # :606-611
+            num_frames = num_frames // self.vae_scale_factor_temporal * self.vae_scale_factor_temporal + 1
+        num_frames = max(num_frames, 1)
+        self._guidance_scale, self._attention_kwargs, self._current_timestep, self._interrupt = guidance_scale, attention_kwargs, None, False
+        device = self._execution_device
+        if self.text_guardrail_runner is not None and not self.text_guardrail_runner(prompt):  # :621-629
+            raise Exception(f"Guardrail blocked text2world generation. Prompt: {prompt}")
+
+        if prompt is not None and isinstance(prompt, str):
+            batch_size = 1
+        elif prompt is not None and isinstance(prompt, list):
+            batch_size = len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        prompt_embeds, negative_prompt_embeds = self.encode_prompt(
+            prompt=prompt, negative_prompt=negative_prompt, do_classifier_free_guidance=self.do_classifier_free_guidance,
+            num_videos_per_prompt=num_videos_per_prompt, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
+            max_sequence_length=max_sequence_length, device=device)
+        if offload_model and self.text_encoder is not None:
+            self.text_encoder.cpu()
+        tdtype = self.transformer.dtype
+        prompt_embeds = prompt_embeds.to(device=device, dtype=tdtype)
+        if negative_prompt_embeds is not None:
+            negative_prompt_embeds = negative_prompt_embeds.to(device=device, dtype=tdtype)
+        if image_embeds is None:
+            image_embeds = self.encode_image(image, device)
+        image_embeds = image_embeds.to(device=device, dtype=tdtype)
+        if image_embeds.shape[0] != batch_size:
+            image_embeds = image_embeds.repeat(batch_size, 1, 1)
+        if offload_model and self.image_encoder is not None:
+            self.image_encoder.cpu()
+
+        B = batch_size * num_videos_per_prompt
+        img = self.preprocess_image(image, height, width).to(device=device, dtype=torch.bfloat16)
+        latents, condition = self.prepare_latents(img, B, self.vae.config.z_dim, height, width, num_frames, torch.bfloat16, device,
+                                                  generator, latents)
+        if B > 1:
+            raise NotImplementedError("the engine denoises one edit per call (batch_size * num_videos_per_prompt == 1); loop over prompts")
+
+        def on_step_end(i, t, lat):
+            self._current_timestep = t
+            if callback_on_step_end is None:
+                return None
+            pool = {"latents": lat, "prompt_embeds": prompt_embeds, "negative_prompt_embeds": negative_prompt_embeds}
+            outs = callback_on_step_end(self, i, t, {k: pool[k] for k in callback_on_step_end_tensor_inputs})
+            return outs.pop("latents", lat) if outs else None
+
+        self._num_timesteps = num_inference_steps
+        latents = denoise(self.transformer, self.scheduler, latents, condition, prompt_embeds,
+                          negative_prompt_embeds if self.do_classifier_free_guidance else None, image_embeds, num_inference_steps,
+                          guidance_scale, enable_temporal_reasoning, num_temporal_reasoning_steps, use_graph=self.use_graph,
+                          on_step_end=on_step_end, interrupted=lambda: self._interrupt)
+        if offload_model and self.transformer is not None:
+            self.transformer.cpu()
+            torch.cuda.empty_cache()
+        self._current_timestep = None
+
+        if output_type != "latent":
+            video = decode_latents(self.vae, latents, enable_temporal_reasoning, num_temporal_reasoning_steps)
+            if self.video_guardrail_runner is not None:  # :784-799
+                video = self.video_guardrail_runner(video)
+                if video is None:
+                    raise Exception("Guardrail blocked video2world generation.")
+            video = self.postprocess_video(video, output_type=output_type)
+        else:
+            video = latents
+        self.maybe_free_model_hooks()
+        if not return_dict:
+            return (video,)
+        return WanPipelineOutput(frames=video)
+
+    @torch.no_grad()
+    def edit_tensors(self, image: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: Optional[torch.Tensor],
+                     image_embeds: Optional[torch.Tensor], num_frames: int = 5, num_inference_steps: int = 50, guidance_scale: float = 5.0,
+                     enable_temporal_reasoning: bool = False, num_temporal_reasoning_steps: int = 0, generator=None,
+                     latents: Optional[torch.Tensor] = None, output_type: str = "pt"):
+        """Tensor-level form of the same edit (no pre / post processing): image [1,3,H,W] in [-1,1] -> video [1,3,F,H,W] in
+        [-1,1] ("pt") or the final latents ("latent").  What the parity tests and tools/full_edit.py drive."""
         H, W = image.shape[-2:]
         if H % 16 != 0 or W % 16 != 0:
             raise ValueError(f"`height` and `width` have to be divisible by 16 but are {H} and {W}.")  # pipeline_chronoedit.py:361-362
@@ -276,7 +647,8 @@ class ChronoEditPipeline:
             num_frames = max(num_frames // 4 * 4 + 1, 1)  # :606-611
         latents, condition = prepare_latents(self.vae, image, num_frames, latents, generator)
         latents = denoise(self.transformer, self.scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
-                          num_inference_steps, guidance_scale, enable_temporal_reasoning, num_temporal_reasoning_steps)
+                          num_inference_steps, guidance_scale, enable_temporal_reasoning, num_temporal_reasoning_steps,
+                          use_graph=self.use_graph)
         if output_type == "latent":
             return latents
         return decode_latents(self.vae, latents, enable_temporal_reasoning, num_temporal_reasoning_steps)

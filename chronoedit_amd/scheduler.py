@@ -139,6 +139,10 @@ class FlowUniPCMultistepScheduler:
         self.last_sample: Optional[torch.Tensor] = None
         self._step_index = None
         self._coef_dev = None
+        # torch.float32 (default): latents and history keep full fp32 values for the whole trajectory.  torch.bfloat16: they are
+        # rounded to bf16 values after every step, the rounding points of the reference, whose latents / model_outputs /
+        # last_sample are bf16 tensors (pipeline_chronoedit.py:681,739) - "reference-precision trajectory" mode.
+        self.trajectory_dtype = torch.float32
 
     @classmethod
     def from_config(cls, config, **overrides):
@@ -216,7 +220,8 @@ class FlowUniPCMultistepScheduler:
         if coef is None:
             coef = self._coef_row(i, guidance_scale, sample.device)
         ops.cfg_unipc_step(v_cond.to(torch.bfloat16).contiguous(), None if v_uncond is None else v_uncond.to(torch.bfloat16).contiguous(),
-                           sample, self.last_sample, m0, m1, coef, round_sigma_v=False)
+                           sample, self.last_sample, m0, m1, coef, round_sigma_v=self.trajectory_dtype == torch.bfloat16,
+                           bf16_state=self.trajectory_dtype == torch.bfloat16)
         self._step_index = i + 1
         return sample
 

@@ -190,6 +190,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
         self.gemm_dtype = "bf16"    # "fp8": the six large Linears of every block on the OCP-e4m3 MX matrix path
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
+        self._cfgp = None           # CFG parallelism on top of it (two Ulysses groups), off by default
 
     # -- reference-compatible helpers --------------------------------------------------
     @property
@@ -250,7 +251,27 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self._sp = Ulysses(group)
         if self.config.num_attention_heads % self._sp.world:
             raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
+        if self._engine is not None:
+            self._engine._ws = {}  # workspaces carry the exchange buffers of the group
         return self
+
+    def enable_cfg_parallel(self):
+        """World of W = 2 S ranks: the conditional / unconditional passes of a guidance step run side by side on two S-way
+        Ulysses groups (parallel.CFGParallel); `pipeline.denoise_step` exchanges the two predictions.  Collective: every
+        rank of the world must call it."""
+        from .parallel import CFGParallel, Ulysses
+        self._cfgp = CFGParallel()
+        self._sp = Ulysses(self._cfgp.sp_group)
+        if self.config.num_attention_heads % self._sp.world:
+            raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
+        self._engine = None if self._engine is None else self._engine  # packed weights stay valid; workspaces are per shape
+        if self._engine is not None:
+            self._engine._ws = {}
+        return self
+
+    def clear_context_cache(self):
+        if self._engine is not None:
+            self._engine.clear_context_cache()
 
     def invalidate(self):
         """Call after changing parameters in place (LoRA fuse, load_state_dict): re-packs on next forward."""
@@ -484,6 +505,37 @@ class DiTEngine:
         wq, sw = getattr(p, "q_" + name)
         return ops.gemm_fp8(aq, ws.s8, wq, sw, b, out=out, **kw)
 
+    def _self_attention_ulysses(self, ws, sp, x, a_row, b_row, p, cs, N: int, Nl: int):
+        """Self-attention of ONE sample with the tokens sharded over sp.world ranks (parallel.py has the layout story).
+        The fused q|k|v projection runs as two GEMMs - [k | v] first - so that the k|v exchange (2/3 of the volume) is on
+        the wire while the q projection is still computing; q / k are normalised and rotated by the pass that writes the
+        all-to-all send layout; the attention kernel and the out-projection read the receive buffers in place."""
+        D, H, hd, eps, W = self.D, self.H, self.cfg.attention_head_dim, self.cfg.eps, sp.world
+        Dl = D // W
+        if not self.fp8:
+            ops.ln_affine(x, a_row, b_row, eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
+            lin = lambda lo, hi, out: ops.gemm(ws.h, p.w_qkv[lo:hi], p.b_qkv[lo:hi], out=out)
+        else:
+            aq = ws.a8[:, :D]
+            ops.ln_affine_fp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=Nl, ab_stride=6 * D)
+            wq, sw = p.q_qkv
+            lin = lambda lo, hi, out: ops.gemm_fp8(aq, ws.s8, wq[lo:hi], sw[lo:hi], p.b_qkv[lo:hi], out=out)
+        lin(D, 3 * D, ws.qkv[:, D:])
+        ops.rope_scatter(ws.qkv, (D, 2 * D), (p.nk1, None), D, W, cs, hd, eps, out=ws.send_kv)
+        _, wait_kv = sp.all_to_all(ws.send_kv, ws.recv_kv, async_op=True)
+        lin(0, D, ws.qkv[:, :D])
+        ops.rope_scatter(ws.qkv, (0,), (p.nq1,), D, W, cs, hd, eps, out=ws.send_q)
+        _, wait_q = sp.all_to_all(ws.send_q, ws.recv_q, async_op=True)
+        wait_kv.wait()
+        wait_q.wait()
+        kv = sp.gathered_view(ws.recv_kv)  # [W*Nl = global token, k | v of this rank's heads]
+        ops.attention(sp.gathered_view(ws.recv_q), kv[:N, :Dl], kv[:N, Dl:], H // W, out=ws.att_g)
+        y, _ = sp.all_to_all(ws.att_g.view(W, Nl, Dl), ws.att_seg)  # [head group][local row][Dl]
+        if self.fp8:  # the row quantiser wants plain rows: secondary mode, one gather pass
+            ws.att.copy_(sp.merge_heads_reference(y))
+            return ws.att
+        return y  # K-segmented A operand of the out-projection (ce_gemm_aseg_bf16)
+
     # -- workspaces --------------------------------------------------------------------
     def _workspace(self, N: int):
         ws = self._ws.get(N)
@@ -495,6 +547,12 @@ class DiTEngine:
             if self.fp8:  # activation rows as fp8 + one scale per row
                 ws.a8 = torch.empty((N, max(D, F)), dtype=torch.uint8, device=dev)
                 ws.s8 = torch.empty((N,), dtype=torch.float32, device=dev)
+            sp = self.model._sp
+            if sp is not None and sp.world > 1:  # Ulysses exchange buffers (chronoedit_amd/parallel.py): N = local rows
+                W, Dl = sp.world, D // sp.world
+                ws.send_kv, ws.recv_kv = e(W, N, 2, Dl), e(W, N, 2, Dl)
+                ws.send_q, ws.recv_q = e(W, N, 1, Dl), e(W, N, 1, Dl)
+                ws.att_g, ws.att_seg = e(W * N, Dl), e(W, N, Dl)
             self._ws = {N: ws}  # keep one shape resident
         return ws
 
@@ -615,8 +673,8 @@ class DiTEngine:
         if sp is None:
             for b in range(B):
                 ops.patchify(hidden[b], self.kpatch, out=ws.cols[rows[b]])
-        else:
-            ws.cols.copy_(sp.take_rows(ops.patchify(hidden[0], self.kpatch), N))
+        else:  # only this rank's token rows (zero rows past the last token: wan_video_new_chronoedit.py:1450-1453)
+            ops.patchify(hidden[0], self.kpatch, out=ws.cols, row0=sp.rank * Nl, nrows=Nl)
         ops.gemm(ws.cols, self.w_patch, self.b_patch, out=ws.x)
 
         # K2 per sample: sinusoid -> time_embedder (fp32) -> temb (bf16-rounded) -> silu -> time_proj -> AdaLN tables
@@ -643,18 +701,14 @@ class DiTEngine:
         x = ws.x
         for li, p in enumerate(self.blk):
             # 1. self-attention
-            self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)
-            ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)  # q and k, all samples
             if sp is None:  # all samples in one launch (stacked rows)
+                self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)
+                ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)  # q and k, all samples
                 ops.attention(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :], H, out=ws.att, batch=B)
-            else:  # Ulysses: tokens gathered / heads scattered around the attention kernel
-                Dl = D // sp.world
-                for b in range(B):
-                    qkv = ws.qkv[rows[b]]
-                    g = sp.scatter_heads(qkv, H, hd)  # [W*Nl, 3*Dl]
-                    og = ops.attention(g[:, :Dl], g[:N, Dl : 2 * Dl], g[:N, 2 * Dl :], H // sp.world)
-                    ws.att[rows[b]].copy_(sp.gather_heads(og, H, hd))
-            self._linear(ws, ws.att, p, "o1", x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
+                att = ws.att
+            else:
+                att = self._self_attention_ulysses(ws, sp, x, mod[li, 0, 1], mod[li, 0, 0], p, cs, N, Nl)
+            self._linear(ws, att, p, "o1", x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
                          res=x, gate_rows=grow)
             # 2. cross-attention (text + image segments)
             if p.n2w is not None:

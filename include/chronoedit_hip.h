@@ -59,6 +59,15 @@ int ce_rmsnorm_rope_bf16(void* x, const float* w, void* x2, const float* w2, con
 int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res,
                  int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, hipStream_t stream);
 
+/* ce_gemm_bf16 with a K-SEGMENTED A operand: column k of A lives at A + (k / a_seg_k) * a_seg_stride + m * lda + k % a_seg_k
+ * (elements; a_seg_k % 64 == 0, K % a_seg_k == 0; a_seg_k == 0 is ce_gemm_bf16).  This is the layout the second Ulysses
+ * all-to-all leaves the attention output in - [source rank = head group][local token][D / W] - so the out-projection reads
+ * it in place instead of a gather pass (reference design: chronoedit_diffsynth/wan_video_new_chronoedit.py:330-355; the
+ * reference's xfuser path materialises the gathered tensor). */
+int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res,
+                      int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k,
+                      long long a_seg_stride, hipStream_t stream);
+
 /* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default), 0 force the 128x128
  * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows.  Host-side test/bench knob. */
 int ce_set_gemm_variant(int variant);
@@ -118,6 +127,20 @@ int ce_modulation(const float* table, const float* v, float* mod, int L, int J, 
  * Replaces patch_embedding + flatten/transpose (transformer_chronoedit.py:429-430). */
 int ce_patchify_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, hipStream_t stream);
 
+/* The same for token rows [row0, row0 + nrows) only (cols has nrows rows; rows past the last token are zero): the local
+ * shard of a sequence-parallel rank (zero pad: wan_video_new_chronoedit.py:1450-1453). */
+int ce_patchify_rows_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, int row0, int nrows, hipStream_t stream);
+
+/* Ulysses send side fused into the RMSNorm(+RoPE) pass.  For each of nt (<= 3) column blocks of x [M][ldx] (block i = columns
+ * [col_i, col_i + D)): w_i != NULL -> RMSNorm across the D channels * w_i, then RoPE when cos_sin != NULL (as
+ * ce_rmsnorm_rope_bf16); w_i == NULL -> copy (v).  Output: send[r][m][i][D/W] for destination rank r = n / (D/W), i.e. the
+ * contiguous per-destination chunks all_to_all_single needs (no permute pass).  Replaces the q/k/v head-scatter of the
+ * reference's sequence-parallel attention (wan_video_new_chronoedit.py:330-355 via xfuser) after
+ * transformer_chronoedit.py:62-79. */
+int ce_rope_scatter_bf16(const void* x, int ldx, void* send, int M, int D, int W, int nt, int col0, const float* w0, int col1,
+                         const float* w1, int col2, const float* w2, const float* cos_sin, int head_dim, float eps,
+                         int rope_rows, hipStream_t stream);
+
 /* y [N][ldy] (col = (dh*2+dw)*Cout + c) -> out [Cout][T][H][W].
  * Replaces the reshape/permute/flatten at transformer_chronoedit.py:463-467. */
 int ce_unpatchify_bf16(const void* y, void* out, int Cout, int T, int H, int W, int ldy, hipStream_t stream);
@@ -129,6 +152,8 @@ int ce_unpatchify_bf16(const void* y, void* out, int Cout, int T, int H, int W, 
  *   x   = p0*xc + p1*x0 + p2*m0 ; x_last = xc ; m1 = m0 ; m0 = x0    UniP + history, :365-499,706-751
  * coef = device float[10] {g, sigma, use_corr, a0..a3, p0..p2} precomputed on the host per step.
  * flags bit0: round sigma*v to bf16 (the reference multiplies a 0-dim fp32 sigma into a bf16 tensor).
+ * flags bit1: round the stored x, x_last and m0 to bf16 values (the reference keeps latents and scheduler history as bf16
+ *             tensors, pipeline_chronoedit.py:681,739): the "reference-precision trajectory" mode of the pipeline.
  * Replaces scheduler.step + the CFG line of ChronoEditPipeline.__call__ (pipeline_chronoedit.py:736-739). */
 int ce_cfg_unipc_step(const void* v_cond, const void* v_uncond, float* x, float* x_last, float* m0, float* m1,
                       float* x0_out, const float* coef, const void* reserved, long long n, int flags, hipStream_t stream);

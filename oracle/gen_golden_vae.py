@@ -33,12 +33,18 @@ CASES = {
     # name: (cfg kwargs, frames, H, W)
     "small_5f": (dict(dim=32, z_dim=16), 5, 32, 48),
     "small_9f": (dict(dim=32, z_dim=16), 9, 16, 32),
+    # the real Wan 2.1 widths (dim 96 -> 96 / 192 / 384 / 384 channels): the MFMA and the HBM-bound conv paths, the Cin padding
+    # and the 384-channel mid-block attention at the channel counts the 14B pipeline runs (round-1 VERDICT: toy width only)
+    "full_5f": (dict(dim=96, z_dim=16), 5, 64, 96),
 }
 
 
 def main():
     ns = load_reference_classes()
+    only = sys.argv[1:]
     for name, (kw, T, H, W) in CASES.items():
+        if only and name not in only:
+            continue
         cfg = V.VAEConfig(**kw)
         p = V.make_synthetic_params(cfg)
         m = ns["WanVAE_"](dim=cfg.dim, z_dim=cfg.z_dim, dim_mult=list(cfg.dim_mult), num_res_blocks=cfg.num_res_blocks,

@@ -151,10 +151,11 @@ def test_edit_end_to_end_fp8_mode_vs_fp8_contract_oracle():
                                      added_kv_proj_dim=256, device="cuda:0")
     m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
     m.enable_fp8_gemms()
-    pipe = ChronoEditPipeline(AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16), m, FlowUniPCMultistepScheduler(flow_shift=5.0))
+    pipe = ChronoEditPipeline(vae=AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16), transformer=m,
+                              scheduler=FlowUniPCMultistepScheduler(flow_shift=5.0))
     args = (image.cuda().to(BF), prompt.cuda().to(BF), negative.cuda().to(BF), img_emb.cuda().to(BF))
-    lat = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent")
-    vid = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda())
+    lat = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent")
+    vid = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda())
     print(f"fp8 edit: latents vs fp8-contract oracle {rel_l2(lat, lat8):.3e}, video {rel_l2(vid, vid8):.3e}; "
           f"contract vs exact edit (latents) {rel_l2(lat8, lat_x):.3e}")
     assert rel_l2(lat, lat8) < 8e-2 and rel_l2(vid, vid8) < 1e-1

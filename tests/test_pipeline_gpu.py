@@ -42,10 +42,10 @@ def test_edit_end_to_end_vs_oracle():
                                      added_kv_proj_dim=256, device="cuda:0")
     m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
     vae = AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16)
-    pipe = ChronoEditPipeline(vae, m, FlowUniPCMultistepScheduler(flow_shift=5.0))
+    pipe = ChronoEditPipeline(vae=vae, transformer=m, scheduler=FlowUniPCMultistepScheduler(flow_shift=5.0))
     args = (image.cuda().to(bf), prompt.cuda().to(bf), negative.cuda().to(bf), img_emb.cuda().to(bf))
-    lat = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent")
-    vid = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda())
+    lat = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent")
+    vid = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda())
     e_lat, e_vid = rel_l2(lat, lat_ref), rel_l2(vid, vid_ref)
     print(f"edit: latents rel-L2 {e_lat:.3e}, video rel-L2 {e_vid:.3e}")
     assert vid.shape == (1, 3, F, H, W)
@@ -95,13 +95,13 @@ def test_pipeline_encoders_feed_the_edit():
     am[0, :11] = 1
     nids, nam = torch.randint(2, 300, (1, 64), device="cuda:0"), torch.zeros((1, 64), dtype=torch.long, device="cuda:0")
     nam[0, :5] = 1
-    pos, neg = pipe.encode_prompt(ids, am, nids, nam)
+    pos, neg = pipe.encode_prompt(input_ids=ids, attention_mask=am, negative_input_ids=nids, negative_attention_mask=nam)
     assert pos.shape == neg.shape == (1, 64, 128) and pos.dtype == torch.bfloat16
     assert pos[0, 11:].abs().max().item() == 0 and neg[0, 5:].abs().max().item() == 0 and pos[0, :11].abs().max().item() > 0
     img = pipe.encode_image(torch.randn(1, 3, 56, 56, device="cuda:0"))
     assert img.shape == (1, 17, 320) and torch.isfinite(img.float()).all()
     with pytest.raises(ValueError):
-        ChronoEditPipeline(None, None, None).encode_image(torch.zeros(1, 3, 56, 56, device="cuda:0"))
+        ChronoEditPipeline().encode_image(torch.zeros(1, 3, 56, 56, device="cuda:0"))
 
 
 def test_temporal_reasoning_edit_vs_oracle():
@@ -134,10 +134,10 @@ def test_temporal_reasoning_edit_vs_oracle():
                                      added_kv_proj_dim=256, device="cuda:0")
     m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
     vae = AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16)
-    pipe = ChronoEditPipeline(vae, m, FlowUniPCMultistepScheduler(flow_shift=5.0))
+    pipe = ChronoEditPipeline(vae=vae, transformer=m, scheduler=FlowUniPCMultistepScheduler(flow_shift=5.0))
     args = (image.cuda().to(bf), prompt.cuda().to(bf), negative.cuda().to(bf), img_emb.cuda().to(bf))
-    lat = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent", **kw)
-    vid = pipe(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), **kw)
+    lat = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent", **kw)
+    vid = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), **kw)
     e_lat, e_vid = rel_l2(lat, lat_ref), rel_l2(vid, vid_ref)
     print(f"reasoning edit: latents rel-L2 {e_lat:.3e}, video rel-L2 {e_vid:.3e}")
     assert lat.shape == lat_ref.shape and vid.shape == vid_ref.shape
@@ -147,6 +147,70 @@ def test_temporal_reasoning_edit_vs_oracle():
     with torch.no_grad():
         lat_ref2, vid_ref2 = P.edit(dp32, dcfg, vp, vcfg, image.to(bf).float(), prompt.to(bf).float(), negative.to(bf).float(),
                                     img_emb.to(bf).float(), lat0.clone(), num_frames=F, steps=3, **kw2)
-    vid2 = pipe(*args, num_frames=F, num_inference_steps=3, guidance_scale=5.0, latents=lat0.cuda(), **kw2)
+    vid2 = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=3, guidance_scale=5.0, latents=lat0.cuda(), **kw2)
     print(f"reasoning (no truncation): video rel-L2 {rel_l2(vid2, vid_ref2):.3e}  shape {tuple(vid2.shape)}")
     assert vid2.shape == vid_ref2.shape and rel_l2(vid2, vid_ref2) < 8e-2
+
+
+def _oracle_loop(dp, dcfg, lat0, cond, prompt, negative, img, steps, guidance, dtype):
+    """The reference loop (pipeline_chronoedit.py:694-756) on the CPU oracles, everything in `dtype`: float32 = the exact
+    answer; bfloat16 = the reference's own run mode (bf16 weights, bf16 latents, bf16 scheduler history - :681,:739)."""
+    from oracle.unipc_oracle import UniPCOracle
+    p = {k: v.to(dtype) for k, v in dp.items()}
+    sch = UniPCOracle()
+    sch.set_timesteps(steps, shift=5.0)
+    lat = lat0.to(dtype)
+    c_, pr, ng, im = cond.to(dtype), prompt.to(dtype), negative.to(dtype), img.to(dtype)
+    with torch.no_grad():
+        for t in sch.timesteps:
+            inp = torch.cat([lat, c_], dim=1)
+            ts = t.expand(1)
+            c = D.dit_forward(p, dcfg, inp, ts, pr, im)
+            u = D.dit_forward(p, dcfg, inp, ts, ng, im)
+            c = u + guidance * (c - u)
+            lat = sch.step(c.to(lat.dtype), lat)
+    return lat.float()
+
+
+def test_fifty_step_cfg_trajectory_vs_oracle_and_reference_precision():
+    """a 50-step, guidance-5 trajectory at narrow width vs the fp32 CPU oracle, with the END-of-trajectory
+    error bounded - and the deviation the engine takes from the reference's rounding points quantified: the reference carries
+    bf16 latents / scheduler history through the loop (pipeline_chronoedit.py:681,712,739), the engine fp32.  Four runs:
+      exact     fp32 oracle                                   (the yardstick)
+      ref_bf16  the oracle run entirely in bf16               (what the reference's eager path does; its own error vs exact)
+      hip_fp32  the engine, fp32 latents (default)
+      hip_bf16  the engine, scheduler.trajectory_dtype = bf16 (latents / history rounded to bf16 after every step)
+    Bounds: hip_fp32 vs exact <= 5e-2 and <= the reference's own bf16 error (keeping latents in fp32 must not be WORSE than the
+    reference's rounding); hip_bf16 vs ref_bf16 <= 2 x ref_bf16's own error + 2e-2 (same rounding points, different kernels)."""
+    from chronoedit_amd.pipeline import denoise
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    dcfg = D.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    dp = D.make_synthetic_params(dcfg, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(21)
+    bf = torch.bfloat16
+    lat0 = torch.randn(1, 16, 2, 8, 12, generator=g).to(bf).float()
+    cond = torch.randn(1, 20, 2, 8, 12, generator=g).to(bf).float()
+    prompt = torch.randn(1, 40, 128, generator=g).to(bf).float()
+    negative = torch.randn(1, 40, 128, generator=g).to(bf).float()
+    img = torch.randn(1, 257, 64, generator=g).to(bf).float()
+    steps, guidance = 50, 5.0
+    exact = _oracle_loop(dp, dcfg, lat0, cond, prompt, negative, img, steps, guidance, torch.float32)
+    ref_bf16 = _oracle_loop(dp, dcfg, lat0, cond, prompt, negative, img, steps, guidance, bf)
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
+    outs = {}
+    for name, tdt in (("hip_fp32", torch.float32), ("hip_bf16", bf)):
+        sch = FlowUniPCMultistepScheduler(flow_shift=5.0)
+        sch.trajectory_dtype = tdt
+        outs[name] = denoise(m, sch, lat0.cuda(), cond.cuda().to(bf), prompt.cuda().to(bf), negative.cuda().to(bf), img.cuda().to(bf),
+                             steps, guidance).clone()
+        assert torch.isfinite(outs[name]).all()
+    e_ref = rel_l2(ref_bf16, exact)
+    e_fp32, e_bf16 = rel_l2(outs["hip_fp32"], exact), rel_l2(outs["hip_bf16"], exact)
+    d_bf16 = rel_l2(outs["hip_bf16"], ref_bf16)
+    print(f"50-step CFG trajectory, end-of-trajectory rel-L2 vs the fp32 oracle: reference-precision (bf16 oracle) {e_ref:.3e} | "
+          f"engine fp32 latents {e_fp32:.3e} | engine bf16 trajectory {e_bf16:.3e}; engine bf16 trajectory vs bf16 oracle {d_bf16:.3e}")
+    assert e_fp32 < 5e-2 and e_fp32 <= e_ref + 5e-3, (e_fp32, e_ref)
+    assert d_bf16 < 2 * e_ref + 2e-2, (d_bf16, e_ref)

@@ -38,7 +38,7 @@ def test_conv_igemm_matches_conv3d():
     assert float(out.data[:, 0].abs().max()) == 0.0 and float(out.data[:, :, 0].abs().max()) == 0.0  # border untouched
 
 
-@pytest.mark.parametrize("name", ["small_5f", "small_9f"])
+@pytest.mark.parametrize("name", ["small_5f", "small_9f", "full_5f"])
 def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
     from chronoedit_amd.vae import AutoencoderKLWan
     fx = torch.load(os.path.join(golden_dir, f"vae_{name}.pt"))

@@ -51,10 +51,10 @@ def main():
     px = torch.randn((1, 3, 224, 224), generator=g, device=dev)
 
     def edit(steps):
-        pos, neg = pipe.encode_prompt(ids, am, nids, nam)
+        pos, neg = pipe.encode_prompt(input_ids=ids, attention_mask=am, negative_input_ids=nids, negative_attention_mask=nam)
         img = pipe.encode_image(px)
-        return pipe(image=image, prompt_embeds=pos, negative_prompt_embeds=neg if a.guidance > 1 else None, image_embeds=img,
-                    num_frames=a.frames, num_inference_steps=steps, guidance_scale=a.guidance)
+        return pipe.edit_tensors(image, pos, neg if a.guidance > 1 else None, img, num_frames=a.frames, num_inference_steps=steps,
+                                 guidance_scale=a.guidance)
 
     edit(2)  # warm-up: packs every engine, sizes the workspaces
     torch.cuda.synchronize()
