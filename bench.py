@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE.json configs[4] arithmetic: the six large Linears of every block in fp8 e4m3 (MX matrix instruction); "
                          "reported with dtype fp8, never the headline bf16 number")
+    ap.add_argument("--fp8-gemms-only", action="store_true", help="with --fp8: keep the self-attention in bf16 (round-1 fp8 mode)")
     ap.add_argument("--attn-kernel", type=int, default=0,
                     help="(tuning) self-attention kernel knob of ce_set_attention_waves: 0 auto, 8 plain, 64 sw-pipelined")
     return ap.parse_args()
@@ -148,8 +149,8 @@ def _baseline_config_name(a, T) -> str:
     if (a.width, a.height) == (1280, 720) and T == 8:
         return "BASELINE.json configs[3] (temporal reasoning, 8 latent frames)"
     if (a.width, a.height) == (1584, 1056):
-        return ("BASELINE.json configs[4] (fp8 GEMM mode: fp8 weights / activations in the six large Linears, attention in bf16)"
-                if a.fp8 else "BASELINE.json configs[4] shape, run in bf16")
+        return ("BASELINE.json configs[4] (fp8 weights / activations in the six large Linears" +
+                (", attention in bf16)" if a.fp8_gemms_only else " + MXFP8 self-attention)") if a.fp8 else "BASELINE.json configs[4] shape, run in bf16")
     return "non-BASELINE shape"
 
 
@@ -203,6 +204,8 @@ def main():
     model.cache_context = a.cache_context
     if a.fp8:
         model.enable_fp8_gemms()
+        if not a.fp8_gemms_only:
+            model.enable_fp8_attention()
     mode = a.parallel
     if mode == "auto":
         mode = "ulysses" if world > 1 else "replica"
@@ -343,7 +346,9 @@ def main():
             "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None,
-            "dtype": "fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if a.fp8 else "bf16", "data": "synthetic",
+            "dtype": ("fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if a.fp8_gemms_only else
+                      "fp8: e4m3 GEMMs + MXFP8 self-attention on the MX matrix instruction (fp32 accumulate); bf16 cross-attention / norms / residual")
+                     if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
                                    f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "
                                    + _baseline_config_name(a, T),
@@ -362,7 +367,7 @@ def main():
             "strong_scaling_speedup_vs_one_gpu": None if not single_same else round(steps_per_s / single_same, 3),
             "replica_mode": replica,
             "steps_per_sec_with_context_kv_cache": single["cached_rate"],
-            "steps_per_sec_fp8_gemm_mode": single["fp8_rate"],
+            "steps_per_sec_fp8_mode": single["fp8_rate"],
             "vae": vae_s,
             "encoders": enc_s,
             "sec_per_edit": {"configs[2] 8-step distilled schedule, guidance 1 (measured end to end)": single["edit8"],
@@ -406,6 +411,7 @@ def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w,
     # reported beside the bf16 `value`, never as it
     if not a.fp8 and not a.graph and not a.no_fp8_leg:
         model.enable_fp8_gemms()
+        model.enable_fp8_attention()
         step(4)  # packs the e4m3 weights
         torch.cuda.synchronize()
         tc = time.perf_counter()
@@ -414,6 +420,7 @@ def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w,
         torch.cuda.synchronize()
         out["fp8_rate"] = round(2 / (time.perf_counter() - tc), 4)
         model.enable_fp8_gemms(False)
+        model.enable_fp8_attention(False)
     # VAE encode + decode at the same resolution (once per edit)
     vae = None
     if not a.no_vae:

@@ -1,0 +1,418 @@
+// MXFP8 self-attention for the fp8 mode of the DiT (BASELINE.json configs[4]: "fp8 weights+attn (CDNA4 fp8 MFMA)").
+//
+// The reference has no fp8 inference path, so the arithmetic CONTRACT is defined here and restated in
+// oracle/dit_oracle.py::attention_mxfp8; what it replaces is F.scaled_dot_product_attention at transformer_chronoedit.py:91-104.
+//   * Q, K (after RMSNorm + RoPE) and V are quantised to OCP MXFP8: e4m3 elements with one E8M0 (power-of-two) scale per block
+//     of 32 consecutive elements ALONG THE CONTRACTION AXIS - the head channels d for Q and K, the keys for V.  Scale of a block =
+//     2^(floor(log2 amax) - 8); elements = RNE(x / scale) clamped to +-448.
+//   * S = Q.K^T and O = P.V run on v_mfma_scale_f32_32x32x64_f8f6f4 (block scales applied by the matrix pipe, fp32 accumulate).
+//   * P = exp2((S - rowmax) * scale * log2e + 8) is rounded to e4m3 with unit scale (P <= 2^8, so nothing saturates and
+//     probabilities down to 2^-17 of the row maximum survive); the row sum that normalises O is the fp32 sum of the un-rounded P.
+//   * Online softmax over 64-key tiles with an exact running maximum; O / l rounded to bf16.
+//
+// Three kernels (all hand-written for gfx950, wave64):
+//   rmsnorm_rope_mxfp8_kernel   K7+K8 of the bf16 path, writing MXFP8 q / k (+ scale bytes) instead of bf16: the quantisation is
+//                               done ONCE per element by the producer, not once per consuming workgroup (29 of them at N = 7200).
+//   v_mxfp8_transpose_kernel    V -> V^T tiles [head][d][key] in the key order the P operand has in the accumulator registers
+//                               (so that NO cross-lane movement of P is needed), quantised per (d, 32-key block).
+//   attn_fwd_mxfp8_kernel       8 waves x 32 query rows; K / V^T / scale tiles arrive by LDS-DMA (global_load_lds, no VGPR staging,
+//                               no transposes in the loop), three stages, ONE barrier per 64-key tile; per tile and wave
+//                               4 + 4 MFMAs of 32x32x64 (half the matrix-pipe time of the bf16 kernel) and 16 ds_read_b128.
+// Bound: MX-fp8 MFMA (5 PFLOP/s dense); algorithmic flops = 4 * Nq * Nkv * 128 per head.
+#include "ce_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+constexpr int HD = 128, QW = 32, KVB = 64;
+constexpr int ROW_MAXC = 10;
+
+// E8M0 scale byte and its inverse (as a float) for a block with the given amax: scale = 2^(floor(log2 amax) - 8)
+__device__ __forceinline__ int mx_scale_byte(float amax) {
+  const int ef = (int)(__float_as_uint(amax) >> 23);  // biased exponent (amax >= 0)
+  return max(ef - 8, 1);
+}
+__device__ __forceinline__ float mx_inv_scale(int byte) { return __uint_as_float((uint32_t)(254 - byte) << 23); }
+__device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm(across heads) [+ RoPE] -> MXFP8 (same rounding points as rmsnorm_rope_kernel up to the bf16 value, then quantised)
+// ------------------------------------------------------------------------------------------------
+template <bool FULL>
+__global__ __launch_bounds__(256) void rmsnorm_rope_mxfp8_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ cs, unsigned char* __restrict__ q8,
+                                                                 unsigned char* __restrict__ sc, int M, int D, int ldx, int ldq,
+                                                                 int head_dim, float eps, int rope_rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int cs_row = rope_rows > 0 ? row % rope_rows : row;
+  const int nch = D >> 3;
+  const bf16* xr = x + (size_t)row * ldx;
+  u32x4 raw[ROW_MAXC];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    if (FULL || c < nch) {
+      raw[i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v0 = bf16lo(raw[i][j]), v1 = bf16hi(raw[i][j]);
+        s += v0 * v0 + v1 * v1;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(s) / (float)D + eps);
+  const int half = head_dim >> 1;
+  unsigned char* qr = q8 + (size_t)row * ldq;
+  unsigned char* sr = sc + (size_t)row * (D >> 5);
+#pragma unroll
+  for (int i = 0; i < ROW_MAXC; ++i) {
+    const int c = lane + 64 * i;
+    const bool on = FULL || c < nch;
+    float v[8];
+    float amax = 0.f;
+    if (on) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c * 8), w1 = *reinterpret_cast<const f32x4*>(w + c * 8 + 4);
+      f32x4 cs0, cs1;
+      if (cs != nullptr) {
+        const int pair0 = ((c * 8) % head_dim) >> 1;
+        const float* p = cs + ((size_t)cs_row * half + pair0) * 2;
+        cs0 = *reinterpret_cast<const f32x4*>(p);
+        cs1 = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float ww0 = j < 2 ? w0[2 * j] : w1[2 * j - 4], ww1 = j < 2 ? w0[2 * j + 1] : w1[2 * j - 3];
+        float v0 = round_bf16(round_bf16(bf16lo(raw[i][j]) * rstd) * ww0);
+        float v1 = round_bf16(round_bf16(bf16hi(raw[i][j]) * rstd) * ww1);
+        if (cs != nullptr) {
+          const float co = j < 2 ? cs0[2 * j] : cs1[2 * j - 4], si = j < 2 ? cs0[2 * j + 1] : cs1[2 * j - 3];
+          const float r0 = v0 * co - v1 * si, r1 = v0 * si + v1 * co;
+          v0 = r0;
+          v1 = r1;
+        }
+        v[2 * j] = round_bf16(v0);      // the value the bf16 path would have stored
+        v[2 * j + 1] = round_bf16(v1);
+        amax = fmaxf(amax, fmaxf(fabsf(v[2 * j]), fabsf(v[2 * j + 1])));
+      }
+    }
+    // a 32-element block = 4 consecutive chunks = lanes 4a .. 4a+3
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    if (on) {
+      const int byte = mx_scale_byte(amax);
+      const float inv = mx_inv_scale(byte);
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv), clamp448(v[1] * inv), w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[2] * inv), clamp448(v[3] * inv), w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[4] * inv), clamp448(v[5] * inv), w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[6] * inv), clamp448(v[7] * inv), w1, true);
+      const u32x2 o = {(uint32_t)w0, (uint32_t)w1};
+      *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+      if ((lane & 3) == 0) sr[c >> 2] = (unsigned char)byte;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V [tokens][ldv] (head h = columns h*128..) -> V^T tiles: v8t[(b*H + h)*128 + d][npad] bytes, sv[b][h][npad/64][d][2].
+// Inside every 64-key tile the keys are stored in the order the P operand has in the S^T accumulator registers of the
+// attention kernel: position p = 32 g + j  <->  key = 32 (j >> 4) + (j & 3) + 8 ((j & 15) >> 2) + 4 g   (g = lane half).
+// One MX block = 32 CONSECUTIVE keys (sv[..][2 t + beta] = scale of keys 64 t + 32 beta ..).  Keys past the end are zeros.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int slot_key(int g, int j) { return 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * g; }
+
+__global__ __launch_bounds__(256) void v_mxfp8_transpose_kernel(const bf16* __restrict__ V, int ldv, unsigned char* __restrict__ v8t,
+                                                                unsigned char* __restrict__ sv, int n_tokens, int H, int npad) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[KVB * HD * 2];  // [64 keys][128 d] bf16
+  const int t = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const bf16* vb = V + (size_t)b * n_tokens * ldv + h * HD;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (tid >> 4) + 16 * i, ck = tid & 15;
+    const int kv = t * KVB + r;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (kv < n_tokens) val = *reinterpret_cast<const u32x4*>(vb + (size_t)kv * ldv + ck * 8);
+    *reinterpret_cast<u32x4*>(tile + r * (HD * 2) + ck * 16) = val;
+  }
+  __syncthreads();
+  const int d = tid & 127, g = tid >> 7;
+  // MX blocks of V are 32 CONSECUTIVE keys: in the P operand bytes 0-15 of both lane halves are keys 0-31 of the tile and bytes
+  // 16-31 are keys 32-63 (slot_key), and the matrix unit takes the scale of byte half beta from lane (d, beta).
+  float col[KVB];
+  float am0 = 0.f, am1 = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) {
+    col[kk] = (float)*reinterpret_cast<const bf16*>(tile + kk * (HD * 2) + d * 2);
+    col[32 + kk] = (float)*reinterpret_cast<const bf16*>(tile + (32 + kk) * (HD * 2) + d * 2);
+    am0 = fmaxf(am0, fabsf(col[kk]));
+    am1 = fmaxf(am1, fabsf(col[32 + kk]));
+  }
+  const int byte0 = mx_scale_byte(am0), byte1 = mx_scale_byte(am1);
+  const float inv0 = mx_inv_scale(byte0), inv1 = mx_inv_scale(byte1);
+  const int byte = g ? byte1 : byte0;  // this thread stores the scale of key block g
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float inv = i < 4 ? inv0 : inv1;  // positions j = 4 i .. 4 i + 3: j < 16 are keys of block 0, j >= 16 of block 1
+    int wv = 0;
+    wv = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(col[slot_key(g, 4 * i)] * inv), clamp448(col[slot_key(g, 4 * i + 1)] * inv), wv, false);
+    wv = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(col[slot_key(g, 4 * i + 2)] * inv), clamp448(col[slot_key(g, 4 * i + 3)] * inv), wv, true);
+    o[i] = (uint32_t)wv;
+  }
+  const size_t rowi = ((size_t)b * H + h) * HD + d;
+  unsigned char* dst = v8t + rowi * npad + t * KVB + 32 * g;
+  const u32x4 o0 = {o[0], o[1], o[2], o[3]}, o1 = {o[4], o[5], o[6], o[7]};
+  *reinterpret_cast<u32x4*>(dst) = o0;
+  *reinterpret_cast<u32x4*>(dst + 16) = o1;
+  // scale bytes tile-major: sv[b][h][tile][d][beta] - one contiguous 256-B record per (head, tile), fetched by the attention kernel
+  // with dword LDS-DMA (sub-dword LDS-DMA lanes land on a 4-byte pitch, so 2-byte pieces cannot be packed)
+  sv[((((size_t)b * H + h) * (npad >> 6) + t) * HD + d) * 2 + g] = (unsigned char)byte;
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention
+// ------------------------------------------------------------------------------------------------
+constexpr int ST_K = 0, ST_V = 8192, ST_SK = 16384, ST_SV = 16640, STAGE = 17408;  // one stage: K8 8K | V8T 8K | sk 256 | sv 256 (+pad)
+constexpr int NSTAGE = 3;
+constexpr int OST_ROW = HD * 2 + 16;
+constexpr int SMEM = NSTAGE * STAGE > 8 * QW * OST_ROW ? NSTAGE * STAGE : 8 * QW * OST_ROW;
+constexpr float NEG_BIG = -1.0e30f;
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ SQ,
+                                                               const unsigned char* __restrict__ K8, const unsigned char* __restrict__ SK,
+                                                               const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ SV,
+                                                               bf16* __restrict__ O, int Nq, int Nkv, int npad, int H, int ldq8,
+                                                               int ldk8, int ldo, int nqb, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D32 = (H * HD) >> 5;  // scale bytes per row of q / k
+  {
+    const size_t bz = blockIdx.y;
+    Q8 += bz * Nq * ldq8;
+    SQ += bz * Nq * D32;
+    K8 += bz * Nkv * ldk8;
+    SK += bz * Nkv * D32;
+    V8T += bz * H * HD * npad;
+    SV += bz * H * HD * (npad >> 5);  // [H][npad / 64][128][2]
+    O += bz * Nq * ldo;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * (QW * 8) + wave * QW;
+  const int hoff = head * HD;
+  const int ntiles = (Nkv + KVB - 1) / KVB;
+
+  // Operand geometry of v_mfma_scale_f32_32x32x64_f8f6f4 (tools/probes/mx32_probe*.hip, profiles/r02_mx32_probe.txt): lane
+  // (row r = l31, half g = hh) supplies 32 bytes; bytes 0-15 are k = 16 g .. 16 g + 15 and bytes 16-31 are k = 32 + 16 g .. of the
+  // 64-deep step, i.e. MX block 0 (k < 32) is bytes 0-15 of BOTH halves and block 1 is bytes 16-31 of both; the scale byte
+  // of block beta is taken from lane (r, beta).  So lane (r, g) fetches the 16-B chunks g and 2 + g of its row's 64 bytes and
+  // passes the scale of block g.
+  // Q^T B-operand
+  i32x8 qf[2];
+  int sqv[2];
+  {
+    const int qr = min(q0 + l31, Nq - 1);
+    const unsigned char* qrow = Q8 + (size_t)qr * ldq8 + hoff + 16 * hh;
+    const uint32_t sw = *reinterpret_cast<const uint32_t*>(SQ + (size_t)qr * D32 + head * 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(qrow + 64 * ks), b = *reinterpret_cast<const u32x4*>(qrow + 64 * ks + 32);
+      qf[ks] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      sqv[ks] = (int)((sw >> (16 * ks + 8 * hh)) & 0xffu);
+    }
+  }
+
+  // per-lane DMA source offsets (the 16-B-chunk swizzles live on the SOURCE side: the LDS image of a DMA is lane-linear)
+  const int k_row = 8 * wave + (lane >> 3);                       // K8 tile row this lane fetches (64 rows x 128 B)
+  const int k_chunk = (lane & 7) ^ ((k_row >> 1) & 7);
+  const int v_row = 16 * wave + (lane >> 2);                      // V8T tile row (128 d x 64 B)
+  const int v_chunk = (lane & 3) ^ ((v_row >> 2) & 3);
+  const unsigned char* vsrc = V8T + ((size_t)head * HD + v_row) * npad + v_chunk * 16;
+  const unsigned char* svsrc = SV + (size_t)head * (npad >> 6) * 256 + 32 * wave + 4 * (lane & 7);  // + 256 per tile
+  auto stage_tile = [&](int t, int slot) {  // tile t -> stage `slot`
+    unsigned char* st = smem + slot * STAGE;
+    const int kr = min(t * KVB + k_row, Nkv - 1);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(K8 + (size_t)kr * ldk8 + hoff + k_chunk * 16), (lds_void*)(st + ST_K + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc + (size_t)t * KVB), (lds_void*)(st + ST_V + wave * 1024), 16, 0, 0);
+    if (lane < 8) {   // 8 key rows' scale words (4 B each) per wave
+      const int sr = min(t * KVB + 8 * wave + lane, Nkv - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(SK + (size_t)sr * D32 + head * 4), (lds_void*)(st + ST_SK + wave * 32), 4, 0, 0);
+    }
+    if (lane < 8)     // 16 d rows' scale pairs (8 dwords) per wave
+      __builtin_amdgcn_global_load_lds((gbl_void*)(svsrc + (size_t)t * 256), (lds_void*)(st + ST_SV + wave * 32), 4, 0, 0);
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  stage_tile(0, 0);
+  stage_tile(ntiles > 1 ? 1 : 0, 1);  // surplus prefetches re-fetch a valid tile into a free stage (their data is never read)
+
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wave's pieces of tile t have landed (tile t+1's four stay in flight)
+    __builtin_amdgcn_s_barrier();                     // ... everybody's have, and everybody is done reading tile t-1's stage
+    stage_tile(t + 2 < ntiles ? t + 2 : ntiles - 1, (t + 2) % NSTAGE);
+    const unsigned char* st = smem + (t % NSTAGE) * STAGE;
+
+    // ---- S^T = K . Q^T : two 32-key halves x two 64-deep k-steps
+    f32x16 sacc[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[f][r] = 0.f;
+      const int row = 32 * f + l31;
+      const unsigned char* krow = st + ST_K + row * 128;
+      const int sw = (row >> 1) & 7;
+      const uint32_t skw = *reinterpret_cast<const uint32_t*>(st + ST_SK + row * 4);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c0 = 4 * ks + hh;  // chunks g and 2 + g of this k-step
+        const u32x4 a = *reinterpret_cast<const u32x4*>(krow + ((c0 ^ sw) << 4)), b = *reinterpret_cast<const u32x4*>(krow + (((c0 + 2) ^ sw) << 4));
+        const i32x8 kf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+        const int ska = (int)((skw >> (16 * ks + 8 * hh)) & 0xffu);
+        sacc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[ks], sacc[f], 0, 0, 0, ska, 0, sqv[ks]);
+      }
+    }
+    // ---- mask the key tail of the last tile: key = 64 t + 32 f + (r & 3) + 8 (r >> 2) + 4 hh
+    if ((t + 1) * KVB > Nkv) {
+      const int base = t * KVB + 4 * hh;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (base + 32 * f + (r & 3) + 8 * (r >> 2) >= Nkv) sacc[f][r] = NEG_BIG;
+    }
+    // ---- online softmax: this lane's query row; the partner lane ^ 32 holds the other half of the keys
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[f][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
+    const float mc = m_new * scale_log2e - 8.0f;  // P = 2^8 exp2((S - m) c): uses the e4m3 range up to 256
+    m_run = m_new;
+    float psum = 0.f;
+    i32x8 pf;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          p[e] = __builtin_amdgcn_exp2f(fmaf(sacc[f][4 * i + e], scale_log2e, -mc));
+          psum += p[e];
+        }
+        int wv = 0;
+        wv = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], wv, false);
+        wv = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], wv, true);
+        pf[4 * f + i] = wv;  // k-slot j = 16 f + 4 i + e of lane half hh  <->  key 32 f + (r & 3) + 8 (r >> 2) + 4 hh, r = 4 i + e
+      }
+    l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha;
+    }
+    // ---- O^T += V^T . P^T : four 32-d blocks, one 64-deep k-step each
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int dv = 32 * m + l31;
+      const unsigned char* vrow = st + ST_V + dv * 64;
+      const int sw = (dv >> 2) & 3;
+      const u32x4 a = *reinterpret_cast<const u32x4*>(vrow + (((2 * hh) ^ sw) << 4)), b = *reinterpret_cast<const u32x4*>(vrow + (((2 * hh + 1) ^ sw) << 4));
+      const i32x8 vf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      const int sva = (int)((*reinterpret_cast<const uint16_t*>(st + ST_SV + dv * 2) >> (8 * hh)) & 0xffu);
+      oacc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, oacc[m], 0, 0, 0, sva, 0, 0x7f);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // surplus prefetches must land before the staging rows reuse the LDS
+  __builtin_amdgcn_s_barrier();
+
+  // ---- normalise, round to bf16, stage this wave's 32 x 128 tile and store whole 256-B rows
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  unsigned char* ost = smem + (size_t)(wave * QW + l31) * OST_ROW;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const u32x2 val = {pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv), pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv)};
+      *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = q0 + rl;
+    if (q < Nq) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ce_rmsnorm_rope_mxfp8(const void* x, const float* w, const float* cos_sin, void* q8, void* scale8, int M, int D, int ldx,
+                                     int ldq, int head_dim, float eps, int rope_rows, hipStream_t stream) {
+  if (!x || !w || !q8 || !scale8) return CE_ERR_ARG;
+  if (M <= 0 || D <= 0 || (D & 31) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (head_dim & 31) || D % head_dim) return CE_ERR_SHAPE;
+  if (D == 64 * 8 * ROW_MAXC)
+    hipLaunchKernelGGL(rmsnorm_rope_mxfp8_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, w, cos_sin, (unsigned char*)q8,
+                       (unsigned char*)scale8, M, D, ldx, ldq, head_dim, eps, rope_rows);
+  else
+    hipLaunchKernelGGL(rmsnorm_rope_mxfp8_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, w, cos_sin, (unsigned char*)q8,
+                       (unsigned char*)scale8, M, D, ldx, ldq, head_dim, eps, rope_rows);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv, int n_tokens, int batch, int H, int npad, hipStream_t stream) {
+  if (!v || !v8t || !sv) return CE_ERR_ARG;
+  if (n_tokens <= 0 || batch <= 0 || H <= 0 || (ldv & 7) || (npad & 63) || npad < n_tokens) return CE_ERR_SHAPE;
+  hipLaunchKernelGGL(v_mxfp8_transpose_kernel, dim3(npad / KVB, H, batch), dim3(256), 0, stream, (const bf16*)v, ldv, (unsigned char*)v8t,
+                     (unsigned char*)sv, n_tokens, H, npad);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
+                                  int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, float softmax_scale, int batch,
+                                  hipStream_t stream) {
+  if (!q8 || !sq || !k8 || !sk || !v8t || !sv || !O) return CE_ERR_ARG;
+  if (head_dim != HD || Nq <= 0 || Nkv <= 0 || H <= 0 || batch <= 0 || (npad & 63) || npad < Nkv || npad - Nkv >= KVB) return CE_ERR_SHAPE;
+  if ((ldq8 & 15) || (ldk8 & 15) || (ldo & 7)) return CE_ERR_ALIGN;
+  const int nqb = (Nq + QW * 8 - 1) / (QW * 8);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr = true;
+  }
+  hipLaunchKernelGGL(attn_fwd_mxfp8_kernel, dim3(H * nqb, batch), dim3(512), SMEM, stream, (const unsigned char*)q8, (const unsigned char*)sq,
+                     (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t, (const unsigned char*)sv, (bf16*)O, Nq, Nkv,
+                     npad, H, ldq8, ldk8, ldo, nqb, softmax_scale * 1.4426950408889634f);
+  return (int)hipGetLastError();
+}

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
 extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw);
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                 int a_seg_k, long long a_seg_stride, hipStream_t stream);
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
 extern "C" void ce_gemm256_set_staggered(int on);
 
@@ -240,10 +240,15 @@ extern "C" int ce_set_gemm_variant(int v) {
 // Column k of A lives at A + (k / a_seg_k) * a_seg_stride + m * lda + k % a_seg_k: the layout an all-to-all leaves the
 // attention output in ([source rank][local row][D / W], chronoedit_amd/parallel.py), consumed by the out-projection
 // without a gather pass.  a_seg_k == 0 (or >= K): plain row-major A.
-extern "C" int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
-                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                 int a_seg_k, long long a_seg_stride, hipStream_t stream) {
+// ... and the same for W (w_seg_k, w_seg_stride): weights re-packed K-slab-major ([K/64][N][64]) so that every 16 KiB
+// half-tile of the LDS-DMA stream is one contiguous block (tools/probes/l2_pattern_probe.hip: 21.7 vs 18.3 TB/s for the
+// row-strided form).  Segmented W needs the 256-tile kernel (CE_ERR_SHAPE otherwise).
+extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
   if (!A || !W || !C) return CE_ERR_ARG;
+  if (w_seg_k < 0 || (w_seg_k > 0 && w_seg_k < K && ((w_seg_k % BK) || (K % w_seg_k) || (w_seg_stride & 7)))) return CE_ERR_SHAPE;
+  if (w_seg_k >= K) w_seg_k = 0;
   if (a_seg_k < 0 || (a_seg_k > 0 && a_seg_k < K && ((a_seg_k % BK) || (K % a_seg_k) || (a_seg_stride & 7)))) return CE_ERR_SHAPE;
   if (a_seg_k >= K) a_seg_k = 0;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7)) return CE_ERR_SHAPE;
@@ -253,11 +258,11 @@ extern "C" int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const fl
   if (epilogue != EPI_F32 && epilogue != EPI_MUL) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant >= 1 || (g_gemm_variant == -1 && big);
-    if (want && ce_gemm256_supported(M, N, K, lda, ldw) &&
-        (a_seg_k == 0 || ((long long)(K / a_seg_k - 1) * a_seg_stride + (long long)M * lda) * 2 < (1ll << 32)))
+    if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw))
       return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
-                               stream);
+                               w_seg_k, w_seg_stride, stream);
   }
+  if (w_seg_k) return CE_ERR_SHAPE;
   const int a_seg_tiles = a_seg_k > 0 ? a_seg_k / BK : 0;
   const long long a_seg_extra = a_seg_k > 0 ? a_seg_stride - a_seg_k : 0;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -279,10 +284,16 @@ extern "C" int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const fl
   return (int)hipGetLastError();
 }
 
+extern "C" int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, hipStream_t stream) {
+  return ce_gemm_seg_bf16(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, 0, 0, stream);
+}
+
 extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                             const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                             hipStream_t stream) {
-  return ce_gemm_aseg_bf16(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, 0, 0, stream);
+  return ce_gemm_seg_bf16(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, 0, 0, 0, 0, stream);
 }
 
 // batch0 x batch1 independent products with two-level element strides (e.g. head within sample): operand z = (z0, z1) is

@@ -61,6 +61,8 @@ struct Stager {
   int kt0;               // first K-tile of this block (split-K tail pieces start past 0)
   uint32_t a_seg_magic;
   uint32_t a_seg_extra;  // bytes
+  uint32_t w_seg_magic;  // the same for W (ce_gemm_seg_bf16: weights re-packed K-slab-major)
+  uint32_t w_seg_extra;
 };
 
 template <int SLOT_ID>
@@ -69,7 +71,8 @@ __device__ __forceinline__ void stage_half(unsigned char* smem, const Stager& s,
   constexpr bool isB = (SLOT_ID & 2) != 0;
   const int t = tile < s.kt_last ? tile : s.kt_last;  // clamp: surplus prefetches re-read the last K-tile
   const int ta = s.kt0 + t;  // absolute K-tile
-  const char* base = (isB ? s.w_base : s.a_base + (size_t)(((uint32_t)(ta * s.a_seg_magic) >> 16) * s.a_seg_extra)) + (size_t)ta * (BK * 2);
+  const char* base = (isB ? s.w_base + (size_t)(((uint32_t)(ta * s.w_seg_magic) >> 16) * s.w_seg_extra)
+                          : s.a_base + (size_t)(((uint32_t)(ta * s.a_seg_magic) >> 16) * s.a_seg_extra)) + (size_t)ta * (BK * 2);
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const uint32_t off = isB ? s.w_off[half][r] : s.a_off[half][r];
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
                                                      const float* __restrict__ gate, const bf16* __restrict__ res, int M,
                                                      int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                                      int tiles_m, int tiles_n, int t_full, int split,
-                                                     float* __restrict__ ws, uint32_t a_seg_magic, uint32_t a_seg_extra) {
+                                                     float* __restrict__ ws, uint32_t a_seg_magic, uint32_t a_seg_extra,
+                                                     uint32_t w_seg_magic, uint32_t w_seg_extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -197,6 +201,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   st.kt0 = kt0;
   st.a_seg_magic = a_seg_magic;
   st.a_seg_extra = a_seg_extra;
+  st.w_seg_magic = w_seg_magic;
+  st.w_seg_extra = w_seg_extra;
   st.wave = wave;
   st.kt_last = ktn - 1;
 #pragma unroll
@@ -465,21 +471,25 @@ extern "C" int ce_set_gemm_workspace(void* ptr, size_t bytes) {
 
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                 int a_seg_k, long long a_seg_stride, hipStream_t stream) {
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n, kt = K / BK;
-  // segmented A: column k of A lives at A + (k / a_seg_k) * a_seg_stride + m * lda + k % a_seg_k (elements)
-  uint32_t a_seg_magic = 0, a_seg_extra = 0;
-  if (a_seg_k > 0 && a_seg_k < K) {
-    if (a_seg_k % BK) return CE_ERR_SHAPE;
-    const int tps = a_seg_k / BK;
-    a_seg_magic = 65536u / (uint32_t)tps + 1u;
+  // segmented operand: column k lives at base + (k / seg_k) * seg_stride + row * ld + k % seg_k (elements)
+  uint32_t a_seg_magic = 0, a_seg_extra = 0, w_seg_magic = 0, w_seg_extra = 0;
+  auto seg = [&](int seg_k, long long seg_stride, uint32_t& magic, uint32_t& extra_out) -> int {
+    if (seg_k <= 0 || seg_k >= K) return CE_OK;
+    if (seg_k % BK) return CE_ERR_SHAPE;
+    const int tps = seg_k / BK;
+    magic = 65536u / (uint32_t)tps + 1u;
     for (int t = 0; t < kt; ++t)
-      if ((int)(((uint32_t)t * a_seg_magic) >> 16) != t / tps) return CE_ERR_SHAPE;
-    const long long extra = (a_seg_stride - a_seg_k) * 2;  // bytes on top of the contiguous advance
-    if (extra < 0 || extra * (K / a_seg_k) >= (1ll << 32)) return CE_ERR_SHAPE;
-    a_seg_extra = (uint32_t)extra;
-  }
+      if ((int)(((uint32_t)t * magic) >> 16) != t / tps) return CE_ERR_SHAPE;
+    const long long extra = (seg_stride - seg_k) * 2;  // bytes on top of the contiguous advance
+    if (extra < 0 || extra * (K / seg_k) >= (1ll << 32)) return CE_ERR_SHAPE;
+    extra_out = (uint32_t)extra;
+    return CE_OK;
+  };
+  if (int rc = seg(a_seg_k, a_seg_stride, a_seg_magic, a_seg_extra)) return rc;
+  if (int rc = seg(w_seg_k, w_seg_stride, w_seg_magic, w_seg_extra)) return rc;
   // split-K only for the tail of the last, partially filled round of workgroups
   int tail = nwg % g_cus, split = 1;
   if (tail > 0 && g_ws != nullptr) {
@@ -504,11 +514,11 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
     if (staggered)                                                                                                    \
       hipLaunchKernelGGL((gemm_bf16_256<E, true>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
                          bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n,    \
-                         t_full2, split, g_ws, a_seg_magic, a_seg_extra);                                             \
+                         t_full2, split, g_ws, a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                             \
     else                                                                                                              \
       hipLaunchKernelGGL((gemm_bf16_256<E, false>), grid, block, LDS_BYTES, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, \
                          bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n,    \
-                         t_full2, split, g_ws, a_seg_magic, a_seg_extra);                                             \
+                         t_full2, split, g_ws, a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                             \
     if (tail)                                                                                                         \
       hipLaunchKernelGGL((gemm256_reduce<E>), dim3(4 * tail), block, 128 * QROW, stream, (bf16*)C, bias, gate,        \
                          (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);      \

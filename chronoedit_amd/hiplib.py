@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
 HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
 
-SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_attn.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip"]
+SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_attn.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip"]
 
 _c = ctypes
 _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
@@ -30,6 +30,10 @@ SIGNATURES: Dict[str, List] = {
     "ce_rmsnorm_rope_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_gemm_aseg_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _P],
+    "ce_gemm_seg_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _I, _c.c_longlong, _P],
+    "ce_rmsnorm_rope_mxfp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ce_v_mxfp8_transpose": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "ce_attention_mxfp8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_rope_scatter_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _I, _P],
     "ce_patchify_rows_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_gemm_variant": [_I],

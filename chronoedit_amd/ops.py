@@ -566,3 +566,76 @@ def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Ten
                              lda, ldw, ldc, ldres, int(gate_rows), _stream()), "ce_gemm_fp8")
     _prof_end(st, f"gemm_fp8_{M}x{N}x{K}_epi{epilogue}", 2.0 * M * N * K)
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# MXFP8 self-attention (fp8 mode; contract: chronoedit_amd/csrc/ce_attn_fp8.hip, oracle.dit_oracle.attention_mxfp8)
+# ------------------------------------------------------------------------------------------
+def rmsnorm_rope_mxfp8(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tensor], head_dim: int, eps: float,
+                       out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """RMSNorm across heads (+ RoPE) of x [M, D] (bf16, row stride free) -> (q8 [M, D] uint8 e4m3, s8 [M, D/32] uint8 E8M0):
+    MXFP8 blocks of 32 head channels."""
+    _dev(x, torch.bfloat16, "x"), _dev(w, torch.float32, "w")
+    M, D, ldx = _rows(x, "x")
+    rope_rows = 0
+    if cos_sin is not None:
+        _dev(cos_sin, torch.float32, "cos_sin")
+        assert cos_sin.is_contiguous() and cos_sin.shape[1:] == (head_dim // 2, 2) and M % cos_sin.shape[0] == 0
+        rope_rows = cos_sin.shape[0]
+    if out is None:
+        out = torch.empty((M, D), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty((M, D // 32), dtype=torch.uint8, device=x.device)
+    _dev(out, torch.uint8, "out"), _dev(scale, torch.uint8, "scale")
+    assert scale.is_contiguous() and scale.shape == (M, D // 32)
+    _, _, ldq = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_rmsnorm_rope_mxfp8(_ptr(x), _ptr(w), _ptr(cos_sin), _ptr(out), _ptr(scale), M, D, ldx, ldq, head_dim, float(eps), rope_rows,
+                                       _stream()), "ce_rmsnorm_rope_mxfp8")
+    _prof_end(st, f"rmsnorm_rope_mxfp8_{M}x{D}", 3.0 * M * D)
+    return out, scale
+
+
+def v_mxfp8_transpose(v: torch.Tensor, n_tokens: int, batch: int, heads: int, out: Optional[torch.Tensor] = None,
+                      scale: Optional[torch.Tensor] = None):
+    """v [batch*n_tokens, heads*128] bf16 (row stride free) -> (v8t [batch, heads, 128, npad] uint8, sv [batch, heads, npad/64, 128, 2] uint8),
+    npad = n_tokens rounded up to 64: V^T tiles in the key order of the attention kernel's P operand, MXFP8 blocks of 32 consecutive keys
+    (sv[.., t, d, beta] = E8M0 scale of keys 64 t + 32 beta .. of channel d)."""
+    _dev(v, torch.bfloat16, "v")
+    Mv, Dv, ldv = _rows(v, "v")
+    assert Mv == batch * n_tokens and Dv == heads * 128
+    npad = (n_tokens + 63) // 64 * 64
+    if out is None:
+        out = torch.empty((batch, heads, 128, npad), dtype=torch.uint8, device=v.device)
+    if scale is None:
+        scale = torch.empty((batch, heads, npad // 64, 128, 2), dtype=torch.uint8, device=v.device)
+    assert out.is_contiguous() and scale.is_contiguous() and out.shape == (batch, heads, 128, npad) and scale.shape == (batch, heads, npad // 64, 128, 2)
+    st = _prof_begin()
+    _check(lib().ce_v_mxfp8_transpose(_ptr(v), ldv, _ptr(out), _ptr(scale), n_tokens, batch, heads, npad, _stream()), "ce_v_mxfp8_transpose")
+    _prof_end(st, f"v_mxfp8_transpose_{Mv}x{Dv}", 3.0 * Mv * Dv)
+    return out, scale
+
+
+def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: torch.Tensor, v8t: torch.Tensor, sv: torch.Tensor,
+                    heads: int, out: Optional[torch.Tensor] = None, scale: Optional[float] = None, batch: int = 1):
+    """Self-attention on the MX-fp8 matrix instruction from the operands the two producers above write; out [batch*Nq, heads*128] bf16."""
+    for n, t in (("q8", q8), ("sq", sq), ("k8", k8), ("sk", sk), ("v8t", v8t), ("sv", sv)):
+        _dev(t, torch.uint8, n)
+    Mq, D, ldq = _rows(q8, "q8")
+    Mk, _, ldk = _rows(k8, "k8")
+    assert D == heads * 128 and Mq % batch == 0 and Mk % batch == 0
+    nq, nkv = Mq // batch, Mk // batch
+    npad = v8t.shape[-1]
+    assert sq.is_contiguous() and sk.is_contiguous() and v8t.is_contiguous() and sv.is_contiguous()
+    assert sq.shape == (Mq, D // 32) and sk.shape == (Mk, D // 32) and v8t.shape == (batch, heads, 128, npad) and sv.shape == (batch, heads, npad // 64, 128, 2)
+    if out is None:
+        out = torch.empty((Mq, D), dtype=torch.bfloat16, device=q8.device)
+    _dev(out, torch.bfloat16, "out")
+    _, _, ldo = _rows(out, "out")
+    if scale is None:
+        scale = 128 ** -0.5
+    st = _prof_begin()
+    _check(lib().ce_attention_mxfp8(_ptr(q8), _ptr(sq), _ptr(k8), _ptr(sk), _ptr(v8t), _ptr(sv), _ptr(out), nq, nkv, npad, heads, 128, ldq, ldk, ldo,
+                                    float(scale), batch, _stream()), "ce_attention_mxfp8")
+    _prof_end(st, f"attention_mxfp8_{nq}x{nkv}_h{heads}" + (f"_b{batch}" if batch > 1 else ""), 4.0 * nq * nkv * 128 * heads * batch)
+    return out

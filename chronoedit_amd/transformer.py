@@ -189,6 +189,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self._engine: Optional["DiTEngine"] = None
         self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
         self.gemm_dtype = "bf16"    # "fp8": the six large Linears of every block on the OCP-e4m3 MX matrix path
+        self.attn_dtype = "bf16"    # "mxfp8": self-attention on the MX-fp8 matrix instruction (csrc/ce_attn_fp8.hip)
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
         self._cfgp = None           # CFG parallelism on top of it (two Ulysses groups), off by default
 
@@ -284,6 +285,17 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         stream, the conditioning projections and the head stay bf16 / fp32 as before.  The bf16 parameters are kept."""
         self.gemm_dtype = "fp8" if on else "bf16"
         self._engine = None
+        return self
+
+    def enable_fp8_attention(self, on: bool = True):
+        """BASELINE.json configs[4] "fp8 weights+attn": the self-attention of every block under the MXFP8 contract of
+        csrc/ce_attn_fp8.hip - q / k (after RMSNorm + RoPE) in e4m3 with one E8M0 scale per 32 head channels, v per 32 keys,
+        Q.K^T and P.V on v_mfma_scale_f32_32x32x64_f8f6f4, P in e4m3, fp32 accumulation.  Cross-attention (769 keys, 3 % of the
+        attention flops) and everything else are unchanged; independent of enable_fp8_gemms."""
+        self.attn_dtype = "mxfp8" if on else "bf16"
+        if self._engine is not None:
+            self._engine.fp8_attn = on
+            self._engine._ws = {}
         return self
 
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() / .cpu() re-create storages
@@ -441,6 +453,7 @@ class DiTEngine:
             p.w_f2, p.b_f2 = blk.ffn.net[2].weight.detach().contiguous(), f32(blk.ffn.net[2].bias)
             tables.append(f32(blk.scale_shift_table).reshape(6, self.D))
             self.blk.append(p)
+        self.fp8_attn = model.attn_dtype == "mxfp8"
         self.fp8 = model.gemm_dtype == "fp8"
         if self.fp8:
             if self.D % 256 or self.F % 256:
@@ -547,6 +560,10 @@ class DiTEngine:
             if self.fp8:  # activation rows as fp8 + one scale per row
                 ws.a8 = torch.empty((N, max(D, F)), dtype=torch.uint8, device=dev)
                 ws.s8 = torch.empty((N,), dtype=torch.float32, device=dev)
+            if self.fp8_attn:  # MXFP8 q / k (+ E8M0 scale bytes); the V^T tiles depend on the batch split and are sized in forward
+                u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
+                ws.q8, ws.k8, ws.sq, ws.sk = u8(N, D), u8(N, D), u8(N, D // 32), u8(N, D // 32)
+                ws.v8t = ws.sv = None
             sp = self.model._sp
             if sp is not None and sp.world > 1:  # Ulysses exchange buffers (chronoedit_amd/parallel.py): N = local rows
                 W, Dl = sp.world, D // sp.world
@@ -701,7 +718,16 @@ class DiTEngine:
         x = ws.x
         for li, p in enumerate(self.blk):
             # 1. self-attention
-            if sp is None:  # all samples in one launch (stacked rows)
+            if sp is None and self.fp8_attn:  # MXFP8: the norm / RoPE pass and a V^T pass write the quantised operands
+                self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)
+                ops.rmsnorm_rope_mxfp8(ws.qkv[:, :D], p.nq1, cs, hd, eps, out=ws.q8, scale=ws.sq)
+                ops.rmsnorm_rope_mxfp8(ws.qkv[:, D : 2 * D], p.nk1, cs, hd, eps, out=ws.k8, scale=ws.sk)
+                if ws.v8t is None or ws.v8t.shape[0] != B:
+                    ws.v8t = ws.sv = None
+                ws.v8t, ws.sv = ops.v_mxfp8_transpose(ws.qkv[:, 2 * D :], Nl, B, H, out=ws.v8t, scale=ws.sv)
+                ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, out=ws.att, batch=B)
+                att = ws.att
+            elif sp is None:  # all samples in one launch (stacked rows)
                 self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)
                 ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)  # q and k, all samples
                 ops.attention(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :], H, out=ws.att, batch=B)

@@ -68,6 +68,14 @@ int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const float* bias, 
                       int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k,
                       long long a_seg_stride, hipStream_t stream);
 
+/* ... with BOTH operands K-segmented (w_seg_k, w_seg_stride as for A).  seg_k = 64 and ld = 64 is the K-slab-major packing
+ * [K/64][rows][64]: every 16 KiB half-tile the 256-tile kernel streams by LDS-DMA is then ONE contiguous block (measured
+ * L2->LDS stream rate 21.7 vs 18.3 TB/s for the row-strided form, profiles/r02_l2_pattern_probe.txt).  Segmented W needs the
+ * 256-tile kernel (K % 128 == 0), else CE_ERR_SHAPE. */
+int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res,
+                     int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride,
+                     int w_seg_k, long long w_seg_stride, hipStream_t stream);
+
 /* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default), 0 force the 128x128
  * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows.  Host-side test/bench knob. */
 int ce_set_gemm_variant(int variant);
@@ -202,6 +210,28 @@ int ce_ln_affine_fp8(const void* x, void* q, float* scale, const float* a, const
 int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias, int epilogue,
                 const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                 hipStream_t stream);
+
+/* ---- MXFP8 self-attention of the fp8 mode ("fp8 weights+attn", BASELINE.json configs[4]).  Contract (csrc/ce_attn_fp8.hip,
+ * oracle/dit_oracle.py::attention_mxfp8): Q, K quantised to OCP MXFP8 - e4m3 elements, one E8M0 scale per 32 head channels - V per
+ * 32 keys, products on v_mfma_scale_f32_32x32x64_f8f6f4, P = exp2((S - max) c + 8) in e4m3, fp32 accumulation; replaces
+ * F.scaled_dot_product_attention at transformer_chronoedit.py:91-104 in that mode. ---- */
+
+/* ce_rmsnorm_rope_bf16 that writes MXFP8 instead of bf16: q8 [M][ldq8] e4m3 bytes, scale8 [M][D/32] E8M0 bytes (x is not modified).
+ * transformer_chronoedit.py:62-65,73-79. */
+int ce_rmsnorm_rope_mxfp8(const void* x, const float* w, const float* cos_sin, void* q8, void* scale8, int M, int D, int ldx, int ldq8,
+                          int head_dim, float eps, int rope_rows, hipStream_t stream);
+
+/* V [batch * n_tokens][ldv] bf16 (head h = columns 128 h ..) -> V^T tiles v8t [batch][H][128][npad] e4m3 bytes + sv
+ * [batch][H][npad/64][128][2] E8M0 bytes (npad = n_tokens rounded up to 64, zero keys at the end).  Inside every 64-key tile position
+ * 32 g + j holds key 32 (j >> 4) + (j & 3) + 8 ((j & 15) >> 2) + 4 g - the order of the P operand in the matrix unit's accumulator
+ * registers; one scale per 32 CONSECUTIVE keys (sv[..][t][d][beta] covers keys 64 t + 32 beta .. of channel d). */
+int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv, int n_tokens, int batch, int H, int npad, hipStream_t stream);
+
+/* O [batch * Nq][ldo] bf16 = attention over the operands above (q8 / k8 row strides in bytes, head h at byte column 128 h; sq / sk
+ * [rows][H * 4]); head_dim == 128. */
+int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O, int Nq,
+                       int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, float softmax_scale, int batch,
+                       hipStream_t stream);
 
 /* ---- conditioning encoders (run once per edit, outside the loop: pipeline_chronoedit.py:205-254; the arithmetic is
  * transformers==4.57.1 CLIPVisionModel / UMT5EncoderModel, restated in oracle/clip_oracle.py, oracle/umt5_oracle.py) ---- */

@@ -249,14 +249,59 @@ def linear_fp8(x, p, name):
     return F.linear(fake_quant_rows_fp8(x), fake_quant_rows_fp8(p[name + ".weight"]), p[name + ".bias"])
 
 
+def mx_quant(x: torch.Tensor, dim: int = -1, block_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """OCP MXFP8 (e4m3 elements, one E8M0 scale per 32 elements along `dim`), returned de-quantised in fp32: the contract of
+    chronoedit_amd/csrc/ce_attn_fp8.hip.  scale = 2^(floor(log2 amax) - 8) (2^-126 for an all-zero block), elements =
+    RNE(x / scale) clamped to +-448.  block_index (optional, [size of dim] long): block id of every element along `dim` when the
+    32-element blocks are not the contiguous ones (the V operand: see attention_mxfp8)."""
+    xf = x.float().movedim(dim, -1)
+    n = xf.shape[-1]
+    if block_index is None:
+        block_index = torch.arange(n) // 32
+    nb = int(block_index.max()) + 1
+    amax = torch.zeros(xf.shape[:-1] + (nb,), dtype=torch.float32)
+    amax = amax.index_reduce(-1, block_index, xf.abs(), "amax", include_self=True)
+    e = torch.floor(torch.log2(torch.clamp(amax, min=2.0 ** -118))) - 8.0
+    e = torch.where(amax > 0, torch.clamp(e, min=-126.0), torch.full_like(e, -126.0))
+    scale = torch.exp2(e).index_select(-1, block_index)
+    q = torch.clamp(xf / scale, -448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+    return q.movedim(-1, dim)
+
+
+def attention_mxfp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """[B, H, N, 128] q / k (normalised, rotated) and v -> softmax(q k^T / sqrt(128)) v under the MXFP8 contract of ce_attn_fp8.hip:
+    q and k quantised in blocks of 32 consecutive head channels, v in blocks of 32 consecutive KEYS, exact fp32 products; online softmax over 64-key tiles: P = exp2((S - running max) c + 8) rounded to e4m3 (unit scale; P <= 256),
+    O and the fp32 sum of the un-rounded P rescaled by exp2((old max - new max) c) when the maximum moves; O / l at the end.
+    The reference has no fp8 path (transformer_chronoedit.py:91-104 is plain SDPA): this IS the definition."""
+    B, H, N, hd = q.shape
+    Nk = k.shape[2]
+    qq, kq = mx_quant(q, -1), mx_quant(k, -1)
+    vq = mx_quant(v, 2)
+    c = hd ** -0.5 * 1.4426950408889634
+    m = torch.full((B, H, N, 1), -1.0e30)
+    l = torch.zeros((B, H, N, 1))
+    o = torch.zeros((B, H, N, hd))
+    for t0 in range(0, Nk, 64):
+        s = qq @ kq[:, :, t0:t0 + 64].transpose(-1, -2)
+        m_new = torch.maximum(m, s.amax(-1, keepdim=True))
+        alpha = torch.exp2((m - m_new) * c)
+        pr = torch.exp2(s * c - (m_new * c - 8.0))
+        o = o * alpha + pr.to(torch.float8_e4m3fn).float() @ vq[:, :, t0:t0 + 64]
+        l = l * alpha + pr.sum(-1, keepdim=True)
+        m = m_new
+    return (o / l).to(q.dtype)
+
+
 # --------------------------------------------------------------------------------------
 # the modules of transformer_chronoedit.py
 # --------------------------------------------------------------------------------------
 
 
-def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=None, fp8=False):
+def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=None, fp8=False, fp8_attn=False):
     """ChronoEditAttnProcessor2_0.__call__ (transformer_chronoedit.py:43-108).  fp8: the projections that chronoedit_amd runs on
-    the fp8 path (q, the self-attention k / v, the output projection) follow linear_fp8; the context k / v stay as they are."""
+    the fp8 path (q, the self-attention k / v, the output projection) follow linear_fp8; the context k / v stay as they are.
+    fp8_attn: the SELF-attention product under the MXFP8 contract (attention_mxfp8); cross-attention stays SDPA."""
+    self_attn = encoder is None
     H = cfg.num_attention_heads
     lin_q = linear_fp8 if fp8 else linear
     lin_kv = linear_fp8 if (fp8 and encoder is None) else linear
@@ -288,7 +333,7 @@ def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=No
         v_img = v_img.unflatten(2, (H, -1)).transpose(1, 2)
         out_img = F.scaled_dot_product_attention(q, k_img, v_img)
         out_img = out_img.transpose(1, 2).flatten(2, 3).type_as(q)
-    out = F.scaled_dot_product_attention(q, k, v)
+    out = attention_mxfp8(q, k, v) if (fp8_attn and self_attn) else F.scaled_dot_product_attention(q, k, v)
     out = out.transpose(1, 2).flatten(2, 3).type_as(q)
     if out_img is not None:
         out = out + out_img
@@ -306,14 +351,14 @@ def feed_forward(p, pre, x, approximate: str, fp8=False):
     return lin(h, p, pre + ".net.2")
 
 
-def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=None, fp8=False):
+def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=None, fp8=False, fp8_attn=False):
     """ChronoEditTransformerBlock.forward (transformer_chronoedit.py:267-295)."""
     b = f"blocks.{i}"
     shift, scale, gate, c_shift, c_scale, c_gate = (p[b + ".scale_shift_table"] + temb6.float()).chunk(6, dim=1)
     h = (fp32_layer_norm(x.float(), None, None, cfg.eps) * (1 + scale) + shift).type_as(x)
     if taps is not None:
         taps[b + ".ln1"] = h
-    a = attention(p, b + ".attn1", cfg, h, None, rotary, taps, fp8=fp8)
+    a = attention(p, b + ".attn1", cfg, h, None, rotary, taps, fp8=fp8, fp8_attn=fp8_attn)
     x = (x.float() + a * gate).type_as(x)
     if taps is not None:
         taps[b + ".x_after_attn1"] = x
@@ -360,9 +405,10 @@ def dit_forward(
     encoder_hidden_states_image: Optional[torch.Tensor] = None,
     taps: Optional[dict] = None,
     fp8: bool = False,
+    fp8_attn: bool = False,
 ) -> torch.Tensor:
     """ChronoEditTransformer3DModel.forward (transformer_chronoedit.py:397-476).  fp8=True restates chronoedit_amd's fp8 GEMM mode
-    (the six large Linears of every block under linear_fp8; everything else unchanged)."""
+    (the six large Linears of every block under linear_fp8; everything else unchanged); fp8_attn=True its MXFP8 self-attention."""
     B, C, T, Hh, Ww = hidden_states.shape
     pt, ph, pw = cfg.patch_size
     ppf, pph, ppw = T // pt, Hh // ph, Ww // pw
@@ -380,7 +426,7 @@ def dit_forward(
     if taps is not None:
         taps["temb"], taps["tproj"], taps["enc"] = temb, tproj, enc
     for i in range(cfg.num_layers):
-        x = block_forward(p, i, cfg, x, enc, tproj, rotary, taps, fp8=fp8)
+        x = block_forward(p, i, cfg, x, enc, tproj, rotary, taps, fp8=fp8, fp8_attn=fp8_attn)
         if taps is not None:
             taps[f"blocks.{i}.out"] = x
     shift, scale = (p["scale_shift_table"] + temb.unsqueeze(1)).chunk(2, dim=1)

@@ -160,3 +160,122 @@ def test_edit_end_to_end_fp8_mode_vs_fp8_contract_oracle():
           f"contract vs exact edit (latents) {rel_l2(lat8, lat_x):.3e}")
     assert rel_l2(lat, lat8) < 8e-2 and rel_l2(vid, vid8) < 1e-1
     assert rel_l2(lat, lat_x) < 0.2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MXFP8 self-attention ("fp8 weights+attn" of BASELINE.json configs[4]; contract: oracle.dit_oracle.attention_mxfp8)
+# ---------------------------------------------------------------------------------------------------------------------
+def _dequant(q8: torch.Tensor, s8: torch.Tensor, axis_blocks_last: bool = True) -> torch.Tensor:
+    """e4m3 bytes [.., n] + E8M0 bytes [.., n/32] -> fp32."""
+    x = q8.view(torch.float8_e4m3fn).float()
+    sc = torch.exp2(s8.float() - 127.0).repeat_interleave(32, dim=-1)
+    return x * sc
+
+
+@pytest.mark.parametrize("M,H,rope", [(70, 2, True), (130, 40, True), (64, 4, False)])
+def test_mxfp8_qk_producer_matches_contract(M, H, rope):
+    """ce_rmsnorm_rope_mxfp8 == MX-quantise(what ce_rmsnorm_rope_bf16 stores), bit for bit (RNE on both sides)."""
+    from chronoedit_amd import ops
+    from oracle import dit_oracle as O
+    D = H * 128
+    g = torch.Generator().manual_seed(31)
+    buf = torch.randn(M, 3 * D, generator=g).to(torch.bfloat16).cuda()
+    w = (1 + 0.05 * torch.randn(D, generator=g)).cuda()
+    cs = None
+    if rope:
+        ang = torch.rand(M, 64, generator=g, dtype=torch.float64) * 6.28
+        cs = torch.stack([ang.cos(), ang.sin()], -1).float().cuda()
+    q8, s8 = ops.rmsnorm_rope_mxfp8(buf[:, D:2 * D], w, cs, 128, 1e-6)
+    ref = buf.clone()
+    ops.rmsnorm_rope_(ref[:, D:2 * D], w, cs, 128, 1e-6)
+    want = O.mx_quant(ref[:, D:2 * D].float().cpu(), -1)
+    got = _dequant(q8.cpu(), s8.cpu())
+    assert torch.equal(got, want), (got - want).abs().max()
+    assert torch.equal(buf, torch.randn(M, 3 * D, generator=torch.Generator().manual_seed(31)).to(torch.bfloat16).cuda())  # source untouched
+
+
+@pytest.mark.parametrize("N,H,B", [(64, 2, 1), (200, 4, 2), (7200 // 8, 2, 1)])
+def test_mxfp8_v_transpose_matches_contract(N, H, B):
+    """ce_v_mxfp8_transpose: de-quantised and un-permuted it equals MX-quantise(V) over blocks of 32 consecutive keys; the key
+    order inside a 64-key tile is the accumulator-register order of the attention kernel; padded keys are zero."""
+    from chronoedit_amd import ops
+    from oracle import dit_oracle as O
+    D = H * 128
+    g = torch.Generator().manual_seed(32)
+    buf = (torch.randn(B * N, 3 * D, generator=g) * 1.7).to(torch.bfloat16).cuda()
+    v8t, sv = ops.v_mxfp8_transpose(buf[:, 2 * D:], N, B, H)
+    npad = v8t.shape[-1]
+    assert npad == (N + 63) // 64 * 64 and sv.shape == (B, H, npad // 64, 128, 2)
+    pos = torch.arange(npad)
+    tile, p = pos // 64, pos % 64
+    gsel, j = p // 32, p % 32
+    key = tile * 64 + 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * gsel  # key stored at position pos
+    vt = torch.zeros(B, H, 128, npad)
+    vt[..., key] = v8t.cpu().view(torch.float8_e4m3fn).float()                   # elements back in key order
+    svk = sv.cpu().permute(0, 1, 3, 2, 4).reshape(B, H, 128, npad // 32)         # [.., d, 32-key block]
+    vt = vt * torch.exp2(svk.float() - 127.0).repeat_interleave(32, dim=-1)       # scale of 32 consecutive keys
+    v = buf[:, 2 * D:].float().cpu().view(B, N, H, 128).permute(0, 2, 1, 3)  # [B, H, N, 128]
+    vp = torch.zeros(B, H, npad, 128)
+    vp[:, :, :N] = v
+    want = O.mx_quant(vp, 2).permute(0, 1, 3, 2)  # blocks of 32 consecutive keys
+    assert torch.equal(vt, want), (vt - want).abs().max()
+
+
+@pytest.mark.parametrize("N,H,B,spread", [(64, 2, 1, 1.0), (200, 2, 1, 1.0), (333, 4, 2, 1.0), (1000, 2, 1, 3.0)])
+def test_mxfp8_attention_kernel_vs_contract(N, H, B, spread):
+    """The three kernels together vs oracle.attention_mxfp8 (same quantisation, same online order): rel-L2 <= 1e-2 (what differs is
+    the fp32 summation order and exp2 at the last ulp, which can flip individual e4m3 roundings of P); the contract's own distance
+    from exact fp32 attention is printed beside it."""
+    from chronoedit_amd import ops
+    from oracle import dit_oracle as O
+    D = H * 128
+    g = torch.Generator().manual_seed(33)
+    qkv = torch.randn(B * N, 3 * D, generator=g)
+    qkv[:, :2 * D] *= spread ** 0.5  # spread > 1: peakier softmax (forces running-max updates and rescales)
+    qkv = qkv.to(torch.bfloat16)
+    one = torch.ones(D).cuda()
+    dev = qkv.cuda()
+    q8, sq = ops.rmsnorm_rope_mxfp8(dev[:, :D], one, None, 128, 1e-6)
+    k8, sk = ops.rmsnorm_rope_mxfp8(dev[:, D:2 * D], one, None, 128, 1e-6)
+    v8t, sv = ops.v_mxfp8_transpose(dev[:, 2 * D:], N, B, H)
+    out = ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, batch=B).float().cpu()
+    # the oracle on the same normalised q / k (weight 1, no rope)
+    ref_in = dev.clone()
+    ops.rmsnorm_rope_(ref_in[:, :D], one, None, 128, 1e-6, x2=ref_in[:, D:2 * D], w2=one)
+    f = lambda t: t.float().cpu().view(B, N, H, 128).permute(0, 2, 1, 3)
+    q, k, v = f(ref_in[:, :D]), f(ref_in[:, D:2 * D]), f(ref_in[:, 2 * D:])
+    want = O.attention_mxfp8(q, k, v).permute(0, 2, 1, 3).reshape(B * N, D)
+    exact = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(B * N, D)
+    e_k, e_c = rel_l2(out, want), rel_l2(want, exact)
+    print(f"mxfp8 attention N={N} H={H} B={B} spread={spread}: kernel vs contract {e_k:.3e}; contract vs exact fp32 {e_c:.3e}")
+    assert torch.isfinite(out).all() and e_k < 1e-2
+
+
+def test_dit_forward_with_mxfp8_attention_vs_contract_oracle():
+    """fp8 GEMMs + MXFP8 self-attention (bench.py --fp8) through the whole DiT: vs the oracle restating both contracts (<= 2.5e-2), and
+    the mode's distance from exact fp32 bounded against the bf16 path's as SURVEY section 8c prescribes (<= 10 x the bf16 error)."""
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from oracle import dit_oracle as O
+    cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=4, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    p = O.make_synthetic_params(cfg, dtype=torch.bfloat16)
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 16, 24, dtype=torch.bfloat16, text_len=40, real_text=8)
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=4, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in p.items()})
+    ts = torch.tensor([500], device="cuda:0")
+    args = (lat.cuda(), ts, text.cuda(), image.cuda())
+    out_bf16 = m(*args).sample.float().cpu()
+    m.enable_fp8_gemms().enable_fp8_attention()
+    out_fp8 = m(*args).sample.float().cpu()
+    m.enable_fp8_gemms(False)
+    out_attn_only = m(*args).sample.float().cpu()
+    pf = {k: v.float() for k, v in p.items()}
+    with torch.no_grad():
+        a32 = (lat.float(), torch.tensor([500]), text.float(), image.float())
+        exact = O.dit_forward(pf, cfg, *a32)
+        contract = O.dit_forward(pf, cfg, *a32, fp8=True, fp8_attn=True)
+    e_bf16, e_fp8, e_attn = rel_l2(out_bf16, exact), rel_l2(out_fp8, exact), rel_l2(out_attn_only, exact)
+    e_contract = rel_l2(out_fp8, contract)
+    print(f"DiT 4 blocks: bf16 path vs exact {e_bf16:.3e} | fp8 GEMMs + MXFP8 attention vs exact {e_fp8:.3e} (attention only: {e_attn:.3e}) | "
+          f"vs the fp8 contract oracle {e_contract:.3e}")
+    assert e_contract < 2.5e-2 and e_fp8 < 10 * e_bf16 + 1e-2
