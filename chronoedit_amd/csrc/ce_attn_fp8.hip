@@ -19,11 +19,14 @@
 //                               no transposes in the loop), three stages, ONE barrier per 64-key tile; per tile and wave
 //                               4 + 4 MFMAs of 32x32x64 (half the matrix-pipe time of the bf16 kernel) and 16 ds_read_b128.
 // Bound: MX-fp8 MFMA (5 PFLOP/s dense); algorithmic flops = 4 * Nq * Nkv * 128 per head.
+#include <type_traits>
+
 #include "ce_common.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -45,7 +48,7 @@ template <bool FULL>
 __global__ __launch_bounds__(256) void rmsnorm_rope_mxfp8_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ cs, unsigned char* __restrict__ q8,
                                                                  unsigned char* __restrict__ sc, int M, int D, int ldx, int ldq,
-                                                                 int head_dim, float eps, int rope_rows) {
+                                                                 int head_dim, float eps, int rope_rows, float post_scale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -96,8 +99,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_mxfp8_kernel(const bf16* __r
           v0 = r0;
           v1 = r1;
         }
-        v[2 * j] = round_bf16(v0);      // the value the bf16 path would have stored
-        v[2 * j + 1] = round_bf16(v1);
+        // the value the bf16 path would have stored, times post_scale (q: softmax_scale * log2 e, so that Q.K^T comes out of the
+        // matrix pipe in the exp2 domain and P is a bare v_exp_f32 per element; k: 1)
+        v[2 * j] = round_bf16(v0) * post_scale;
+        v[2 * j + 1] = round_bf16(v1) * post_scale;
         amax = fmaxf(amax, fmaxf(fabsf(v[2 * j]), fabsf(v[2 * j + 1])));
       }
     }
@@ -144,16 +149,22 @@ __global__ __launch_bounds__(256) void v_mxfp8_transpose_kernel(const bf16* __re
   __syncthreads();
   const int d = tid & 127, g = tid >> 7;
   // MX blocks of V are 32 CONSECUTIVE keys: in the P operand bytes 0-15 of both lane halves are keys 0-31 of the tile and bytes
-  // 16-31 are keys 32-63 (slot_key), and the matrix unit takes the scale of byte half beta from lane (d, beta).
-  float col[KVB];
+  // 16-31 are keys 32-63 (slot_key), and the matrix unit takes the scale of byte half beta from lane (d, beta).  Thread (d, g)
+  // holds the 32 keys of its lane half - 16 of each block - and meets its partner (d, 1 - g) through LDS for the block maxima.
+  __shared__ float amx[2][2][HD];  // [lane half][key block][d]
+  float v[32];
   float am0 = 0.f, am1 = 0.f;
 #pragma unroll
-  for (int kk = 0; kk < 32; ++kk) {
-    col[kk] = (float)*reinterpret_cast<const bf16*>(tile + kk * (HD * 2) + d * 2);
-    col[32 + kk] = (float)*reinterpret_cast<const bf16*>(tile + (32 + kk) * (HD * 2) + d * 2);
-    am0 = fmaxf(am0, fabsf(col[kk]));
-    am1 = fmaxf(am1, fabsf(col[32 + kk]));
+  for (int j = 0; j < 32; ++j) {
+    v[j] = (float)*reinterpret_cast<const bf16*>(tile + slot_key(g, j) * (HD * 2) + d * 2);
+    if (j < 16) am0 = fmaxf(am0, fabsf(v[j]));
+    else am1 = fmaxf(am1, fabsf(v[j]));
   }
+  amx[g][0][d] = am0;
+  amx[g][1][d] = am1;
+  __syncthreads();
+  am0 = fmaxf(am0, amx[1 - g][0][d]);
+  am1 = fmaxf(am1, amx[1 - g][1][d]);
   const int byte0 = mx_scale_byte(am0), byte1 = mx_scale_byte(am1);
   const float inv0 = mx_inv_scale(byte0), inv1 = mx_inv_scale(byte1);
   const int byte = g ? byte1 : byte0;  // this thread stores the scale of key block g
@@ -162,8 +173,8 @@ __global__ __launch_bounds__(256) void v_mxfp8_transpose_kernel(const bf16* __re
   for (int i = 0; i < 8; ++i) {
     const float inv = i < 4 ? inv0 : inv1;  // positions j = 4 i .. 4 i + 3: j < 16 are keys of block 0, j >= 16 of block 1
     int wv = 0;
-    wv = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(col[slot_key(g, 4 * i)] * inv), clamp448(col[slot_key(g, 4 * i + 1)] * inv), wv, false);
-    wv = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(col[slot_key(g, 4 * i + 2)] * inv), clamp448(col[slot_key(g, 4 * i + 3)] * inv), wv, true);
+    wv = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[4 * i] * inv), clamp448(v[4 * i + 1] * inv), wv, false);
+    wv = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[4 * i + 2] * inv), clamp448(v[4 * i + 3] * inv), wv, true);
     o[i] = (uint32_t)wv;
   }
   const size_t rowi = ((size_t)b * H + h) * HD + d;
@@ -189,8 +200,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_kernel(const unsigned c
                                                                const unsigned char* __restrict__ K8, const unsigned char* __restrict__ SK,
                                                                const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ SV,
                                                                bf16* __restrict__ O, int Nq, int Nkv, int npad, int H, int ldq8,
-                                                               int ldk8, int ldo, int nqb, float scale_log2e) {
+                                                               int ldk8, int ldo, int nqb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr float scale_log2e = 1.0f;  // q arrives multiplied by softmax_scale * log2(e) (producer): S is in the exp2 domain
   const int D32 = (H * HD) >> 5;  // scale bytes per row of q / k
   {
     const size_t bz = blockIdx.y;
@@ -376,18 +388,751 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_kernel(const unsigned c
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined form (default).  The plain kernel above spends ~3000 cycles per 64-key tile and SIMD for 1024 cycles of
+// matrix work: after halving the MFMA time the loop is VALU-bound (max, fma, exp2, sum, convert: ~180 VALU instructions per wave
+// and tile) and nothing of it overlaps.  Here, per iteration and wave (the recipe of attn_fwd_sp_kernel in ce_attn.hip, adapted):
+//     vmcnt / barrier / LDS-DMA of tile t+2
+//   | S(t) = K(t).Q^T : 4 MFMAs whose accumulators START at -mc (the offset in use), so S arrives as "score - mc" in the exp2
+//     domain (q is pre-multiplied by softmax_scale * log2 e by the producer) and P = exp2(S) is ONE v_exp_f32 per element;
+//   | O += V^T(t-1).P^T(t-1) : 4 MFMAs, each followed by the v_exp and the e4m3 conversion of 8 elements of P(t) and the fetch of a
+//     K(t+1) fragment;  then ONE more MFMA, ones.P(t), leaves the row sums of the rounded P(t) in every lane;
+//   | speculative offset: no row maximum and no row-sum adds on the common path.  mc is set from the exact row maximum of tile 0 so
+//     that P <= 2^3 there; later tiles are exponentiated against the same offset.  An element that outgrows e4m3 converts to NaN,
+//     the NaN reaches the row sums, and one compare at the top of the next iteration sends that wave through the exact route:
+//     S(t) again from the K tile still in LDS, offset moved to the true maximum, O and l rescaled, P(t) and its sums redone.
+//     Nothing of a failed attempt survives (P(t) meets V(t) only in the next iteration, after the check).
+// Five stages (LDS-DMA three tiles ahead; tile t-1 is still read while tile t+3 lands), one barrier per tile.
+// ------------------------------------------------------------------------------------------------
+constexpr int NSTAGE_SP = 5;
+
+// acc += A.B as an asm statement: written with the builtin, hipcc SANK the four P.V MFMAs of a tile below the speculation check
+// (their results are not needed until the next iteration), behind all of the softmax VALU work they are meant to run beside.
+// A volatile asm stays where it is written.  "s_nop 1": a VALU-written scale register needs two wait states in front of the
+// MFMA that reads it, and nothing inside an asm statement is padded by the compiler (cdna guide 5.7).
+// the same with the accumulator in the ACCUMULATOR half of the register file ("a" constraint): the one-wave-per-SIMD kernel keeps O
+// and the row sums there so that the S accumulators, which the VALU reads, get arch VGPRs (with "v" here hipcc did the opposite
+// and moved 170 registers per tile between the two halves)
+__device__ __forceinline__ void mfma_scale_acc_pinned_agpr(f32x16& acc, const i32x8& a, const i32x8& b, int sa, int sb) {
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+// S accumulators in ARCH VGPRs ("v"): the VALU reads them (v_exp_f32), and left to itself hipcc gives MFMA results of a 512-register
+// kernel accumulator registers, one v_accvgpr_read per element away from the VALU.  The reader must keep 18 wait states from the
+// last of these (cdna guide 5.7: nothing is padded around an asm statement).
+// (the B operand - the loop-invariant Q fragments - sits in the accumulator half ("a"): an MFMA reads it from there directly)
+__device__ __forceinline__ void mfma_scale_zero_v(f32x16& d, const i32x8& a, const i32x8& b, int sa, int sb) {
+  asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(d) : "v"(a), "a"(b), "v"(sa), "v"(sb));
+}
+__device__ __forceinline__ void mfma_scale_acc_v(f32x16& d, const i32x8& a, const i32x8& b, int sa, int sb) {
+  asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(a), "a"(b), "v"(sa), "v"(sb));
+}
+__device__ __forceinline__ void mfma_scale_acc_pinned(f32x16& acc, const i32x8& a, const i32x8& b, int sa, int sb) {
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+}
+constexpr int SMEM_SP = NSTAGE_SP * STAGE > 8 * QW * OST_ROW ? NSTAGE_SP * STAGE : 8 * QW * OST_ROW;
+constexpr float P_OFF = 3.0f;  // P = exp2(score - rowmax + 3) <= 8 when the offset is the row maximum: 5.8 octaves of headroom to 464
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ SQ,
+                                                                  const unsigned char* __restrict__ K8, const unsigned char* __restrict__ SK,
+                                                                  const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ SV,
+                                                                  bf16* __restrict__ O, int Nq, int Nkv, int npad, int H, int ldq8,
+                                                                  int ldk8, int ldo, int nqb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D32 = (H * HD) >> 5;
+  {
+    const size_t bz = blockIdx.y;
+    Q8 += bz * Nq * ldq8;
+    SQ += bz * Nq * D32;
+    K8 += bz * Nkv * ldk8;
+    SK += bz * Nkv * D32;
+    V8T += bz * H * HD * npad;
+    SV += bz * H * HD * (npad >> 5);
+    O += bz * Nq * ldo;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * (QW * 8) + wave * QW;
+  const int hoff = head * HD;
+  const int ntiles = (Nkv + KVB - 1) / KVB;
+
+  i32x8 qf[2];
+  int sqv[2];
+  {
+    const int qr = min(q0 + l31, Nq - 1);
+    const unsigned char* qrow = Q8 + (size_t)qr * ldq8 + hoff + 16 * hh;
+    const uint32_t sw = *reinterpret_cast<const uint32_t*>(SQ + (size_t)qr * D32 + head * 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(qrow + 64 * ks), b = *reinterpret_cast<const u32x4*>(qrow + 64 * ks + 32);
+      qf[ks] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      sqv[ks] = (int)((sw >> (16 * ks + 8 * hh)) & 0xffu);
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(sqv[ks]));  // retire the Q loads before the loop
+
+  const int k_row = 8 * wave + (lane >> 3);
+  const int k_chunk = (lane & 7) ^ ((k_row >> 1) & 7);
+  const int v_row = 16 * wave + (lane >> 2);
+  const int v_chunk = (lane & 3) ^ ((v_row >> 2) & 3);
+  const unsigned char* vsrc = V8T + ((size_t)head * HD + v_row) * npad + v_chunk * 16;
+  const unsigned char* svsrc = SV + (size_t)head * (npad >> 6) * 256 + 32 * wave + 4 * (lane & 7);
+  auto stage_tile = [&](int t, int slot) __attribute__((always_inline)) {
+    unsigned char* st = smem + slot * STAGE;
+    const int kr = min(t * KVB + k_row, Nkv - 1);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(K8 + (size_t)kr * ldk8 + hoff + k_chunk * 16), (lds_void*)(st + ST_K + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc + (size_t)t * KVB), (lds_void*)(st + ST_V + wave * 1024), 16, 0, 0);
+    if (lane < 8) {
+      const int sr = min(t * KVB + 8 * wave + lane, Nkv - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(SK + (size_t)sr * D32 + head * 4), (lds_void*)(st + ST_SK + wave * 32), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(svsrc + (size_t)t * 256), (lds_void*)(st + ST_SV + wave * 32), 4, 0, 0);
+    }
+  };
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[m][r] = 0.f;
+  // The offset mc of a row is an INTEGER (exp2 domain): P = exp2(score) / 2^mc is then one v_exp_f32 and the scaled conversion
+  // v_cvt_scalef32_pk_fp8_f32 (divides by the power of two of its scale operand: tools/probes/fp8_cvt_scale_probe.hip) - no subtract,
+  // no accumulator-initialisation registers, and every rescale of O / l is an exact power of two.
+  float l_run = 0.f, mc = 0.f, pscale = 1.0f;  // pscale = 2^mc
+  i32x8 pf = {0, 0, 0, 0, 0, 0, 0, 0};         // P(t-1) as e4m3 bytes in k-slot order
+
+  // per-lane LDS read offsets inside a stage (all per-tile addresses are these + the stage base + immediates)
+  const int k_sw = (l31 >> 1) & 7;   // rows 32 f + l31: (row >> 1) & 7 does not depend on f
+  const int k_off = ST_K + l31 * 128, sk_off = ST_SK + l31 * 4;
+  const int v_sw = (l31 >> 2) & 3;   // rows 32 m + l31
+  const int v_off = ST_V + l31 * 64 + (((2 * hh) ^ v_sw) << 4), v_off2 = ST_V + l31 * 64 + (((2 * hh + 1) ^ v_sw) << 4);
+  const int sv_off = ST_SV + l31 * 2;
+
+  // fragment fetches (two ds_read_b128 + the block-scale byte each); K rows / V rows of all fragments share one per-lane base
+  auto load_k = [&](const unsigned char* st, int i, i32x8& frag, int& sc) __attribute__((always_inline)) {  // fragment i: key half f = i >> 1, k-step ks = i & 1
+    const int f = i >> 1, ks = i & 1;
+    const unsigned char* krow = st + k_off + f * 32 * 128;
+    const int c0 = 4 * ks + hh;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(krow + ((c0 ^ k_sw) << 4)), b = *reinterpret_cast<const u32x4*>(krow + (((c0 + 2) ^ k_sw) << 4));
+    frag = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    sc = (int)((*reinterpret_cast<const uint32_t*>(st + sk_off + f * 32 * 4) >> (16 * ks + 8 * hh)) & 0xffu);
+  };
+  auto load_v = [&](const unsigned char* st, int m, i32x8& frag, int& sc) __attribute__((always_inline)) {
+    const unsigned char* vb = st + m * 32 * 64;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(vb + v_off), b = *reinterpret_cast<const u32x4*>(vb + v_off2);
+    frag = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    sc = (int)((*reinterpret_cast<const uint16_t*>(st + sv_off + m * 64) >> (8 * hh)) & 0xffu);
+  };
+
+  // LDS-DMA runs THREE tiles ahead (five stages): at the barrier of iteration t tile t+1 is already complete, so its K fragments
+  // can be fetched under the P.V MFMAs of iteration t and the S MFMAs of iteration t+1 start straight after the barrier
+  // (with fragments fetched right in front of their MFMA every one of the eight MFMAs of a tile waited a full LDS round trip:
+  // ~2800 cycles per tile and SIMD for 1024 cycles of matrix work).
+  stage_tile(0, 0);
+  stage_tile(min(1, ntiles - 1), 1);
+  stage_tile(min(2, ntiles - 1), 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  i32x8 kf[4], vf[4];
+  int ksc[4], vsc[4];
+  int unit_scale = 0x7f;  // E8M0 2^0 for the P operand
+  asm volatile("" : "+v"(unit_scale));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    load_k(smem, i, kf[i], ksc[i]);
+    vf[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    vsc[i] = 0x7f;
+  }
+  // Row sums on the matrix pipe: a ones operand against P (e4m3) gives every lane its full row sum of the ROUNDED P - and a NaN
+  // if any element of the tile overflowed e4m3 (the conversion returns NaN above 464: tools/probes/fp8_cvt_probe.hip), which is the
+  // speculation check: one MFMA + one compare per tile instead of 32 adds per lane beside MFMAs that cannot hide them.
+  i32x8 ones;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) ones[w] = 0x38383838;  // e4m3 1.0
+  asm volatile("" : "+v"(ones));
+  f32x16 lsum;  // row sums of P(t-1), all 16 registers equal
+#pragma unroll
+  for (int r = 0; r < 16; ++r) lsum[r] = 0.f;
+
+  auto mask_tail = [&](f32x16 (&sacc)[2], int t) __attribute__((always_inline)) {
+    if ((t + 1) * KVB > Nkv) {
+      const int base = t * KVB + 4 * hh;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (base + 32 * f + (r & 3) + 8 * (r >> 2) >= Nkv) sacc[f][r] = NEG_BIG;
+    }
+  };
+  // exact tile maximum of the row (lane ^ 32 holds the other half of the keys): raise the offset so that P <= 2^P_OFF; returns the
+  // (power-of-two) factor that brings quantities at the old offset to the new one
+  auto rebase = [&](const f32x16 (&sacc)[2], bool first) __attribute__((always_inline)) -> float {
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[f][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float want = ceilf(mx - P_OFF);
+    const float mc_new = first ? want : fmaxf(mc, want);  // the offset only ever rises after the first tile
+    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(mc - mc_new);
+    mc = mc_new;
+    pscale = __builtin_amdgcn_exp2f(mc);
+    return alpha;
+  };
+  auto softmax_part = [&](const f32x16 (&sacc)[2], int m, i32x8& dst) __attribute__((always_inline)) {  // elements 8 m .. 8 m + 7 of the lane's 32 scores
+    float p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sacc[m >> 1][8 * (m & 1) + i]);
+    s16x2 w0 = {0, 0}, w1 = {0, 0};
+    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, p[0], p[1], pscale, false);
+    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, p[2], p[3], pscale, true);
+    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, p[4], p[5], pscale, false);
+    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, p[6], p[7], pscale, true);
+    dst[2 * m] = __builtin_bit_cast(int, w0);
+    dst[2 * m + 1] = __builtin_bit_cast(int, w1);
+  };
+  // repair of tile tt (its K tile is still in LDS): S again, true row maximum, offset raised, O and l brought to the new offset,
+  // P (exp2 of the score minus the offset: no fp32 overflow whatever the score) and its row sums redone
+  auto exact_tile = [&](int tt) __attribute__((always_inline)) {
+    const unsigned char* st = smem + (tt % NSTAGE_SP) * STAGE;
+    f32x16 sacc[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = i >> 1, ks = i & 1;
+      i32x8 kt;
+      int sc;
+      load_k(st, i, kt, sc);
+      f32x16 zero16;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+      sacc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kt, qf[ks], ks == 0 ? zero16 : sacc[f], 0, 0, 0, sc, 0, sqv[ks]);
+    }
+    mask_tail(sacc, tt);
+    const float alpha = rebase(sacc, false);
+    l_run *= alpha;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha;
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float p[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sacc[m >> 1][8 * (m & 1) + i] - mc);
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(p[4], p[5], w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(p[6], p[7], w1, true);
+      pf[2 * m] = w0;
+      pf[2 * m + 1] = w1;
+    }
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    lsum = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf, zero16, 0, 0, 0, unit_scale, 0, unit_scale);
+    (void)sum;
+  };
+
+  auto tile_top = [&](int t) __attribute__((always_inline)) {
+#if defined(CE_FP8_ABL) && CE_FP8_ABL == 5
+    __builtin_amdgcn_s_barrier();
+#elif defined(CE_FP8_ABL) && CE_FP8_ABL == 7  // no barrier (and no counted wait) in the loop
+    stage_tile(min(t + 3, ntiles - 1), (t + 3) % NSTAGE_SP);
+#else
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wave's pieces of tile t+1 have landed (tile t+2's four stay in flight)
+    __builtin_amdgcn_s_barrier();                     // ... everybody's have; everybody is done with tile t-2's stage
+    stage_tile(min(t + 3, ntiles - 1), (t + 3) % NSTAGE_SP);
+#endif
+  };
+  // FIRST = true (tile 0, peeled): exact offset, no P.V yet - instantiates the body without the matrix work of "tile -1", so the
+  // steady-state loop carries no per-MFMA branch
+  auto tile_rest = [&](int t, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const unsigned char* st_prev = smem + ((t + NSTAGE_SP - 1) % NSTAGE_SP) * STAGE;  // tile t-1
+    const unsigned char* st_next = smem + ((t + 1) % NSTAGE_SP) * STAGE;              // tile t+1
+    if (!FIRST) l_run += lsum[0];
+    // ---- S^T(t) = K(t).Q^T from the fragments fetched one iteration ago.  In the MFMA shadows: the V^T(t-1) fragments of the
+    // second phase.
+    f32x16 sacc[2];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = i >> 1, ks = i & 1;
+#if defined(CE_FP8_ABL) && CE_FP8_ABL == 3
+      if (ks == 0) sacc[f] = zero16;
+      asm volatile("" : "+v"(sacc[f]) : "v"(kf[i]), "v"(ksc[i]));
+#else
+      sacc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[i], qf[ks], ks == 0 ? zero16 : sacc[f], 0, 0, 0, ksc[i], 0, sqv[ks]);
+#endif
+#if defined(CE_FP8_ABL) && CE_FP8_ABL == 4
+      asm volatile("" : "+v"(vf[i]), "+v"(vsc[i]));
+#else
+      if (!FIRST) load_v(st_prev, i, vf[i], vsc[i]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mask_tail(sacc, t);
+    if (FIRST) rebase(sacc, true);
+    // ---- O^T += V^T(t-1).P^T(t-1) on the matrix pipe; in the shadows P(t) = exp2(S(t)) / 2^mc -> e4m3 and the K(t+1) fragments
+    i32x8 pfn;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      // CE_FP8_ABL (tools/attn8_ablate.py only; results are garbage, durations are the point): 1 no exp / convert, 2 no P.V MFMAs,
+      // 3 no S MFMAs, 4 no fragment reads in the loop, 5 no LDS-DMA in the loop, 6 no row-sum MFMA
+#if defined(CE_FP8_ABL) && CE_FP8_ABL == 2
+      asm volatile("" : "+v"(oacc[m]) : "v"(vf[m]), "v"(pf), "v"(vsc[m]));
+#else
+      if (!FIRST) mfma_scale_acc_pinned(oacc[m], vf[m], pf, vsc[m], unit_scale);
+#endif
+#if defined(CE_FP8_ABL) && CE_FP8_ABL == 4
+      asm volatile("" : "+v"(kf[m]), "+v"(ksc[m]));
+#else
+      load_k(st_next, m, kf[m], ksc[m]);
+#endif
+#if defined(CE_FP8_ABL) && CE_FP8_ABL == 1
+      pfn[2 * m] = __float_as_int(sacc[m >> 1][8 * (m & 1)]);
+      pfn[2 * m + 1] = __float_as_int(sacc[m >> 1][8 * (m & 1) + 4]);
+#else
+      softmax_part(sacc, m, pfn);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // row sums of P(t) (rounded) on the matrix pipe, checked at the top of the next iteration
+#if defined(CE_FP8_ABL) && CE_FP8_ABL == 6
+    asm volatile("" : "+v"(lsum) : "v"(pfn));
+#else
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&v"(lsum) : "v"(ones), "v"(pfn), "v"(unit_scale));
+#endif
+    pf = pfn;
+  };
+  tile_top(0);
+  tile_rest(0, std::true_type{});
+  // The steady-state loop leaves through `break` when the speculation check of tile t-1 fails (NaN row sums = an element of P(t-1)
+  // passed the e4m3 range); the repair runs OUTSIDE it and re-enters without repeating the iteration's barrier / DMA issue: as a
+  // branch inside the loop it joined the common path in phi nodes that hipcc resolved with 26 register moves (and a spill reload
+  // behind a vmcnt(0)) per tile.
+  {
+    int t = 1;
+    bool skip_top = false;
+    for (;;) {
+      bool bad = false;
+      for (; t < ntiles; ++t) {
+        if (!skip_top) tile_top(t);
+        skip_top = false;
+        asm volatile("s_nop 7" : "+v"(lsum));  // result of the asm MFMA of the previous iteration (issued a barrier ago); no padding is inserted for asm
+        if (__builtin_expect(__any(lsum[0] != lsum[0]), 0)) {
+          bad = true;
+          break;
+        }
+        tile_rest(t, std::false_type{});
+      }
+      if (!bad) break;
+      exact_tile(t - 1);
+      skip_top = true;
+    }
+  }
+  // ---- drain: check and add the row sums of the last tile, then P(ntiles-1).V(ntiles-1) (its stage became visible at the last
+  // barrier and nothing was staged over it)
+  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lsum));  // the asm MFMA's result: 18 wait states before a VALU may read it (cdna guide 5.7)
+  if (__builtin_expect(__any(lsum[0] != lsum[0]), 0)) exact_tile(ntiles - 1);
+  l_run += lsum[0];
+  {
+    const unsigned char* st_last = smem + ((ntiles - 1) % NSTAGE_SP) * STAGE;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      i32x8 vfl;
+      int scl;
+      load_v(st_last, m, vfl, scl);
+      oacc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vfl, pf, oacc[m], 0, 0, 0, scl, 0, unit_scale);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const float inv = 1.0f / l_run;  // the matrix pipe summed over all 64 k-slots: every lane holds its row's full sum
+  unsigned char* ost = smem + (size_t)(wave * QW + l31) * OST_ROW;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const u32x2 val = {pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv), pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv)};
+      *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = min(q0 + rl, Nq - 1);  // clamped address, predicated store: no per-chunk branch around the LDS read
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+    if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "w4": four waves per workgroup = ONE wave per SIMD, 64 query rows per wave as two 32-row sub-blocks that share every K / V^T
+// fragment.  Ablations of the 8-wave form above (tools/attn8_ablate.py, profiles/r02_attn_mxfp8_ablate_*.txt): the fragment reads
+// are the largest single cost (-23 % without them) and two waves sharing a SIMD contend for its issue slots.  Here a fragment
+// fetched once feeds two MFMAs (LDS read traffic per flop halves), a wave has the SIMD's matrix pipe to itself, and 512 registers:
+// O (128) and the row sums live in the accumulator half of the file, which only MFMAs touch inside the loop.
+// Per tile and wave: 8 + 8 + 2 MFMAs of 64 cycles; 64 v_exp + 32 scaled conversions in their shadows.  Same contract, same staging
+// (five stages, LDS-DMA three tiles ahead, one barrier per tile), same speculation check and repair as the 8-wave form.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_mxfp8_w4_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ SQ,
+                                                               const unsigned char* __restrict__ K8, const unsigned char* __restrict__ SK,
+                                                               const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ SV,
+                                                               bf16* __restrict__ O, int Nq, int Nkv, int npad, int H, int ldq8,
+                                                               int ldk8, int ldo, int nqb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int D32 = (H * HD) >> 5;
+  {
+    const size_t bz = blockIdx.y;
+    Q8 += bz * Nq * ldq8;
+    SQ += bz * Nq * D32;
+    K8 += bz * Nkv * ldk8;
+    SK += bz * Nkv * D32;
+    V8T += bz * H * HD * npad;
+    SV += bz * H * HD * (npad >> 5);
+    O += bz * Nq * ldo;
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  int head, qb;
+  if ((H & 7) == 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    head = xcd + 8 * (local / nqb);
+    qb = local % nqb;
+  } else {
+    head = blockIdx.x / nqb;
+    qb = blockIdx.x % nqb;
+  }
+  const int q0 = qb * 256 + wave * 64;  // this wave's 64 rows: sub-block b = rows q0 + 32 b ..
+  const int hoff = head * HD;
+  const int ntiles = (Nkv + KVB - 1) / KVB;
+
+  i32x8 qf[2][2];  // [sub-block][k-step]
+  int sqv[2][2];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const int qr = min(q0 + 32 * sb + l31, Nq - 1);
+    const unsigned char* qrow = Q8 + (size_t)qr * ldq8 + hoff + 16 * hh;
+    const uint32_t sw = *reinterpret_cast<const uint32_t*>(SQ + (size_t)qr * D32 + head * 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const u32x4 a = *reinterpret_cast<const u32x4*>(qrow + 64 * ks), b = *reinterpret_cast<const u32x4*>(qrow + 64 * ks + 32);
+      qf[sb][ks] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      sqv[sb][ks] = (int)((sw >> (16 * ks + 8 * hh)) & 0xffu);
+    }
+  }
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+a"(qf[sb][ks]), "+v"(sqv[sb][ks]));  // retire the Q loads before the loop; Q lives in the accumulator half
+
+  // LDS-DMA shares of a wave per tile: K pieces wave and wave + 4 (8 rows of 128 B each), V^T pieces wave and wave + 4 (16 rows of
+  // 64 B each), and ONE dword piece with both scale records: lanes 0-15 fetch 16 key rows' scale words, lanes 16-31 sixteen
+  // dwords (32 d rows) of the tile's V scale record - five wave-instructions
+  const int k_row0 = 8 * wave + (lane >> 3);                        // second piece: + 32 rows
+  const int k_chunk = (lane & 7) ^ ((k_row0 >> 1) & 7);             // (row >> 1) & 7 is the same for row and row + 32
+  const int v_row0 = 16 * wave + (lane >> 2);                       // second piece: + 64 rows
+  const int v_chunk = (lane & 3) ^ ((v_row0 >> 2) & 3);
+  const unsigned char* vsrc = V8T + ((size_t)head * HD + v_row0) * npad + v_chunk * 16;
+  const unsigned char* svsrc = SV + (size_t)head * (npad >> 6) * 256 + 64 * wave + 4 * (lane & 15);
+  auto stage_tile = [&](int t, int slot) __attribute__((always_inline)) {
+    unsigned char* st = smem + slot * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kr = min(t * KVB + k_row0 + 32 * j, Nkv - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(K8 + (size_t)kr * ldk8 + hoff + k_chunk * 16), (lds_void*)(st + ST_K + (wave + 4 * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc + (size_t)(64 * j) * npad + (size_t)t * KVB), (lds_void*)(st + ST_V + (wave + 4 * j) * 1024), 16, 0, 0);
+    }
+    if (lane < 32) {
+      const int sr = min(t * KVB + 16 * wave + (lane & 15), Nkv - 1);
+      const unsigned char* src = lane < 16 ? SK + (size_t)sr * D32 + head * 4 : svsrc + (size_t)t * 256;
+      // LDS image per wave: 64 B of key scale words (rows 16 wave ..) then 64 B of the V record (d rows 32 wave ..)
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(st + ST_SK + wave * 128), 4, 0, 0);
+    }
+  };
+  // scale bytes inside a stage: key row r -> ST_SK + (r >> 4) * 128 + (r & 15) * 4; V channel d -> ST_SK + (d >> 5) * 128 + 64 + (d & 31) * 2
+
+  f32x16 oacc[2][4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[sb][m][r] = 0.f;
+  float l_run[2] = {0.f, 0.f}, mc[2] = {0.f, 0.f}, pscale[2] = {1.0f, 1.0f};
+  i32x8 pf[2];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) pf[sb] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int k_sw = (l31 >> 1) & 7;
+  const int k_off = ST_K + l31 * 128;
+  const int sk_off = ST_SK + (l31 >> 4) * 128 + (l31 & 15) * 4;  // rows 32 f + l31: + f * 256
+  const int v_sw = (l31 >> 2) & 3;
+  const int v_off = ST_V + l31 * 64 + (((2 * hh) ^ v_sw) << 4), v_off2 = ST_V + l31 * 64 + (((2 * hh + 1) ^ v_sw) << 4);
+  const int sv_off = ST_SK + 64 + l31 * 2;                       // channels 32 m + l31: + m * 128
+
+  auto load_k = [&](const unsigned char* st, int i, i32x8& frag, int& sc) __attribute__((always_inline)) {
+    const int f = i >> 1, ks = i & 1;
+    const unsigned char* krow = st + k_off + f * 32 * 128;
+    const int c0 = 4 * ks + hh;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(krow + ((c0 ^ k_sw) << 4)), b = *reinterpret_cast<const u32x4*>(krow + (((c0 + 2) ^ k_sw) << 4));
+    frag = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    sc = (int)((*reinterpret_cast<const uint32_t*>(st + sk_off + f * 256) >> (16 * ks + 8 * hh)) & 0xffu);
+  };
+  auto load_v = [&](const unsigned char* st, int m, i32x8& frag, int& sc) __attribute__((always_inline)) {
+    const unsigned char* vb = st + m * 32 * 64;
+    const u32x4 a = *reinterpret_cast<const u32x4*>(vb + v_off), b = *reinterpret_cast<const u32x4*>(vb + v_off2);
+    frag = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    sc = (int)((*reinterpret_cast<const uint16_t*>(st + sv_off + m * 128) >> (8 * hh)) & 0xffu);
+  };
+
+  stage_tile(0, 0);
+  stage_tile(min(1, ntiles - 1), 1);
+  stage_tile(min(2, ntiles - 1), 2);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // ONE set of four fragment registers: fr[i] holds K fragment i of tile t until its two S MFMAs have issued, then V^T fragment i of
+  // tile t-1 until its two P.V MFMAs have issued, then K fragment i of tile t+1 (kept as two arrays the allocator held both sets
+  // live and moved 170 registers per tile through the accumulator file)
+  i32x8 fr[4];
+  int fsc[4];
+  int unit_scale = 0x7f;
+  asm volatile("" : "+v"(unit_scale));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) load_k(smem, i, fr[i], fsc[i]);
+  i32x8 ones;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) ones[w] = 0x38383838;
+  asm volatile("" : "+a"(ones));
+  f32x16 lsum[2];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lsum[sb][r] = 0.f;
+
+  auto mask_tail = [&](f32x16 (&sacc)[2], int t) __attribute__((always_inline)) {
+    if ((t + 1) * KVB > Nkv) {
+      const int base = t * KVB + 4 * hh;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (base + 32 * f + (r & 3) + 8 * (r >> 2) >= Nkv) sacc[f][r] = NEG_BIG;
+    }
+  };
+  auto rebase = [&](const f32x16 (&sacc)[2], int sb, bool first) __attribute__((always_inline)) -> float {
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[f][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float want = ceilf(mx - P_OFF);
+    const float mc_new = first ? want : fmaxf(mc[sb], want);
+    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(mc[sb] - mc_new);
+    mc[sb] = mc_new;
+    pscale[sb] = __builtin_amdgcn_exp2f(mc_new);
+    return alpha;
+  };
+  auto softmax_part = [&](const f32x16 (&sacc)[2], int m, float ps, i32x8& dst) __attribute__((always_inline)) {
+    float p[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sacc[m >> 1][8 * (m & 1) + i]);
+    s16x2 w0 = {0, 0}, w1 = {0, 0};
+    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, p[0], p[1], ps, false);
+    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, p[2], p[3], ps, true);
+    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, p[4], p[5], ps, false);
+    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, p[6], p[7], ps, true);
+    dst[2 * m] = __builtin_bit_cast(int, w0);
+    dst[2 * m + 1] = __builtin_bit_cast(int, w1);
+  };
+  // repair of sub-block sb of tile tt (K tile still in LDS)
+  auto exact_tile = [&](int tt, int sb) __attribute__((always_inline)) {
+    const unsigned char* st = smem + (tt % NSTAGE_SP) * STAGE;
+    f32x16 sacc[2];
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = i >> 1, ks = i & 1;
+      i32x8 kt;
+      int sc;
+      load_k(st, i, kt, sc);
+      sacc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kt, qf[sb][ks], ks == 0 ? zero16 : sacc[f], 0, 0, 0, sc, 0, sqv[sb][ks]);
+    }
+    mask_tail(sacc, tt);
+    const float alpha = rebase(sacc, sb, false);
+    l_run[sb] *= alpha;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float p[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sacc[m >> 1][8 * (m & 1) + i] - mc[sb]);
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(p[4], p[5], w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(p[6], p[7], w1, true);
+      pf[sb][2 * m] = w0;
+      pf[sb][2 * m + 1] = w1;
+    }
+    lsum[sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf[sb], zero16, 0, 0, 0, unit_scale, 0, unit_scale);
+  };
+
+  auto tile_top = [&](int t) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // this wave's pieces of tile t+1 have landed (tile t+2's five stay in flight)
+    __builtin_amdgcn_s_barrier();
+    stage_tile(min(t + 3, ntiles - 1), (t + 3) % NSTAGE_SP);
+  };
+  auto tile_rest = [&](int t, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const unsigned char* st_prev = smem + ((t + NSTAGE_SP - 1) % NSTAGE_SP) * STAGE;
+    const unsigned char* st_next = smem + ((t + 1) % NSTAGE_SP) * STAGE;
+    if (!FIRST) {
+      l_run[0] += lsum[0][0];
+      l_run[1] += lsum[1][0];
+    }
+    // ---- S^T(t) for both sub-blocks: every K fragment feeds two MFMAs; in their shadows the V^T(t-1) fragments
+    f32x16 sacc[2][2];  // [sub-block][key half]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = i >> 1, ks = i & 1;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        if (ks == 0) mfma_scale_zero_v(sacc[sb][f], fr[i], qf[sb][0], fsc[i], sqv[sb][0]);
+        else mfma_scale_acc_v(sacc[sb][f], fr[i], qf[sb][1], fsc[i], sqv[sb][1]);
+      }
+      if (!FIRST) load_v(st_prev, i, fr[i], fsc[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0][1]), "+v"(sacc[1][1]));  // the last S MFMAs' results, before the VALU (mask / maximum) reads them
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      mask_tail(sacc[sb], t);
+      if (FIRST) rebase(sacc[sb], sb, true);
+    }
+    // ---- O^T += V^T(t-1).P^T(t-1) for both sub-blocks (every V^T fragment feeds two MFMAs); in their shadows P(t) and K(t+1)
+    i32x8 pfn[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        if (!FIRST) mfma_scale_acc_pinned_agpr(oacc[sb][m], fr[m], pf[sb], fsc[m], unit_scale);
+        softmax_part(sacc[sb], m, pscale[sb], pfn[sb]);
+        if (sb == 1) load_k(st_next, m, fr[m], fsc[m]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&a"(lsum[sb]) : "a"(ones), "v"(pfn[sb]), "v"(unit_scale));
+      pf[sb] = pfn[sb];
+    }
+  };
+  tile_top(0);
+  tile_rest(0, std::true_type{});
+  {
+    int t = 1;
+    bool skip_top = false;
+    for (;;) {
+      bool bad = false;
+      for (; t < ntiles; ++t) {
+        if (!skip_top) tile_top(t);
+        skip_top = false;
+        // (the row-sum MFMAs of the previous iteration issued a barrier and an LDS-DMA burst ago: far beyond the 18 wait states an
+        // asm MFMA's result needs before the VALU may read it)
+        if (__builtin_expect(__any(lsum[0][0] != lsum[0][0] || lsum[1][0] != lsum[1][0]), 0)) {
+          bad = true;
+          break;
+        }
+        tile_rest(t, std::false_type{});
+      }
+      if (!bad) break;
+      if (__any(lsum[0][0] != lsum[0][0])) exact_tile(t - 1, 0);
+      if (__any(lsum[1][0] != lsum[1][0])) exact_tile(t - 1, 1);
+      skip_top = true;
+    }
+  }
+  // ---- drain
+  asm volatile("s_nop 15\n\ts_nop 3" : "+a"(lsum[0]), "+a"(lsum[1]));
+  if (__builtin_expect(__any(lsum[0][0] != lsum[0][0]), 0)) exact_tile(ntiles - 1, 0);
+  if (__builtin_expect(__any(lsum[1][0] != lsum[1][0]), 0)) exact_tile(ntiles - 1, 1);
+  l_run[0] += lsum[0][0];
+  l_run[1] += lsum[1][0];
+  {
+    const unsigned char* st_last = smem + ((ntiles - 1) % NSTAGE_SP) * STAGE;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      i32x8 vfl;
+      int scl;
+      load_v(st_last, m, vfl, scl);
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+        oacc[sb][m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vfl, pf[sb], oacc[sb][m], 0, 0, 0, scl, 0, unit_scale);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const float inv = 1.0f / l_run[sb];
+    unsigned char* ost = smem + (size_t)(wave * 64 + 32 * sb + l31) * OST_ROW;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const u32x2 val = {pack_bf16(oacc[sb][m][4 * a + 0] * inv, oacc[sb][m][4 * a + 1] * inv),
+                           pack_bf16(oacc[sb][m][4 * a + 2] * inv, oacc[sb][m][4 * a + 3] * inv)};
+        *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    const int q = min(q0 + rl, Nq - 1);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * 64 + rl) * OST_ROW + cc * 16);
+    if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+  }
+}
+
 }  // namespace
 
 extern "C" int ce_rmsnorm_rope_mxfp8(const void* x, const float* w, const float* cos_sin, void* q8, void* scale8, int M, int D, int ldx,
-                                     int ldq, int head_dim, float eps, int rope_rows, hipStream_t stream) {
+                                     int ldq, int head_dim, float eps, int rope_rows, float post_scale, hipStream_t stream) {
   if (!x || !w || !q8 || !scale8) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 31) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (head_dim & 31) || D % head_dim) return CE_ERR_SHAPE;
   if (D == 64 * 8 * ROW_MAXC)
     hipLaunchKernelGGL(rmsnorm_rope_mxfp8_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, w, cos_sin, (unsigned char*)q8,
-                       (unsigned char*)scale8, M, D, ldx, ldq, head_dim, eps, rope_rows);
+                       (unsigned char*)scale8, M, D, ldx, ldq, head_dim, eps, rope_rows, post_scale);
   else
     hipLaunchKernelGGL(rmsnorm_rope_mxfp8_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, w, cos_sin, (unsigned char*)q8,
-                       (unsigned char*)scale8, M, D, ldx, ldq, head_dim, eps, rope_rows);
+                       (unsigned char*)scale8, M, D, ldx, ldq, head_dim, eps, rope_rows, post_scale);
   return (int)hipGetLastError();
 }
 
@@ -399,9 +1144,15 @@ extern "C" int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv,
   return (int)hipGetLastError();
 }
 
+static int g_mxfp8_variant = 1;  // 0: plain kernel, 1: software-pipelined, 8 waves x 32 rows (default), 2: one wave per SIMD x 64 rows (measured slower)
+extern "C" int ce_set_attention_mxfp8_variant(int v) {
+  const int old = g_mxfp8_variant;
+  g_mxfp8_variant = v;
+  return old;
+}
+
 extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
-                                  int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, float softmax_scale, int batch,
-                                  hipStream_t stream) {
+                                  int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, hipStream_t stream) {
   if (!q8 || !sq || !k8 || !sk || !v8t || !sv || !O) return CE_ERR_ARG;
   if (head_dim != HD || Nq <= 0 || Nkv <= 0 || H <= 0 || batch <= 0 || (npad & 63) || npad < Nkv || npad - Nkv >= KVB) return CE_ERR_SHAPE;
   if ((ldq8 & 15) || (ldk8 & 15) || (ldo & 7)) return CE_ERR_ALIGN;
@@ -409,10 +1160,21 @@ extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_SP);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_SP);
     attr = true;
   }
-  hipLaunchKernelGGL(attn_fwd_mxfp8_kernel, dim3(H * nqb, batch), dim3(512), SMEM, stream, (const unsigned char*)q8, (const unsigned char*)sq,
-                     (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t, (const unsigned char*)sv, (bf16*)O, Nq, Nkv,
-                     npad, H, ldq8, ldk8, ldo, nqb, softmax_scale * 1.4426950408889634f);
+  if (g_mxfp8_variant == 0)
+    hipLaunchKernelGGL(attn_fwd_mxfp8_kernel, dim3(H * nqb, batch), dim3(512), SMEM, stream, (const unsigned char*)q8, (const unsigned char*)sq,
+                       (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t, (const unsigned char*)sv, (bf16*)O, Nq, Nkv,
+                       npad, H, ldq8, ldk8, ldo, nqb);
+  else if (g_mxfp8_variant == 2)
+    hipLaunchKernelGGL(attn_fwd_mxfp8_w4_kernel, dim3(H * nqb, batch), dim3(256), SMEM_SP, stream, (const unsigned char*)q8,
+                       (const unsigned char*)sq, (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t,
+                       (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb);
+  else
+    hipLaunchKernelGGL(attn_fwd_mxfp8_sp_kernel, dim3(H * nqb, batch), dim3(512), SMEM_SP, stream, (const unsigned char*)q8,
+                       (const unsigned char*)sq, (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t,
+                       (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb);
   return (int)hipGetLastError();
 }

@@ -31,9 +31,10 @@ SIGNATURES: Dict[str, List] = {
     "ce_gemm_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_gemm_aseg_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _P],
     "ce_gemm_seg_bf16": [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _c.c_longlong, _I, _c.c_longlong, _P],
-    "ce_rmsnorm_rope_mxfp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ce_rmsnorm_rope_mxfp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _P],
     "ce_v_mxfp8_transpose": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
-    "ce_attention_mxfp8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ce_attention_mxfp8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_set_attention_mxfp8_variant": [_I],
     "ce_rope_scatter_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _I, _P],
     "ce_patchify_rows_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_gemm_variant": [_I],

@@ -571,10 +571,14 @@ def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Ten
 # ------------------------------------------------------------------------------------------
 # MXFP8 self-attention (fp8 mode; contract: chronoedit_amd/csrc/ce_attn_fp8.hip, oracle.dit_oracle.attention_mxfp8)
 # ------------------------------------------------------------------------------------------
+MXFP8_Q_SCALE = 128 ** -0.5 * 1.4426950408889634  # softmax_scale * log2(e): what the q producer multiplies in (head_dim 128)
+
+
 def rmsnorm_rope_mxfp8(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tensor], head_dim: int, eps: float,
-                       out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
-    """RMSNorm across heads (+ RoPE) of x [M, D] (bf16, row stride free) -> (q8 [M, D] uint8 e4m3, s8 [M, D/32] uint8 E8M0):
-    MXFP8 blocks of 32 head channels."""
+                       out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, post_scale: float = 1.0):
+    """RMSNorm across heads (+ RoPE) of x [M, D] (bf16, row stride free), times post_scale -> (q8 [M, D] uint8 e4m3, s8 [M, D/32]
+    uint8 E8M0): MXFP8 blocks of 32 head channels.  The attention kernel expects q produced with post_scale = MXFP8_Q_SCALE
+    (scores then come out of the matrix pipe in the exp2 domain) and k with 1."""
     _dev(x, torch.bfloat16, "x"), _dev(w, torch.float32, "w")
     M, D, ldx = _rows(x, "x")
     rope_rows = 0
@@ -591,7 +595,7 @@ def rmsnorm_rope_mxfp8(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch
     _, _, ldq = _rows(out, "out")
     st = _prof_begin()
     _check(lib().ce_rmsnorm_rope_mxfp8(_ptr(x), _ptr(w), _ptr(cos_sin), _ptr(out), _ptr(scale), M, D, ldx, ldq, head_dim, float(eps), rope_rows,
-                                       _stream()), "ce_rmsnorm_rope_mxfp8")
+                                       float(post_scale), _stream()), "ce_rmsnorm_rope_mxfp8")
     _prof_end(st, f"rmsnorm_rope_mxfp8_{M}x{D}", 3.0 * M * D)
     return out, scale
 
@@ -616,9 +620,16 @@ def v_mxfp8_transpose(v: torch.Tensor, n_tokens: int, batch: int, heads: int, ou
     return out, scale
 
 
+def set_attention_mxfp8_variant(v: int) -> int:
+    """0: plain loop, 1: software-pipelined with the speculative offset, 8 waves x 32 rows (default), 2: the same with one wave per
+    SIMD (4 waves x 64 rows; measured slower: 1.20 vs 1.71 PFLOP/s at 28 800 keys); returns the previous setting."""
+    return lib().ce_set_attention_mxfp8_variant(int(v))
+
+
 def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: torch.Tensor, v8t: torch.Tensor, sv: torch.Tensor,
-                    heads: int, out: Optional[torch.Tensor] = None, scale: Optional[float] = None, batch: int = 1):
-    """Self-attention on the MX-fp8 matrix instruction from the operands the two producers above write; out [batch*Nq, heads*128] bf16."""
+                    heads: int, out: Optional[torch.Tensor] = None, batch: int = 1):
+    """Self-attention on the MX-fp8 matrix instruction from the operands the two producers above write (q with post_scale =
+    MXFP8_Q_SCALE); out [batch*Nq, heads*128] bf16."""
     for n, t in (("q8", q8), ("sq", sq), ("k8", k8), ("sk", sk), ("v8t", v8t), ("sv", sv)):
         _dev(t, torch.uint8, n)
     Mq, D, ldq = _rows(q8, "q8")
@@ -632,10 +643,8 @@ def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: to
         out = torch.empty((Mq, D), dtype=torch.bfloat16, device=q8.device)
     _dev(out, torch.bfloat16, "out")
     _, _, ldo = _rows(out, "out")
-    if scale is None:
-        scale = 128 ** -0.5
     st = _prof_begin()
     _check(lib().ce_attention_mxfp8(_ptr(q8), _ptr(sq), _ptr(k8), _ptr(sk), _ptr(v8t), _ptr(sv), _ptr(out), nq, nkv, npad, heads, 128, ldq, ldk, ldo,
-                                    float(scale), batch, _stream()), "ce_attention_mxfp8")
+                                    batch, _stream()), "ce_attention_mxfp8")
     _prof_end(st, f"attention_mxfp8_{nq}x{nkv}_h{heads}" + (f"_b{batch}" if batch > 1 else ""), 4.0 * nq * nkv * 128 * heads * batch)
     return out

@@ -40,10 +40,17 @@ class _Done:
 
 
 class Ulysses:
-    def __init__(self, group: Optional[dist.ProcessGroup] = None):
+    @property
+    def sharded(self) -> bool:
+        return self.world > 1 or self.force
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, force: bool = False):
+        """force: take the sharded code path even in a group of ONE rank (every exchange then runs as a real collective of the
+        backend on a single rank) - how the RCCL call sequence is exercised on a one-GPU box (tests/test_ulysses.py)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised before enabling Ulysses sequence parallelism")
         self.group = group
+        self.force = bool(force)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
@@ -77,7 +84,7 @@ class Ulysses:
         assert recv.is_contiguous() and recv.shape == send.shape
         self.stats["all_to_all_calls"] += 1
         self.stats["all_to_all_bytes_sent_off_rank"] += send.numel() * send.element_size() * (self.world - 1) // self.world
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             recv.copy_(send)
             return recv, _Done()
         if self._host_staged and send.is_cuda:
@@ -92,7 +99,7 @@ class Ulysses:
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n_local, C] -> [W*n_local, C] in rank order."""
         self.stats["all_gather_calls"] += 1
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return x_local
         x_local = x_local.contiguous()
         if self._host_staged and x_local.is_cuda:

@@ -48,7 +48,7 @@ def make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds):
 
 def _token_sharded(transformer) -> bool:
     sp = getattr(transformer, "_sp", None)
-    return sp is not None and sp.world > 1
+    return sp is not None and sp.sharded
 
 
 @torch.no_grad()

@@ -245,11 +245,11 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.invalidate()
         return self
 
-    def enable_sequence_parallel(self, group=None):
-        """Shard the token axis over the ranks of `group` (Ulysses: two all-to-all per self-attention).  Every rank
-        must call forward with the same (replicated) inputs and receives the full output."""
+    def enable_sequence_parallel(self, group=None, force: bool = False):
+        """Shard the token axis over the ranks of `group` (Ulysses: three all-to-all per self-attention).  Every rank
+        must call forward with the same (replicated) inputs and receives the full output.  force: see parallel.Ulysses."""
         from .parallel import Ulysses
-        self._sp = Ulysses(group)
+        self._sp = Ulysses(group, force=force)
         if self.config.num_attention_heads % self._sp.world:
             raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
         if self._engine is not None:
@@ -565,7 +565,7 @@ class DiTEngine:
                 ws.q8, ws.k8, ws.sq, ws.sk = u8(N, D), u8(N, D), u8(N, D // 32), u8(N, D // 32)
                 ws.v8t = ws.sv = None
             sp = self.model._sp
-            if sp is not None and sp.world > 1:  # Ulysses exchange buffers (chronoedit_amd/parallel.py): N = local rows
+            if sp is not None and sp.sharded:  # Ulysses exchange buffers (chronoedit_amd/parallel.py): N = local rows
                 W, Dl = sp.world, D // sp.world
                 ws.send_kv, ws.recv_kv = e(W, N, 2, Dl), e(W, N, 2, Dl)
                 ws.send_q, ws.recv_q = e(W, N, 1, Dl), e(W, N, 1, Dl)
@@ -669,7 +669,7 @@ class DiTEngine:
         eps = cfg.eps
         cs = self._rope_table(T, Hp, Wp)  # raises AssertionError for unsupported frame counts (:205)
         sp = self.model._sp
-        if sp is not None and sp.world > 1:
+        if sp is not None and sp.sharded:
             if B != 1:
                 raise ValueError("sequence parallelism shards the tokens of ONE sample; call with batch size 1")
             Nl = sp.shard(N)[0]  # local (zero-padded) token rows
@@ -720,7 +720,7 @@ class DiTEngine:
             # 1. self-attention
             if sp is None and self.fp8_attn:  # MXFP8: the norm / RoPE pass and a V^T pass write the quantised operands
                 self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)
-                ops.rmsnorm_rope_mxfp8(ws.qkv[:, :D], p.nq1, cs, hd, eps, out=ws.q8, scale=ws.sq)
+                ops.rmsnorm_rope_mxfp8(ws.qkv[:, :D], p.nq1, cs, hd, eps, out=ws.q8, scale=ws.sq, post_scale=ops.MXFP8_Q_SCALE)
                 ops.rmsnorm_rope_mxfp8(ws.qkv[:, D : 2 * D], p.nk1, cs, hd, eps, out=ws.k8, scale=ws.sk)
                 if ws.v8t is None or ws.v8t.shape[0] != B:
                     ws.v8t = ws.sv = None

@@ -213,13 +213,15 @@ int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const 
 
 /* ---- MXFP8 self-attention of the fp8 mode ("fp8 weights+attn", BASELINE.json configs[4]).  Contract (csrc/ce_attn_fp8.hip,
  * oracle/dit_oracle.py::attention_mxfp8): Q, K quantised to OCP MXFP8 - e4m3 elements, one E8M0 scale per 32 head channels - V per
- * 32 keys, products on v_mfma_scale_f32_32x32x64_f8f6f4, P = exp2((S - max) c + 8) in e4m3, fp32 accumulation; replaces
+ * 32 keys, products on v_mfma_scale_f32_32x32x64_f8f6f4, P = exp2(S - offset) <= 8 in e4m3 (offset = a row maximum - 3), fp32
+ * accumulation; replaces
  * F.scaled_dot_product_attention at transformer_chronoedit.py:91-104 in that mode. ---- */
 
-/* ce_rmsnorm_rope_bf16 that writes MXFP8 instead of bf16: q8 [M][ldq8] e4m3 bytes, scale8 [M][D/32] E8M0 bytes (x is not modified).
- * transformer_chronoedit.py:62-65,73-79. */
+/* ce_rmsnorm_rope_bf16 that writes MXFP8 instead of bf16: q8 [M][ldq8] e4m3 bytes, scale8 [M][D/32] E8M0 bytes (x is not modified);
+ * the bf16-rounded value is multiplied by post_scale before the quantisation - softmax_scale * log2(e) for q (the scores then leave
+ * the matrix pipe in the exp2 domain), 1 for k.  transformer_chronoedit.py:62-65,73-79. */
 int ce_rmsnorm_rope_mxfp8(const void* x, const float* w, const float* cos_sin, void* q8, void* scale8, int M, int D, int ldx, int ldq8,
-                          int head_dim, float eps, int rope_rows, hipStream_t stream);
+                          int head_dim, float eps, int rope_rows, float post_scale, hipStream_t stream);
 
 /* V [batch * n_tokens][ldv] bf16 (head h = columns 128 h ..) -> V^T tiles v8t [batch][H][128][npad] e4m3 bytes + sv
  * [batch][H][npad/64][128][2] E8M0 bytes (npad = n_tokens rounded up to 64, zero keys at the end).  Inside every 64-key tile position
@@ -230,8 +232,12 @@ int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv, int n_toke
 /* O [batch * Nq][ldo] bf16 = attention over the operands above (q8 / k8 row strides in bytes, head h at byte column 128 h; sq / sk
  * [rows][H * 4]); head_dim == 128. */
 int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O, int Nq,
-                       int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, float softmax_scale, int batch,
-                       hipStream_t stream);
+                       int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, hipStream_t stream);
+
+/* Loop body of ce_attention_mxfp8 (returns the previous value): 0 plain (exact running maximum every tile), 1 software-pipelined
+ * with a speculative integer offset, row sums on the matrix pipe and an exact repair route per tile, 8 waves x 32 rows (default),
+ * 2 the same as 4 waves x 64 rows (one wave per SIMD; measured slower).  Host-side tuning knob. */
+int ce_set_attention_mxfp8_variant(int variant);
 
 /* ---- conditioning encoders (run once per edit, outside the loop: pipeline_chronoedit.py:205-254; the arithmetic is
  * transformers==4.57.1 CLIPVisionModel / UMT5EncoderModel, restated in oracle/clip_oracle.py, oracle/umt5_oracle.py) ---- */

@@ -268,27 +268,45 @@ def mx_quant(x: torch.Tensor, dim: int = -1, block_index: Optional[torch.Tensor]
     return q.movedim(-1, dim)
 
 
-def attention_mxfp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+def attention_mxfp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, lazy_offset: bool = True) -> torch.Tensor:
     """[B, H, N, 128] q / k (normalised, rotated) and v -> softmax(q k^T / sqrt(128)) v under the MXFP8 contract of ce_attn_fp8.hip:
-    q and k quantised in blocks of 32 consecutive head channels, v in blocks of 32 consecutive KEYS, exact fp32 products; online softmax over 64-key tiles: P = exp2((S - running max) c + 8) rounded to e4m3 (unit scale; P <= 256),
-    O and the fp32 sum of the un-rounded P rescaled by exp2((old max - new max) c) when the maximum moves; O / l at the end.
+    q * (softmax_scale * log2 e) and k quantised in blocks of 32 consecutive head channels, v in blocks of 32 consecutive KEYS,
+    exact fp32 products (scores in the exp2 domain); online softmax over 64-key tiles: P = exp2(S - offset) rounded to e4m3 (unit
+    scale), O and l rescaled by exp2(old - new offset) when the offset moves; O / l at the end.  Two offset schedules:
+      lazy_offset=True   (default kernel, variant 1) the offset of a row is an INTEGER: ceil(row maximum of tile 0 - 3), so P <= 8;
+                         afterwards it is raised - for the 32 query rows one wave owns together - only when an element of a tile
+                         converts to NaN (exp2(S - offset) > 464, above the e4m3 range): then each of those rows takes
+                         max(offset, ceil(its tile maximum - 3)).  l is the sum of the ROUNDED P (it leaves the matrix pipe).
+      lazy_offset=False  (plain loop, variant 0) running row maximum - 3 after every tile; l is the fp32 sum of the un-rounded P.
+    e4m3 is a floating-point format, so the two schedules differ in individual roundings of P, not in their distribution.
     The reference has no fp8 path (transformer_chronoedit.py:91-104 is plain SDPA): this IS the definition."""
     B, H, N, hd = q.shape
     Nk = k.shape[2]
-    qq, kq = mx_quant(q, -1), mx_quant(k, -1)
-    vq = mx_quant(v, 2)
     c = hd ** -0.5 * 1.4426950408889634
-    m = torch.full((B, H, N, 1), -1.0e30)
+    qq, kq = mx_quant(q.float() * c, -1), mx_quant(k, -1)
+    vq = mx_quant(v, 2)
+    off = torch.full((B, H, N, 1), -1.0e30)
     l = torch.zeros((B, H, N, 1))
     o = torch.zeros((B, H, N, hd))
-    for t0 in range(0, Nk, 64):
+    nblk = (N + 31) // 32
+    for ti, t0 in enumerate(range(0, Nk, 64)):
         s = qq @ kq[:, :, t0:t0 + 64].transpose(-1, -2)
-        m_new = torch.maximum(m, s.amax(-1, keepdim=True))
-        alpha = torch.exp2((m - m_new) * c)
-        pr = torch.exp2(s * c - (m_new * c - 8.0))
-        o = o * alpha + pr.to(torch.float8_e4m3fn).float() @ vq[:, :, t0:t0 + 64]
-        l = l * alpha + pr.sum(-1, keepdim=True)
-        m = m_new
+        tmax = s.amax(-1, keepdim=True)
+        if not lazy_offset:
+            new_off = torch.maximum(off, tmax - 3.0)
+        elif ti == 0:
+            new_off = torch.ceil(tmax - 3.0)
+        else:
+            over = (torch.exp2(s - off) > 464.0).any(-1)                                   # [B, H, N]: an element would convert to NaN
+            over = torch.nn.functional.pad(over, (0, nblk * 32 - N)).view(B, H, nblk, 32)
+            trig = over.any(-1, keepdim=True).expand(B, H, nblk, 32).reshape(B, H, nblk * 32)[..., :N, None]
+            new_off = torch.where(trig, torch.maximum(off, torch.ceil(tmax - 3.0)), off)
+        alpha = torch.exp2(off - new_off)
+        pr = torch.exp2(s - new_off)
+        p8 = pr.to(torch.float8_e4m3fn).float()
+        o = o * alpha + p8 @ vq[:, :, t0:t0 + 64]
+        l = l * alpha + (p8 if lazy_offset else pr).sum(-1, keepdim=True)
+        off = new_off
     return (o / l).to(q.dtype)
 
 

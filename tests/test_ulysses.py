@@ -246,3 +246,38 @@ def test_denoise_loop_with_cfg_sharded_over_ranks(world, mode):
     (bit-equal when no GEMM changes its tile decomposition)."""
     for rank, shape, err, finite in _spawn(_loop_worker, world, mode, timeout=600):
         assert shape == (1, 16, 2, 8, 12) and finite and err < 5e-3, (rank, shape, err)
+
+
+def _rccl_one_rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
+    from chronoedit_amd.pipeline import denoise
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    m, cfg, O = _tiny_model()
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 18, 22, dtype=BF, text_len=40, real_text=8)
+    ts = torch.tensor([321], device="cuda:0")
+    ref = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample.clone()
+    m.enable_sequence_parallel(force=True)  # the sharded path with every exchange issued through RCCL (async k|v, q, output, gather)
+    out = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample
+    g = torch.Generator().manual_seed(11)
+    lat0 = torch.randn(1, 16, 2, 8, 12, generator=g).cuda()
+    cond = torch.randn(1, 20, 2, 8, 12, generator=g).cuda().to(BF)
+    pr, ng = torch.randn(1, 40, 128, generator=g).cuda().to(BF), torch.randn(1, 40, 128, generator=g).cuda().to(BF)
+    img = torch.randn(1, 257, 64, generator=g).cuda().to(BF)
+    loop = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 3, 5.0)
+    torch.cuda.synchronize()
+    q.put((rank, dist.get_backend(), bool(torch.equal(out, ref)), float((out.float() - ref.float()).abs().max()), m._sp.stats["all_to_all_calls"],
+           bool(torch.isfinite(loop).all())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_path_over_rccl_on_one_rank():
+    """The Ulysses code path with its collectives issued through RCCL (backend "nccl") in a group of one rank - the only RCCL
+    exercise a one-GPU box allows: asynchronous all_to_all_single + work.wait() ordering against the compute stream, the
+    exchange buffers as strided kernel operands, all_gather_into_tensor; the result must equal the un-sharded forward."""
+    (rank, backend, equal, err, calls, finite), = _spawn(_rccl_one_rank_worker, 1, timeout=300)
+    assert backend == "nccl" and (equal or err < 2e-2) and finite, (backend, equal, err, finite)
+    assert calls == 3 * 2 + 3 * 2 * 2 * 3  # forward: 2 layers x 3; loop: 3 steps x 2 passes x 2 layers x 3

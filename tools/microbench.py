@@ -149,20 +149,25 @@ def main():
             qkv = torch.randn(B * N, 3 * D, generator=g).to(BF).to(dev)
             one = torch.ones(D, device=dev)
             out = torch.empty(B * N, D, dtype=BF, device=dev)
-            q8, sq = ops.rmsnorm_rope_mxfp8(qkv[:, :D], one, None, 128, 1e-6)
+            q8, sq = ops.rmsnorm_rope_mxfp8(qkv[:, :D], one, None, 128, 1e-6, post_scale=ops.MXFP8_Q_SCALE)
             k8, sk = ops.rmsnorm_rope_mxfp8(qkv[:, D:2 * D], one, None, 128, 1e-6)
             v8t, sv = ops.v_mxfp8_transpose(qkv[:, 2 * D:], N, B, H)
             t_q = timeit(lambda: ops.rmsnorm_rope_mxfp8(qkv[:, :D], one, None, 128, 1e-6, out=q8, scale=sq), iters=10)
             t_v = timeit(lambda: ops.v_mxfp8_transpose(qkv[:, 2 * D:], N, B, H, out=v8t, scale=sv), iters=10)
             t_qb = timeit(lambda: ops.rmsnorm_rope_(qkv[:, :D], one, None, 128, 1e-6, x2=qkv[:, D:2 * D], w2=one), iters=10)
-            t8 = t16 = 1e9
+            t8 = t8p = t8s = t16 = 1e9
             for _ in range(3):
                 t16 = min(t16, timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], H, out=out, batch=B), iters=3))
+                ops.set_attention_mxfp8_variant(0)
+                t8p = min(t8p, timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3))
+                ops.set_attention_mxfp8_variant(2)
+                t8s = min(t8s, timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3))
+                ops.set_attention_mxfp8_variant(1)
                 t8 = min(t8, timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3))
             fl = 4.0 * N * N * 128 * H * B
             res[f"attn8_{N}x{H}_b{B}"] = {"mxfp8_ms": t8 * 1e3, "mxfp8_tflops": fl / t8 / 1e12, "bf16_ms": t16 * 1e3, "bf16_tflops": fl / t16 / 1e12,
                                           "qk_quant_ms_each": t_q * 1e3, "v_transpose_ms": t_v * 1e3, "bf16_norm_rope_qk_ms": t_qb * 1e3}
-            print(f"attn N={N} H={H} B={B}: mxfp8 {t8*1e3:.3f} ms {fl/t8/1e12:.1f} TF | bf16 {t16*1e3:.3f} ms {fl/t16/1e12:.1f} TF | producers: q or k norm+rope+quant "
+            print(f"attn N={N} H={H} B={B}: mxfp8 {t8*1e3:.3f} ms {fl/t8/1e12:.1f} TF (one-wave-per-SIMD form {t8s*1e3:.3f} ms {fl/t8s/1e12:.1f} TF, plain loop {t8p*1e3:.3f} ms {fl/t8p/1e12:.1f} TF) | bf16 {t16*1e3:.3f} ms {fl/t16/1e12:.1f} TF | producers: q or k norm+rope+quant "
                   f"{t_q*1e3:.3f} ms each, V^T quant {t_v*1e3:.3f} ms (bf16 path: q+k norm+rope {t_qb*1e3:.3f} ms)", flush=True)
             del qkv, out, q8, k8, v8t
     if "row" in only:
