@@ -41,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0  # MI355X dense fp8 MFMA (MI355X_MICROARCH.md) - the denominator of every kernel computing in e4m3
 
 
 def parse():
@@ -293,14 +294,15 @@ def main():
         dom = max((k for k in summ if k.startswith(("gemm", "attention"))), key=lambda k: summ[k]["total_ms"])
         ach = summ[dom]["work"] / (summ[dom]["avg_ms"] * 1e-3) / 1e12
         traffic, traffic_src = _pmc_traffic(dom)
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        peak = PEAK_FP8_TFLOPS if ("fp8" in dom) else PEAK_BF16_TFLOPS  # attention_mxfp8_* / gemm_fp8_* run the fp8 MFMA
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches": summ[dom]["n"], "avg_ms": round(summ[dom]["avg_ms"], 4),
                     # context, not the denominator: what a loop of nothing but MFMAs sustains on this chip when the operands
                     # toggle (power-limited clock; tools/probes/mfma_rate_probe.hip, profiles/r01_mfma_rate_probe.txt)
                     "sustained_mfma_only_random_operands": {"32x32x16": 2030.0, "16x16x32": 2160.0, "unit": "TFLOP/s",
                                                             "source": "profiles/r01_mfma_rate_probe.txt"}}
-        big = {k: d for k, d in summ.items() if k.startswith("gemm_") and d["work"] >= 2.0 * 256 * 256 * 128 * 64}  # the 256-tile kernel's launches
+        big = {k: d for k, d in summ.items() if k.startswith("gemm_") and "fp8" not in k and d["work"] >= 2.0 * 256 * 256 * 128 * 64}  # the 256-tile kernel's launches
         if big:
             fam_ms = sum(d["total_ms"] for d in big.values())
             fam_fl = sum(d["work"] * d["n"] for d in big.values())

@@ -410,22 +410,6 @@ constexpr int NSTAGE_SP = 5;
 // (their results are not needed until the next iteration), behind all of the softmax VALU work they are meant to run beside.
 // A volatile asm stays where it is written.  "s_nop 1": a VALU-written scale register needs two wait states in front of the
 // MFMA that reads it, and nothing inside an asm statement is padded by the compiler (cdna guide 5.7).
-// the same with the accumulator in the ACCUMULATOR half of the register file ("a" constraint): the one-wave-per-SIMD kernel keeps O
-// and the row sums there so that the S accumulators, which the VALU reads, get arch VGPRs (with "v" here hipcc did the opposite
-// and moved 170 registers per tile between the two halves)
-__device__ __forceinline__ void mfma_scale_acc_pinned_agpr(f32x16& acc, const i32x8& a, const i32x8& b, int sa, int sb) {
-  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+a"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
-}
-// S accumulators in ARCH VGPRs ("v"): the VALU reads them (v_exp_f32), and left to itself hipcc gives MFMA results of a 512-register
-// kernel accumulator registers, one v_accvgpr_read per element away from the VALU.  The reader must keep 18 wait states from the
-// last of these (cdna guide 5.7: nothing is padded around an asm statement).
-// (the B operand - the loop-invariant Q fragments - sits in the accumulator half ("a"): an MFMA reads it from there directly)
-__device__ __forceinline__ void mfma_scale_zero_v(f32x16& d, const i32x8& a, const i32x8& b, int sa, int sb) {
-  asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(d) : "v"(a), "a"(b), "v"(sa), "v"(sb));
-}
-__device__ __forceinline__ void mfma_scale_acc_v(f32x16& d, const i32x8& a, const i32x8& b, int sa, int sb) {
-  asm("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(d) : "v"(a), "a"(b), "v"(sa), "v"(sb));
-}
 __device__ __forceinline__ void mfma_scale_acc_pinned(f32x16& acc, const i32x8& a, const i32x8& b, int sa, int sb) {
   asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(acc) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
@@ -436,32 +420,52 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
                                                                   const unsigned char* __restrict__ K8, const unsigned char* __restrict__ SK,
                                                                   const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ SV,
                                                                   bf16* __restrict__ O, int Nq, int Nkv, int npad, int H, int ldq8,
-                                                                  int ldk8, int ldo, int nqb) {
+                                                                  int ldk8, int ldo, int nqb, int batch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D32 = (H * HD) >> 5;
-  {
-    const size_t bz = blockIdx.y;
-    Q8 += bz * Nq * ldq8;
-    SQ += bz * Nq * D32;
-    K8 += bz * Nkv * ldk8;
-    SK += bz * Nkv * D32;
-    V8T += bz * H * HD * npad;
-    SV += bz * H * HD * (npad >> 5);
-    O += bz * Nq * ldo;
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  int head, qb;
-  if ((H & 7) == 0) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    head = xcd + 8 * (local / nqb);
-    qb = local % nqb;
-  } else {
-    head = blockIdx.x / nqb;
-    qb = blockIdx.x % nqb;
+  // Work order (batch folded into blockIdx.x, as in the bf16 kernel): every XCD takes its heads' FULL 256-row query blocks first,
+  // sample by sample, and the remainder blocks (Nq % 256 rows: only their first waves have rows, the others merely stage) last -
+  // they fill the partially occupied final round of workgroups instead of heading it.  Nq = 7200, H = 40, two samples: 2320
+  // workgroups = 9.06 rounds of 256 CUs would cost ten.
+  int head, qb, bz;
+  {
+    const int nqb_full = Nq / (QW * 8);
+    if ((H & 7) == 0) {
+      const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, hx_n = H >> 3;
+      const int full = batch * hx_n * nqb_full;
+      if (local < full) {
+        bz = local / (hx_n * nqb_full);
+        const int r = local % (hx_n * nqb_full);
+        head = xcd + 8 * (r / nqb_full);
+        qb = r % nqb_full;
+      } else {
+        const int l2 = local - full;
+        bz = l2 / hx_n;
+        head = xcd + 8 * (l2 % hx_n);
+        qb = nqb_full;
+      }
+    } else {
+      bz = blockIdx.x / (nqb * H);
+      const int r = blockIdx.x % (nqb * H);
+      head = r / nqb;
+      qb = r % nqb;
+    }
+  }
+  {
+    const size_t b = bz;
+    Q8 += b * Nq * ldq8;
+    SQ += b * Nq * D32;
+    K8 += b * Nkv * ldk8;
+    SK += b * Nkv * D32;
+    V8T += b * H * HD * npad;
+    SV += b * H * HD * (npad >> 5);
+    O += b * Nq * ldo;
   }
   const int q0 = qb * (QW * 8) + wave * QW;
+  const bool active = q0 < Nq;  // wave-uniform: a wave past the last query row only stages tiles and keeps the barriers
   const int hoff = head * HD;
   const int ntiles = (Nkv + KVB - 1) / KVB;
 
@@ -646,15 +650,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
   };
 
   auto tile_top = [&](int t) __attribute__((always_inline)) {
-#if defined(CE_FP8_ABL) && CE_FP8_ABL == 5
-    __builtin_amdgcn_s_barrier();
-#elif defined(CE_FP8_ABL) && CE_FP8_ABL == 7  // no barrier (and no counted wait) in the loop
-    stage_tile(min(t + 3, ntiles - 1), (t + 3) % NSTAGE_SP);
-#else
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wave's pieces of tile t+1 have landed (tile t+2's four stay in flight)
     __builtin_amdgcn_s_barrier();                     // ... everybody's have; everybody is done with tile t-2's stage
     stage_tile(min(t + 3, ntiles - 1), (t + 3) % NSTAGE_SP);
-#endif
   };
   // FIRST = true (tile 0, peeled): exact offset, no P.V yet - instantiates the body without the matrix work of "tile -1", so the
   // steady-state loop carries no per-MFMA branch
@@ -672,17 +670,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = i >> 1, ks = i & 1;
-#if defined(CE_FP8_ABL) && CE_FP8_ABL == 3
-      if (ks == 0) sacc[f] = zero16;
-      asm volatile("" : "+v"(sacc[f]) : "v"(kf[i]), "v"(ksc[i]));
-#else
       sacc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf[i], qf[ks], ks == 0 ? zero16 : sacc[f], 0, 0, 0, ksc[i], 0, sqv[ks]);
-#endif
-#if defined(CE_FP8_ABL) && CE_FP8_ABL == 4
-      asm volatile("" : "+v"(vf[i]), "+v"(vsc[i]));
-#else
       if (!FIRST) load_v(st_prev, i, vf[i], vsc[i]);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     mask_tail(sacc, t);
@@ -691,74 +680,59 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
     i32x8 pfn;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      // CE_FP8_ABL (tools/attn8_ablate.py only; results are garbage, durations are the point): 1 no exp / convert, 2 no P.V MFMAs,
-      // 3 no S MFMAs, 4 no fragment reads in the loop, 5 no LDS-DMA in the loop, 6 no row-sum MFMA
-#if defined(CE_FP8_ABL) && CE_FP8_ABL == 2
-      asm volatile("" : "+v"(oacc[m]) : "v"(vf[m]), "v"(pf), "v"(vsc[m]));
-#else
       if (!FIRST) mfma_scale_acc_pinned(oacc[m], vf[m], pf, vsc[m], unit_scale);
-#endif
-#if defined(CE_FP8_ABL) && CE_FP8_ABL == 4
-      asm volatile("" : "+v"(kf[m]), "+v"(ksc[m]));
-#else
       load_k(st_next, m, kf[m], ksc[m]);
-#endif
-#if defined(CE_FP8_ABL) && CE_FP8_ABL == 1
-      pfn[2 * m] = __float_as_int(sacc[m >> 1][8 * (m & 1)]);
-      pfn[2 * m + 1] = __float_as_int(sacc[m >> 1][8 * (m & 1) + 4]);
-#else
       softmax_part(sacc, m, pfn);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
     // row sums of P(t) (rounded) on the matrix pipe, checked at the top of the next iteration
-#if defined(CE_FP8_ABL) && CE_FP8_ABL == 6
-    asm volatile("" : "+v"(lsum) : "v"(pfn));
-#else
     asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&v"(lsum) : "v"(ones), "v"(pfn), "v"(unit_scale));
-#endif
     pf = pfn;
   };
-  tile_top(0);
-  tile_rest(0, std::true_type{});
-  // The steady-state loop leaves through `break` when the speculation check of tile t-1 fails (NaN row sums = an element of P(t-1)
-  // passed the e4m3 range); the repair runs OUTSIDE it and re-enters without repeating the iteration's barrier / DMA issue: as a
-  // branch inside the loop it joined the common path in phi nodes that hipcc resolved with 26 register moves (and a spill reload
-  // behind a vmcnt(0)) per tile.
-  {
-    int t = 1;
-    bool skip_top = false;
-    for (;;) {
-      bool bad = false;
-      for (; t < ntiles; ++t) {
-        if (!skip_top) tile_top(t);
-        skip_top = false;
-        asm volatile("s_nop 7" : "+v"(lsum));  // result of the asm MFMA of the previous iteration (issued a barrier ago); no padding is inserted for asm
-        if (__builtin_expect(__any(lsum[0] != lsum[0]), 0)) {
-          bad = true;
-          break;
+  if (active) {
+    tile_top(0);
+    tile_rest(0, std::true_type{});
+    // The steady-state loop leaves through `break` when the speculation check of tile t-1 fails (NaN row sums = an element of P(t-1)
+    // passed the e4m3 range); the repair runs OUTSIDE it and re-enters without repeating the iteration's barrier / DMA issue: as a
+    // branch inside the loop it joined the common path in phi nodes that hipcc resolved with 26 register moves (and a spill reload
+    // behind a vmcnt(0)) per tile.
+    {
+      int t = 1;
+      bool skip_top = false;
+      for (;;) {
+        bool bad = false;
+        for (; t < ntiles; ++t) {
+          if (!skip_top) tile_top(t);
+          skip_top = false;
+          asm volatile("s_nop 7" : "+v"(lsum));  // result of the asm MFMA of the previous iteration (issued a barrier ago); no padding is inserted for asm
+          if (__builtin_expect(__any(lsum[0] != lsum[0]), 0)) {
+            bad = true;
+            break;
+          }
+          tile_rest(t, std::false_type{});
         }
-        tile_rest(t, std::false_type{});
+        if (!bad) break;
+        exact_tile(t - 1);
+        skip_top = true;
       }
-      if (!bad) break;
-      exact_tile(t - 1);
-      skip_top = true;
     }
-  }
-  // ---- drain: check and add the row sums of the last tile, then P(ntiles-1).V(ntiles-1) (its stage became visible at the last
-  // barrier and nothing was staged over it)
-  asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lsum));  // the asm MFMA's result: 18 wait states before a VALU may read it (cdna guide 5.7)
-  if (__builtin_expect(__any(lsum[0] != lsum[0]), 0)) exact_tile(ntiles - 1);
-  l_run += lsum[0];
-  {
-    const unsigned char* st_last = smem + ((ntiles - 1) % NSTAGE_SP) * STAGE;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      i32x8 vfl;
-      int scl;
-      load_v(st_last, m, vfl, scl);
-      oacc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vfl, pf, oacc[m], 0, 0, 0, scl, 0, unit_scale);
+    // ---- drain: check and add the row sums of the last tile, then P(ntiles-1).V(ntiles-1) (its stage became visible at the last
+    // barrier and nothing was staged over it)
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(lsum));  // the asm MFMA's result: 18 wait states before a VALU may read it (cdna guide 5.7)
+    if (__builtin_expect(__any(lsum[0] != lsum[0]), 0)) exact_tile(ntiles - 1);
+    l_run += lsum[0];
+    {
+      const unsigned char* st_last = smem + ((ntiles - 1) % NSTAGE_SP) * STAGE;
+  #pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        i32x8 vfl;
+        int scl;
+        load_v(st_last, m, vfl, scl);
+        oacc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vfl, pf, oacc[m], 0, 0, 0, scl, 0, unit_scale);
+      }
     }
+  } else {
+    for (int t = 0; t < ntiles; ++t) tile_top(t);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -779,344 +753,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
     const int rl = c >> 4, cc = c & 15;
     const int q = min(q0 + rl, Nq - 1);  // clamped address, predicated store: no per-chunk branch around the LDS read
     const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
-    if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// "w4": four waves per workgroup = ONE wave per SIMD, 64 query rows per wave as two 32-row sub-blocks that share every K / V^T
-// fragment.  Ablations of the 8-wave form above (tools/attn8_ablate.py, profiles/r02_attn_mxfp8_ablate_*.txt): the fragment reads
-// are the largest single cost (-23 % without them) and two waves sharing a SIMD contend for its issue slots.  Here a fragment
-// fetched once feeds two MFMAs (LDS read traffic per flop halves), a wave has the SIMD's matrix pipe to itself, and 512 registers:
-// O (128) and the row sums live in the accumulator half of the file, which only MFMAs touch inside the loop.
-// Per tile and wave: 8 + 8 + 2 MFMAs of 64 cycles; 64 v_exp + 32 scaled conversions in their shadows.  Same contract, same staging
-// (five stages, LDS-DMA three tiles ahead, one barrier per tile), same speculation check and repair as the 8-wave form.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_mxfp8_w4_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ SQ,
-                                                               const unsigned char* __restrict__ K8, const unsigned char* __restrict__ SK,
-                                                               const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ SV,
-                                                               bf16* __restrict__ O, int Nq, int Nkv, int npad, int H, int ldq8,
-                                                               int ldk8, int ldo, int nqb) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int D32 = (H * HD) >> 5;
-  {
-    const size_t bz = blockIdx.y;
-    Q8 += bz * Nq * ldq8;
-    SQ += bz * Nq * D32;
-    K8 += bz * Nkv * ldk8;
-    SK += bz * Nkv * D32;
-    V8T += bz * H * HD * npad;
-    SV += bz * H * HD * (npad >> 5);
-    O += bz * Nq * ldo;
-  }
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, hh = lane >> 5;
-  int head, qb;
-  if ((H & 7) == 0) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    head = xcd + 8 * (local / nqb);
-    qb = local % nqb;
-  } else {
-    head = blockIdx.x / nqb;
-    qb = blockIdx.x % nqb;
-  }
-  const int q0 = qb * 256 + wave * 64;  // this wave's 64 rows: sub-block b = rows q0 + 32 b ..
-  const int hoff = head * HD;
-  const int ntiles = (Nkv + KVB - 1) / KVB;
-
-  i32x8 qf[2][2];  // [sub-block][k-step]
-  int sqv[2][2];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    const int qr = min(q0 + 32 * sb + l31, Nq - 1);
-    const unsigned char* qrow = Q8 + (size_t)qr * ldq8 + hoff + 16 * hh;
-    const uint32_t sw = *reinterpret_cast<const uint32_t*>(SQ + (size_t)qr * D32 + head * 4);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const u32x4 a = *reinterpret_cast<const u32x4*>(qrow + 64 * ks), b = *reinterpret_cast<const u32x4*>(qrow + 64 * ks + 32);
-      qf[sb][ks] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
-      sqv[sb][ks] = (int)((sw >> (16 * ks + 8 * hh)) & 0xffu);
-    }
-  }
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+a"(qf[sb][ks]), "+v"(sqv[sb][ks]));  // retire the Q loads before the loop; Q lives in the accumulator half
-
-  // LDS-DMA shares of a wave per tile: K pieces wave and wave + 4 (8 rows of 128 B each), V^T pieces wave and wave + 4 (16 rows of
-  // 64 B each), and ONE dword piece with both scale records: lanes 0-15 fetch 16 key rows' scale words, lanes 16-31 sixteen
-  // dwords (32 d rows) of the tile's V scale record - five wave-instructions
-  const int k_row0 = 8 * wave + (lane >> 3);                        // second piece: + 32 rows
-  const int k_chunk = (lane & 7) ^ ((k_row0 >> 1) & 7);             // (row >> 1) & 7 is the same for row and row + 32
-  const int v_row0 = 16 * wave + (lane >> 2);                       // second piece: + 64 rows
-  const int v_chunk = (lane & 3) ^ ((v_row0 >> 2) & 3);
-  const unsigned char* vsrc = V8T + ((size_t)head * HD + v_row0) * npad + v_chunk * 16;
-  const unsigned char* svsrc = SV + (size_t)head * (npad >> 6) * 256 + 64 * wave + 4 * (lane & 15);
-  auto stage_tile = [&](int t, int slot) __attribute__((always_inline)) {
-    unsigned char* st = smem + slot * STAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kr = min(t * KVB + k_row0 + 32 * j, Nkv - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(K8 + (size_t)kr * ldk8 + hoff + k_chunk * 16), (lds_void*)(st + ST_K + (wave + 4 * j) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(vsrc + (size_t)(64 * j) * npad + (size_t)t * KVB), (lds_void*)(st + ST_V + (wave + 4 * j) * 1024), 16, 0, 0);
-    }
-    if (lane < 32) {
-      const int sr = min(t * KVB + 16 * wave + (lane & 15), Nkv - 1);
-      const unsigned char* src = lane < 16 ? SK + (size_t)sr * D32 + head * 4 : svsrc + (size_t)t * 256;
-      // LDS image per wave: 64 B of key scale words (rows 16 wave ..) then 64 B of the V record (d rows 32 wave ..)
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(st + ST_SK + wave * 128), 4, 0, 0);
-    }
-  };
-  // scale bytes inside a stage: key row r -> ST_SK + (r >> 4) * 128 + (r & 15) * 4; V channel d -> ST_SK + (d >> 5) * 128 + 64 + (d & 31) * 2
-
-  f32x16 oacc[2][4];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[sb][m][r] = 0.f;
-  float l_run[2] = {0.f, 0.f}, mc[2] = {0.f, 0.f}, pscale[2] = {1.0f, 1.0f};
-  i32x8 pf[2];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) pf[sb] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
-
-  const int k_sw = (l31 >> 1) & 7;
-  const int k_off = ST_K + l31 * 128;
-  const int sk_off = ST_SK + (l31 >> 4) * 128 + (l31 & 15) * 4;  // rows 32 f + l31: + f * 256
-  const int v_sw = (l31 >> 2) & 3;
-  const int v_off = ST_V + l31 * 64 + (((2 * hh) ^ v_sw) << 4), v_off2 = ST_V + l31 * 64 + (((2 * hh + 1) ^ v_sw) << 4);
-  const int sv_off = ST_SK + 64 + l31 * 2;                       // channels 32 m + l31: + m * 128
-
-  auto load_k = [&](const unsigned char* st, int i, i32x8& frag, int& sc) __attribute__((always_inline)) {
-    const int f = i >> 1, ks = i & 1;
-    const unsigned char* krow = st + k_off + f * 32 * 128;
-    const int c0 = 4 * ks + hh;
-    const u32x4 a = *reinterpret_cast<const u32x4*>(krow + ((c0 ^ k_sw) << 4)), b = *reinterpret_cast<const u32x4*>(krow + (((c0 + 2) ^ k_sw) << 4));
-    frag = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
-    sc = (int)((*reinterpret_cast<const uint32_t*>(st + sk_off + f * 256) >> (16 * ks + 8 * hh)) & 0xffu);
-  };
-  auto load_v = [&](const unsigned char* st, int m, i32x8& frag, int& sc) __attribute__((always_inline)) {
-    const unsigned char* vb = st + m * 32 * 64;
-    const u32x4 a = *reinterpret_cast<const u32x4*>(vb + v_off), b = *reinterpret_cast<const u32x4*>(vb + v_off2);
-    frag = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
-    sc = (int)((*reinterpret_cast<const uint16_t*>(st + sv_off + m * 128) >> (8 * hh)) & 0xffu);
-  };
-
-  stage_tile(0, 0);
-  stage_tile(min(1, ntiles - 1), 1);
-  stage_tile(min(2, ntiles - 1), 2);
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  // ONE set of four fragment registers: fr[i] holds K fragment i of tile t until its two S MFMAs have issued, then V^T fragment i of
-  // tile t-1 until its two P.V MFMAs have issued, then K fragment i of tile t+1 (kept as two arrays the allocator held both sets
-  // live and moved 170 registers per tile through the accumulator file)
-  i32x8 fr[4];
-  int fsc[4];
-  int unit_scale = 0x7f;
-  asm volatile("" : "+v"(unit_scale));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) load_k(smem, i, fr[i], fsc[i]);
-  i32x8 ones;
-#pragma unroll
-  for (int w = 0; w < 8; ++w) ones[w] = 0x38383838;
-  asm volatile("" : "+a"(ones));
-  f32x16 lsum[2];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lsum[sb][r] = 0.f;
-
-  auto mask_tail = [&](f32x16 (&sacc)[2], int t) __attribute__((always_inline)) {
-    if ((t + 1) * KVB > Nkv) {
-      const int base = t * KVB + 4 * hh;
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (base + 32 * f + (r & 3) + 8 * (r >> 2) >= Nkv) sacc[f][r] = NEG_BIG;
-    }
-  };
-  auto rebase = [&](const f32x16 (&sacc)[2], int sb, bool first) __attribute__((always_inline)) -> float {
-    float mx = sacc[0][0];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[f][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float want = ceilf(mx - P_OFF);
-    const float mc_new = first ? want : fmaxf(mc[sb], want);
-    const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(mc[sb] - mc_new);
-    mc[sb] = mc_new;
-    pscale[sb] = __builtin_amdgcn_exp2f(mc_new);
-    return alpha;
-  };
-  auto softmax_part = [&](const f32x16 (&sacc)[2], int m, float ps, i32x8& dst) __attribute__((always_inline)) {
-    float p[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sacc[m >> 1][8 * (m & 1) + i]);
-    s16x2 w0 = {0, 0}, w1 = {0, 0};
-    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, p[0], p[1], ps, false);
-    w0 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w0, p[2], p[3], ps, true);
-    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, p[4], p[5], ps, false);
-    w1 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(w1, p[6], p[7], ps, true);
-    dst[2 * m] = __builtin_bit_cast(int, w0);
-    dst[2 * m + 1] = __builtin_bit_cast(int, w1);
-  };
-  // repair of sub-block sb of tile tt (K tile still in LDS)
-  auto exact_tile = [&](int tt, int sb) __attribute__((always_inline)) {
-    const unsigned char* st = smem + (tt % NSTAGE_SP) * STAGE;
-    f32x16 sacc[2];
-    f32x16 zero16;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = i >> 1, ks = i & 1;
-      i32x8 kt;
-      int sc;
-      load_k(st, i, kt, sc);
-      sacc[f] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kt, qf[sb][ks], ks == 0 ? zero16 : sacc[f], 0, 0, 0, sc, 0, sqv[sb][ks]);
-    }
-    mask_tail(sacc, tt);
-    const float alpha = rebase(sacc, sb, false);
-    l_run[sb] *= alpha;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      float p[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(sacc[m >> 1][8 * (m & 1) + i] - mc[sb]);
-      int w0 = 0, w1 = 0;
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], w0, false);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w0, true);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(p[4], p[5], w1, false);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(p[6], p[7], w1, true);
-      pf[sb][2 * m] = w0;
-      pf[sb][2 * m + 1] = w1;
-    }
-    lsum[sb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, pf[sb], zero16, 0, 0, 0, unit_scale, 0, unit_scale);
-  };
-
-  auto tile_top = [&](int t) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // this wave's pieces of tile t+1 have landed (tile t+2's five stay in flight)
-    __builtin_amdgcn_s_barrier();
-    stage_tile(min(t + 3, ntiles - 1), (t + 3) % NSTAGE_SP);
-  };
-  auto tile_rest = [&](int t, auto first_tag) __attribute__((always_inline)) {
-    constexpr bool FIRST = decltype(first_tag)::value;
-    const unsigned char* st_prev = smem + ((t + NSTAGE_SP - 1) % NSTAGE_SP) * STAGE;
-    const unsigned char* st_next = smem + ((t + 1) % NSTAGE_SP) * STAGE;
-    if (!FIRST) {
-      l_run[0] += lsum[0][0];
-      l_run[1] += lsum[1][0];
-    }
-    // ---- S^T(t) for both sub-blocks: every K fragment feeds two MFMAs; in their shadows the V^T(t-1) fragments
-    f32x16 sacc[2][2];  // [sub-block][key half]
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int f = i >> 1, ks = i & 1;
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
-        if (ks == 0) mfma_scale_zero_v(sacc[sb][f], fr[i], qf[sb][0], fsc[i], sqv[sb][0]);
-        else mfma_scale_acc_v(sacc[sb][f], fr[i], qf[sb][1], fsc[i], sqv[sb][1]);
-      }
-      if (!FIRST) load_v(st_prev, i, fr[i], fsc[i]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc[0][1]), "+v"(sacc[1][1]));  // the last S MFMAs' results, before the VALU (mask / maximum) reads them
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      mask_tail(sacc[sb], t);
-      if (FIRST) rebase(sacc[sb], sb, true);
-    }
-    // ---- O^T += V^T(t-1).P^T(t-1) for both sub-blocks (every V^T fragment feeds two MFMAs); in their shadows P(t) and K(t+1)
-    i32x8 pfn[2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
-        if (!FIRST) mfma_scale_acc_pinned_agpr(oacc[sb][m], fr[m], pf[sb], fsc[m], unit_scale);
-        softmax_part(sacc[sb], m, pscale[sb], pfn[sb]);
-        if (sb == 1) load_k(st_next, m, fr[m], fsc[m]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]" : "=&a"(lsum[sb]) : "a"(ones), "v"(pfn[sb]), "v"(unit_scale));
-      pf[sb] = pfn[sb];
-    }
-  };
-  tile_top(0);
-  tile_rest(0, std::true_type{});
-  {
-    int t = 1;
-    bool skip_top = false;
-    for (;;) {
-      bool bad = false;
-      for (; t < ntiles; ++t) {
-        if (!skip_top) tile_top(t);
-        skip_top = false;
-        // (the row-sum MFMAs of the previous iteration issued a barrier and an LDS-DMA burst ago: far beyond the 18 wait states an
-        // asm MFMA's result needs before the VALU may read it)
-        if (__builtin_expect(__any(lsum[0][0] != lsum[0][0] || lsum[1][0] != lsum[1][0]), 0)) {
-          bad = true;
-          break;
-        }
-        tile_rest(t, std::false_type{});
-      }
-      if (!bad) break;
-      if (__any(lsum[0][0] != lsum[0][0])) exact_tile(t - 1, 0);
-      if (__any(lsum[1][0] != lsum[1][0])) exact_tile(t - 1, 1);
-      skip_top = true;
-    }
-  }
-  // ---- drain
-  asm volatile("s_nop 15\n\ts_nop 3" : "+a"(lsum[0]), "+a"(lsum[1]));
-  if (__builtin_expect(__any(lsum[0][0] != lsum[0][0]), 0)) exact_tile(ntiles - 1, 0);
-  if (__builtin_expect(__any(lsum[1][0] != lsum[1][0]), 0)) exact_tile(ntiles - 1, 1);
-  l_run[0] += lsum[0][0];
-  l_run[1] += lsum[1][0];
-  {
-    const unsigned char* st_last = smem + ((ntiles - 1) % NSTAGE_SP) * STAGE;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      i32x8 vfl;
-      int scl;
-      load_v(st_last, m, vfl, scl);
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb)
-        oacc[sb][m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vfl, pf[sb], oacc[sb][m], 0, 0, 0, scl, 0, unit_scale);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    const float inv = 1.0f / l_run[sb];
-    unsigned char* ost = smem + (size_t)(wave * 64 + 32 * sb + l31) * OST_ROW;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const u32x2 val = {pack_bf16(oacc[sb][m][4 * a + 0] * inv, oacc[sb][m][4 * a + 1] * inv),
-                           pack_bf16(oacc[sb][m][4 * a + 2] * inv, oacc[sb][m][4 * a + 3] * inv)};
-        *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
-      }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = lane + 64 * i;
-    const int rl = c >> 4, cc = c & 15;
-    const int q = min(q0 + rl, Nq - 1);
-    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * 64 + rl) * OST_ROW + cc * 16);
     if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
   }
 }
@@ -1144,10 +780,10 @@ extern "C" int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv,
   return (int)hipGetLastError();
 }
 
-static int g_mxfp8_variant = 1;  // 0: plain kernel, 1: software-pipelined, 8 waves x 32 rows (default), 2: one wave per SIMD x 64 rows (measured slower)
+static int g_mxfp8_variant = 1;  // 0: plain kernel (exact running maximum every tile), 1: software-pipelined (default)
 extern "C" int ce_set_attention_mxfp8_variant(int v) {
   const int old = g_mxfp8_variant;
-  g_mxfp8_variant = v;
+  if (v == 0 || v == 1) g_mxfp8_variant = v;
   return old;
 }
 
@@ -1161,20 +797,15 @@ extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_SP);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_SP);
     attr = true;
   }
   if (g_mxfp8_variant == 0)
     hipLaunchKernelGGL(attn_fwd_mxfp8_kernel, dim3(H * nqb, batch), dim3(512), SMEM, stream, (const unsigned char*)q8, (const unsigned char*)sq,
                        (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t, (const unsigned char*)sv, (bf16*)O, Nq, Nkv,
                        npad, H, ldq8, ldk8, ldo, nqb);
-  else if (g_mxfp8_variant == 2)
-    hipLaunchKernelGGL(attn_fwd_mxfp8_w4_kernel, dim3(H * nqb, batch), dim3(256), SMEM_SP, stream, (const unsigned char*)q8,
-                       (const unsigned char*)sq, (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t,
-                       (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb);
   else
-    hipLaunchKernelGGL(attn_fwd_mxfp8_sp_kernel, dim3(H * nqb, batch), dim3(512), SMEM_SP, stream, (const unsigned char*)q8,
+    hipLaunchKernelGGL(attn_fwd_mxfp8_sp_kernel, dim3(H * nqb * batch), dim3(512), SMEM_SP, stream, (const unsigned char*)q8,
                        (const unsigned char*)sq, (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t,
-                       (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb);
+                       (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb, batch);
   return (int)hipGetLastError();
 }

@@ -244,8 +244,8 @@ def set_gemm_variant(v: int) -> int:
 
 
 def set_attention_waves(n: int) -> int:
-    """Attention loop body: 0 auto (= 64), 4 / 8 plain, 16 first pipelined, 32 ping-pong, 64 software-pipelined (default),
-    128 one wave per SIMD; returns the previous value (see include/chronoedit_hip.h)."""
+    """Attention loop body: 0 auto (= 64), 4 / 8 plain kernel with that many waves, 64 software-pipelined (default); returns
+    the previous value (see include/chronoedit_hip.h)."""
     return lib().ce_set_attention_waves(int(n))
 
 
@@ -621,8 +621,9 @@ def v_mxfp8_transpose(v: torch.Tensor, n_tokens: int, batch: int, heads: int, ou
 
 
 def set_attention_mxfp8_variant(v: int) -> int:
-    """0: plain loop, 1: software-pipelined with the speculative offset, 8 waves x 32 rows (default), 2: the same with one wave per
-    SIMD (4 waves x 64 rows; measured slower: 1.20 vs 1.71 PFLOP/s at 28 800 keys); returns the previous setting."""
+    """0: plain loop (exact running maximum every tile), 1: software-pipelined with the speculative offset (default); returns the
+    previous setting.  (A one-wave-per-SIMD form, 4 waves x 64 rows, measured 1.20 vs 1.71 PFLOP/s at 28 800 keys and was removed:
+    profiles/r02_microbench_attn_mxfp8.txt.)"""
     return lib().ce_set_attention_mxfp8_variant(int(v))
 
 

@@ -102,11 +102,9 @@ int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int
                               int ldo, float softmax_scale, int batch, hipStream_t stream);
 
 /* Loop body behind ce_attention_bf16 / ce_attention_batched_bf16 (returns the previous value; all are tested against the
- * same reference): 0 automatic (= 64); 4 / 8 the plain kernel with 4 / 8 waves per workgroup; 16 first software-pipelined
- * kernel; 32 ping-pong (two wave groups one barrier apart); 64 software-pipelined, K by LDS-DMA, pre-scaled Q, speculative
- * softmax with an exact fall-back route per tile (default); 128 one wave per SIMD, 64 query rows per wave (single KV segment only; two
- * segments fall back to 8).  Host-side tuning knob; the environment variable CE_ATTN_ORDER=0 (read once at load) switches
- * kernel 64 back to the plain workgroup order for A/B measurements. */
+ * same reference): 0 automatic (= 64); 4 / 8 the plain kernel with 4 / 8 waves per workgroup; 64 software-pipelined, K by
+ * LDS-DMA, pre-scaled Q, speculative softmax with an exact fall-back route per tile (default).  Other values are ignored.
+ * Host-side tuning knob. */
 int ce_set_attention_waves(int nwave);
 
 /* out[dim] = [cos(t f_i), sin(t f_i)], f_i = 1e4^(-i/(dim/2)), fp32; t is a device int64.
@@ -235,8 +233,8 @@ int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const voi
                        int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, hipStream_t stream);
 
 /* Loop body of ce_attention_mxfp8 (returns the previous value): 0 plain (exact running maximum every tile), 1 software-pipelined
- * with a speculative integer offset, row sums on the matrix pipe and an exact repair route per tile, 8 waves x 32 rows (default),
- * 2 the same as 4 waves x 64 rows (one wave per SIMD; measured slower).  Host-side tuning knob. */
+ * with a speculative integer offset, row sums on the matrix pipe and an exact repair route per tile (default).  Other values are
+ * ignored.  Host-side tuning knob. */
 int ce_set_attention_mxfp8_variant(int variant);
 
 /* ---- conditioning encoders (run once per edit, outside the loop: pipeline_chronoedit.py:205-254; the arithmetic is

@@ -221,7 +221,8 @@ def test_mxfp8_v_transpose_matches_contract(N, H, B):
     assert torch.equal(vt, want), (vt - want).abs().max()
 
 
-@pytest.mark.parametrize("N,H,B,spread", [(64, 2, 1, 1.0), (200, 2, 1, 1.0), (333, 4, 2, 1.0), (1000, 2, 1, 3.0), (700, 2, 1, 40.0)])
+@pytest.mark.parametrize("N,H,B,spread", [(64, 2, 1, 1.0), (200, 2, 1, 1.0), (333, 4, 2, 1.0), (1000, 2, 1, 3.0), (700, 2, 1, 40.0),
+                                          (300, 8, 2, 1.0), (560, 16, 1, 2.0)])  # H % 8 == 0: the XCD-aware work order, remainder blocks last
 def test_mxfp8_attention_kernel_vs_contract(N, H, B, spread):
     """The three kernels together vs oracle.attention_mxfp8 (same quantisation, same online order, same offset schedule - lazy for
     the default kernel, per tile for the plain loop): rel-L2 <= 1.5e-2 (what differs is the fp32 summation order and exp2 at the
@@ -241,12 +242,11 @@ def test_mxfp8_attention_kernel_vs_contract(N, H, B, spread):
     k8, sk = ops.rmsnorm_rope_mxfp8(dev[:, D:2 * D], one, None, 128, 1e-6)
     v8t, sv = ops.v_mxfp8_transpose(dev[:, 2 * D:], N, B, H)
     outs = {}
-    for variant in (0, 1, 2):  # plain loop / software-pipelined, 8 waves x 32 rows (default) / one wave per SIMD x 64 rows
+    for variant in (0, 1):  # plain loop / software-pipelined (default)
         ops.set_attention_mxfp8_variant(variant)
         outs[variant] = ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, batch=B).float().cpu()
     ops.set_attention_mxfp8_variant(1)
     out = outs[1]
-    assert torch.equal(outs[1], outs[2]), (outs[1] - outs[2]).abs().max()  # same arithmetic, same order per row: bit-identical
     # the oracle on the same normalised q / k (weight 1, no rope)
     ref_in = dev.clone()
     ops.rmsnorm_rope_(ref_in[:, :D], one, None, 128, 1e-6, x2=ref_in[:, D:2 * D], w2=one)

@@ -55,3 +55,14 @@ def test_row_kernels_issue_their_row_loads_back_to_back():
     for r in _pick(rows, "ln_affine_kernel", "ELb1EE"):  # FULL variants (bf16 and fp8 output)
         assert r[3] == 0 and r[2] <= 168, r
         assert r[5] <= 20, r  # the (a, b) table reads of the third pass (L2 hits); the ten row loads are not among them
+
+
+def test_mxfp8_attention_kernels_have_no_spills_and_their_matrix_work_per_tile():
+    rows = _rows("ce_attn_fp8.hip")
+    for r in rows:
+        assert r[3] == 0, f"{r[0]}: scratch"
+    (sp,) = _pick(rows, "attn_fwd_mxfp8_sp_kernel")
+    assert sp[2] <= 256, sp  # 512 threads per workgroup = two waves per SIMD
+    assert sp[5] == 0, sp    # no load waited for where it is issued (the tiles come by LDS-DMA three iterations ahead)
+    # 4 S + 4 P.V + 1 row-sum MFMA in the steady-state body, the peeled first tile (4 + 1), the repair route (4) and the drain (4 + 1 ...)
+    assert 20 <= sp[4] <= 28, sp

@@ -7,6 +7,4 @@ bash tools/gpu_pmc.sh attn_sp3 attn 7200 7200 40 3 > gpurun_out/pmc_attn_sp3.txt
 timeout 500 python tools/microbench.py attn gemm row 2>&1 | grep -v amdgpu.ids > gpurun_out/microbench.log
 timeout 300 python tools/full_edit.py --steps 50 2>/dev/null | tail -1 > gpurun_out/full_edit_50.json
 timeout 200 python tools/full_edit.py --steps 8 --guidance 1.0 2>/dev/null | tail -1 > gpurun_out/full_edit_8.json
-timeout 100 python tools/attn_ablate.py stamps_sp 2>&1 | grep -v amdgpu.ids > gpurun_out/attn_stamps_sp.txt
-ATTN_KERNEL=64 timeout 100 python tools/attn_ablate.py 7200 2>&1 | grep -v amdgpu.ids > gpurun_out/attn_ablate_sp.txt
 tail -3 gpurun_out/microbench.log; cat gpurun_out/full_edit_50.json | cut -c1-300; ls gpurun_out/prof | head

@@ -4,4 +4,3 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_fp8_gpu.py -m gpu -q --no-header -p no:cacheprovider -x -s -k "mxfp8" > gpurun_out/pytest_mxfp8.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_mxfp8.log
 grep -E "passed|failed|mxfp8|DiT|Error|assert" gpurun_out/pytest_mxfp8.log | tail -14
-timeout 300 python tools/attn8_ablate.py 28800 2>&1 | grep -v amdgpu.ids > gpurun_out/attn8_ablate_28800.txt; cat gpurun_out/attn8_ablate_28800.txt

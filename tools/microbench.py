@@ -109,15 +109,7 @@ def main():
             t4 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(8)
             t8 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
-            ops.set_attention_waves(32)
-            tpp = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
-            ops.set_attention_waves(128)
-            tw4 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
-            print(f"attn {Nq}x{Nkv} H{H}: one-wave-per-SIMD (w4) {tw4*1e3:.3f} ms {4.0*Nq*Nkv*128*H/tw4/1e12:.1f} TF", flush=True)
             ops.set_attention_waves(64)
-            tsp = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
-            print(f"attn {Nq}x{Nkv} H{H}: sw-pipelined (sp) {tsp*1e3:.3f} ms {4.0*Nq*Nkv*128*H/tsp/1e12:.1f} TF", flush=True)
-            ops.set_attention_waves(16)
             t = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(0)
             qh = q.reshape(Nq, H, 128).transpose(0, 1)[None].contiguous()
@@ -141,7 +133,7 @@ def main():
                 del qkv2, out2
             fl = 4.0 * Nq * Nkv * 128 * H
             res[f"attn_{Nq}x{Nkv}x{H}"] = {"ms": t * 1e3, "tflops": fl / t / 1e12, "sdpa_ms": t_ref * 1e3, "sdpa_tflops": fl / t_ref / 1e12}
-            print(f"attn {Nq}x{Nkv} H{H}: 4-wave {fl/t4/1e12:.1f} TF | 8-wave {fl/t8/1e12:.1f} TF | ping-pong {fl/tpp/1e12:.1f} TF | pipelined {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | torch sdpa {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
+            print(f"attn {Nq}x{Nkv} H{H}: plain 4-wave {fl/t4/1e12:.1f} TF | plain 8-wave {fl/t8/1e12:.1f} TF | software-pipelined {t*1e3:.3f} ms {fl/t/1e12:.1f} TF | torch sdpa {t_ref*1e3:.3f} ms {fl/t_ref/1e12:.1f} TF", flush=True)
             del qkv, qh, kh, vh
     if "attn8" in only:  # MXFP8 self-attention (three kernels) beside the bf16 kernel, per launch of a batched-CFG step
         for (N, H, B) in [(7200, 40, 2), (13068, 40, 2), (28800, 40, 1)]:
@@ -155,19 +147,17 @@ def main():
             t_q = timeit(lambda: ops.rmsnorm_rope_mxfp8(qkv[:, :D], one, None, 128, 1e-6, out=q8, scale=sq), iters=10)
             t_v = timeit(lambda: ops.v_mxfp8_transpose(qkv[:, 2 * D:], N, B, H, out=v8t, scale=sv), iters=10)
             t_qb = timeit(lambda: ops.rmsnorm_rope_(qkv[:, :D], one, None, 128, 1e-6, x2=qkv[:, D:2 * D], w2=one), iters=10)
-            t8 = t8p = t8s = t16 = 1e9
+            t8 = t8p = t16 = 1e9
             for _ in range(3):
                 t16 = min(t16, timeit(lambda: ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], H, out=out, batch=B), iters=3))
                 ops.set_attention_mxfp8_variant(0)
                 t8p = min(t8p, timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3))
-                ops.set_attention_mxfp8_variant(2)
-                t8s = min(t8s, timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3))
                 ops.set_attention_mxfp8_variant(1)
                 t8 = min(t8, timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3))
             fl = 4.0 * N * N * 128 * H * B
             res[f"attn8_{N}x{H}_b{B}"] = {"mxfp8_ms": t8 * 1e3, "mxfp8_tflops": fl / t8 / 1e12, "bf16_ms": t16 * 1e3, "bf16_tflops": fl / t16 / 1e12,
                                           "qk_quant_ms_each": t_q * 1e3, "v_transpose_ms": t_v * 1e3, "bf16_norm_rope_qk_ms": t_qb * 1e3}
-            print(f"attn N={N} H={H} B={B}: mxfp8 {t8*1e3:.3f} ms {fl/t8/1e12:.1f} TF (one-wave-per-SIMD form {t8s*1e3:.3f} ms {fl/t8s/1e12:.1f} TF, plain loop {t8p*1e3:.3f} ms {fl/t8p/1e12:.1f} TF) | bf16 {t16*1e3:.3f} ms {fl/t16/1e12:.1f} TF | producers: q or k norm+rope+quant "
+            print(f"attn N={N} H={H} B={B}: mxfp8 {t8*1e3:.3f} ms {fl/t8/1e12:.1f} TF (plain loop {t8p*1e3:.3f} ms {fl/t8p/1e12:.1f} TF) | bf16 {t16*1e3:.3f} ms {fl/t16/1e12:.1f} TF | producers: q or k norm+rope+quant "
                   f"{t_q*1e3:.3f} ms each, V^T quant {t_v*1e3:.3f} ms (bf16 path: q+k norm+rope {t_qb*1e3:.3f} ms)", flush=True)
             del qkv, out, q8, k8, v8t
     if "row" in only:
