@@ -60,7 +60,9 @@ def parse():
     ap.add_argument("--parallel", choices=["auto", "replica", "ulysses"], default="auto",
                     help="N>1: 'ulysses' (default via auto) = ONE edit with the token axis sharded over the GPUs (all-to-all over "
                          "RCCL/xGMI, strong scaling); 'replica' = independent edits per GPU (weak scaling)")
-    ap.add_argument("--cfg-parallel", action="store_true", help="Ulysses mode: the cond / uncond passes on two (N/2)-way groups")
+    ap.add_argument("--cfg-parallel", dest="cfg_parallel", action="store_true", default=None,
+                    help="sharded mode: the cond / uncond passes side by side on two (N/2)-way Ulysses groups (default on 2 GPUs)")
+    ap.add_argument("--no-cfg-parallel", dest="cfg_parallel", action="store_false", help="sharded mode: one N-way Ulysses group, passes in sequence")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
@@ -211,6 +213,12 @@ def main():
     if mode == "auto":
         mode = "ulysses" if world > 1 else "replica"
     ulysses = world > 1 and mode == "ulysses"
+    # Default split of the N ranks (tools/scaling_model.py): on TWO GPUs the guidance pair is split - each
+    # GPU runs one of the two forwards whole, no all-to-all at all, one 3.7 MB exchange per step - because a 2-rank Ulysses group
+    # talks over ONE of the seven xGMI links (predicted 0.90 vs 0.66 steps/s); from four GPUs on Ulysses over all ranks has the
+    # links (3 resp. 7 per GPU) and wins or ties.  --cfg-parallel / --no-cfg-parallel override.
+    if a.cfg_parallel is None:
+        a.cfg_parallel = bool(ulysses and world == 2 and a.guidance > 1)
     if a.cfg_parallel and not (ulysses and world % 2 == 0 and a.guidance > 1):
         raise RuntimeError("--cfg-parallel needs the Ulysses mode on an even number of GPUs with guidance > 1")
     T = a.frames if a.frames is not None else (8 if ulysses else 2)
@@ -276,7 +284,9 @@ def main():
                 "cfg_parallel_groups": 2 if a.cfg_parallel else 1,
                 "all_to_all_per_layer_per_forward": st["all_to_all_calls"] / max(1, n_fwd * a.layers),
                 "bytes_sent_off_rank_per_layer_per_forward": st["all_to_all_bytes_sent_off_rank"] // max(1, n_fwd * a.layers),
-                "exchange": "k|v all-to-all overlapped with the q projection; q; attention output (K-segmented operand of the out-projection)"}
+                "exchange": ("k|v all-to-all overlapped with the q projection; q; attention output (K-segmented operand of the out-projection)"
+                             if model._sp.world > 1 else "none inside a forward: each GPU runs one guidance pass whole") +
+                            ("; one all_gather of the two predictions per step" if a.cfg_parallel else "")}
 
     # ---- per-kernel HIP-event profile of ONE more step (outside the timed region) -> roofline of the dominant kernel
     roofline = roofline_family = breakdown = None

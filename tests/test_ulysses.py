@@ -239,7 +239,7 @@ def _loop_worker(rank, world, port, q, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mode", [(2, "sp"), (4, "cfgp")])
+@pytest.mark.parametrize("world,mode", [(2, "sp"), (2, "cfgp"), (4, "cfgp")])  # (2, cfgp): the guidance pair split, no token sharding
 def test_denoise_loop_with_cfg_sharded_over_ranks(world, mode):
     """`denoise()` must work with the tokens sharded (it used to hand the B = 2 batched-CFG forward to the Ulysses
     path, which raised).  Result vs the single-process loop: identical arithmetic per sample, so rel-L2 <= 5e-3 after 4 steps

@@ -1,5 +1,5 @@
 """Launch ONE kernel shape a few times (for rocprofv3 --pmc passes).  usage:
-   one_kernel.py gemm M N K epi variant [iters]   |   one_kernel.py attn Nq Nkv H [iters]"""
+   one_kernel.py gemm M N K epi variant [iters]   |   one_kernel.py attn Nq Nkv H [iters]   |   one_kernel.py attn8 N H B [iters]"""
 import os
 import sys
 
@@ -23,6 +23,18 @@ if kind == "gemm":
     ops.set_gemm_variant(var)
     for _ in range(iters):
         ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+elif kind == "attn8":  # MXFP8 self-attention, B samples per launch (producers run once, outside the counted launches' names)
+    N, H, B = map(int, sys.argv[2:5])
+    iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    D = H * 128
+    qkv = torch.randn(B * N, 3 * D, generator=g).to(BF).to(dev)
+    one = torch.ones(D, device=dev)
+    q8, sq = ops.rmsnorm_rope_mxfp8(qkv[:, :D], one, None, 128, 1e-6, post_scale=ops.MXFP8_Q_SCALE)
+    k8, sk = ops.rmsnorm_rope_mxfp8(qkv[:, D:2 * D], one, None, 128, 1e-6)
+    v8t, sv = ops.v_mxfp8_transpose(qkv[:, 2 * D:], N, B, H)
+    out = torch.empty(B * N, D, dtype=BF, device=dev)
+    for _ in range(iters):
+        ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B)
 else:
     Nq, Nkv, H = map(int, sys.argv[2:5])
     iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5

@@ -1,0 +1,80 @@
+"""Strong-scaling PREDICTION for `bench.py --gpus N` (Ulysses over RCCL, BASELINE.json configs[3]: N = 28 800 tokens, guidance 5).
+
+A model, not a measurement: it prices the sharded step from (a) the per-kernel times measured on ONE MI355X for the same workload
+(profiles/r02_bench_n28800_one_gpu.json), (b) the tile / workgroup-round quantisation the smaller per-rank shapes meet on 256 CUs
+and (c) the xGMI all-to-all time of the three exchanges per layer.  DESIGN.md section 6 quotes its output next to what the
+driver's SCALE run measured.  Usage: python tools/scaling_model.py [--link-GBps 55] [--latency-us 25]"""
+import argparse
+import json
+import math
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_TOK, D, F, H, L, CUS = 28800, 5120, 13824, 40, 40, 256
+
+
+def rounds(n_wg: float) -> float:
+    """Workgroups on 256 CUs, one per CU: whole rounds, except that a thin last round is worth its fill (the split-K tail of the
+    GEMM and the remainder-last order of the attention spread it) - priced at max(fill, 1/2) of a round."""
+    full, frac = divmod(n_wg / CUS, 1.0)
+    return full + (0.0 if frac < 1e-9 else max(frac, 0.5))
+
+
+def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_gpu: dict):
+    sp = W // 2 if cfg_parallel else W  # ranks per Ulysses group
+    batch = 1  # one sample per forward: the sharded path runs the two guidance passes one after the other (or side by side: cfg-parallel)
+    rows = batch * math.ceil(N_TOK / sp)
+    heads = H // sp
+    kb = one_gpu["kernel_breakdown"]
+
+    # ---- attention: measured 26.47 ms for 2 samples x 40 heads x 113 query blocks on one GPU = per (workgroup round) cost
+    wg1 = 2 * H * math.ceil(N_TOK / 256)
+    per_round = kb["attention_28800x28800+0_h40_b2"]["avg_ms"] / rounds(wg1)
+    attn = per_round * rounds(batch * heads * math.ceil(N_TOK / 256))
+    xattn = kb["attention_28800x512+257_h40_b2"]["avg_ms"] / sp  # cross-attention: queries sharded by token, all heads local
+
+    # ---- GEMMs: measured per launch at M = 57 600 rows; tiles of 256 x 256, rounds of 256 CUs
+    def gemm(key, ncols):
+        t1 = kb[key]["avg_ms"]
+        per = t1 / rounds(math.ceil(57600 / 256) * (ncols // 256))
+        return per * rounds(math.ceil(rows / 256) * (ncols // 256))
+    g = (gemm("gemm_57600x15360x5120_epi0", 15360) + gemm("gemm_57600x13824x5120_epi1", 13824) + gemm("gemm_57600x5120x13824_epi2", 5120)
+         + 2 * gemm("gemm_57600x5120x5120_epi2", 5120) + gemm("gemm_57600x5120x5120_epi0", 5120))
+    q_gemm = gemm("gemm_57600x5120x5120_epi0", 5120)  # what the k|v exchange hides behind (the q third of the fused projection)
+    row = (3 * kb["ln_affine_57600x5120"]["avg_ms"] + kb["rmsnorm_rope_57600x5120x2"]["avg_ms"] + kb["rmsnorm_rope_57600x5120"]["avg_ms"]) * rows / 57600
+
+    # ---- exchanges (per layer, per rank): k|v, q, attention output; bytes leaving a rank over EACH of its sp-1 links
+    def a2a_ms(ntensors):
+        if sp == 1:
+            return 0.0
+        per_link = ntensors * rows * (D // sp) * 2  # [local rows][D / sp] bf16 to every peer
+        return per_link / (link_GBps * 1e9) * 1e3 + latency_us * 1e-3
+    kv, q, o = a2a_ms(2), a2a_ms(1), a2a_ms(1)
+    exposed = max(0.0, kv - q_gemm) + q + o
+    layer = attn + xattn + g + row + exposed
+    fwd = L * layer + 6.0 / sp  # + context K/V projections (3 + 3 ms on one GPU), head, patchify
+    passes = 1 if cfg_parallel else 2
+    step = passes * fwd + (0.1 if cfg_parallel else 0.0)  # + the 3.7 MB prediction exchange
+    return dict(W=W, mode="cfg-parallel 2 x %d" % sp if cfg_parallel else "ulysses %d" % sp, rows=rows, heads=heads,
+                attn_ms=attn, gemm_ms=g, exchange_ms=kv + q + o, exposed_ms=exposed, step_ms=step, steps_per_s=1e3 / step)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--link-GBps", type=float, default=55.0, help="sustained one-direction rate of one xGMI link inside an RCCL all-to-all "
+                    "(153.6 GB/s per link both directions -> 76.8 one way at the data sheet; ~70 % of it assumed)")
+    ap.add_argument("--latency-us", type=float, default=25.0, help="fixed cost of one all_to_all_single (launch + sync)")
+    a = ap.parse_args()
+    one = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n28800_one_gpu.json")))
+    base = one["ms_per_step"]
+    print(f"measured on one MI355X: {base:.0f} ms/step ({1e3 / base:.3f} steps/s); link {a.link_GBps} GB/s one way, {a.latency_us} us per collective")
+    print(f"{'GPUs':>4} {'mode':>18} {'rows/rank':>9} {'heads':>5} {'attn':>7} {'GEMMs':>7} {'a2a':>6} {'exposed':>7} | {'ms/step':>8} {'steps/s':>8} {'speed-up':>8} {'eff.':>5}")
+    for W in (1, 2, 4, 8):
+        for cfgp in ((False,) if W == 1 else (False, True)):
+            r = model(W, cfgp, a.link_GBps, a.latency_us, one)
+            print(f"{W:>4} {r['mode']:>18} {r['rows']:>9} {r['heads']:>5} {r['attn_ms']:>7.2f} {r['gemm_ms']:>7.2f} {r['exchange_ms']:>6.2f} {r['exposed_ms']:>7.2f} |"
+                  f" {r['step_ms']:>8.1f} {r['steps_per_s']:>8.3f} {base / r['step_ms']:>8.2f} {base / r['step_ms'] / W:>5.2f}")
+
+
+if __name__ == "__main__":
+    main()
