@@ -180,12 +180,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # CE_BENCH_TEST_BACKEND=gloo (tools/gpu_r2_g.sh only): the N > 1 code path of this file on a ONE-GPU box - all ranks share GPU 0
+    # and the collectives are host-staged.  The line it prints is marked and is not a measurement of anything.
+    test_backend = os.environ.get("CE_BENCH_TEST_BACKEND")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if test_backend:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")  # == RCCL on ROCm
-        if dist.get_world_size() != world or dist.get_backend() != "nccl":
+        dist.init_process_group(test_backend or "nccl")  # "nccl" == RCCL on ROCm
+        if not test_backend and (dist.get_world_size() != world or dist.get_backend() != "nccl"):
             raise RuntimeError(f"RCCL group came up with {dist.get_world_size()} ranks on backend {dist.get_backend()}, expected {world} on nccl")
         if a.gpus != world:
             raise RuntimeError(f"--gpus {a.gpus} but the launcher started {world} ranks")
@@ -263,7 +268,7 @@ def main():
         sync_all()
         dt_ = time.perf_counter() - t0
         if world > 1:
-            tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt_], device="cpu" if test_backend else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt_ = float(tt.item())
         return dt_
@@ -373,6 +378,7 @@ def main():
             "achieved_tflops_per_gpu": round(per_gpu, 1),
             "mfma_roofline_frac_whole_step": round(per_gpu / PEAK_BF16_TFLOPS, 4),
             "finite": finite,
+            **({"TEST_ONLY": f"ranks share one GPU, collectives host-staged over {test_backend}: exercises the code path, measures nothing"} if test_backend else {}),
             "launch": "hipGraph replay" if a.graph else "eager",
             "rccl": rccl,
             "single_gpu_same_workload_steps_per_sec": single_same,
