@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--cfg-parallel", dest="cfg_parallel", action="store_true", default=None,
                     help="sharded mode: the cond / uncond passes side by side on two (N/2)-way Ulysses groups (default on 2 GPUs)")
     ap.add_argument("--no-cfg-parallel", dest="cfg_parallel", action="store_false", help="sharded mode: one N-way Ulysses group, passes in sequence")
+    ap.add_argument("--no-transposed-v", action="store_true",
+                    help="(A/B) fused q|k|v GEMM + register-staged attention kernel instead of V^T from the swapped GEMM + LDS-DMA staging")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
@@ -210,6 +212,8 @@ def main():
         ops.set_attention_waves(a.attn_kernel)
     model = build_model(a.layers, dev)
     model.cache_context = a.cache_context
+    if a.no_transposed_v:
+        model.enable_transposed_v(False)
     if a.fp8:
         model.enable_fp8_gemms()
         if not a.fp8_gemms_only:

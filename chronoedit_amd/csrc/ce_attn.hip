@@ -338,7 +338,7 @@ constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow t
 constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
 constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 * QW * OST_ROW : SP_TILE_BYTES; }
 
-template <bool TWO_SEG>
+template <bool TWO_SEG, bool VT = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
                                                               KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
                                                               float scale_log2e, int batch) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     Q += (size_t)bz * Nq * ldq;
     O += (size_t)bz * Nq * ldo;
     seg0.k += (size_t)bz * seg0.len * seg0.ldk;
-    seg0.v += (size_t)bz * seg0.len * seg0.ldv;
+    seg0.v += VT ? (size_t)bz * seg0.len : (size_t)bz * seg0.len * seg0.ldv;  // VT: the samples' keys sit side by side in the columns of V^T
     if (TWO_SEG) {
       seg1.k += (size_t)bz * seg1.len * seg1.ldk;
       seg1.v += (size_t)bz * seg1.len * seg1.ldv;
@@ -424,6 +424,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
   const unsigned char* k_rd = smem + (l31 >> 2) * K_GRP + k_w * 256 + ((hh ^ (k_w & 1)) << 4);  // + buf*PK_TILE + f*8*K_GRP
   const int k_eo[2] = {(k_w >> 1) << 5, ((k_w >> 1) ^ 1) << 5};                                    // + k_eo[ks & 1] + (ks >> 1)*64
   const unsigned char* v_rd = smem + SP_V0 + l31 * PV_ROW + hh * 16;    // + buf*PV_TILE + m*32*PV_ROW + s*32
+  // VT (V arrives transposed, [head_dim row][keys], and its tiles come by LDS-DMA like K's): image = 128 rows x 128 B, lane-linear
+  // per 1 KiB wave-instruction (8 rows), chunk c of row d kept in slot c ^ ((d >> 1) & 7) on the SOURCE side: the 16 lanes of a
+  // ds_read_b128 group (16 consecutive d, one chunk) hit slots 8 (d & 1) + (c ^ (d >> 1 & 7)) - all distinct.  With c = 2 s + h the
+  // slot is 2 (s ^ x >> 1) + (h ^ x & 1), x = (d >> 1) & 7: four per-lane bases (one per k-step) + immediates.
+  int vt_off[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int x = (l31 >> 1) & 7;
+    vt_off[s4] = l31 * 128 + ((2 * (s4 ^ (x >> 1)) + (hh ^ (x & 1))) << 4);
+  }
   unsigned char* v_wr = smem + SP_V0 + (4 * v_dvq) * PV_ROW + v_chunk * 8;  // + buf*PV_TILE + j*PV_ROW
 
 #pragma unroll
@@ -431,7 +441,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     const KVSeg sg = sidx == 0 ? seg0 : seg1;
     const int ntiles = (sg.len + KVB - 1) / KVB;
     const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (sg.len - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
-    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + hoff), 0, (sg.len - 1) * sg.ldv * 2 + HD * 2, 0x00020000);
+    // VT: rows hoff .. hoff + 127 of V^T [H * 128][ldv]; a tile is a 128-B column strip.  Columns past this sample's keys hold the
+    // next sample's keys or the (finite, zeroed) padding of the buffer: they only ever meet P = 0.
+    const auto v_rsrc = VT ? __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + (size_t)hoff * sg.ldv), 0, ((HD - 1) * sg.ldv + ntiles * KVB) * 2, 0x00020000)
+                           : __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + hoff), 0, (sg.len - 1) * sg.ldv * 2 + HD * 2, 0x00020000);
     int v_voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) v_voff[i] = (4 * v_kvq + i) * sg.ldv * 2 + v_dvq * 8;
@@ -453,7 +466,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 
     pp_u2 vreg[4];
     // wave-instruction j fills group wave + 8 j of the image: lane -> row 4 (wave + 8 j) + (lane >> 4), chunk (lane & 15) ^ (lane >> 4)
-    const int kd_voff0 = (4 * wave + (lane >> 4)) * sg.ldk * 2 + (((lane & 15) ^ (lane >> 4)) << 4), kd_voff1 = kd_voff0 + 32 * sg.ldk * 2;
+    // VT: image row rho holds key pi(rho) = rho with bits 2 and 3 swapped, so that the 8 keys a lane half owns per k-step of P.V
+    // (accumulator rows 16 s + 8 b + 4 h + i) are the CONTIGUOUS keys 16 s + 8 h + 4 b + i: its V^T fragment is one 16-B chunk of
+    // the natural layout (the register-staged path gets the same effect by permuting V while it transposes it).
+    const int kd_row = VT ? (lane >> 4) + 4 * ((wave >> 1) & 1) + 8 * (wave & 1) + 16 * (wave >> 2) : 4 * wave + (lane >> 4);
+    const int kd_voff0 = kd_row * sg.ldk * 2 + (((lane & 15) ^ (lane >> 4)) << 4), kd_voff1 = kd_voff0 + 32 * sg.ldk * 2;
+    // V^T piece j of this wave: rows 8 (wave + 8 j) + (lane >> 3), slot lane & 7 <- chunk slot ^ ((row >> 1) & 7)
+    const int vd_row = 8 * wave + (lane >> 3);
+    const int vd_voff0 = vd_row * sg.ldv * 2 + (((lane & 7) ^ ((vd_row >> 1) & 7)) << 4), vd_voff1 = vd_voff0 + 64 * sg.ldv * 2;
+    auto dma_v = [&](int t, int buf, int j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + SP_V0 + buf * PV_TILE + (wave + 8 * j) * 1024), 16,
+                                               j ? vd_voff1 : vd_voff0, t * (KVB * 2), 0, 0);
+    };
     auto dma_k = [&](int t, int buf, int j) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + buf * PK_TILE + (wave + 8 * j) * K_GRP), 16,
                                                j ? kd_voff1 : kd_voff0, t * k_tile_bytes, 0, 0);
@@ -498,17 +522,30 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     dma_k(0, 0, 0);
     dma_k(0, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    load_v(0);
+    if (VT) {
+      dma_v(0, 0, 0);
+      dma_v(0, 0, 1);
+    } else {
+      load_v(0);
+    }
     {
       const pp_u4 z = {0u, 0u, 0u, 0u};
       for (int i = tid; i < PV_TILE / 16; i += NWAVE * 64) *reinterpret_cast<pp_u4*>(smem + SP_V0 + 2 * PV_TILE + i * 16) = z;
     }
-    store_v(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K(0) has landed (its DMA precedes the V(0) fetch just consumed)
-    load_v(1);
+    if (!VT) {
+      store_v(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K(0) has landed (its DMA precedes the V(0) fetch just consumed)
+      load_v(1);
+    }
     // From here on the vector-memory queue of a wave holds, in order: K(t) DMA x2 (tile t-1, units 1 and 3), V(t+1) x4
     // (tile t-1, unit 12): "vmcnt(4)" in front of the barrier of tile t = K(t) is in LDS.
-#define CE_SP_KWAIT() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
+    // VT: the queue holds K(t) DMA x2 (units 1, 3 of tile t-1), V(t) DMA x2 (units 5, 7): "vmcnt(2)" = K(t) and V(t-1) are in LDS;
+    // V(t) is first read one iteration later (P(t).V(t) runs inside tile t+1) and may still be in flight.
+#define CE_SP_KWAIT()                                          \
+  do {                                                         \
+    if (VT) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   \
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      \
+  } while (0)
     int vb_prev = 2, vb_cur = 0;  // V^T buffer of tile t-1 / tile t
 
     // A wave without query rows only stages, behind the same barriers - in a loop of its own: as a `continue` path inside
@@ -521,8 +558,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       dma_k(t + 1, (t + 1) & 1, 0);
       dma_k(t + 1, (t + 1) & 1, 1);
       __builtin_amdgcn_sched_barrier(0);
-      store_v(vb_next);
-      load_v(t + 2);
+      if (VT) {
+        dma_v(t + 1, vb_next, 0);
+        dma_v(t + 1, vb_next, 1);
+      } else {
+        store_v(vb_next);
+        load_v(t + 2);
+      }
       vb_prev = vb_cur;
       vb_cur = vb_next;
     }
@@ -532,6 +574,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       const int vb_next = 3 - vb_prev - vb_cur;
       const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
       const unsigned char* vb = v_rd + vb_prev * PV_TILE;
+      const unsigned char* vtb = smem + SP_V0 + vb_prev * PV_TILE;  // VT image of tile t-1
 
       // ---- S^T(t) = K(t).Q^T: MFMA i works on kv fragment f = i & 1, k-step ks = i >> 1 (alternating accumulators; every
       // unit - MFMA, ring refill, its piece of staging - is its own scheduling region: with sched_group_barrier alone hipcc
@@ -561,8 +604,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
           if (i == 1) dma_k(t + 1, (t + 1) & 1, 0);
           if (i == 3) dma_k(t + 1, (t + 1) & 1, 1);
-          if (i == 12) load_v(t + 2);
-          if (i >= 5 && i < 9) store_v_part(vb_next, i - 5);
+          if (VT) {
+            if (i == 5) dma_v(t + 1, vb_next, 0);
+            if (i == 7) dma_v(t + 1, vb_next, 1);
+          } else {
+            if (i == 12) load_v(t + 2);
+            if (i >= 5 && i < 9) store_v_part(vb_next, i - 5);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
 #undef CE_LDK
@@ -584,7 +632,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int kv = base + 32 * f + (r & 3) + 8 * (r >> 2);
+              const int kv = VT ? t * KVB + 32 * f + 16 * (r >> 3) + 8 * hh + 4 * ((r >> 2) & 1) + (r & 3)  // pi(row), see dma_k
+                                : base + 32 * f + (r & 3) + 8 * (r >> 2);
               if (kv >= sg.len) st[f][r] = NEG_BIG;
             }
         }
@@ -632,7 +681,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       // the transcendental result latency) and one packed bf16 conversion (four units behind: pair j lands in the word of
       // the P fragment that MFMA j + 3 was the last to read, so P(t) replaces P(t-1) in place, without copies).
       {
-#define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vb + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
+#define CE_LDV(u)                                                                                         \
+  (VT ? *reinterpret_cast<const bf16x8*>(vtb + vt_off[(u) >> 2] + ((u) & 3) * 4096)                       \
+      : *reinterpret_cast<const bf16x8*>(vb + ((u) & 3) * 32 * PV_ROW + ((u) >> 2) * 32))
         constexpr int VRING = 6;
         bf16x8 vf[VRING];
 #pragma unroll
@@ -694,11 +745,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[m][r] *= alpha_prev;
     }
+    if (VT) {  // V(ntiles-1) was issued during the last-but-one tile and may still be in flight: land it, for everybody
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     if (active) {
       const unsigned char* vb = v_rd + vb_prev * PV_TILE;
+      const unsigned char* vtb = smem + SP_V0 + vb_prev * PV_TILE;
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const bf16x8 vfd = *reinterpret_cast<const bf16x8*>(vb + (u & 3) * 32 * PV_ROW + (u >> 2) * 32);
+        const bf16x8 vfd = VT ? *reinterpret_cast<const bf16x8*>(vtb + vt_off[u >> 2] + (u & 3) * 4096)
+                              : *reinterpret_cast<const bf16x8*>(vb + (u & 3) * 32 * PV_ROW + (u >> 2) * 32);
         oacc[u & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfd, __builtin_bit_cast(bf16x8, ppk[u >> 2]), oacc[u & 3], 0, 0, 0);
       }
     }
@@ -733,6 +790,53 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? SP_TILE_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
       *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
     }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// V [rows = keys of all samples][ldv] (head h at columns 128 h ..) -> V^T [H * 128][ldvt] (row = head channel, column = key; the
+// samples' keys side by side), the operand layout of the VT form of the attention kernel above.  One workgroup per 64-key strip
+// and head: 16-B loads along the channels, 4 x 4 patches transposed in registers, LDS for the change of the fast axis, 16-B stores
+// along the keys.  Columns [n_keys, ldvt) are zeroed by the strip that owns them (they meet P = 0 and must be finite).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict__ V, int ldv, bf16* __restrict__ VT, int ldvt, int n_keys) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[HD * (KVB * 2 + 16)];  // [128 d][64 keys] bf16, rows 144 B
+  constexpr int TROW = KVB * 2 + 16;
+  const int tid = threadIdx.x, head = blockIdx.y, key0 = blockIdx.x * KVB;
+  // thread -> patch (4 keys x 4 channels): kq = tid & 15 (key quad), dq = tid >> 4 (channel quad, + 16 per pass)
+  const int kq = tid & 15, dq = tid >> 4;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int d0 = 4 * (dq + 16 * pass);
+    pp_u2 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = key0 + 4 * kq + i;
+      r[i] = key < n_keys ? *reinterpret_cast<const pp_u2*>(V + (size_t)key * ldv + head * HD + d0) : pp_u2{0u, 0u};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // channel d0 + j of keys 4 kq .. 4 kq + 3
+      const int w = j >> 1;
+      uint32_t lo, hi;
+      if ((j & 1) == 0) {
+        lo = (r[0][w] & 0xffffu) | (r[1][w] << 16);
+        hi = (r[2][w] & 0xffffu) | (r[3][w] << 16);
+      } else {
+        lo = (r[0][w] >> 16) | (r[1][w] & 0xffff0000u);
+        hi = (r[2][w] >> 16) | (r[3][w] & 0xffff0000u);
+      }
+      *reinterpret_cast<pp_u2*>(tile + (d0 + j) * TROW + kq * 8) = pp_u2{lo, hi};
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i;  // 1024 chunks of 16 B: row d = c >> 3, chunk c & 7
+    const int d = c >> 3, ch = c & 7;
+    const pp_u4 v = *reinterpret_cast<const pp_u4*>(tile + d * TROW + ch * 16);
+    const int col = key0 + 8 * ch;
+    if (col < ldvt) *reinterpret_cast<pp_u4*>(VT + (size_t)(head * HD + d) * ldvt + col) = v;
   }
 }
 
@@ -809,4 +913,35 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
                                  int ldo, float softmax_scale, hipStream_t stream) {
   return ce_attention_batched_bf16(Q, K1, V1, len1, ldk1, ldv1, K2, V2, len2, ldk2, ldv2, O, Nq, H, head_dim, ldq, ldo,
                                    softmax_scale, 1, stream);
+}
+
+/* V [batch * n_tokens][ldv] -> V^T [H * 128][ldvt]: see v_transpose_kernel. */
+extern "C" int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, hipStream_t stream) {
+  if (!v || !vt) return CE_ERR_ARG;
+  if (n_keys <= 0 || H <= 0 || ldvt < n_keys) return CE_ERR_SHAPE;
+  if ((ldv & 3) || (ldvt & 7)) return CE_ERR_ALIGN;
+  hipLaunchKernelGGL(v_transpose_kernel, dim3((ldvt + KVB - 1) / KVB, H), dim3(256), 0, stream, (const bf16*)v, ldv, (bf16*)vt, ldvt, n_keys);
+  return (int)hipGetLastError();
+}
+
+/* Self-attention with V handed over TRANSPOSED (V^T [H * 128][ldvt], sample b's keys in columns [b len, (b + 1) len)): both K and
+ * V^T tiles reach LDS by LDS-DMA, no register staging.  One KV segment, software-pipelined kernel only. */
+extern "C" int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
+                                    int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O) return CE_ERR_ARG;
+  if (head_dim != HD || Nq <= 0 || H <= 0 || len <= 0 || batch <= 0 || batch > 65535) return CE_ERR_SHAPE;
+  if (ldvt < (batch - 1) * len + (len + KVB - 1) / KVB * KVB) return CE_ERR_SHAPE;  // the last tile of the last sample reads whole 64-key strips
+  if ((ldq & 7) || (ldo & 7) || (ldk & 7) || (ldvt & 7) || (batch > 1 && (len & 7))) return CE_ERR_ALIGN;
+  KVSeg s0{(const bf16*)K, (const bf16*)Vt, len, ldk, ldvt};
+  KVSeg s1{nullptr, nullptr, 0, 0, 0};
+  const float sl2 = softmax_scale * 1.4426950408889634f;
+  const int nqb = (Nq + 8 * QW - 1) / (8 * QW);
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(false));
+    done = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_sp_kernel<false, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O,
+                     s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch);
+  return (int)hipGetLastError();
 }

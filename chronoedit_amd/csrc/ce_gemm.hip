@@ -26,6 +26,7 @@
 #define EPI_GATE_RES 2
 #define EPI_BIAS_GELU_ERF 3
 #define EPI_F32 4  // C is float*: raw fp32 accumulators (attention scores of the VAE mid block)
+#define EPI_BIAS_ROW 6  // C = bf16(acc + bias[m]): bias along the rows of C - a product with swapped operand roles (V^T = W_v.X^T)
 #define EPI_MUL 5  // C = bf16(bf16(acc + bias) * res): the gated activation of the UMT5 feed-forward (wi_1(x) * gelu(wi_0(x)))
 
 namespace {
@@ -166,13 +167,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
   for (int j = 0; j < 4; ++j) {
     const int cl = wn * 64 + j * 16 + fr;
     const int n = n0 + cl;
-    const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+    const float bv = (EPI != EPI_BIAS_ROW && bias != nullptr && n < N) ? bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rl = wm * 64 + i * 16 + fg * 4 + r;
-        *reinterpret_cast<bf16*>(smem + rl * LDC_BYTES + cl * 2) = (bf16)(acc[i][j][r] + bv);
+        const float br = EPI == EPI_BIAS_ROW ? bias[min(m0 + rl, M - 1)] : bv;
+        *reinterpret_cast<bf16*>(smem + rl * LDC_BYTES + cl * 2) = (bf16)(acc[i][j][r] + br);
       }
   }
   __syncthreads();
@@ -254,7 +256,7 @@ extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const flo
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) || (N & 7)) return CE_ERR_SHAPE;
   if ((lda & 7) || (ldw & 7) || (ldc & 7)) return CE_ERR_ALIGN;
   if ((epilogue == EPI_GATE_RES || epilogue == EPI_MUL) && (!res || (ldres & 7))) return CE_ERR_ARG;
-  if (epilogue < 0 || epilogue > 5) return CE_ERR_ARG;
+  if (epilogue < 0 || epilogue > 6 || (epilogue == EPI_BIAS_ROW && !bias)) return CE_ERR_ARG;
   if (epilogue != EPI_F32 && epilogue != EPI_MUL) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant >= 1 || (g_gemm_variant == -1 && big);
@@ -278,6 +280,7 @@ extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const flo
     case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
     case EPI_F32: CE_LAUNCH(EPI_F32); break;
     case EPI_MUL: CE_LAUNCH(EPI_MUL); break;
+    case EPI_BIAS_ROW: CE_LAUNCH(EPI_BIAS_ROW); break;
     default: return CE_ERR_ARG;
   }
 #undef CE_LAUNCH

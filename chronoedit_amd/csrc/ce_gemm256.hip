@@ -138,23 +138,37 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2][2][4][2], unsi
                                             int fr, int fg, int m0, int n0, bf16* __restrict__ C,
                                             const float* __restrict__ bias, const float* __restrict__ gate,
                                             const bf16* __restrict__ res, int M, int N, int ldc, int ldres, int gate_rows) {
+  // column bias of this lane's four (j, g) column groups, the same for both passes: four 16-B loads issued together, on clamped
+  // addresses and without a per-lane guard (a guarded load compiles to its own branch with a vmcnt(0) behind it - seven serial
+  // round trips per tile before this was hoisted); n is a multiple of 4 and N of 8, so "n < N" covers all four columns
+  f32x4 bcol[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int n = n0 + j * 128 + wn * 32 + g * 16 + fg * 4;
+      bcol[j][g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   // ---- epilogue, two passes of 128 tile rows (i = 0, 1)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (i == 1) __syncthreads();
+    float brow[4] = {0.f, 0.f, 0.f, 0.f};  // EPI_BIAS_ROW: the bias of this lane's four rows (swapped operand roles)
+    if (EPI == EPI_BIAS_ROW) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) brow[f] = bias[min(m0 + i * 128 + wm * 64 + f * 16 + fr, M - 1)];
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int cl = j * 128 + wn * 32 + g * 16 + fg * 4;
-        const int n = n0 + cl;
-        float bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (bias != nullptr && n + r < N) ? bias[n + r] : 0.f;
+        f32x4 bv = bcol[j][g];
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
           const int rl = wm * 64 + f * 16 + fr;
           const f32x4 v = acc[i][j][f][g];
+          if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow[f];
           const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
           *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
         }
@@ -425,11 +439,10 @@ __global__ __launch_bounds__(512) void gemm256_reduce(bf16* __restrict__ C, cons
   for (int g = 0; g < 2; ++g) {
     const int cl = wn * 32 + g * 16 + fg * 4;
     const int n = n0 + cl;
-    float bv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[r] = (bias != nullptr && n + r < N) ? bias[n + r] : 0.f;
+    f32x4 bv = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
+      if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = bias[min(m0 + wm * 64 + f * 16 + fr, M - 1)];
       const int e = (((((qi * 2 + qj) * 4 + f) * 2 + g) * 512) + tid) * 4;
       f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
       for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
@@ -502,7 +515,7 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
   if (split == 1) tail = 0;
   const int t_full2 = nwg - tail;
   dim3 grid(t_full2 + tail * split), block(512);
-  static bool attr_done[4] = {false, false, false, false};
+  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
 #define CE_LAUNCH(E)                                                                                                  \
   do {                                                                                                                \
     if (!attr_done[E]) {                                                                                              \
@@ -528,6 +541,7 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
     case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;
     case EPI_GATE_RES: CE_LAUNCH(EPI_GATE_RES); break;
     case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
+    case EPI_BIAS_ROW: CE_LAUNCH(EPI_BIAS_ROW); break;
     default: return CE_ERR_ARG;
   }
 #undef CE_LAUNCH

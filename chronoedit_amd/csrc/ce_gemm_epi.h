@@ -8,6 +8,9 @@
 #define EPI_GATE_RES 2
 #define EPI_BIAS_GELU_ERF 3
 #endif
+#ifndef EPI_BIAS_ROW
+#define EPI_BIAS_ROW 6  // C = bf16(acc + bias[m]): the bias runs along the ROWS of C (operand roles swapped: C = W.X^T)
+#endif
 
 namespace {
 

@@ -14,7 +14,7 @@ import torch
 from . import hiplib
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_GATE_RES, EPI_BIAS_GELU_ERF = 0, 1, 2, 3
-EPI_F32, EPI_MUL = 4, 5
+EPI_F32, EPI_MUL, EPI_BIAS_ROW = 4, 5, 6
 
 _lib = None
 
@@ -157,7 +157,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Op
         raise ValueError(f"gemm: K mismatch {K} vs {K2}")
     if bias is not None:
         _dev(bias, torch.float32, "bias")
-        assert bias.numel() == N and bias.is_contiguous()
+        assert bias.numel() == (M if epilogue == EPI_BIAS_ROW else N) and bias.is_contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
     _dev(out, torch.bfloat16, "out")
@@ -279,6 +279,51 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out
                                            nq, heads, head_dim, ldq, ldo, float(scale), batch, _stream()), "ce_attention_bf16")
     _prof_end(st, f"attention_{nq}x{l1}+{l2}_h{heads}" + (f"_b{batch}" if batch > 1 else ""),
               4.0 * nq * (l1 + l2) * head_dim * heads * batch)
+    return out
+
+
+def vt_columns(n_keys_total: int) -> int:
+    """Row length of the V^T operand for `n_keys_total` keys (all samples side by side): whole 64-key strips, 16-B aligned rows."""
+    return (n_keys_total + 63) // 64 * 64 + 64
+
+
+def v_transpose(v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None):
+    """v [keys of all samples, heads*128] (row stride free) -> V^T [heads*128, vt_columns(keys)] bf16, padding columns zeroed:
+    the V operand of `attention_vt`."""
+    _dev(v, torch.bfloat16, "v")
+    n, D, ldv = _rows(v, "v")
+    assert D == heads * 128
+    if out is None:
+        out = torch.empty((D, vt_columns(n)), dtype=torch.bfloat16, device=v.device)
+    _dev(out, torch.bfloat16, "vt")
+    assert out.shape[0] == D and out.is_contiguous() and out.shape[1] >= n
+    st = _prof_begin()
+    _check(lib().ce_v_transpose_bf16(_ptr(v), ldv, _ptr(out), out.shape[1], n, heads, _stream()), "ce_v_transpose_bf16")
+    _prof_end(st, f"v_transpose_{n}x{D}", 4.0 * n * D)
+    return out
+
+
+def attention_vt(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
+                 scale: Optional[float] = None, batch: int = 1):
+    """Self-attention with V transposed (`v_transpose`): q [batch*Nq, H*128], k [batch*Nkv, H*128], vt [H*128, >= batch*Nkv (+pad)];
+    K and V^T tiles both reach LDS by LDS-DMA.  Same arithmetic as `attention` (one KV segment)."""
+    for n, t in (("q", q), ("k", k), ("vt", vt)):
+        _dev(t, torch.bfloat16, n)
+    Nq, Dq, ldq = _rows(q, "q")
+    L1, _, ldk = _rows(k, "k")
+    assert Dq == heads * 128 and vt.shape[0] == Dq and vt.stride(1) == 1
+    if batch < 1 or Nq % batch or L1 % batch:
+        raise ValueError(f"attention_vt: row counts must be multiples of batch={batch}")
+    if out is None:
+        out = torch.empty((Nq, Dq), dtype=torch.bfloat16, device=q.device)
+    _, _, ldo = _rows(out, "out")
+    if scale is None:
+        scale = 128 ** -0.5
+    st = _prof_begin()
+    nq, l1 = Nq // batch, L1 // batch
+    _check(lib().ce_attention_vt_bf16(_ptr(q), _ptr(k), _ptr(vt), l1, ldk, vt.stride(0), _ptr(out), nq, heads, 128, ldq, ldo, float(scale),
+                                      batch, _stream()), "ce_attention_vt_bf16")
+    _prof_end(st, f"attention_{nq}x{l1}+0_h{heads}" + (f"_b{batch}" if batch > 1 else ""), 4.0 * nq * l1 * 128 * heads * batch)
     return out
 
 

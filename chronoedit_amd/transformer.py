@@ -190,6 +190,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
         self.gemm_dtype = "bf16"    # "fp8": the six large Linears of every block on the OCP-e4m3 MX matrix path
         self.attn_dtype = "bf16"    # "mxfp8": self-attention on the MX-fp8 matrix instruction (csrc/ce_attn_fp8.hip)
+        self.v_transposed = True    # bf16 self-attention takes V^T straight from the projection (swapped GEMM) and stages it by LDS-DMA
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
         self._cfgp = None           # CFG parallelism on top of it (two Ulysses groups), off by default
 
@@ -285,6 +286,17 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         stream, the conditioning projections and the head stay bf16 / fp32 as before.  The bf16 parameters are kept."""
         self.gemm_dtype = "fp8" if on else "bf16"
         self._engine = None
+        return self
+
+    def enable_transposed_v(self, on: bool = True):
+        """bf16 self-attention operand form (default on): the V third of the fused projection is taken as V^T = W_v.h^T (the GEMM
+        with its operand roles swapped and the bias along rows, CE_EPI_BIAS_ROW) so that K and V^T tiles both reach the attention
+        kernel's LDS by LDS-DMA (`ce_attention_vt_bf16`: +4.4 % on the kernel, no transpose pass).  Off = the fused q|k|v GEMM and
+        the register-staged kernel; same arithmetic up to the summation order inside a key tile."""
+        self.v_transposed = bool(on)
+        if self._engine is not None:
+            self._engine.v_transposed = self.v_transposed
+            self._engine._ws = {}
         return self
 
     def enable_fp8_attention(self, on: bool = True):
@@ -455,6 +467,7 @@ class DiTEngine:
             self.blk.append(p)
         self.fp8_attn = model.attn_dtype == "mxfp8"
         self.fp8 = model.gemm_dtype == "fp8"
+        self.v_transposed = bool(getattr(model, "v_transposed", True))
         if self.fp8:
             if self.D % 256 or self.F % 256:
                 raise NotImplementedError("fp8 GEMMs need inner and ffn dims that are multiples of 256")
@@ -726,6 +739,17 @@ class DiTEngine:
                     ws.v8t = ws.sv = None
                 ws.v8t, ws.sv = ops.v_mxfp8_transpose(ws.qkv[:, 2 * D :], Nl, B, H, out=ws.v8t, scale=ws.sv)
                 ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, out=ws.att, batch=B)
+                att = ws.att
+            elif sp is None and self.v_transposed and not self.fp8 and (B * Nl) % 8 == 0 and (B == 1 or Nl % 8 == 0):
+                # q | k as one GEMM, V^T = W_v.h^T as the same GEMM with the operand roles swapped (bias along rows): the attention
+                # kernel's V^T operand [D][keys of all samples] without a transpose pass; K and V^T tiles both go by LDS-DMA
+                if getattr(ws, "vt", None) is None:
+                    ws.vt = torch.zeros((D, ops.vt_columns(B * Nl)), dtype=torch.bfloat16, device=self.dev)  # padding columns stay zero
+                ops.ln_affine(x, mod[li, 0, 1], mod[li, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
+                ops.gemm(ws.h, p.w_qkv[: 2 * D], p.b_qkv[: 2 * D], out=ws.qkv[:, : 2 * D])
+                ops.gemm(p.w_qkv[2 * D :], ws.h, p.b_qkv[2 * D :], out=ws.vt[:, : B * Nl], epilogue=ops.EPI_BIAS_ROW)
+                ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)
+                ops.attention_vt(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.vt, H, out=ws.att, batch=B)
                 att = ws.att
             elif sp is None:  # all samples in one launch (stacked rows)
                 self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)

@@ -35,6 +35,8 @@ typedef struct ihipStream_t* hipStream_t;
 #define CE_EPI_BIAS_GELU 1 /* C = bf16(gelu_tanh(bf16(A.W^T + bias)))   diffusers FeedForward("gelu-approximate") */
 #define CE_EPI_GATE_RES 2  /* C = bf16(res + bf16(A.W^T + bias) * gate[n]); gate == NULL -> 1 */
 #define CE_EPI_BIAS_GELU_ERF 3 /* exact-erf GELU: diffusers FeedForward("gelu") of the image embedder */
+#define CE_EPI_BIAS_ROW 6      /* C = bf16(A.W^T + bias[m]): bias along the ROWS of C - a product taken with the operand roles swapped
+                                * (V^T = W_v.X^T: the attention kernel's V^T operand straight out of the projection, no transpose pass) */
 #define CE_EPI_F32 4           /* C is float* (ldc in floats): raw fp32 A.W^T, no bias (VAE mid-block attention scores) */
 
 /* y = LayerNorm_fp32(x, eps) * a[d] + b[d] -> bf16.   One wave64 per row; D % 8 == 0, D <= 5120.
@@ -100,6 +102,18 @@ int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, i
 int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
                               const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq,
                               int ldo, float softmax_scale, int batch, hipStream_t stream);
+
+/* The same self-attention (one KV segment, `batch` samples per launch) with V handed over TRANSPOSED: Vt [H * 128][ldvt] bf16, row =
+ * head channel, column = key, sample b's keys in columns [b len, (b + 1) len); ldvt >= (batch - 1) len + 64 ceil(len / 64), every
+ * column up to ldvt finite (ce_v_transpose_bf16 zeroes the padding).  K and V^T tiles both reach LDS by LDS-DMA - no register
+ * staging, no in-kernel transpose; the arithmetic and its order per row are those of ce_attention_batched_bf16.
+ * Replaces the same F.scaled_dot_product_attention call (transformer_chronoedit.py:91-96). */
+int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int head_dim,
+                         int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream);
+
+/* v [n_keys][ldv] bf16 (head h at columns [128 h, 128 h + 128)) -> vt [H * 128][ldvt] (ldvt >= n_keys, multiple of 8; columns
+ * [n_keys, ldvt) zeroed): the producer of ce_attention_vt_bf16's V operand. */
+int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, hipStream_t stream);
 
 /* Loop body behind ce_attention_bf16 / ce_attention_batched_bf16 (returns the previous value; all are tested against the
  * same reference): 0 automatic (= 64); 4 / 8 the plain kernel with 4 / 8 waves per workgroup; 64 software-pipelined, K by

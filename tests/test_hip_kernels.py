@@ -104,6 +104,26 @@ def test_gemm_bias(M, N, K, gemm_variant):
     assert (out.float() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item() + 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 136, 64), (5120, 1000, 1024), (640, 14400, 512), (5120, 7200, 5120)])
+def test_gemm_row_bias_is_the_transpose_of_the_column_bias_product(M, N, K, gemm_variant):
+    """CE_EPI_BIAS_ROW (bias along the rows of C: the product with its operand roles swapped, V^T = W_v.X^T) == the transpose of
+    the ordinary product, bit for bit where both run the same kernel (one rounding point: bf16(acc + bias)); also into a wider,
+    strided output (the V^T buffer with its padding columns, which must stay untouched)."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    wv = (torch.randn(M, K, generator=g) * 0.05).to(BF).to(dev)   # "weights": rows of C
+    x = torch.randn(N, K, generator=g).to(BF).to(dev)             # "tokens": columns of C
+    bias = torch.randn(M, generator=g).to(dev)
+    buf = torch.full((M, N + 72), 7.0, dtype=BF, device=dev)
+    ops.gemm(wv, x, bias, out=buf[:, :N], epilogue=ops.EPI_BIAS_ROW)
+    ref = wv.float() @ x.float().t() + bias[:, None]
+    assert rel_l2(buf[:, :N], ref) < 4e-3
+    assert (buf[:, N:] == 7.0).all()
+    plain = ops.gemm(x, wv, bias)  # [N, M] = X.W^T + bias[col]
+    assert rel_l2(buf[:, :N], plain.t()) < 1e-4  # same products and rounding point; the fp32 summation order may differ (split-K tail tiles)
+
+
 def test_gemm_epilogues(gemm_variant):
     from chronoedit_amd import ops
     dev = _dev()
@@ -246,6 +266,47 @@ def test_attention_single_segment(Nq, Nkv, H, attn_waves):
     ref = _sdpa_ref(q, k, v, H)
     assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
     assert (out.float() - ref).abs().max().item() < 3e-2
+
+
+@pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (512, 104, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2),
+                                         (7200, 7200, 8, 2), (1056, 1056, 5, 2)])
+def test_attention_vt_matches_sdpa_and_the_register_staged_kernel(Nq, Nkv, H, B):
+    """ce_attention_vt_bf16 (V handed over transposed by ce_v_transpose_bf16; K rows permuted inside the tile so that a lane's
+    keys are contiguous in V^T): vs torch SDPA <= 1e-2, vs the register-staged kernel <= 3e-3 (same products, the row sums and
+    the P.V contraction run over the keys of a tile in a different order); the padding columns of V^T are zero."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(23)
+    D = H * 128
+    q = torch.randn(B * Nq, D, generator=g).to(BF).to(dev)
+    kv = torch.randn(B * Nkv, 2 * D, generator=g).to(BF).to(dev)
+    kv[:, D:].mul_(torch.linspace(0.5, 1.5, D, device=dev).to(BF))  # asymmetric across dv and ...
+    kv[:, D:].add_((torch.arange(B * Nkv, device=dev) % 7).to(BF)[:, None] * 0.25)  # ... across keys: a permuted P.V shows up
+    vt = ops.v_transpose(kv[:, D:], H)
+    assert vt.shape == (D, ops.vt_columns(B * Nkv))
+    assert torch.equal(vt[:, :B * Nkv], kv[:, D:].t()) and not vt[:, B * Nkv:].any()
+    out = ops.attention_vt(q, kv[:, :D], vt, H, batch=B)
+    base = ops.attention(q, kv[:, :D], kv[:, D:], H, batch=B)
+    assert rel_l2(out, base) < 3e-3, rel_l2(out, base)
+    for b in range(B):
+        ref = _sdpa_ref(q[b * Nq:(b + 1) * Nq], kv[b * Nkv:(b + 1) * Nkv, :D], kv[b * Nkv:(b + 1) * Nkv, D:], H)
+        assert rel_l2(out[b * Nq:(b + 1) * Nq], ref) < 1e-2, (b, rel_l2(out[b * Nq:(b + 1) * Nq], ref))
+
+
+@pytest.mark.parametrize("slope", [0.5, 10.0])
+def test_attention_vt_spiked_scores_take_the_exact_route(slope):
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    H, N = 2, 520
+    q = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
+    k = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
+    v = torch.randn(N, H * 128, generator=g).to(BF).to(dev)
+    for t in range(N // 64):
+        k[t * 64 + 5] = q[7] * (0.5 + slope * t)
+    out = ops.attention_vt(q, k, ops.v_transpose(v, H), H)
+    ref = _sdpa_ref(q, k, v, H)
+    assert rel_l2(out, ref) < 1e-2 and torch.isfinite(out.float()).all()
 
 
 @pytest.mark.parametrize("slope", [0.5, 10.0])

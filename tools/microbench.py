@@ -111,6 +111,12 @@ def main():
             t8 = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
             ops.set_attention_waves(64)
             t = timeit(lambda: ops.attention(q, k, v, H, out=out), iters=5)
+            tvt = ttr = float("nan")
+            if Nq == Nkv:
+                vt = ops.v_transpose(v, H)
+                tvt = timeit(lambda: ops.attention_vt(q, k, vt, H, out=out), iters=5)
+                ttr = timeit(lambda: ops.v_transpose(v, H, out=vt), iters=5)
+                print(f"attn {Nq}x{Nkv} H{H}: V^T by LDS-DMA {tvt*1e3:.3f} ms {4.0*Nq*Nkv*128*H/tvt/1e12:.1f} TF (+ transpose pass {ttr*1e3:.3f} ms) vs register-staged {t*1e3:.3f} ms", flush=True)
             ops.set_attention_waves(0)
             qh = q.reshape(Nq, H, 128).transpose(0, 1)[None].contiguous()
             kh = k.reshape(Nkv, H, 128).transpose(0, 1)[None].contiguous()
@@ -125,6 +131,13 @@ def main():
                 out2 = torch.empty(2 * Nq, D, dtype=BF, device=dev)
                 if Nq == Nkv:
                     tb = timeit(lambda: ops.attention(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], H, out=out2, batch=2), iters=5)
+                    vt2 = ops.v_transpose(qkv2[:, 2 * D:], H)
+                    tb_vt = tb_tr = 1e9
+                    for _ in range(3):  # interleaved, best of each
+                        tb = min(tb, timeit(lambda: ops.attention(qkv2[:, :D], qkv2[:, D:2 * D], qkv2[:, 2 * D:], H, out=out2, batch=2), iters=5))
+                        tb_vt = min(tb_vt, timeit(lambda: ops.attention_vt(qkv2[:, :D], qkv2[:, D:2 * D], vt2, H, out=out2, batch=2), iters=5))
+                        tb_tr = min(tb_tr, timeit(lambda: ops.v_transpose(qkv2[:, 2 * D:], H, out=vt2), iters=5))
+                    print(f"attn {Nq}x{Nkv} H{H} batch 2: V^T by LDS-DMA {tb_vt*1e3:.3f} ms {2*4.0*Nq*Nkv*128*H/tb_vt/1e12:.1f} TF (+ transpose pass {tb_tr*1e3:.3f} ms) vs register-staged {tb*1e3:.3f} ms {2*4.0*Nq*Nkv*128*H/tb/1e12:.1f} TF", flush=True)
                 else:
                     q2 = qkv2[:2 * Nq, :D]
                     tb = timeit(lambda: ops.attention(q2, qkv2[:2 * Nkv, D:2 * D], qkv2[:2 * Nkv, 2 * D:], H, out=out2, batch=2), iters=5)

@@ -1,5 +1,6 @@
 """Launch ONE kernel shape a few times (for rocprofv3 --pmc passes).  usage:
-   one_kernel.py gemm M N K epi variant [iters]   |   one_kernel.py attn Nq Nkv H [iters]   |   one_kernel.py attn8 N H B [iters]"""
+   one_kernel.py gemm M N K epi variant [iters]  |  one_kernel.py attn Nq Nkv H [iters]  |  one_kernel.py attn8 N H B [iters]
+   |  one_kernel.py attnvt N H B [iters]   (the V^T / LDS-DMA form of the bf16 self-attention, B samples per launch)"""
 import os
 import sys
 
@@ -23,6 +24,15 @@ if kind == "gemm":
     ops.set_gemm_variant(var)
     for _ in range(iters):
         ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+elif kind == "attnvt":
+    N, H, B = map(int, sys.argv[2:5])
+    iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+    D = H * 128
+    qkv = torch.randn(B * N, 3 * D, generator=g).to(BF).to(dev)
+    vt = ops.v_transpose(qkv[:, 2 * D:], H)
+    out = torch.empty(B * N, D, dtype=BF, device=dev)
+    for _ in range(iters):
+        ops.attention_vt(qkv[:, :D], qkv[:, D:2 * D], vt, H, out=out, batch=B)
 elif kind == "attn8":  # MXFP8 self-attention, B samples per launch (producers run once, outside the counted launches' names)
     N, H, B = map(int, sys.argv[2:5])
     iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
