@@ -112,11 +112,7 @@ __device__ __forceinline__ void mma_half(f32x4 (&acc)[4][2], const bf16x8 (&a)[4
 }
 
 #define CE_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0)
-#if defined(CE_GEMM_ABL) && CE_GEMM_ABL == 6  // LDS-DMA stream with no counted waits at all: how fast can the path go?
-#define CE_VM(N) asm volatile("s_waitcnt vmcnt(63)" ::: "memory")
-#else
 #define CE_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#endif
 #define CE_BAR() __builtin_amdgcn_s_barrier()
 
 __device__ __forceinline__ void tile_origin(int wg, int tiles_m, int tiles_n, int& m0, int& n0) {
@@ -261,31 +257,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_256(const bf16* __restrict__ A,
   read_b<S_B1, 0>(smem, wn, fr, fg, b1k0);
   read_b<S_B1, 1>(smem, wn, fr, fg, b1k1);
 
-  // CE_GEMM_ABL (tools/gemm_ablate.py only; results are garbage, durations are the point): 1 no barriers in the loop,
-  // 2 no LDS-DMA staging in the loop, 3 no fragment reads in the loop, 4 no MFMAs, 5 = 1 + 3 + 4 (LDS-DMA stream only)
-#if defined(CE_GEMM_ABL) && CE_GEMM_ABL == 2
-#define CE_STAGE(SLOT_EVEN, SLOT_ODD, CURV, TILEV)
-#else
+  // (the ablation build of round 1 - this loop with its barriers / staging / fragment reads / MFMAs removed one at a time - gave
+  // the cost table of DESIGN.md section 4.1, profiles/r01_gemm_ablate_14400x15360x5120.txt; git history has the switches)
 #define CE_STAGE(SLOT_EVEN, SLOT_ODD, CURV, TILEV) \
   if (CURV == 0) stage_half<SLOT_EVEN>(smem, st, (TILEV)); else stage_half<SLOT_ODD>(smem, st, (TILEV));
-#endif
-#if defined(CE_GEMM_ABL) && (CE_GEMM_ABL == 1 || CE_GEMM_ABL == 5 || CE_GEMM_ABL == 6)
-#define CE_LBAR()
-#else
 #define CE_LBAR() CE_BAR()
-#endif
-#if defined(CE_GEMM_ABL) && (CE_GEMM_ABL == 3 || CE_GEMM_ABL == 5 || CE_GEMM_ABL == 6)
-#define CE_RDA(S, K, R) asm volatile("" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]))
-#define CE_RDB(S, K, R) asm volatile("" : "+v"(R[0]), "+v"(R[1]))
-#else
 #define CE_RDA(S, K, R) read_a<S, K>(smem, wm, fr, fg, R)
 #define CE_RDB(S, K, R) read_b<S, K>(smem, wn, fr, fg, R)
-#endif
-#if defined(CE_GEMM_ABL) && (CE_GEMM_ABL == 4 || CE_GEMM_ABL == 5 || CE_GEMM_ABL == 6)
-#define CE_MMA(ACC, A, B) asm volatile("" : "+v"(ACC[0][0]), "+v"(ACC[3][1]) : "v"(A[0]), "v"(A[3]), "v"(B[0]), "v"(B[1]))
-#else
 #define CE_MMA(ACC, A, B) mma_half(ACC, A, B)
-#endif
 
   // The LDS-DMA issue (address math + M0 + 2 global_load_lds) sits BETWEEN the two 8-MFMA k-steps of a phase, so it
   // overlaps the matrix pipe instead of extending the barrier-to-first-MFMA gap.

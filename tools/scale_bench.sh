@@ -14,8 +14,10 @@ for n in 2 4 8; do
   python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py \
       --gpus $n --steps $steps --warmup $warm | tail -1 > gpurun_out/scale_n$n.json
   port=$((port+1))
-  [ "$n" -ge 4 ] && python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py \
-      --gpus $n --steps $steps --warmup $warm --cfg-parallel --no-secondary | tail -1 > gpurun_out/scale_n${n}_cfgp.json
+  # the other split of the same N ranks (default: guidance pair split on 2 GPUs, one Ulysses group from 4 on - DESIGN.md section 6)
+  alt=$([ "$n" -eq 2 ] && echo "--no-cfg-parallel" || echo "--cfg-parallel")
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $port bench.py \
+      --gpus $n --steps $steps --warmup $warm $alt --no-secondary | tail -1 > gpurun_out/scale_n${n}_alt.json
   port=$((port+1))
 done
 python - <<'PY'
