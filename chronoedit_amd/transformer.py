@@ -555,7 +555,13 @@ class DiTEngine:
         wait_kv.wait()
         wait_q.wait()
         kv = sp.gathered_view(ws.recv_kv)  # [W*Nl = global token, k | v of this rank's heads]
-        ops.attention(sp.gathered_view(ws.recv_q), kv[:N, :Dl], kv[:N, Dl:], H // W, out=ws.att_g)
+        if self.v_transposed:  # the LDS-DMA form of the kernel wants V^T: one small transpose pass over this rank's heads
+            if getattr(ws, "vt_sp", None) is None or ws.vt_sp.shape != (Dl, ops.vt_columns(N)):
+                ws.vt_sp = torch.zeros((Dl, ops.vt_columns(N)), dtype=torch.bfloat16, device=self.dev)
+            ops.v_transpose(kv[:N, Dl:], H // W, out=ws.vt_sp)
+            ops.attention_vt(sp.gathered_view(ws.recv_q), kv[:N, :Dl], ws.vt_sp, H // W, out=ws.att_g)
+        else:
+            ops.attention(sp.gathered_view(ws.recv_q), kv[:N, :Dl], kv[:N, Dl:], H // W, out=ws.att_g)
         y, _ = sp.all_to_all(ws.att_g.view(W, Nl, Dl), ws.att_seg)  # [head group][local row][Dl]
         if self.fp8:  # the row quantiser wants plain rows: secondary mode, one gather pass
             ws.att.copy_(sp.merge_heads_reference(y))

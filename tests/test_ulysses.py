@@ -227,7 +227,6 @@ def _loop_worker(rank, world, port, q, mode):
     negative = torch.randn(1, 40, 128, generator=g).cuda().to(BF)
     img = torch.randn(1, 257, 64, generator=g).cuda().to(BF)
     kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)  # includes the 8 -> 2 frame truncation
-    m.enable_transposed_v(False)  # the sharded path stages V through registers: compare like with like (same summation order per key tile)
     ref = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, prompt, negative, img, 4, 5.0, **kw).clone()
     if mode == "cfgp":
         m.enable_cfg_parallel()

@@ -9,9 +9,9 @@ tail -4 gpurun_out/pytest_gpu.log
 timeout 900 python bench.py --steps 6 --warmup 2 2>/dev/null | tail -1 > gpurun_out/bench.json
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-vae --no-encoders --no-fp8-leg > $R/gpurun_out/rocprof.log 2>&1)
 ls gpurun_out/prof/* | head
-bash tools/gpu_pmc_traffic.sh attn_bf16_7200_b1 attn 7200 7200 40 3 > /dev/null 2>&1
+bash tools/gpu_pmc_traffic.sh attn_vt_7200_b2 attnvt 7200 40 2 3 > /dev/null 2>&1
 bash tools/gpu_pmc_traffic.sh attn_mxfp8_7200_b2 attn8 7200 40 2 3 > /dev/null 2>&1
-cat gpurun_out/pmc_attn_bf16_7200_b1.txt gpurun_out/pmc_attn_mxfp8_7200_b2.txt | grep -v "^ *SQ_" | head -60
+cat gpurun_out/pmc_attn_vt_7200_b2.txt gpurun_out/pmc_attn_mxfp8_7200_b2.txt | grep -v "^ *SQ_" | head -60
 python - <<'PY'
 import json
 d = json.load(open("gpurun_out/bench.json"))
