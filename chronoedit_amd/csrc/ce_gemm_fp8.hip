@@ -77,7 +77,9 @@ __device__ __forceinline__ void mma_quad(f32x4 (&acc)[4][2], const u32x4 (&a0)[4
     for (int g = 0; g < 2; ++g) {
       const i32x8 av = {(int)a0[f][0], (int)a0[f][1], (int)a0[f][2], (int)a0[f][3], (int)a1[f][0], (int)a1[f][1], (int)a1[f][2], (int)a1[f][3]};
       const i32x8 bv = {(int)b0[g][0], (int)b0[g][1], (int)b0[g][2], (int)b0[g][3], (int)b1[g][0], (int)b1[g][1], (int)b1[g][2], (int)b1[g][3]};
-      acc[f][g] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, acc[f][g], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      // W fragment first (as in the bf16 kernel): the lane then owns FOUR CONSECUTIVE COLUMNS of one row of C - 8-byte LDS stores and
+      // 16-byte scale / bias loads in the epilogue instead of 2-byte stores (the A-first form left 128 ds_write_b16 per thread and tile)
+      acc[f][g] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bv, av, acc[f][g], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     }
   __builtin_amdgcn_s_setprio(0);
 }
@@ -197,44 +199,45 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const unsigned char* __restr
   F8_LGKM0();
   F8_BAR();
 
-  // ---- epilogue: scales, bias -> bf16 -> LDS (two passes of 128 rows) -> row-contiguous activation / residual math and stores
+  // ---- epilogue: scales, bias -> bf16 -> LDS (two passes of 128 rows) -> row-contiguous activation / residual math and stores.
+  // Column scales / bias of the lane's four (j, g) column groups: the same for both passes, 16-byte loads on clamped addresses,
+  // issued together and without a per-lane guard (a guarded load compiles to its own branch with a vmcnt(0) behind it).
+  // (the gated-residual epilogue is at its register limit: there the 32 registers are re-loaded per pass instead of living across both)
+  f32x4 swv[2][2], bvv[2][2];
+  auto load_cols = [&](int opaque) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        int nc = min(n0 + j * 128 + wn * 32 + g * 16 + fg * 4, N - 4) + opaque;  // n is a multiple of 4 and N of 8
+        swv[j][g] = *reinterpret_cast<const f32x4*>(sw + nc);
+        bvv[j][g] = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  if (EPI != EPI_GATE_RES) load_cols(0);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if (i == 1) __syncthreads();
-    // row scales of this pass (4 consecutive rows per f: one 16-byte load each, clamped, issued together - per (j, g, f) and
-    // guarded they were 16 serial round trips per pass), then the column scale / bias of each (j, g)
-    f32x4 sav[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const int mrow = m0 + i * 128 + wm * 64 + f * 16 + fg * 4;
-      if (mrow + 3 < M) {
-        sav[f] = *reinterpret_cast<const f32x4*>(sa + mrow);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sav[f][r] = sa[min(mrow + r, M - 1)];
-      }
+    if (EPI == EPI_GATE_RES) {
+      int zero = 0;
+      asm volatile("" : "+v"(zero));  // keeps the second pass's loads from being merged with (and kept live since) the first's
+      load_cols(zero);
     }
-    float swv[2][2], bvv[2][2];
+    float sav[4];  // row scale of this lane's row in each of the four 16-row fragments
+#pragma unroll
+    for (int f = 0; f < 4; ++f) sav[f] = sa[min(m0 + i * 128 + wm * 64 + f * 16 + fr, M - 1)];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        const int nc = min(n0 + j * 128 + wn * 32 + g * 16 + fr, N - 1);
-        swv[j][g] = sw[nc];
-        bvv[j][g] = bias != nullptr ? bias[nc] : 0.f;
-      }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        const int cl = j * 128 + wn * 32 + g * 16 + fr;
+        const int cl = j * 128 + wn * 32 + g * 16 + fg * 4;
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rl = wm * 64 + f * 16 + fg * 4 + r;
-            *reinterpret_cast<bf16*>(smem + rl * CROW + cl * 2) = (bf16)(acc[i][j][f][g][r] * (sav[f][r] * swv[j][g]) + bvv[j][g]);
-          }
+          const int rl = wm * 64 + f * 16 + fr;
+          const f32x4 v = acc[i][j][f][g];
+          const u32x2 pk = {pack_bf16(v[0] * (sav[f] * swv[j][g][0]) + bvv[j][g][0], v[1] * (sav[f] * swv[j][g][1]) + bvv[j][g][1]),
+                            pack_bf16(v[2] * (sav[f] * swv[j][g][2]) + bvv[j][g][2], v[3] * (sav[f] * swv[j][g][3]) + bvv[j][g][3])};
+          *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
         }
       }
     __syncthreads();

@@ -101,6 +101,10 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: the HIP extension is the only compute path of chronoedit_amd "
             "(no CPU/eager fallback). Build it with `python -c 'import __graft_entry__ as g; g.build()'`."
         )
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 and must be the first to load it - our library's
+    # DT_NEEDED then resolves to that copy.  Loaded the other way round (this library before `import torch`) the process holds
+    # two runtimes, and a kernel launched through one on a stream of the other fails with hipErrorNoDevice (100).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name in header_symbols():
         if not hasattr(lib, name):

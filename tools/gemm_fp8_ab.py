@@ -1,0 +1,73 @@
+"""A/B timing of builds of the fp8 GEMM in ONE process (see tools/gemm_ab.py):
+    python tools/gemm_fp8_ab.py <base.so> [<variant.so> ...]
+Each library is `hipcc -shared` of ce_gemm_fp8.hip; all run ce_gemm_fp8 on the same quantised operands, interleaved, best of each."""
+import ctypes
+import sys
+
+import torch
+
+BF = torch.bfloat16
+
+
+def bind(path):
+    lib = ctypes.CDLL(path)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    f = lib.ce_gemm_fp8
+    f.restype = I
+    f.argtypes = [P, P, P, P, P, P, I, P, P] + [I] * 8 + [P]
+    q = lib.ce_quant_rows_fp8
+    q.restype = I
+    q.argtypes = [P, P, P, I, I, I, I, P]
+    return lib, f, q
+
+
+def main():
+    libs = [bind(p) for p in sys.argv[1:]]
+    names = [p.split("/")[-1].replace("lib", "").replace(".so", "") for p in sys.argv[1:]]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K, epi) in [(14400, 15360, 5120, 0), (14400, 13824, 5120, 1), (14400, 5120, 13824, 2), (14400, 5120, 5120, 2),
+                           (26136, 15360, 5120, 0)]:
+        a = torch.randn(M, K, generator=g).to(BF).to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
+        aq, wq = torch.empty(M, K, dtype=torch.uint8, device=dev), torch.empty(N, K, dtype=torch.uint8, device=dev)
+        sa, sw = torch.empty(M, device=dev), torch.empty(N, device=dev)
+        assert libs[0][2](a.data_ptr(), aq.data_ptr(), sa.data_ptr(), M, K, K, K, st) == 0
+        assert libs[0][2](w.data_ptr(), wq.data_ptr(), sw.data_ptr(), N, K, K, K, st) == 0
+        b = torch.randn(N, generator=g).to(dev)
+        gate = torch.randn(N, generator=g).to(dev)
+        res = torch.randn(M, N, generator=g).to(BF).to(dev)
+        outs = [torch.empty(M, N, dtype=BF, device=dev) for _ in libs]
+
+        def run(f, o):
+            rc = f(aq.data_ptr(), wq.data_ptr(), o.data_ptr(), sa.data_ptr(), sw.data_ptr(), b.data_ptr(), epi, gate.data_ptr() if epi == 2 else None,
+                   res.data_ptr() if epi == 2 else None, M, N, K, K, K, N, N, 0, st)
+            assert rc == 0, rc
+
+        def timeit(f, o, iters=10):
+            run(f, o)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                run(f, o)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters
+
+        best = [1e9] * len(libs)
+        for _ in range(4):
+            for i, (_, f, _) in enumerate(libs):
+                best[i] = min(best[i], timeit(f, outs[i]))
+        fl = 2.0 * M * N * K
+        line = f"gemm fp8 {M}x{N}x{K} epi{epi}:"
+        for i, n in enumerate(names):
+            d = (outs[0].float() - outs[i].float()).norm().item() / outs[0].float().norm().item()
+            line += f" | {n} {best[i]:.3f} ms {fl/best[i]/1e9:.0f} TF ({(best[0]/best[i]-1)*100:+.1f} %, rel {d:.1e})"
+        print(line, flush=True)
+        del a, w, res, outs, aq, wq
+
+
+if __name__ == "__main__":
+    main()
