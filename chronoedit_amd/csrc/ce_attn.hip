@@ -587,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       f32x16 st[2];
       {
-        constexpr int RING = 6;
+        constexpr int RING = VT ? 4 : 6;  // K fragments in flight (A/B of 2 / 3 / 4 / 6 / 8 with the DMA-staged V: all within 0.8 %, 4 best)
         bf16x8 kf[RING];
 #define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + k_eo[((i) >> 1) & 1] + ((i) & 1) * 8 * K_GRP + ((i) >> 2) * 64))
 #pragma unroll
