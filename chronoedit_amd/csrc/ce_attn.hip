@@ -931,7 +931,7 @@ extern "C" int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt
   if (!Q || !K || !Vt || !O) return CE_ERR_ARG;
   if (head_dim != HD || Nq <= 0 || H <= 0 || len <= 0 || batch <= 0 || batch > 65535) return CE_ERR_SHAPE;
   if (ldvt < (batch - 1) * len + (len + KVB - 1) / KVB * KVB) return CE_ERR_SHAPE;  // the last tile of the last sample reads whole 64-key strips
-  if ((ldq & 7) || (ldo & 7) || (ldk & 7) || (ldvt & 7) || (batch > 1 && (len & 7))) return CE_ERR_ALIGN;
+  if ((ldq & 7) || (ldo & 7) || (ldk & 7) || (ldvt & 7) || (batch > 1 && (len & 1))) return CE_ERR_ALIGN;  // sample b's columns start at byte 2 b len: dword-aligned DMA source
   KVSeg s0{(const bf16*)K, (const bf16*)Vt, len, ldk, ldvt};
   KVSeg s1{nullptr, nullptr, 0, 0, 0};
   const float sl2 = softmax_scale * 1.4426950408889634f;

@@ -746,7 +746,7 @@ class DiTEngine:
                 ws.v8t, ws.sv = ops.v_mxfp8_transpose(ws.qkv[:, 2 * D :], Nl, B, H, out=ws.v8t, scale=ws.sv)
                 ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, out=ws.att, batch=B)
                 att = ws.att
-            elif sp is None and self.v_transposed and not self.fp8 and (B * Nl) % 8 == 0 and (B == 1 or Nl % 8 == 0):
+            elif sp is None and self.v_transposed and not self.fp8 and (B * Nl) % 8 == 0 and (B == 1 or Nl % 2 == 0):
                 # q | k as one GEMM, V^T = W_v.h^T as the same GEMM with the operand roles swapped (bias along rows): the attention
                 # kernel's V^T operand [D][keys of all samples] without a transpose pass; K and V^T tiles both go by LDS-DMA
                 if getattr(ws, "vt", None) is None:

@@ -105,7 +105,8 @@ int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int
 
 /* The same self-attention (one KV segment, `batch` samples per launch) with V handed over TRANSPOSED: Vt [H * 128][ldvt] bf16, row =
  * head channel, column = key, sample b's keys in columns [b len, (b + 1) len); ldvt >= (batch - 1) len + 64 ceil(len / 64), every
- * column up to ldvt finite (ce_v_transpose_bf16 zeroes the padding).  K and V^T tiles both reach LDS by LDS-DMA - no register
+ * column up to ldvt finite (ce_v_transpose_bf16 zeroes the padding); len even when batch > 1 (dword-aligned sample offsets).
+ * K and V^T tiles both reach LDS by LDS-DMA - no register
  * staging, no in-kernel transpose; the arithmetic and its order per row are those of ce_attention_batched_bf16.
  * Replaces the same F.scaled_dot_product_attention call (transformer_chronoedit.py:91-96). */
 int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int head_dim,
