@@ -23,7 +23,7 @@ def bind(path):
 
 def main():
     libs = [bind(p) for p in sys.argv[1:]]
-    names = [p.split("/")[-1].replace("lib", "").replace(".so", "") for p in sys.argv[1:]]
+    names = [p.split("/")[-1].replace("lib", "").replace(".so", "") for p in sys.argv[1:]]  # NOTE: one knob value per library FILE (the knob is a global of the library)
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     st = torch.cuda.current_stream().cuda_stream

@@ -41,7 +41,8 @@ def lint(path, min_insts):
     rows = []
     for k in kernels:
         body = text[text.index(f"\n{k}:"):]
-        body = body[:body.index("s_endpgm")]
+        end = body.find(".Lfunc_end")  # (not the first s_endpgm: block placement can put an exit path in the middle of a function)
+        body = body[:end] if end >= 0 else body[:body.index("s_endpgm")]
         lines = [l.strip() for l in body.split("\n") if l.startswith("\t")]
         lines = [l for l in lines if l and not l.startswith((";", "."))]
         ops = [l.split()[0] for l in lines]
