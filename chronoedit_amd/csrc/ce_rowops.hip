@@ -8,6 +8,9 @@
 #include "ce_common.h"
 
 #define ROW_MAXC 10  // 16-B chunks per lane: D <= 64 * 8 * 10 = 5120
+#ifndef CE_LN_ROWS
+#define CE_LN_ROWS 2  // activation rows per wave of the full-width LN-modulate kernel (A/B in profiles/r02_row_kernels_ab.txt)
+#endif
 
 // ------------------------------------------------------------------------------------
 // LN * a + b
@@ -17,84 +20,106 @@
 // FULL: D == 64 * 8 * ROW_MAXC, every lane owns exactly ROW_MAXC chunks and the per-chunk guards vanish.  With the guards hipcc
 // wrapped every 16-byte load in its own exec-mask branch and waited for it (`global_load_dwordx4; s_waitcnt vmcnt(0)` ten
 // times per row): one load in flight per wave, 3.7 TB/s by occupancy alone.
-template <bool FP8, bool FULL>
+// R rows per wave: the (a, b) rows are fp32 - 40 KB of L2 reads per activation row against 10 KB read + 10 KB written of HBM traffic,
+// which made the L2, not HBM, the limit of the one-row-per-wave form (4.2 TB/s).  A wave that owns R consecutive rows of one
+// sample reads each (a, b) chunk once for all of them.  The launcher picks R so that a wave's rows never straddle two samples.
+template <bool FP8, bool FULL, int R>
 __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                         const float* __restrict__ a, const float* __restrict__ b,
                                                         int M, int D, int ldx, int ldy, float eps, int ab_rows, int ab_stride,
                                                         unsigned char* __restrict__ q8, float* __restrict__ qscale, int ldq) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
   if (ab_rows > 0) {  // one (a, b) pair per group of ab_rows rows (samples stacked along M)
-    a += (size_t)(row / ab_rows) * ab_stride;
-    b += (size_t)(row / ab_rows) * ab_stride;
+    a += (size_t)(row0 / ab_rows) * ab_stride;
+    b += (size_t)(row0 / ab_rows) * ab_stride;
   }
   const int nch = D >> 3;
-  const bf16* xr = x + (size_t)row * ldx;
-  u32x4 raw[ROW_MAXC];
-  float s = 0.f;
+  u32x4 raw[R][ROW_MAXC];
+  float mean[R], rstd[R];
 #pragma unroll
-  for (int i = 0; i < ROW_MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (FULL || c < nch) {
-      raw[i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
+  for (int k = 0; k < R; ++k) {  // all loads of all rows first (rows past M re-read the last row; their stores are predicated)
+    const bf16* xr = x + (size_t)min(row0 + k, M - 1) * ldx;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += bf16lo(raw[i][j]) + bf16hi(raw[i][j]);
+    for (int i = 0; i < ROW_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (FULL || c < nch) raw[k][i] = *reinterpret_cast<const u32x4*>(xr + c * 8);
     }
   }
-  const float mean = wave_sum(s) / (float)D;
-  float v = 0.f;
 #pragma unroll
-  for (int i = 0; i < ROW_MAXC; ++i) {
-    const int c = lane + 64 * i;
-    if (FULL || c < nch) {
+  for (int k = 0; k < R; ++k) {
+    float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d0 = bf16lo(raw[i][j]) - mean, d1 = bf16hi(raw[i][j]) - mean;
-        v += d0 * d0 + d1 * d1;
+    for (int i = 0; i < ROW_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (FULL || c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += bf16lo(raw[k][i][j]) + bf16hi(raw[k][i][j]);
       }
     }
+    mean[k] = wave_sum(s) / (float)D;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (FULL || c < nch) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d0 = bf16lo(raw[k][i][j]) - mean[k], d1 = bf16hi(raw[k][i][j]) - mean[k];
+          v += d0 * d0 + d1 * d1;
+        }
+      }
+    }
+    rstd[k] = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)D + eps);
-  bf16* yr = FP8 ? nullptr : y + (size_t)row * ldy;
-  float amax = 0.f;
+  float amax[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) amax[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < ROW_MAXC; ++i) {
     const int c = lane + 64 * i;
     if (FULL || c < nch) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + c * 8), a1 = *reinterpret_cast<const f32x4*>(a + c * 8 + 4);
       const f32x4 b0 = *reinterpret_cast<const f32x4*>(b + c * 8), b1 = *reinterpret_cast<const f32x4*>(b + c * 8 + 4);
-      u32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float aa0 = j < 2 ? a0[2 * j] : a1[2 * j - 4], aa1 = j < 2 ? a0[2 * j + 1] : a1[2 * j - 3];
-        const float bb0 = j < 2 ? b0[2 * j] : b1[2 * j - 4], bb1 = j < 2 ? b0[2 * j + 1] : b1[2 * j - 3];
-        const float n0 = (bf16lo(raw[i][j]) - mean) * rstd, n1 = (bf16hi(raw[i][j]) - mean) * rstd;
-        o[j] = pack_bf16(n0 * aa0 + bb0, n1 * aa1 + bb1);
-        if (FP8) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(o[j])), fabsf(bf16hi(o[j]))));
+      for (int k = 0; k < R; ++k) {
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float aa0 = j < 2 ? a0[2 * j] : a1[2 * j - 4], aa1 = j < 2 ? a0[2 * j + 1] : a1[2 * j - 3];
+          const float bb0 = j < 2 ? b0[2 * j] : b1[2 * j - 4], bb1 = j < 2 ? b0[2 * j + 1] : b1[2 * j - 3];
+          const float n0 = (bf16lo(raw[k][i][j]) - mean[k]) * rstd[k], n1 = (bf16hi(raw[k][i][j]) - mean[k]) * rstd[k];
+          o[j] = pack_bf16(n0 * aa0 + bb0, n1 * aa1 + bb1);
+          if (FP8) amax[k] = fmaxf(amax[k], fmaxf(fabsf(bf16lo(o[j])), fabsf(bf16hi(o[j]))));
+        }
+        if (FP8) raw[k][i] = o;
+        else if (row0 + k < M) *reinterpret_cast<u32x4*>(y + (size_t)(row0 + k) * ldy + c * 8) = o;
       }
-      if (FP8) raw[i] = o;
-      else *reinterpret_cast<u32x4*>(yr + c * 8) = o;
     }
   }
   if (FP8) {
-    amax = wave_max(amax);
-    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
-    const float inv = 1.0f / sc;
-    if (lane == 0) qscale[row] = sc;
-    unsigned char* qr = q8 + (size_t)row * ldq;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXC; ++i) {
-      const int c = lane + 64 * i;
-      if (FULL || c < nch) {
-        const u32x4 v = raw[i];
-        int w0 = 0, w1 = 0;
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[0]) * inv, bf16hi(v[0]) * inv, w0, false);
-        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[1]) * inv, bf16hi(v[1]) * inv, w0, true);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[2]) * inv, bf16hi(v[2]) * inv, w1, false);
-        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[3]) * inv, bf16hi(v[3]) * inv, w1, true);
-        u32x2 o = {(uint32_t)w0, (uint32_t)w1};
-        *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+    for (int k = 0; k < R; ++k) {
+      const float am = wave_max(amax[k]);
+      const float sc = am > 0.f ? am * (1.0f / 448.0f) : 1.0f;
+      const float inv = 1.0f / sc;
+      if (row0 + k >= M) continue;
+      if (lane == 0) qscale[row0 + k] = sc;
+      unsigned char* qr = q8 + (size_t)(row0 + k) * ldq;
+#pragma unroll
+      for (int i = 0; i < ROW_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (FULL || c < nch) {
+          const u32x4 v = raw[k][i];
+          int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[0]) * inv, bf16hi(v[0]) * inv, w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[1]) * inv, bf16hi(v[1]) * inv, w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[2]) * inv, bf16hi(v[2]) * inv, w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo(v[3]) * inv, bf16hi(v[3]) * inv, w1, true);
+          u32x2 o = {(uint32_t)w0, (uint32_t)w1};
+          *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+        }
       }
     }
   }
@@ -369,11 +394,16 @@ extern "C" int ce_ln_affine_bf16(const void* x, void* y, const float* a, const f
                                  float eps, int ab_rows, int ab_stride, hipStream_t stream) {
   if (!x || !y || !a || !b) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldy & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
-  if (D == 64 * 8 * ROW_MAXC)
-    hipLaunchKernelGGL((ln_affine_kernel<false, true>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
+  // rows per wave (see the kernel): the full-width form shares each (a, b) chunk between CE_LN_ROWS rows of one sample
+  const bool multi = D == 64 * 8 * ROW_MAXC && (ab_rows <= 0 || ab_rows % CE_LN_ROWS == 0);
+  if (multi)
+    hipLaunchKernelGGL((ln_affine_kernel<false, true, CE_LN_ROWS>), dim3((M + 4 * CE_LN_ROWS - 1) / (4 * CE_LN_ROWS)), dim3(256), 0, stream,
+                       (const bf16*)x, (bf16*)y, a, b, M, D, ldx, ldy, eps, ab_rows, ab_stride, nullptr, nullptr, 0);
+  else if (D == 64 * 8 * ROW_MAXC)
+    hipLaunchKernelGGL((ln_affine_kernel<false, true, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
                        D, ldx, ldy, eps, ab_rows, ab_stride, nullptr, nullptr, 0);
   else
-    hipLaunchKernelGGL((ln_affine_kernel<false, false>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
+    hipLaunchKernelGGL((ln_affine_kernel<false, false, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
                        D, ldx, ldy, eps, ab_rows, ab_stride, nullptr, nullptr, 0);
   return (int)hipGetLastError();
 }
@@ -382,11 +412,12 @@ extern "C" int ce_ln_affine_fp8(const void* x, void* q, float* scale, const floa
                                 float eps, int ab_rows, int ab_stride, hipStream_t stream) {
   if (!x || !q || !scale || !a || !b) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
+  // (one row per wave here: with two the fp8 form needs 360 registers - the quantised rows stay live for the amax)
   if (D == 64 * 8 * ROW_MAXC)
-    hipLaunchKernelGGL((ln_affine_kernel<true, true>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
+    hipLaunchKernelGGL((ln_affine_kernel<true, true, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
                        ldx, 0, eps, ab_rows, ab_stride, (unsigned char*)q, scale, ldq);
   else
-    hipLaunchKernelGGL((ln_affine_kernel<true, false>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
+    hipLaunchKernelGGL((ln_affine_kernel<true, false, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
                        ldx, 0, eps, ab_rows, ab_stride, (unsigned char*)q, scale, ldq);
   return (int)hipGetLastError();
 }

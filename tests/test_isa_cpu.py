@@ -52,9 +52,11 @@ def test_row_kernels_issue_their_row_loads_back_to_back():
     rows = _rows("ce_rowops.hip")
     (rr,) = _pick(rows, "rmsnorm_rope_kernel", "ILb1E")  # FULL variant (D = 5120)
     assert rr[5] == 0 and rr[3] == 0 and rr[2] <= 168, rr  # three waves per SIMD
-    for r in _pick(rows, "ln_affine_kernel", "ELb1EE"):  # FULL variants (bf16 and fp8 output)
+    for r in _pick(rows, "ln_affine_kernel", "ELb1ELi1E"):  # FULL variants, one row per wave (fp8 output; bf16 fallback)
         assert r[3] == 0 and r[2] <= 168, r
         assert r[5] <= 20, r  # the (a, b) table reads of the third pass (L2 hits); the ten row loads are not among them
+    (two,) = _pick(rows, "ln_affine_kernel", "ILb0ELb1ELi2E")  # bf16, two rows per wave sharing the (a, b) chunks
+    assert two[3] == 0 and two[2] <= 256 and two[5] == 0, two
 
 
 def test_mxfp8_attention_kernels_have_no_spills_and_their_matrix_work_per_tile():

@@ -67,7 +67,9 @@ def main():
         rr(i)()
     torch.cuda.synchronize()
     for i, n in enumerate(names[1:], 1):
-        print(f"{n}: ln equal {torch.equal(outs[0], outs[i])}, rmsnorm_rope equal {torch.equal(qkvs[0], qkvs[i])}")
+        d = (outs[0].float() - outs[i].float()).abs()
+        print(f"{n}: ln equal {torch.equal(outs[0], outs[i])} (differing elements {float((d > 0).float().mean()):.2e}, max |d| {float(d.max()):.3e}, "
+              f"max |d| / |value| {float((d / outs[0].float().abs().clamp_min(1e-3)).max()):.3e}), rmsnorm_rope equal {torch.equal(qkvs[0], qkvs[i])}")
 
 
 if __name__ == "__main__":
