@@ -38,8 +38,9 @@ def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_g
         t1 = kb[key]["avg_ms"]
         per = t1 / rounds(math.ceil(57600 / 256) * (ncols // 256))
         return per * rounds(math.ceil(rows / 256) * (ncols // 256))
-    g = (gemm("gemm_57600x15360x5120_epi0", 15360) + gemm("gemm_57600x13824x5120_epi1", 13824) + gemm("gemm_57600x5120x13824_epi2", 5120)
-         + 2 * gemm("gemm_57600x5120x5120_epi2", 5120) + gemm("gemm_57600x5120x5120_epi0", 5120))
+    # (the one-GPU line projects q | k as one GEMM and V^T as the swapped one; the sharded path runs [k | v] and q: same column counts)
+    g = (gemm("gemm_57600x10240x5120_epi0", 10240) + gemm("gemm_57600x5120x5120_epi0", 5120) + gemm("gemm_57600x13824x5120_epi1", 13824)
+         + gemm("gemm_57600x5120x13824_epi2", 5120) + 2 * gemm("gemm_57600x5120x5120_epi2", 5120) + gemm("gemm_57600x5120x5120_epi0", 5120))
     q_gemm = gemm("gemm_57600x5120x5120_epi0", 5120)  # what the k|v exchange hides behind (the q third of the fused projection)
     row = (3 * kb["ln_affine_57600x5120"]["avg_ms"] + kb["rmsnorm_rope_57600x5120x2"]["avg_ms"] + kb["rmsnorm_rope_57600x5120"]["avg_ms"]) * rows / 57600
 
