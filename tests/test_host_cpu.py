@@ -73,3 +73,44 @@ def test_product_side_shape_helpers_match_the_oracles():
     assert dit_flops_per_forward(7200, num_layers=2) == float(O.flops_per_forward(O.DiTConfig(num_layers=2), 7200))
     a, b = wan_vae_param_shapes(), V.param_shapes(V.VAEConfig())
     assert set(a) == set(b) and all(tuple(a[k]) == tuple(b[k]) for k in a)
+
+
+def test_scaling_model_runs_on_the_committed_one_gpu_line():
+    """tools/scaling_model.py prices the sharded step from profiles/r02_bench_n28800_one_gpu.json: the
+    prediction must be reproducible from the repository alone, every split must beat one GPU, and the defaults bench.py picks per
+    GPU count (guidance-pair split on 2, one Ulysses group from 4 on) must be the model's best or within 5 % of it."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("scaling_model", os.path.join(root, "tools", "scaling_model.py"))
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+    one = json.load(open(os.path.join(root, "profiles", "r02_bench_n28800_one_gpu.json")))
+    base = one["ms_per_step"]
+    best = {}
+    for W in (2, 4, 8):
+        r = {cfgp: sm.model(W, cfgp, 55.0, 25.0, one) for cfgp in (False, True)}
+        for v in r.values():
+            assert v["step_ms"] < base and 0.5 < base / v["step_ms"] / W <= 1.0, v
+        best[W] = r
+    assert best[2][True]["step_ms"] < best[2][False]["step_ms"]          # 2 GPUs: split the guidance pair (one xGMI link between two GPUs)
+    for W in (4, 8):
+        assert best[W][False]["step_ms"] <= 1.05 * best[W][True]["step_ms"]  # 4, 8: one Ulysses group is best or within 5 %
+    # exchange volume of the model == what parallel.Ulysses counts per layer and forward: 4 tensors x rows x D/W x 2 B to each of W-1 peers
+    r8 = best[8][False]
+    assert r8["rows"] == 3600 and r8["heads"] == 5
+
+
+def test_vt_column_padding_helper():
+    """ops.vt_columns: whole 64-key strips plus one spare strip (the last tile of the last sample reads a whole strip), rows 16-B aligned."""
+    import ast
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "chronoedit_amd", "ops.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "vt_columns")
+    ns = {}
+    exec(compile(ast.Module([fn], []), "ops.vt_columns", "exec"), ns)
+    for n in (1, 63, 64, 65, 7200, 14400, 26136, 28800):
+        c = ns["vt_columns"](n)
+        assert c % 64 == 0 and c >= (n + 63) // 64 * 64 + 64 - 64 and c - n >= 64 and c % 8 == 0, (n, c)
