@@ -339,16 +339,23 @@ constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds t
 constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 * QW * OST_ROW : SP_TILE_BYTES; }
 
 template <bool TWO_SEG, bool VT = false>
-__global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
-                                                              KVSeg seg1, int Nq, int H, int ldq, int ldo, int nqb,
+__global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restrict__ Q_, bf16* __restrict__ O_, KVSeg seg0_,
+                                                              KVSeg seg1_, int Nq, int H, int ldq, int ldo, int nqb,
                                                               float scale_log2e, int batch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NWAVE = 8, QB = QW * NWAVE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
+  // Persistent form: a workgroup walks the work order with stride gridDim.x (a multiple of 8: the head stays on its XCD).  Launched
+  // with one workgroup per item the loop runs once; the V^T launcher uses 2 x #CUs workgroups (A/B, profiles/r02_attention_vt_knobs_ab.txt:
+  // +1.5 ... 3 % over one workgroup per item; #CUs, 3 x and 4 x #CUs are level or worse, 1.5 x #CUs -14 %).
+  for (int item = blockIdx.x; item < nqb * H * batch; item += gridDim.x) {
+  const bf16* Q = Q_;
+  bf16* O = O_;
+  KVSeg seg0 = seg0_, seg1 = seg1_;
 
-  // Work order (batch folded into blockIdx.x): every XCD takes its heads' FULL 256-row query blocks first, sample by sample,
+  // Work order (batch folded into item): every XCD takes its heads' FULL 256-row query blocks first, sample by sample,
   // and the remainder blocks (Nq % 256 rows; only their first waves have work and the others merely stage, so they run
   // ~2.5x faster) last - they fill the partially occupied final round of workgroups instead of heading it.  At
   // Nq = 7200, H = 40, two samples: 2320 workgroups = 9.06 rounds of 256 CUs used to cost ten.
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
   {
     const int nqb_full = Nq / QB;
     if ((H & 7) == 0) {
-      const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, hx_n = H >> 3;
+      const int xcd = item & 7, local = item >> 3, hx_n = H >> 3;
       const int full = batch * hx_n * nqb_full;
       if (local < full) {
         bz = local / (hx_n * nqb_full);
@@ -370,8 +377,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
         qb = nqb_full;
       }
     } else {
-      bz = blockIdx.x / (nqb * H);
-      const int r = blockIdx.x % (nqb * H);
+      bz = item / (nqb * H);
+      const int r = item % (nqb * H);
       head = r / nqb;
       qb = r % nqb;
     }
@@ -791,6 +798,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
     }
   }
+  __syncthreads();  // the next item's tile staging overwrites the O staging area
+  }  // item
 }
 
 
@@ -941,7 +950,14 @@ extern "C" int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt
     (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(false));
     done = true;
   }
-  hipLaunchKernelGGL((attn_fwd_sp_kernel<false, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O,
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const int items = nqb * H * batch;
+  const int grid_vt = items <= 2 * cus ? items : ((2 * cus) & ~7);  // persistent: two workgroups per CU walk the work order (see the kernel); a multiple of 8 keeps heads on their XCD
+  hipLaunchKernelGGL((attn_fwd_sp_kernel<false, true>), dim3(grid_vt), dim3(512), sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O,
                      s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch);
   return (int)hipGetLastError();
 }
