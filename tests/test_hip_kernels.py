@@ -269,7 +269,8 @@ def test_attention_single_segment(Nq, Nkv, H, attn_waves):
 
 
 @pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (512, 104, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2),
-                                         (7200, 7200, 8, 2), (1056, 1056, 5, 2), (1090, 1090, 8, 2), (330, 3270, 8, 3), (2000, 200, 40, 3), (3000, 64, 24, 2)])  # last two: sample offsets only 4-byte aligned
+                                         (7200, 7200, 8, 2), (1056, 1056, 5, 2), (1090, 1090, 8, 2), (330, 3270, 8, 3),   # these two: sample offsets only 4-byte aligned
+                                         (2000, 200, 40, 3), (3000, 64, 24, 2)])  # many work items per persistent workgroup
 def test_attention_vt_matches_sdpa_and_the_register_staged_kernel(Nq, Nkv, H, B):
     """ce_attention_vt_bf16 (V handed over transposed by ce_v_transpose_bf16; K rows permuted inside the tile so that a lane's
     keys are contiguous in V^T): vs torch SDPA <= 1e-2, vs the register-staged kernel <= 3e-3 (same products, the row sums and
