@@ -57,6 +57,16 @@ struct KVSeg {
   int ldk;
   int ldv;
 };
+// Blocked row layout of Q / K / O (V^T form only; rows == 0: plain, sample b's token g in row b N + g): token g of sample b sits in
+// row (g / rows) stride + b rows + g % rows - what an all-to-all leaves behind when every rank sent [sample][local token] rows
+// (chronoedit_amd/parallel.py: block = source rank, rows = tokens per rank (a multiple of 64), stride = batch * rows).  The V^T
+// operand is plain per sample (its producer un-blocks while it transposes): sample b's keys at columns [b vt_cols, ...).
+struct BlkRows {
+  int rows;        // tokens per block (0: plain layout)
+  int stride;      // rows between the starts of consecutive blocks
+  uint32_t magic;  // ceil(2^32 / (rows / 64)): tile index -> block by multiply-high (0: rows == 64, block = tile)
+  int vt_cols;     // column stride between samples in V^T
+};
 
 template <bool TWO_SEG, int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 2 : 2) void attn_fwd_kernel(const bf16* __restrict__ Q, bf16* __restrict__ O, KVSeg seg0,
@@ -341,7 +351,7 @@ constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 *
 template <bool TWO_SEG, bool VT = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restrict__ Q_, bf16* __restrict__ O_, KVSeg seg0_,
                                                               KVSeg seg1_, int Nq, int H, int ldq, int ldo, int nqb,
-                                                              float scale_log2e, int batch) {
+                                                              float scale_log2e, int batch, BlkRows blk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NWAVE = 8, QB = QW * NWAVE;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -384,10 +394,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
     }
   }
   {  // stacked samples: sample bz owns rows [bz Nq, (bz+1) Nq) of Q/O and [bz len, (bz+1) len) of each K/V segment
-    Q += (size_t)bz * Nq * ldq;
-    O += (size_t)bz * Nq * ldo;
-    seg0.k += (size_t)bz * seg0.len * seg0.ldk;
-    seg0.v += VT ? (size_t)bz * seg0.len : (size_t)bz * seg0.len * seg0.ldv;  // VT: the samples' keys sit side by side in the columns of V^T
+    if (VT && blk.rows > 0) {  // blocked rows: sample bz starts bz * rows into every block
+      Q += (size_t)bz * blk.rows * ldq;
+      O += (size_t)bz * blk.rows * ldo;
+      seg0.k += (size_t)bz * blk.rows * seg0.ldk;
+      seg0.v += (size_t)bz * blk.vt_cols;
+    } else {
+      Q += (size_t)bz * Nq * ldq;
+      O += (size_t)bz * Nq * ldo;
+      seg0.k += (size_t)bz * seg0.len * seg0.ldk;
+      seg0.v += VT ? (size_t)bz * seg0.len : (size_t)bz * seg0.len * seg0.ldv;  // VT: the samples' keys sit side by side in the columns of V^T
+    }
     if (TWO_SEG) {
       seg1.k += (size_t)bz * seg1.len * seg1.ldk;
       seg1.v += (size_t)bz * seg1.len * seg1.ldv;
@@ -396,10 +413,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
   const int q0 = qb * QB + wave * QW;
   const int hoff = head * HD;
   const bool active = q0 < Nq;  // wave-uniform: a wave past the last query row only helps staging the K / V tiles
+  // row of this wave's first query token (blocked layout: a wave's 32 tokens never straddle a block - blocks are multiples of 64 rows)
+  const int q0row = (VT && blk.rows > 0) ? (q0 / blk.rows) * blk.stride + q0 % blk.rows : q0;
 
   bf16x8 qf[8];
   {
-    const bf16* qrow = Q + (size_t)min(q0 + l31, Nq - 1) * ldq + hoff + 8 * hh;
+    const bf16* qrow = Q + (size_t)(q0 + l31 < Nq ? q0row + l31 : 0) * ldq + hoff + 8 * hh;  // (rows past Nq: any valid row, never stored)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
   }
@@ -447,7 +466,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
   for (int sidx = 0; sidx < (TWO_SEG ? 2 : 1); ++sidx) {
     const KVSeg sg = sidx == 0 ? seg0 : seg1;
     const int ntiles = (sg.len + KVB - 1) / KVB;
-    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (sg.len - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
+    const int k_rows_span = (VT && blk.rows > 0) ? ((sg.len - 1) / blk.rows) * blk.stride + blk.rows : sg.len;  // rows from the first to the last key's
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (k_rows_span - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
     // VT: rows hoff .. hoff + 127 of V^T [H * 128][ldv]; a tile is a 128-B column strip.  Columns past this sample's keys hold the
     // next sample's keys or the (finite, zeroed) padding of the buffer: they only ever meet P = 0.
     const auto v_rsrc = VT ? __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + (size_t)hoff * sg.ldv), 0, ((HD - 1) * sg.ldv + ntiles * KVB) * 2, 0x00020000)
@@ -486,8 +506,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
                                                j ? vd_voff1 : vd_voff0, t * (KVB * 2), 0, 0);
     };
     auto dma_k = [&](int t, int buf, int j) {
+      int soff = t * k_tile_bytes;
+      if (VT && blk.rows > 0) {  // key tile t lives in block t / (rows / 64): scalar multiply-high, no per-lane work
+        const int b_ = blk.magic ? (int)__umulhi((uint32_t)t, blk.magic) : t;  // (magic == 0: one tile per block)
+        soff = (b_ * blk.stride + (t - b_ * (blk.rows >> 6)) * KVB) * sg.ldk * 2;
+      }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + buf * PK_TILE + (wave + 8 * j) * K_GRP), 16,
-                                               j ? kd_voff1 : kd_voff0, t * k_tile_bytes, 0, 0);
+                                               j ? kd_voff1 : kd_voff0, soff, 0, 0);
     };
     auto load_v = [&](int t) {
       const int so = t * v_tile_bytes;
@@ -792,10 +817,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
   for (int i = 0; i < 8; ++i) {
     const int c = lane + 64 * i;
     const int rl = c >> 4, cc = c & 15;
-    const int q = q0 + rl;
-    if (q < Nq) {
+    if (q0 + rl < Nq) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? SP_TILE_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
-      *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+      *reinterpret_cast<u32x4*>(O + (size_t)(q0row + rl) * ldo + hoff + cc * 8) = v;
     }
   }
   __syncthreads();  // the next item's tile staging overwrites the O staging area
@@ -809,10 +833,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 // and head: 16-B loads along the channels, 4 x 4 patches transposed in registers, LDS for the change of the fast axis, 16-B stores
 // along the keys.  Columns [n_keys, ldvt) are zeroed by the strip that owns them (they meet P = 0 and must be finite).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict__ V, int ldv, bf16* __restrict__ VT, int ldvt, int n_keys) {
+// Blocked input (blk_rows > 0, the all-to-all receive layout: key g of sample b = blockIdx.z in row (g / blk_rows) blk_stride + b blk_rows
+// + g % blk_rows; a 64-key strip never straddles a block): the output is plain per sample, sample b at columns [b vt_cols, ...).
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict__ V, int ldv, bf16* __restrict__ VT, int ldvt, int n_keys,
+                                                          int blk_rows, int blk_stride, int vt_cols) {
   __shared__ __attribute__((aligned(16))) unsigned char tile[HD * (KVB * 2 + 16)];  // [128 d][64 keys] bf16, rows 144 B
   constexpr int TROW = KVB * 2 + 16;
   const int tid = threadIdx.x, head = blockIdx.y, key0 = blockIdx.x * KVB;
+  if (blk_rows > 0) {
+    V += ((size_t)(key0 / blk_rows) * blk_stride + (size_t)blockIdx.z * blk_rows + key0 % blk_rows - key0) * ldv;  // row of key0, minus key0
+    VT += (size_t)blockIdx.z * vt_cols;
+  }
+  const int col_end = blk_rows > 0 ? vt_cols : ldvt;  // columns this sample owns
   // thread -> patch (4 keys x 4 channels): kq = tid & 15 (key quad), dq = tid >> 4 (channel quad, + 16 per pass)
   const int kq = tid & 15, dq = tid >> 4;
 #pragma unroll
@@ -845,7 +877,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict
     const int d = c >> 3, ch = c & 7;
     const pp_u4 v = *reinterpret_cast<const pp_u4*>(tile + d * TROW + ch * 16);
     const int col = key0 + 8 * ch;
-    if (col < ldvt) *reinterpret_cast<pp_u4*>(VT + (size_t)(head * HD + d) * ldvt + col) = v;
+    if (col < col_end) *reinterpret_cast<pp_u4*>(VT + (size_t)(head * HD + d) * ldvt + col) = v;
   }
 }
 
@@ -891,7 +923,7 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
       done = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL((attn_fwd_sp_kernel<TWO>), dim3(nqb * H * batch), block, sp_smem_bytes(TWO), stream, (const bf16*)Q, \
-                       (bf16*)O, s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch);                                          \
+                       (bf16*)O, s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, BlkRows{0, 0, 0u, 0});                    \
   } while (0)
     if (two) CE_ATTN_SP(true); else CE_ATTN_SP(false);
 #undef CE_ATTN_SP
@@ -929,20 +961,52 @@ extern "C" int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, i
   if (!v || !vt) return CE_ERR_ARG;
   if (n_keys <= 0 || H <= 0 || ldvt < n_keys) return CE_ERR_SHAPE;
   if ((ldv & 3) || (ldvt & 7)) return CE_ERR_ALIGN;
-  hipLaunchKernelGGL(v_transpose_kernel, dim3((ldvt + KVB - 1) / KVB, H), dim3(256), 0, stream, (const bf16*)v, ldv, (bf16*)vt, ldvt, n_keys);
+  hipLaunchKernelGGL(v_transpose_kernel, dim3((ldvt + KVB - 1) / KVB, H), dim3(256), 0, stream, (const bf16*)v, ldv, (bf16*)vt, ldvt, n_keys, 0, 0, 0);
   return (int)hipGetLastError();
 }
 
-/* Self-attention with V handed over TRANSPOSED (V^T [H * 128][ldvt], sample b's keys in columns [b len, (b + 1) len)): both K and
- * V^T tiles reach LDS by LDS-DMA, no register staging.  One KV segment, software-pipelined kernel only. */
-extern "C" int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
-                                    int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
+/* The same from the BLOCKED row layout (ce_attention_vt_blocked_bf16): key g of sample b in row (g / blk_rows) blk_stride + b blk_rows +
+ * g % blk_rows of v; output plain per sample, sample b's n_keys keys at columns [b vt_sample_cols, ...), the rest of its vt_sample_cols
+ * columns zeroed.  vt_sample_cols: a multiple of 64, >= 64 ceil(n_keys / 64); ldvt >= batch * vt_sample_cols. */
+extern "C" int ce_v_transpose_blocked_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, int batch, int blk_rows, int blk_stride,
+                                           int vt_sample_cols, hipStream_t stream) {
+  if (!v || !vt) return CE_ERR_ARG;
+  if (n_keys <= 0 || H <= 0 || batch <= 0 || blk_rows <= 0 || (blk_rows & 63) || blk_stride < batch * blk_rows || (vt_sample_cols & 63) ||
+      vt_sample_cols < (n_keys + KVB - 1) / KVB * KVB || ldvt < batch * vt_sample_cols)
+    return CE_ERR_SHAPE;
+  if ((ldv & 3) || (ldvt & 7)) return CE_ERR_ALIGN;
+  hipLaunchKernelGGL(v_transpose_kernel, dim3(vt_sample_cols / KVB, H, batch), dim3(256), 0, stream, (const bf16*)v, ldv, (bf16*)vt, ldvt, n_keys,
+                     blk_rows, blk_stride, vt_sample_cols);
+  return (int)hipGetLastError();
+}
+
+/* Self-attention with V handed over TRANSPOSED (V^T [H * 128][ldvt]): both K and V^T tiles reach LDS by LDS-DMA, no register
+ * staging.  One KV segment, software-pipelined kernel only.  blk_rows == 0: plain layout (sample b's token g in row b N + g of Q / K / O,
+ * its keys in columns [b len, (b + 1) len) of V^T).  blk_rows > 0 (a multiple of 64): the BLOCKED layout an all-to-all leaves behind -
+ * token g of sample b in row (g / blk_rows) blk_stride + b blk_rows + g % blk_rows of Q / K / O; V^T plain per sample with column
+ * stride vt_sample_cols; Nq = number of query tokens per sample (a multiple of blk_rows), len = number of VALID keys. */
+static int attention_vt_launch(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int head_dim,
+                               int ldq, int ldo, float softmax_scale, int batch, int blk_rows, int blk_stride, int vt_sample_cols,
+                               hipStream_t stream) {
   if (!Q || !K || !Vt || !O) return CE_ERR_ARG;
   if (head_dim != HD || Nq <= 0 || H <= 0 || len <= 0 || batch <= 0 || batch > 65535) return CE_ERR_SHAPE;
-  if (ldvt < (batch - 1) * len + (len + KVB - 1) / KVB * KVB) return CE_ERR_SHAPE;  // the last tile of the last sample reads whole 64-key strips
-  if ((ldq & 7) || (ldo & 7) || (ldk & 7) || (ldvt & 7) || (batch > 1 && (len & 1))) return CE_ERR_ALIGN;  // sample b's columns start at byte 2 b len: dword-aligned DMA source
+  const int ntiles_cols = (len + KVB - 1) / KVB * KVB;
+  if (blk_rows == 0) {
+    vt_sample_cols = len;
+    if (ldvt < (batch - 1) * len + ntiles_cols) return CE_ERR_SHAPE;  // the last tile of the last sample reads whole 64-key strips
+  } else {
+    if ((blk_rows & 63) || blk_stride < batch * blk_rows || (Nq % blk_rows) || vt_sample_cols < ntiles_cols ||
+        ldvt < (batch - 1) * vt_sample_cols + ntiles_cols)
+      return CE_ERR_SHAPE;
+  }
+  if ((ldq & 7) || (ldo & 7) || (ldk & 7) || (ldvt & 7) || (batch > 1 && (vt_sample_cols & 1))) return CE_ERR_ALIGN;  // sample b's columns start at byte 2 b cols: dword-aligned DMA source
   KVSeg s0{(const bf16*)K, (const bf16*)Vt, len, ldk, ldvt};
   KVSeg s1{nullptr, nullptr, 0, 0, 0};
+  BlkRows blk{blk_rows, blk_stride, 0u, vt_sample_cols};
+  if (blk_rows > 0) {
+    const uint32_t tps = (uint32_t)(blk_rows >> 6);
+    blk.magic = tps == 1 ? 0u : (uint32_t)(((1ull << 32) + tps - 1) / tps);  // exact for tile indices < 2^16
+  }
   const float sl2 = softmax_scale * 1.4426950408889634f;
   const int nqb = (Nq + 8 * QW - 1) / (8 * QW);
   static bool done = false;
@@ -958,6 +1022,19 @@ extern "C" int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt
   const int items = nqb * H * batch;
   const int grid_vt = items <= 2 * cus ? items : ((2 * cus) & ~7);  // persistent: two workgroups per CU walk the work order (see the kernel); a multiple of 8 keeps heads on their XCD
   hipLaunchKernelGGL((attn_fwd_sp_kernel<false, true>), dim3(grid_vt), dim3(512), sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O,
-                     s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch);
+                     s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, blk);
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
+                                    int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
+  return attention_vt_launch(Q, K, Vt, len, ldk, ldvt, O, Nq, H, head_dim, ldq, ldo, softmax_scale, batch, 0, 0, 0, stream);
+}
+
+extern "C" int ce_attention_vt_blocked_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
+                                            int head_dim, int ldq, int ldo, float softmax_scale, int batch, int blk_rows, int blk_stride,
+                                            int vt_sample_cols, hipStream_t stream) {
+  if (blk_rows <= 0) return CE_ERR_SHAPE;
+  return attention_vt_launch(Q, K, Vt, len, ldk, ldvt, O, Nq, H, head_dim, ldq, ldo, softmax_scale, batch, blk_rows, blk_stride, vt_sample_cols,
+                             stream);
 }

@@ -327,6 +327,46 @@ def attention_vt(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
     return out
 
 
+def v_transpose_blocked(v: torch.Tensor, heads: int, batch: int, blk_rows: int, n_keys: int, out: Optional[torch.Tensor] = None):
+    """v [W * batch * blk_rows, heads*128] in the all-to-all receive layout ([source rank][sample][local token]) -> V^T
+    [heads*128, batch * vt_sample_cols] plain per sample (`attention_vt_blocked`); n_keys = valid tokens per sample."""
+    _dev(v, torch.bfloat16, "v")
+    rows, D, ldv = _rows(v, "v")
+    assert D == heads * 128 and blk_rows % 64 == 0 and rows % (batch * blk_rows) == 0
+    cols = (n_keys + 63) // 64 * 64 + 64
+    if out is None:
+        out = torch.empty((D, batch * cols), dtype=torch.bfloat16, device=v.device)
+    assert out.shape == (D, batch * cols) and out.is_contiguous()
+    st = _prof_begin()
+    _check(lib().ce_v_transpose_blocked_bf16(_ptr(v), ldv, _ptr(out), out.shape[1], n_keys, heads, batch, blk_rows, batch * blk_rows, cols,
+                                             _stream()), "ce_v_transpose_blocked_bf16")
+    _prof_end(st, f"v_transpose_{batch * n_keys}x{D}", 4.0 * batch * n_keys * D)
+    return out
+
+
+def attention_vt_blocked(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, batch: int, blk_rows: int, n_keys: int,
+                         out: Optional[torch.Tensor] = None, scale: Optional[float] = None):
+    """`attention_vt` over the blocked row layout: q / k / out [W * batch * blk_rows, heads*128] with token g of sample b in row
+    (g // blk_rows) * batch * blk_rows + b * blk_rows + g % blk_rows; vt from `v_transpose_blocked`; n_keys valid keys per sample."""
+    for n, t in (("q", q), ("k", k), ("vt", vt)):
+        _dev(t, torch.bfloat16, n)
+    rows, Dq, ldq = _rows(q, "q")
+    rk, _, ldk = _rows(k, "k")
+    assert Dq == heads * 128 and vt.shape[0] == Dq and vt.stride(1) == 1 and rows == rk and rows % (batch * blk_rows) == 0
+    nq = rows // batch  # query tokens per sample = W * blk_rows
+    cols = vt.shape[1] // batch
+    if out is None:
+        out = torch.empty((rows, Dq), dtype=torch.bfloat16, device=q.device)
+    _, _, ldo = _rows(out, "out")
+    if scale is None:
+        scale = 128 ** -0.5
+    st = _prof_begin()
+    _check(lib().ce_attention_vt_blocked_bf16(_ptr(q), _ptr(k), _ptr(vt), n_keys, ldk, vt.stride(0), _ptr(out), nq, heads, 128, ldq, ldo,
+                                              float(scale), batch, blk_rows, batch * blk_rows, cols, _stream()), "ce_attention_vt_blocked_bf16")
+    _prof_end(st, f"attention_{nq}x{n_keys}+0_h{heads}" + (f"_b{batch}" if batch > 1 else ""), 4.0 * nq * n_keys * 128 * heads * batch)
+    return out
+
+
 def timestep_sinusoid(t: torch.Tensor, dim: int, out: Optional[torch.Tensor] = None):
     """[cos, sin] table of one timestep: int64 (diffusers path) or float32 (the sibling stacks' float timesteps)."""
     if t.dtype == torch.float32:

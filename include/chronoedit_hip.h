@@ -112,6 +112,22 @@ int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int
 int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int head_dim,
                          int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream);
 
+/* ce_attention_vt_bf16 over the BLOCKED row layout an all-to-all leaves behind when every rank sent [sample][local token] rows
+ * (Ulysses sequence parallelism with the guidance pair batched: chronoedit_amd/parallel.py): token g of sample b sits in row
+ * (g / blk_rows) blk_stride + b blk_rows + g % blk_rows of Q, K and O (blk_rows = tokens per rank, a multiple of 64; blk_stride =
+ * batch * blk_rows); Nq = query tokens per sample (a multiple of blk_rows), len = VALID keys per sample (the tail of the last block
+ * is padding); Vt plain per sample, sample b's keys at columns [b vt_sample_cols, ...) (ce_v_transpose_blocked_bf16).  A key tile
+ * never straddles a block, so the layout costs one scalar multiply-high per tile.  Replaces the gather + permute copies around
+ * F.scaled_dot_product_attention in the reference's sequence-parallel path (wan_video_new_chronoedit.py:330-355 via xfuser). */
+int ce_attention_vt_blocked_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int head_dim,
+                                 int ldq, int ldo, float softmax_scale, int batch, int blk_rows, int blk_stride, int vt_sample_cols,
+                                 hipStream_t stream);
+
+/* v in the blocked row layout above -> vt [H * 128][ldvt] plain per sample (sample b at columns [b vt_sample_cols, ...), columns past
+ * n_keys zeroed); vt_sample_cols a multiple of 64, ldvt >= batch * vt_sample_cols. */
+int ce_v_transpose_blocked_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, int batch, int blk_rows, int blk_stride,
+                                int vt_sample_cols, hipStream_t stream);
+
 /* v [n_keys][ldv] bf16 (head h at columns [128 h, 128 h + 128)) -> vt [H * 128][ldvt] (ldvt >= n_keys, multiple of 8; columns
  * [n_keys, ldvt) zeroed): the producer of ce_attention_vt_bf16's V operand. */
 int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, hipStream_t stream);

@@ -294,6 +294,33 @@ def test_attention_vt_matches_sdpa_and_the_register_staged_kernel(Nq, Nkv, H, B)
         assert rel_l2(out[b * Nq:(b + 1) * Nq], ref) < 1e-2, (b, rel_l2(out[b * Nq:(b + 1) * Nq], ref))
 
 
+@pytest.mark.parametrize("N,n,W,H,B", [(300, 128, 3, 2, 2), (128, 64, 2, 8, 1), (1000, 256, 4, 8, 2), (7100, 3584, 2, 8, 2), (500, 64, 8, 5, 3)])
+def test_attention_vt_blocked_layout_equals_plain(N, n, W, H, B):
+    """ce_attention_vt_blocked_bf16 + ce_v_transpose_blocked_bf16: q / k / v / out rows in the all-to-all receive layout
+    [source rank][sample][local token] (n tokens per rank, W ranks, the last block padded: N valid tokens) == the plain-layout
+    kernel on the un-blocked tensors, bit for bit (same kernel, only row addresses differ)."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(29)
+    D, T = H * 128, W * n
+    assert (W - 1) * n < N <= T
+    plain = torch.randn(B, T, 3 * D, generator=g).to(BF).to(dev)     # [sample][token][q | k | v]
+    plain[:, N:, D:] = 0.5                                             # padded keys: finite junk the mask must hide
+    blocked = plain.view(B, W, n, 3 * D).permute(1, 0, 2, 3).contiguous().view(W * B * n, 3 * D)  # [src][b][i]
+    vt = ops.v_transpose_blocked(blocked[:, 2 * D:], H, B, n, N)
+    cols = vt.shape[1] // B
+    for b in range(B):
+        assert torch.equal(vt[:, b * cols:b * cols + N], plain[b, :N, 2 * D:].t()) and not vt[:, b * cols + N:(b + 1) * cols].any()
+    out = ops.attention_vt_blocked(blocked[:, :D], blocked[:, D:2 * D], vt, H, B, n, N)
+    got = out.view(W, B, n, D).permute(1, 0, 2, 3).reshape(B, T, D)
+    for b in range(B):
+        vt_b = ops.v_transpose(plain[b, :N, 2 * D:], H)
+        want = ops.attention_vt(plain[b, :, :D], plain[b, :N, D:2 * D], vt_b, H)
+        assert torch.equal(got[b], want), (b, (got[b].float() - want.float()).abs().max())
+        ref = _sdpa_ref(plain[b, :, :D], plain[b, :N, D:2 * D], plain[b, :N, 2 * D:], H)
+        assert rel_l2(got[b], ref) < 1e-2
+
+
 @pytest.mark.parametrize("slope", [0.5, 10.0])
 def test_attention_vt_spiked_scores_take_the_exact_route(slope):
     from chronoedit_amd import ops
