@@ -224,8 +224,8 @@ def main():
     ulysses = world > 1 and mode == "ulysses"
     # Default split of the N ranks (tools/scaling_model.py): on TWO GPUs the guidance pair is split - each
     # GPU runs one of the two forwards whole, no all-to-all at all, one 3.7 MB exchange per step - because a 2-rank Ulysses group
-    # talks over ONE of the seven xGMI links (predicted 0.90 vs 0.66 steps/s); from four GPUs on Ulysses over all ranks has the
-    # links (3 resp. 7 per GPU) and wins or ties.  --cfg-parallel / --no-cfg-parallel override.
+    # talks over ONE of the seven xGMI links (predicted 0.93 vs 0.69 steps/s); from four GPUs on ONE Ulysses group over all ranks, the
+    # guidance pair batched inside it (blocked-layout kernels), has the links (3 resp. 7 per GPU) and wins.  --cfg-parallel / --no-cfg-parallel override.
     if a.cfg_parallel is None:
         a.cfg_parallel = bool(ulysses and world == 2 and a.guidance > 1)
     if a.cfg_parallel and not (ulysses and world % 2 == 0 and a.guidance > 1):
@@ -288,7 +288,8 @@ def main():
     rccl = None
     if ulysses:
         st = model._sp.stats
-        n_fwd = (a.warmup + a.steps) * (1 if a.cfg_parallel else fwd_per_step)
+        pair_batched = not a.cfg_parallel and not a.sequential_cfg and fwd_per_step == 2  # the guidance pair as one B = 2 sharded forward
+        n_fwd = (a.warmup + a.steps) * (1 if (a.cfg_parallel or pair_batched) else fwd_per_step)
         rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ulysses_group": model._sp.world,
                 "cfg_parallel_groups": 2 if a.cfg_parallel else 1,
                 "all_to_all_per_layer_per_forward": st["all_to_all_calls"] / max(1, n_fwd * a.layers),
@@ -375,7 +376,8 @@ def main():
                                    + _baseline_config_name(a, T),
                        "tokens": N, "forwards_per_step": fwd_per_step,
                        "parallelism": (f"ulysses sp{model._sp.world}" + (" x cfg2" if a.cfg_parallel else "")) if ulysses else f"replica x{world}",
-                       "cfg": ("parallel (two Ulysses groups)" if a.cfg_parallel else "sequential (2 x B=1)") if ulysses
+                       "cfg": ("parallel (two Ulysses groups)" if a.cfg_parallel else
+                               "sequential (2 x B=1)" if a.sequential_cfg else "batched (1 x B=2) inside the Ulysses group: blocked receive layout") if ulysses
                               else ("sequential (2 x B=1)" if a.sequential_cfg else "batched (1 x B=2)"),
                        "context_cache": bool(a.cache_context)},
             "model_tflops_per_step": round(fl / 1e12, 2),

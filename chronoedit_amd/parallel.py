@@ -16,6 +16,12 @@ MI355X layout (no permute().contiguous() passes anywhere on the path):
   * the attention output [global token][D/W] is already the send buffer of the second exchange (chunk t = rows of rank t);
   * its receive buffer [src rank = head group][local row][D/W] is consumed in place by the out-projection GEMM as a
     K-segmented A operand (`ce_gemm_aseg_bf16`).
+Several samples per forward (the guidance pair batched, B = 2): local rows are [sample][local token], so the receive buffers are
+[src rank][sample][local token] - token g of sample b in row (g // n) * B * n + b * n + g % n.  The attention kernel and the V
+transposer take that BLOCKED layout as it is (`ce_attention_vt_blocked_bf16`, `ce_v_transpose_blocked_bf16`: one scalar
+multiply-high per key tile; n is rounded up to a multiple of 64 so that no key tile straddles two source blocks), and the
+attention output in the same layout is again the send buffer of the return exchange: twice the rows per GEMM, half the number of
+collectives per step, still no permute pass.
 The k|v exchange is issued asynchronously as soon as the k|v projection is done and overlaps the q projection GEMM
 (SURVEY.md section 5.8); `torch.distributed` owns the communicator (backend "nccl" == RCCL over xGMI: an all-to-all drives
 all 7 links of a GPU at once, each peer gets 1/W of the payload).  With the gloo backend (CPU tests, or several ranks sharing
@@ -58,16 +64,19 @@ class Ulysses:
         self.stats = {"all_to_all_calls": 0, "all_to_all_bytes_sent_off_rank": 0, "all_gather_calls": 0}
 
     # -- token sharding ----------------------------------------------------------------
-    def shard(self, n_tokens: int) -> Tuple[int, int, int]:
-        """(n_local, start, n_valid): every rank holds n_local = ceil(N / W) rows, rows past N are zero padding."""
+    def shard(self, n_tokens: int, align: int = 1) -> Tuple[int, int, int]:
+        """(n_local, start, n_valid): every rank holds n_local = ceil(N / W) rows (rounded up to a multiple of `align`), rows past
+        N are zero padding.  align = 64 is what the batched form needs: with several samples per forward the all-to-all receive
+        buffer is [source rank][sample][local token], and a 64-key attention tile must not straddle two source blocks."""
         n_local = (n_tokens + self.world - 1) // self.world
+        n_local = (n_local + align - 1) // align * align
         start = self.rank * n_local
         n_valid = max(0, min(n_local, n_tokens - start))
         return n_local, start, n_valid
 
-    def take_rows(self, full: torch.Tensor, n_tokens: int) -> torch.Tensor:
+    def take_rows(self, full: torch.Tensor, n_tokens: int, align: int = 1) -> torch.Tensor:
         """Local zero-padded slice [n_local, ...] of a replicated [N, ...] tensor."""
-        n_local, start, n_valid = self.shard(n_tokens)
+        n_local, start, n_valid = self.shard(n_tokens, align)
         out = torch.zeros((n_local,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
         if n_valid:
             out[:n_valid] = full[start : start + n_valid]

@@ -51,6 +51,13 @@ def _token_sharded(transformer) -> bool:
     return sp is not None and sp.sharded
 
 
+def _sharded_batchable(transformer) -> bool:
+    """Can a token-sharded (Ulysses) forward take the guidance pair as ONE batch of two?  Yes on the bf16 V^T attention path (the
+    blocked-layout kernels, chronoedit_amd/parallel.py); the fp8 modes and the register-staged kernel run the passes in sequence."""
+    return (getattr(transformer, "v_transposed", False) and getattr(transformer, "gemm_dtype", "bf16") == "bf16"
+            and getattr(transformer, "attn_dtype", "bf16") == "bf16" and getattr(transformer, "sp_batch_cfg", True))
+
+
 @torch.no_grad()
 def denoise_step(transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPCMultistepScheduler, latents: torch.Tensor,
                  condition: torch.Tensor, t: torch.Tensor, prompt_embeds: torch.Tensor,
@@ -60,7 +67,7 @@ def denoise_step(transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPC
     latent_model_input = torch.cat([latents.to(torch.bfloat16), condition], dim=1)
     B = latents.shape[0]
     timestep = t.expand(B)
-    batch_cfg = batch_cfg and not _token_sharded(transformer)  # Ulysses shards the tokens of ONE sample per forward
+    batch_cfg = batch_cfg and (not _token_sharded(transformer) or _sharded_batchable(transformer))
     cfgp = getattr(transformer, "_cfgp", None)
     if guidance_scale > 1.0 and negative_prompt_embeds is not None:  # do_classifier_free_guidance
         if cfgp is not None:
@@ -164,7 +171,7 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
     the shorter sequence."""
     scheduler.set_timesteps(num_inference_steps, device=latents.device)
     latents = latents.to(torch.float32).contiguous()
-    sharded = _token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None
+    sharded = getattr(transformer, "_cfgp", None) is not None or (_token_sharded(transformer) and not _sharded_batchable(transformer))
     cfg_inputs = None
     if guidance_scale > 1.0 and negative_prompt_embeds is not None and not sharded:
         cfg_inputs = make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)

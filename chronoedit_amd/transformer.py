@@ -191,6 +191,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.gemm_dtype = "bf16"    # "fp8": the six large Linears of every block on the OCP-e4m3 MX matrix path
         self.attn_dtype = "bf16"    # "mxfp8": self-attention on the MX-fp8 matrix instruction (csrc/ce_attn_fp8.hip)
         self.v_transposed = True    # bf16 self-attention takes V^T straight from the projection (swapped GEMM) and stages it by LDS-DMA
+        self.sp_batch_cfg = True    # sequence-parallel forwards take the guidance pair as one batch of two (blocked-layout kernels)
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
         self._cfgp = None           # CFG parallelism on top of it (two Ulysses groups), off by default
 
@@ -531,8 +532,9 @@ class DiTEngine:
         wq, sw = getattr(p, "q_" + name)
         return ops.gemm_fp8(aq, ws.s8, wq, sw, b, out=out, **kw)
 
-    def _self_attention_ulysses(self, ws, sp, x, a_row, b_row, p, cs, N: int, Nl: int):
-        """Self-attention of ONE sample with the tokens sharded over sp.world ranks (parallel.py has the layout story).
+    def _self_attention_ulysses(self, ws, sp, x, a_row, b_row, p, cs, N: int, Nl: int, B: int = 1):
+        """Self-attention with the tokens sharded over sp.world ranks (parallel.py has the layout story); B samples stacked [sample][local
+        token] along the rows (B > 1: the blocked receive layout, Nl a multiple of 64).
         The fused q|k|v projection runs as two GEMMs - [k | v] first - so that the k|v exchange (2/3 of the volume) is on
         the wire while the q projection is still computing; q / k are normalised and rotated by the pass that writes the
         all-to-all send layout; the attention kernel and the out-projection read the receive buffers in place."""
@@ -555,14 +557,18 @@ class DiTEngine:
         wait_kv.wait()
         wait_q.wait()
         kv = sp.gathered_view(ws.recv_kv)  # [W*Nl = global token, k | v of this rank's heads]
-        if self.v_transposed:  # the LDS-DMA form of the kernel wants V^T: one small transpose pass over this rank's heads
+        if B > 1:  # rows are [source rank][sample][local token]: the blocked forms of the transposer and of the attention kernel
+            vt_shape = (Dl, B * ops.vt_columns(N))
+            ws.vt_sp = ops.v_transpose_blocked(kv[:, Dl:], H // W, B, Nl, N, out=ws.vt_sp if getattr(ws, "vt_sp", torch.empty(0)).shape == vt_shape else None)
+            ops.attention_vt_blocked(sp.gathered_view(ws.recv_q), kv[:, :Dl], ws.vt_sp, H // W, B, Nl, N, out=ws.att_g)
+        elif self.v_transposed:  # the LDS-DMA form of the kernel wants V^T: one small transpose pass over this rank's heads
             if getattr(ws, "vt_sp", None) is None or ws.vt_sp.shape != (Dl, ops.vt_columns(N)):
                 ws.vt_sp = torch.zeros((Dl, ops.vt_columns(N)), dtype=torch.bfloat16, device=self.dev)
             ops.v_transpose(kv[:N, Dl:], H // W, out=ws.vt_sp)
             ops.attention_vt(sp.gathered_view(ws.recv_q), kv[:N, :Dl], ws.vt_sp, H // W, out=ws.att_g)
         else:
             ops.attention(sp.gathered_view(ws.recv_q), kv[:N, :Dl], kv[:N, Dl:], H // W, out=ws.att_g)
-        y, _ = sp.all_to_all(ws.att_g.view(W, Nl, Dl), ws.att_seg)  # [head group][local row][Dl]
+        y, _ = sp.all_to_all(ws.att_g.view(W, B * Nl, Dl), ws.att_seg)  # [head group][local row][Dl]
         if self.fp8:  # the row quantiser wants plain rows: secondary mode, one gather pass
             ws.att.copy_(sp.merge_heads_reference(y))
             return ws.att
@@ -689,12 +695,13 @@ class DiTEngine:
         cs = self._rope_table(T, Hp, Wp)  # raises AssertionError for unsupported frame counts (:205)
         sp = self.model._sp
         if sp is not None and sp.sharded:
-            if B != 1:
-                raise ValueError("sequence parallelism shards the tokens of ONE sample; call with batch size 1")
-            Nl = sp.shard(N)[0]  # local (zero-padded) token rows
-            key = ("sp", T, Hp, Wp, sp.rank, sp.world)
+            if B != 1 and (self.fp8 or not self.v_transposed):
+                raise ValueError("several samples per sequence-parallel forward need the bf16 V^T attention path (enable_transposed_v, no fp8 GEMMs)")
+            align = 64 if B > 1 else 1  # B > 1: blocked receive layout, a key tile must not straddle two source ranks' blocks
+            Nl = sp.shard(N, align)[0]  # local (zero-padded) token rows
+            key = ("sp", T, Hp, Wp, sp.rank, sp.world, Nl)
             if key not in self._rope:
-                self._rope[key] = sp.take_rows(cs, N).contiguous()
+                self._rope[key] = sp.take_rows(cs, N, align).contiguous()
             cs = self._rope[key]
         else:
             sp = None
@@ -710,7 +717,8 @@ class DiTEngine:
             for b in range(B):
                 ops.patchify(hidden[b], self.kpatch, out=ws.cols[rows[b]])
         else:  # only this rank's token rows (zero rows past the last token: wan_video_new_chronoedit.py:1450-1453)
-            ops.patchify(hidden[0], self.kpatch, out=ws.cols, row0=sp.rank * Nl, nrows=Nl)
+            for b in range(B):
+                ops.patchify(hidden[b], self.kpatch, out=ws.cols[rows[b]], row0=sp.rank * Nl, nrows=Nl)
         ops.gemm(ws.cols, self.w_patch, self.b_patch, out=ws.x)
 
         # K2 per sample: sinusoid -> time_embedder (fp32) -> temb (bf16-rounded) -> silu -> time_proj -> AdaLN tables
@@ -763,7 +771,7 @@ class DiTEngine:
                 ops.attention(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.qkv[:, 2 * D :], H, out=ws.att, batch=B)
                 att = ws.att
             else:
-                att = self._self_attention_ulysses(ws, sp, x, mod[li, 0, 1], mod[li, 0, 0], p, cs, N, Nl)
+                att = self._self_attention_ulysses(ws, sp, x, mod[li, 0, 1], mod[li, 0, 0], p, cs, N, Nl, B)
             self._linear(ws, att, p, "o1", x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
                          res=x, gate_rows=grow)
             # 2. cross-attention (text + image segments)
@@ -791,6 +799,7 @@ class DiTEngine:
             for b in range(B):
                 ops.unpatchify(ws.head[rows[b]], cfg.out_channels, T, Hh, Ww, out=out[b])
         else:
-            full = sp.all_gather_rows(ws.head)[:N].contiguous()
-            ops.unpatchify(full, cfg.out_channels, T, Hh, Ww, out=out[0])
+            full = sp.all_gather_rows(ws.head).view(sp.world, B, Nl, -1)  # [source rank][sample][local token]
+            for b in range(B):
+                ops.unpatchify(full[:, b].reshape(sp.world * Nl, -1)[:N].contiguous(), cfg.out_channels, T, Hh, Ww, out=out[b])
         return out

@@ -198,23 +198,35 @@ def _gpu_worker(rank, world, port, q):
     lat, text, image = O.make_synthetic_inputs(cfg, 2, 18, 22, dtype=BF, text_len=40, real_text=8)  # N = 198: not divisible by 4
     ts = torch.tensor([321], device="cuda:0")
     ref = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample.clone()
+    # two samples per forward (the guidance pair batched): different latents / timesteps / prompts per sample
+    g = torch.Generator().manual_seed(5)
+    lat2 = torch.cat([lat, torch.randn(lat.shape, generator=g).to(BF)], 0).cuda()
+    text2 = torch.cat([text, torch.randn(text.shape, generator=g).to(BF)], 0).cuda()
+    image2 = torch.cat([image, image], 0).cuda()
+    ts2 = torch.tensor([321, 777], device="cuda:0")
+    ref2 = m(lat2, ts2, text2, image2).sample.clone()
     m.enable_sequence_parallel()
     out = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample
-    st = m._sp.stats
-    q.put((rank, bool(torch.equal(out, ref)), float((out.float() - ref.float()).abs().max()), st["all_to_all_calls"]))
+    calls1 = m._sp.stats["all_to_all_calls"]
+    out2 = m(lat2, ts2, text2, image2).sample  # blocked receive layout [source rank][sample][local token], 64-aligned shards
+    q.put((rank, bool(torch.equal(out, ref)), float((out.float() - ref.float()).abs().max()), calls1,
+           float((out2.float() - ref2.float()).abs().max()), m._sp.stats["all_to_all_calls"] - calls1))
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_ulysses_hip_forward_two_ranks_one_gpu():
-    for rank, equal, err, calls in _spawn(_gpu_worker, 2):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ulysses_hip_forward_ranks_sharing_one_gpu(world):
+    for rank, equal, err, calls, err2, calls2 in _spawn(_gpu_worker, world):
         assert equal or err < 2e-2, (rank, equal, err)
-        assert calls == 3 * 2  # per layer: k|v, q, output
+        assert err2 < 2e-2, (rank, err2)   # B = 2 in one sharded forward == the single-process B = 2 forward
+        assert calls == 3 * 2 and calls2 == 3 * 2  # per layer: k|v, q, output - the same number of collectives for two samples
 
 
 def _loop_worker(rank, world, port, q, mode):
-    """denoise() with guidance 5: single process (batched CFG) vs sharded (sequential CFG inside one Ulysses group, or the
-    2 x (world/2) CFG-parallel grouping)."""
+    """denoise() with guidance 5: single process (batched CFG) vs sharded (the pair batched inside one Ulysses group - blocked receive
+    layout, 64-aligned shards, a rank with NO valid token after the frame truncation at world 4 - or the 2 x (world/2) CFG-parallel
+    grouping)."""
     _init(rank, world, port)
     torch.cuda.set_device(0)
     from chronoedit_amd.pipeline import denoise
@@ -239,7 +251,7 @@ def _loop_worker(rank, world, port, q, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,mode", [(2, "sp"), (2, "cfgp"), (4, "cfgp")])  # (2, cfgp): the guidance pair split, no token sharding
+@pytest.mark.parametrize("world,mode", [(2, "sp"), (4, "sp"), (2, "cfgp"), (4, "cfgp")])  # sp: guidance pair BATCHED inside the Ulysses group; (2, cfgp): the pair split, no token sharding
 def test_denoise_loop_with_cfg_sharded_over_ranks(world, mode):
     """`denoise()` must work with the tokens sharded (it used to hand the B = 2 batched-CFG forward to the Ulysses
     path, which raised).  Result vs the single-process loop: identical arithmetic per sample, so rel-L2 <= 5e-3 after 4 steps
@@ -280,4 +292,4 @@ def test_sharded_path_over_rccl_on_one_rank():
     exchange buffers as strided kernel operands, all_gather_into_tensor; the result must equal the un-sharded forward."""
     (rank, backend, equal, err, calls, finite), = _spawn(_rccl_one_rank_worker, 1, timeout=300)
     assert backend == "nccl" and (equal or err < 2e-2) and finite, (backend, equal, err, finite)
-    assert calls == 3 * 2 + 3 * 2 * 2 * 3  # forward: 2 layers x 3; loop: 3 steps x 2 passes x 2 layers x 3
+    assert calls == 3 * 2 + 3 * 1 * 2 * 3  # forward: 2 layers x 3; loop: 3 steps x ONE batched pass x 2 layers x 3

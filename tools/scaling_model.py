@@ -20,10 +20,15 @@ def rounds(n_wg: float) -> float:
     return full + (0.0 if frac < 1e-9 else max(frac, 0.5))
 
 
-def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_gpu: dict):
+def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_gpu: dict, pair_batched: bool = False):
     sp = W // 2 if cfg_parallel else W  # ranks per Ulysses group
-    batch = 1  # one sample per forward: the sharded path runs the two guidance passes one after the other (or side by side: cfg-parallel)
-    rows = batch * math.ceil(N_TOK / sp)
+    # samples per forward: 1 (the two guidance passes in sequence, or side by side on two groups: cfg-parallel) or 2 (pair_batched: one
+    # sharded forward of B = 2 on the blocked-layout kernels; shards rounded up to 64 tokens)
+    batch = 2 if (pair_batched and not cfg_parallel) else 1
+    n_loc = math.ceil(N_TOK / sp)
+    if batch == 2:
+        n_loc = (n_loc + 63) // 64 * 64
+    rows = batch * n_loc
     heads = H // sp
     kb = one_gpu["kernel_breakdown"]
 
@@ -54,9 +59,9 @@ def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_g
     exposed = max(0.0, kv - q_gemm) + q + o
     layer = attn + xattn + g + row + exposed
     fwd = L * layer + 6.0 / sp  # + context K/V projections (3 + 3 ms on one GPU), head, patchify
-    passes = 1 if cfg_parallel else 2
+    passes = 1 if (cfg_parallel or batch == 2) else 2
     step = passes * fwd + (0.1 if cfg_parallel else 0.0)  # + the 3.7 MB prediction exchange
-    return dict(W=W, mode="cfg-parallel 2 x %d" % sp if cfg_parallel else "ulysses %d" % sp, rows=rows, heads=heads,
+    return dict(W=W, mode="cfg-parallel 2 x %d" % sp if cfg_parallel else ("ulysses %d, B=2" % sp if batch == 2 else "ulysses %d" % sp), rows=rows, heads=heads,
                 attn_ms=attn, gemm_ms=g, exchange_ms=kv + q + o, exposed_ms=exposed, step_ms=step, steps_per_s=1e3 / step)
 
 
@@ -71,8 +76,8 @@ def main():
     print(f"measured on one MI355X: {base:.0f} ms/step ({1e3 / base:.3f} steps/s); link {a.link_GBps} GB/s one way, {a.latency_us} us per collective")
     print(f"{'GPUs':>4} {'mode':>18} {'rows/rank':>9} {'heads':>5} {'attn':>7} {'GEMMs':>7} {'a2a':>6} {'exposed':>7} | {'ms/step':>8} {'steps/s':>8} {'speed-up':>8} {'eff.':>5}")
     for W in (1, 2, 4, 8):
-        for cfgp in ((False,) if W == 1 else (False, True)):
-            r = model(W, cfgp, a.link_GBps, a.latency_us, one)
+        for cfgp, pb in (((False, False), (False, True)) if W == 1 else ((False, False), (False, True), (True, False))):
+            r = model(W, cfgp, a.link_GBps, a.latency_us, one, pair_batched=pb)
             print(f"{W:>4} {r['mode']:>18} {r['rows']:>9} {r['heads']:>5} {r['attn_ms']:>7.2f} {r['gemm_ms']:>7.2f} {r['exchange_ms']:>6.2f} {r['exposed_ms']:>7.2f} |"
                   f" {r['step_ms']:>8.1f} {r['steps_per_s']:>8.3f} {base / r['step_ms']:>8.2f} {base / r['step_ms'] / W:>5.2f}")
 
