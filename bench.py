@@ -14,8 +14,10 @@ N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL): BASELINE.
 8 latent frames = 28 800 tokens, ONE edit with the token axis sharded over the N GPUs (Ulysses: three all-to-all per self-attention
 over xGMI, chronoedit_amd/parallel.py), "scaling": "strong".  The line also carries, measured in the same run outside the timed
 region: the same workload on ONE GPU (rank 0, so that the strong-scaling speed-up can be read off the line itself) and the
-replica figure (N independent configs[1] edits, weak scaling).  `--parallel replica` makes the replica mode the headline instead;
-`--cfg-parallel` runs the two guidance passes as two (N/2)-way Ulysses groups side by side.
+replica figure (N independent configs[1] edits, weak scaling).  `--parallel replica` makes the replica mode the headline instead.
+How the N ranks are split (tools/scaling_model.py): N = 2 - the guidance pair split, one whole forward per GPU
+(`--cfg-parallel`, the default there); N >= 4 - one N-way Ulysses group with the guidance pair batched INSIDE it (B = 2 per sharded
+forward on the blocked-layout kernels); `--cfg-parallel` / `--no-cfg-parallel` / `--sequential-cfg` select the other splits.
 Timing: barrier + synchronize on both sides, MAX over ranks.
 
 The JSON line carries:
@@ -62,7 +64,7 @@ def parse():
                          "RCCL/xGMI, strong scaling); 'replica' = independent edits per GPU (weak scaling)")
     ap.add_argument("--cfg-parallel", dest="cfg_parallel", action="store_true", default=None,
                     help="sharded mode: the cond / uncond passes side by side on two (N/2)-way Ulysses groups (default on 2 GPUs)")
-    ap.add_argument("--no-cfg-parallel", dest="cfg_parallel", action="store_false", help="sharded mode: one N-way Ulysses group, passes in sequence")
+    ap.add_argument("--no-cfg-parallel", dest="cfg_parallel", action="store_false", help="sharded mode: one N-way Ulysses group (guidance pair batched inside it; --sequential-cfg: one pass after the other)")
     ap.add_argument("--no-transposed-v", action="store_true",
                     help="(A/B) fused q|k|v GEMM + register-staged attention kernel instead of V^T from the swapped GEMM + LDS-DMA staging")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
