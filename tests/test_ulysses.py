@@ -86,6 +86,52 @@ def test_ulysses_layout_roundtrip_gloo(N, H):
         assert err < 1e-5 and err2 < 1e-5 and bytes_ok, (rank, err, err2, bytes_ok)
 
 
+def _cpu_worker_batched(rank, world, port, q, N, H, B):
+    """B samples per sharded forward: local rows [sample][local token] (shards rounded up to 64 tokens), receive buffers
+    [source rank][sample][local token].  The plain-torch statement of what ce_attention_vt_blocked_bf16 / ce_v_transpose_blocked_bf16
+    / the K-segmented out-projection operand read: token g of sample b lives in row (g // n) * B * n + b * n + g % n."""
+    _init(rank, world, port)
+    from chronoedit_amd.parallel import Ulysses
+    u = Ulysses()
+    hd, D = 128, H * 128
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B, N, 3 * D, generator=g)  # replicated "truth", per sample
+
+    def sdpa(qq, kk, vv, heads):
+        f = lambda t: t.reshape(-1, heads, hd).transpose(0, 1)[None]
+        return torch.nn.functional.scaled_dot_product_attention(f(qq), f(kk), f(vv))[0].transpose(0, 1).reshape(-1, heads * hd)
+    n, start, n_valid = u.shard(N, align=64)
+    assert n % 64 == 0 and world * n >= N
+    local = torch.cat([u.take_rows(qkv[b], N, align=64) for b in range(B)], 0)  # [B * n, 3D]: rows b * n + i
+    Dl, hl = D // world, H // world
+    recv_kv, _ = u.all_to_all(u.send_layout_reference([local[:, D:2 * D], local[:, 2 * D:]]))
+    recv_q, _ = u.all_to_all(u.send_layout_reference([local[:, :D]]))
+    kv, qg = u.gathered_view(recv_kv), u.gathered_view(recv_q)  # [W * B * n, ...]: row (src * B + b) * n + i
+    row = lambda b, gtok: (gtok // n) * B * n + b * n + gtok % n
+    o = torch.zeros(world * B * n, Dl)
+    for b in range(B):
+        idx_all = torch.tensor([row(b, t) for t in range(world * n)])
+        idx_valid = idx_all[:N]
+        o[idx_all] = sdpa(qg[idx_all], kv[idx_valid, :Dl], kv[idx_valid, Dl:], hl)  # queries: every row incl. padding; keys: the N valid tokens
+    y, _ = u.all_to_all(o.view(world, B * n, Dl))  # chunk dst = rows [dst * B * n, ...) = [sample][local token] of rank dst
+    back = u.merge_heads_reference(y)  # [B * n, D]
+    err = 0.0
+    for b in range(B):
+        ref = sdpa(*qkv[b].split(D, dim=1), H)
+        if n_valid:
+            err = max(err, (back[b * n:b * n + n_valid] - ref[start:start + n_valid]).abs().max().item())
+    q.put((rank, err, n, n_valid))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,H,B,world", [(150, 2, 2, 2), (70, 4, 3, 2), (300, 4, 2, 4)])
+def test_ulysses_batched_blocked_layout_gloo(N, H, B, world):
+    res = _spawn(_cpu_worker_batched, world, N, H, B)
+    for rank, err, n, n_valid in res:
+        assert err < 1e-5 and n % 64 == 0, (rank, err, n, n_valid)
+    assert sum(nv for *_, nv in res) == N  # the shards cover every token exactly once (some ranks may hold none)
+
+
 def _cfgp_worker(rank, world, port, q):
     _init(rank, world, port)
     from chronoedit_amd.parallel import CFGParallel, Ulysses
