@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE - stand-ins for the diffusers / imaginaire names that the reference's own pipeline source
 (/root/reference/chronoedit_diffusers/pipeline_chronoedit.py) refers to, so that `oracle/build_ref.py` can lift the reference's
 `__call__`, `prepare_latents`, `encode_prompt`, `encode_image`, `check_inputs` and property sources VERBATIM into
-`oracle/_ref/pipeline_ref.py` (generated at build time, never committed) and run them over the chronoedit_amd drop-ins.
+`oracle/_ref/pipeline_ref.bin` (a compiled code object generated at build time, never committed) and run them over the chronoedit_amd drop-ins.
 
 Nothing here restates reference logic: these are the un-vendored leaves (diffusers==0.35.2 is not installable here) - a logger,
 a progress bar, `randn_tensor`, `VideoProcessor` pre / post processing, the output dataclass.  Only tests/ may import this."""

@@ -1,7 +1,7 @@
-"""The drop-in boundary, proven with the reference's OWN caller code: `oracle/_ref/pipeline_ref.py` holds the source of
-ChronoEditPipeline.__call__ / prepare_latents / encode_prompt / encode_image / check_inputs lifted verbatim from
-/root/reference/chronoedit_diffusers/pipeline_chronoedit.py by oracle/build_ref.py at build time (git-ignored, shipped to the
-GPU box like the built .so).  Here it RUNS - `self.transformer(hidden_states=..., timestep=..., encoder_hidden_states=...,
+"""The drop-in boundary, proven with the reference's OWN caller code: `oracle/_ref/pipeline_ref.bin` holds the compiled code of
+ChronoEditPipeline.__call__ / prepare_latents / encode_prompt / encode_image / check_inputs, lifted verbatim from
+/root/reference/chronoedit_diffusers/pipeline_chronoedit.py and compiled by oracle/build_ref.py at build time (a marshalled code
+object: git-ignored, shipped to the GPU box like the built .so; no reference source text lives in this repository).  Here it RUNS - `self.transformer(hidden_states=..., timestep=..., encoder_hidden_states=...,
 encoder_hidden_states_image=..., attention_kwargs=..., return_dict=False)[0]`, `self.scheduler.step(noise_pred, t, latents,
 return_dict=False)[0]`, the in-place slicing of `scheduler.model_outputs` / `last_sample`, `self.vae.encode / decode`,
 `self.image_encoder(**image, output_hidden_states=True)` - over the chronoedit_amd drop-ins, and its frames are compared with
@@ -21,7 +21,7 @@ from oracle import vae_oracle as V
 
 pytestmark = pytest.mark.gpu
 
-REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "pipeline_ref.py")
+REF = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "pipeline_ref.bin")
 
 
 def rel_l2(a, b):
@@ -64,13 +64,14 @@ def _components():
     return m, vae, ie, mk_sched
 
 
-@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/pipeline_ref.py not built (needs /root/reference at build time)")
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/pipeline_ref.bin not built (needs /root/reference at build time)")
 @pytest.mark.parametrize("reasoning", [False, True])
 def test_reference_call_source_over_the_dropins_matches_the_engine_pipeline(reasoning):
     from PIL import Image
 
     from chronoedit_amd.pipeline import ChronoEditPipeline, WanPipelineOutput
-    from oracle._ref.pipeline_ref import RefChronoEditPipeline
+    from oracle import build_ref
+    RefChronoEditPipeline = build_ref.load().RefChronoEditPipeline
     m, vae, ie, mk_sched = _components()
     g = torch.Generator().manual_seed(3)
     H, W = 64, 96
