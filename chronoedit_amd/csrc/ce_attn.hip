@@ -422,6 +422,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
   }
+  auto scale_q = [&]() __attribute__((always_inline)) {
   // Q is scaled ONCE by softmax_scale * log2(e) (fp32 multiply, rounded back to bf16): S comes out of the matrix pipe in
   // the exp2 domain and, with the running max folded into the accumulator init below, P is a bare v_exp_f32 per element.
   // (Plain VALU ops beside MFMAs are not hidden on this chip - probe in tools/probes - and the fma per element was a
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));  // retire the Q loads before the loop (else hipcc keeps them pending into it)
 
+  };
   // staging shares and LDS bases: V^T rows of 144 B in (h, b) chunk order (above), K by LDS-DMA (below)
   const int v_dvq = (tid & 1) | (((tid >> 4) & 15) << 1), v_kvq = ((tid >> 1) & 7) | (((tid >> 8) & 1) << 3);
   const int v_chunk = (v_kvq & ~3) | ((v_kvq & 1) << 1) | ((v_kvq >> 1) & 1);
@@ -569,6 +571,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K(0) has landed (its DMA precedes the V(0) fetch just consumed)
       load_v(1);
     }
+    // the Q rows were requested before the first tile DMAs: waiting for them here (not before issuing the DMAs) overlaps the two
+    // latencies of an item's prologue (+0.3 ... 0.5 % in the A/B of profiles/r02_attention_vt_knobs_ab.txt)
+    if (sidx == 0) scale_q();
+
     // From here on the vector-memory queue of a wave holds, in order: K(t) DMA x2 (tile t-1, units 1 and 3), V(t+1) x4
     // (tile t-1, unit 12): "vmcnt(4)" in front of the barrier of tile t = K(t) is in LDS.
     // VT: the queue holds K(t) DMA x2 (units 1, 3 of tile t-1), V(t) DMA x2 (units 5, 7): "vmcnt(2)" = K(t) and V(t-1) are in LDS;
