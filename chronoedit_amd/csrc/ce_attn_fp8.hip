@@ -416,17 +416,21 @@ __device__ __forceinline__ void mfma_scale_acc_pinned(f32x16& acc, const i32x8& 
 constexpr int SMEM_SP = NSTAGE_SP * STAGE > 8 * QW * OST_ROW ? NSTAGE_SP * STAGE : 8 * QW * OST_ROW;
 constexpr float P_OFF = 3.0f;  // P = exp2(score - rowmax + 3) <= 8 when the offset is the row maximum: 5.8 octaves of headroom to 464
 
-__global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigned char* __restrict__ Q8, const unsigned char* __restrict__ SQ,
-                                                                  const unsigned char* __restrict__ K8, const unsigned char* __restrict__ SK,
-                                                                  const unsigned char* __restrict__ V8T, const unsigned char* __restrict__ SV,
-                                                                  bf16* __restrict__ O, int Nq, int Nkv, int npad, int H, int ldq8,
+__global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigned char* __restrict__ Q8_, const unsigned char* __restrict__ SQ_,
+                                                                  const unsigned char* __restrict__ K8_, const unsigned char* __restrict__ SK_,
+                                                                  const unsigned char* __restrict__ V8T_, const unsigned char* __restrict__ SV_,
+                                                                  bf16* __restrict__ O_, int Nq, int Nkv, int npad, int H, int ldq8,
                                                                   int ldk8, int ldo, int nqb, int batch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D32 = (H * HD) >> 5;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, hh = lane >> 5;
-  // Work order (batch folded into blockIdx.x, as in the bf16 kernel): every XCD takes its heads' FULL 256-row query blocks first,
+#pragma clang loop unroll(disable)
+  for (int item = blockIdx.x; item < nqb * H * batch; item += gridDim.x) {
+  const unsigned char *Q8 = Q8_, *SQ = SQ_, *K8 = K8_, *SK = SK_, *V8T = V8T_, *SV = SV_;
+  bf16* O = O_;
+  // Work order (batch folded into the item index, as in the bf16 kernel): every XCD takes its heads' FULL 256-row query blocks first,
   // sample by sample, and the remainder blocks (Nq % 256 rows: only their first waves have rows, the others merely stage) last -
   // they fill the partially occupied final round of workgroups instead of heading it.  Nq = 7200, H = 40, two samples: 2320
   // workgroups = 9.06 rounds of 256 CUs would cost ten.
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
   {
     const int nqb_full = Nq / (QW * 8);
     if ((H & 7) == 0) {
-      const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, hx_n = H >> 3;
+      const int xcd = item & 7, local = item >> 3, hx_n = H >> 3;
       const int full = batch * hx_n * nqb_full;
       if (local < full) {
         bz = local / (hx_n * nqb_full);
@@ -448,8 +452,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
         qb = nqb_full;
       }
     } else {
-      bz = blockIdx.x / (nqb * H);
-      const int r = blockIdx.x % (nqb * H);
+      bz = item / (nqb * H);
+      const int r = item % (nqb * H);
       head = r / nqb;
       qb = r % nqb;
     }
@@ -755,6 +759,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
     const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
     if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
   }
+  __syncthreads();
+  }  // item
 }
 
 }  // namespace
@@ -780,6 +786,12 @@ extern "C" int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv,
   return (int)hipGetLastError();
 }
 
+static int g_mxfp8_persist = 512;  // workgroups of the persistent form (0: one workgroup per work item); a multiple of 8
+extern "C" int ce_set_attention_mxfp8_persistent(int n) {
+  const int old = g_mxfp8_persist;
+  if (n >= 0 && (n & 7) == 0) g_mxfp8_persist = n;
+  return old;
+}
 static int g_mxfp8_variant = 1;  // 0: plain kernel (exact running maximum every tile), 1: software-pipelined (default)
 extern "C" int ce_set_attention_mxfp8_variant(int v) {
   const int old = g_mxfp8_variant;
@@ -804,7 +816,7 @@ extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8
                        (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t, (const unsigned char*)sv, (bf16*)O, Nq, Nkv,
                        npad, H, ldq8, ldk8, ldo, nqb);
   else
-    hipLaunchKernelGGL(attn_fwd_mxfp8_sp_kernel, dim3(H * nqb * batch), dim3(512), SMEM_SP, stream, (const unsigned char*)q8,
+    hipLaunchKernelGGL(attn_fwd_mxfp8_sp_kernel, dim3(g_mxfp8_persist > 0 && H * nqb * batch > g_mxfp8_persist ? g_mxfp8_persist : H * nqb * batch), dim3(512), SMEM_SP, stream, (const unsigned char*)q8,
                        (const unsigned char*)sq, (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t,
                        (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb, batch);
   return (int)hipGetLastError();

@@ -268,6 +268,11 @@ int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const voi
  * ignored.  Host-side tuning knob. */
 int ce_set_attention_mxfp8_variant(int variant);
 
+/* Workgroups of the persistent form of the software-pipelined MXFP8 kernel (returns the previous value): n > 0 (a multiple of 8) -
+ * n workgroups walk the work order with stride n (default 512 = 2 x #CUs: +2 % at 7 200 keys, +0.3 ... 0.5 % above); 0 - one
+ * workgroup per (head, query block, sample).  Host-side tuning knob. */
+int ce_set_attention_mxfp8_persistent(int n);
+
 /* ---- conditioning encoders (run once per edit, outside the loop: pipeline_chronoedit.py:205-254; the arithmetic is
  * transformers==4.57.1 CLIPVisionModel / UMT5EncoderModel, restated in oracle/clip_oracle.py, oracle/umt5_oracle.py) ---- */
 

@@ -27,6 +27,22 @@ def demangle(names):
     return {n: n for n in names}
 
 
+def loop_scratch_free(path, kernel_substr):
+    """True when no basic block of the kernel that sits in a loop (`Depth=`) and issues MFMAs touches scratch."""
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-S", "--cuda-device-only", path, "-o", asm],
+                       check=True, stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+    m = re.search(r"^([A-Za-z0-9_]*" + re.escape(kernel_substr) + r"[A-Za-z0-9_]*):", text, flags=re.M)
+    body = text[m.end():text.index(".Lfunc_end", m.end())]
+    parts = re.split(r"\n(\.LBB[0-9_]+:|; %bb\.[0-9]+:[^\n]*)", body)
+    for blk in parts[2::2]:
+        if "v_mfma" in blk and "Depth=2" in blk and "scratch_" in blk:
+            return False
+    return True
+
+
 def lint(path, min_insts):
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
