@@ -115,3 +115,14 @@ def test_vt_column_padding_helper():
     for n in (1, 63, 64, 65, 7200, 14400, 26136, 28800):
         c = ns["vt_columns"](n)
         assert c % 64 == 0 and c >= (n + 63) // 64 * 64 + 64 - 64 and c - n >= 64 and c % 8 == 0, (n, c)
+
+
+def test_blocked_layout_tile_to_block_magic_is_exact():
+    """ce_attention_vt_blocked_bf16 finds the source block of key tile t with one multiply-high: (t * ceil(2^32 / tps)) >> 32 must equal
+    t // tps for every tile index a sequence can have (tiles of 64 keys: 2^16 tiles = 4 M keys) and every block size in tiles."""
+    import numpy as np
+    t = np.arange(1 << 16, dtype=np.uint64)
+    for tps in list(range(2, 130)) + [225, 226, 450, 451, 900, 1024, 4095, 65535]:
+        magic = np.uint64(((1 << 32) + tps - 1) // tps)
+        assert magic < (1 << 32)
+        assert np.array_equal((t * magic) >> np.uint64(32), t // np.uint64(tps)), tps
