@@ -227,10 +227,13 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
                                  int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
 extern "C" void ce_gemm256_set_staggered(int on);
+extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                   const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                   int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream);
 
 // kernel selection: -1 = automatic (256-tile LDS-DMA kernel for large shapes), 0 = always the 128-tile kernel,
 // 1 = the 256-tile kernel whenever the shape allows it, 2 = same with the staggered (two wave groups one barrier apart)
-// main loop
+// main loop, 3 / 4 = the one-wave-per-SIMD main loop of ce_gemm256w4.hip (A ring of 3 / 2 stages) whenever the shape allows it
 static int g_gemm_variant = -1;
 extern "C" int ce_set_gemm_variant(int v) {
   const int old = g_gemm_variant;
@@ -260,6 +263,9 @@ extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const flo
   if (epilogue != EPI_F32 && epilogue != EPI_MUL) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant >= 1 || (g_gemm_variant == -1 && big);
+    if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw) && (g_gemm_variant == 3 || g_gemm_variant == 4))
+      return ce_gemm256w4_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
+                                 w_seg_k, w_seg_stride, g_gemm_variant == 3 ? 3 : 2, stream);
     if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw))
       return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
                                w_seg_k, w_seg_stride, stream);

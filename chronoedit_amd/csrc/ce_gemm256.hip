@@ -170,7 +170,7 @@ __device__ __forceinline__ void epilogue256(const f32x4 (&acc)[2][2][4][2], unsi
         }
       }
     __syncthreads();
-    epi_chunks<EPI, 8>(smem, CROW, [&](int tt, int& rl, int& cc) { const int c = tid + 512 * tt; rl = c >> 5; cc = c & 31; },
+    epi_chunks<EPI, 8>(smem, CROW, [&](int tt, int& rl, int& cc, int& mr) { const int c = tid + 512 * tt; rl = mr = c >> 5; cc = c & 31; },
                        m0 + i * 128, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
   }
 }
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void gemm256_reduce(bf16* __restrict__ C, cons
     }
   }
   __syncthreads();
-  epi_chunks<EPI, 4>(smem, QROW, [&](int tt, int& rl, int& cc) { const int c = tid + 512 * tt; rl = c >> 4; cc = c & 15; }, m0, n0, C,
+  epi_chunks<EPI, 4>(smem, QROW, [&](int tt, int& rl, int& cc, int& mr) { const int c = tid + 512 * tt; rl = mr = c >> 4; cc = c & 15; }, m0, n0, C,
                      gate, res, M, N, ldc, ldres, gate_rows);
 }
 
@@ -459,6 +459,12 @@ extern "C" int ce_set_gemm_workspace(void* ptr, size_t bytes) {
   if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
     g_cus = cus;
   return CE_OK;
+}
+
+extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus) {  // for the other main loop (ce_gemm256w4.hip)
+  *ws = g_ws;
+  *bytes = g_ws_bytes;
+  *cus = g_cus;
 }
 
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,

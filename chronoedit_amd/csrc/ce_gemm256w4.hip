@@ -1,0 +1,371 @@
+// 256x256x64 bf16 GEMM, ONE WAVE PER SIMD: 4 waves (2 x 2) x up to 512 registers, wave tile 128 x 128.
+// Same contract, epilogues, split-K tail and segmented operands as ce_gemm256.hip (`ce_set_gemm_variant(3 / 4)` selects it).
+//
+// Why a second main loop: the 8-wave kernel reads 192 KiB of LDS fragments per K-tile and CU (a 64x32 quadrant = 12
+// ds_read_b128 per 32 MFMAs and k-step) and runs four workgroup barriers per K-tile between waves that share SIMDs pairwise.
+// Here a wave owns a 128x128 quadrant - 16 fragment reads per 64 MFMAs and k-step, 128 KiB per K-tile and CU (-33 %) - its
+// 256 accumulator registers live in the AGPR half of the register file and the VGPR half holds THREE fragment sets, so that a
+// whole K-tile's fragments are fetched one unit ahead; two barriers per K-tile, no intra-SIMD arbitration at all.
+//
+//  * LDS: A ring of NSA (3 or 2) K-tile stages [256 rows][128 B] + W ring of 2 stages = 160 KiB (NSA = 3) or 128 KiB.
+//    Rows are 128 B (one K-tile of one row = one full cache line per LDS-DMA row piece), 16-byte chunk c of row r sits in
+//    slot c ^ ((r >> 1) & 7): applied to the per-lane SOURCE address of the lane-linear LDS-DMA image and to the read address.
+//  * Global -> LDS: buffer_load_dwordx4 ... lds (1 KiB per wave instruction): per-lane voffset (row, swizzled chunk; computed
+//    once), the K-tile offset in the scalar soffset - no vector address arithmetic in the loop.  8 pieces per unit and wave.
+//  * K-tile t = two units (k-steps) of 64 MFMAs:
+//        unit (t,0): s_barrier; MFMAs on set S0 [k-step 0]; between the 8-MFMA groups: the 8 W pieces of tile t+2 -> W stage t%2;
+//                    vmcnt(8 (NSA-1)): tile t+1 has landed
+//        unit (t,1): s_barrier; MFMAs on set S1|S2 [k-step 1]; between the groups: the 8 A pieces of tile t+NSA -> A stage t%NSA,
+//                    and the 32 fragment reads of tile t+1 (k-step 0 -> S0, k-step 1 -> the set the previous tile used);
+//                    lgkmcnt(0)
+//    Hazards: a stage is overwritten only after a barrier that every wave reaches with its reads of that stage complete
+//    (the lgkmcnt(0) closing unit (t-1,1) precedes the barrier opening (t,0)); a stage is read only after the barrier that follows
+//    every wave's counted vmcnt for it.  Every piece has >= 2 units (NSA = 3: A pieces >= 3) between issue and first use.
+#include <algorithm>
+
+#include "ce_common.h"
+#include "ce_gemm_epi.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE = 256 * BK * 2;  // one operand K-tile, 32 KiB
+constexpr int CROW = BN * 2 + 16;   // padded epilogue staging row (528 B)
+constexpr int QROW = 128 * 2 + 16;  // padded staging row of a quadrant (split-K reduce)
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+#define W4_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define W4_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define W4_BAR() __builtin_amdgcn_s_barrier()
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ void tile_origin_w4(int wg, int tiles_m, int tiles_n, int& m0, int& n0) {
+  constexpr int GROUP = 4;  // same raster as ce_gemm256.hip (the split-K reduce of either kernel must agree with its producer)
+  const int group_sz = GROUP * tiles_n;
+  const int gid = wg / group_sz;
+  const int first_m = gid * GROUP;
+  const int gm = min(tiles_m - first_m, GROUP);
+  m0 = (first_m + (wg % group_sz) % gm) * BM;
+  n0 = ((wg % group_sz) / gm) * BN;
+}
+
+struct FragSet {
+  bf16x8 a[8], b[8];  // one k-step (32 deep) of a 128 x 128 wave tile: 8 row fragments, 8 column fragments (64 VGPRs)
+};
+
+// One MFMA of row fragment F against column fragment G.  The W fragment is the first operand, so the accumulator holds C^T:
+// lane (fr, fg) of acc[F][G] owns row F*16 + fr and the four consecutive columns G*16 + fg*4 + [0,4).
+// asm: D tied to C in the accumulator file ("+a").  As a builtin hipcc picks the untied form and, with all 256 AGPRs holding
+// accumulators, shuffles every result back through VGPRs (hundreds of v_accvgpr_* per K-tile).  Hazards: the operands come from
+// ds_reads the compiler waits for; consecutive MFMAs never share an accumulator; the first reader of the accumulators after the
+// loop sits behind explicit wait states.
+#define W4_MMA(F, G, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((S).b[G]), "v"((S).a[F]))
+
+template <int EPI, int NSA>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4(
+    const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ bias,
+    const float* __restrict__ gate, const bf16* __restrict__ res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+    int gate_rows, int tiles_m, int tiles_n, int t_full, int split, float* __restrict__ ws, uint32_t a_seg_magic,
+    uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int W_RING = NSA * TILE;
+  constexpr int VMW = 8 * (NSA - 1);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  const bool partial = (int)blockIdx.x >= t_full;
+  int wg, kt0 = 0, ktn = K / BK;
+  if (!partial) {
+    wg = xcd_remap(blockIdx.x, t_full);
+  } else {
+    const int tb = blockIdx.x - t_full;
+    wg = t_full + tb / split;
+    ktn = ktn / split;
+    kt0 = (tb % split) * ktn;
+  }
+  int m0, n0;
+  tile_origin_w4(wg, tiles_m, tiles_n, m0, n0);
+  const int kt_last = ktn - 1;
+
+  // LDS-DMA sources: piece p of this wave = rows 8 (wave + 4 p) .. + 8 of the operand tile, lane l -> row + (l >> 3), slot l & 7
+  uint32_t a_voff[8], w_voff[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = 8 * (wave + 4 * p) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    a_voff[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)(lda * 2) + chunk * 16;
+    w_voff[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)(ldw * 2) + chunk * 16;
+  }
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xffffffffu, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xffffffffu, 0x00020000);
+  // byte offset of K-tile t of an operand (clamped: surplus prefetches re-read the last tile; segmented operands: see ce_gemm256.hip)
+  auto koff = [&](int t, uint32_t magic, uint32_t extra) __attribute__((always_inline)) -> int {
+    const int ta = kt0 + min(t, kt_last);
+    return ta * (BK * 2) + (int)((((uint32_t)ta * magic) >> 16) * extra);
+  };
+  auto dma_a = [&](int p, int stage_bytes, int soff) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + stage_bytes + (wave + 4 * p) * 1024), 16, a_voff[p], soff, 0, 0);
+  };
+  auto dma_w = [&](int p, int stage_bytes, int soff) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + W_RING + stage_bytes + (wave + 4 * p) * 1024), 16, w_voff[p], soff, 0, 0);
+  };
+
+  // fragment read addresses: row (wm|wn)*128 + f*16 + fr, chunk (fg + 4 ks) ^ ((row >> 1) & 7) = (fg + 4 ks) ^ (fr >> 1);  + stage + f*2048
+  int a_rd[2], w_rd[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    a_rd[ks] = (wm * 128 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
+    w_rd[ks] = W_RING + (wn * 128 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
+  }
+  // read number r (0..31) of a tile: k-step r >> 4, operand (r >> 3) & 1 (A, then W), fragment r & 7
+  auto read_frag = [&](int r, int a_stage_bytes, int w_stage_bytes, FragSet& k0, FragSet& k1) __attribute__((always_inline)) {
+    FragSet& s = (r >> 4) ? k1 : k0;
+    const int ks = r >> 4, f = r & 7;
+    if (((r >> 3) & 1) == 0)
+      s.a[f] = *reinterpret_cast<const bf16x8*>(smem + a_rd[ks] + a_stage_bytes + f * 2048);
+    else
+      s.b[f] = *reinterpret_cast<const bf16x8*>(smem + w_rd[ks] + w_stage_bytes + f * 2048);
+  };
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: tiles 0, 1 (and A of tile 2)
+  {
+    const int a0 = koff(0, a_seg_magic, a_seg_extra), w0 = koff(0, w_seg_magic, w_seg_extra);
+    const int a1 = koff(1, a_seg_magic, a_seg_extra), w1 = koff(1, w_seg_magic, w_seg_extra);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma_a(p, 0, a0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma_w(p, 0, w0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma_a(p, TILE, a1);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) dma_w(p, TILE, w1);
+    if (NSA == 3) {
+      const int a2 = koff(2, a_seg_magic, a_seg_extra);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) dma_a(p, 2 * TILE, a2);
+    }
+  }
+  if (NSA == 3) W4_VM(24); else W4_VM(16);  // tile 0 has landed
+  W4_BAR();
+  FragSet s0, s1, s2;
+#pragma unroll
+  for (int r = 0; r < 32; ++r) read_frag(r, 0, 0, s0, s1);
+  W4_LGKM0();
+  W4_PIN();
+
+  int a_st = 0;  // A ring stage (bytes) of the tile being multiplied; the stage of tile t + 1 is the next one, tile t + NSA lands in a_st
+  // one K-tile: k-step 0 on K0, k-step 1 on K1; the next tile's fragments go to K0 (k-step 0) and KN (k-step 1)
+#define W4_TILE(T, WP, K0, K1, KN)                                                                              \
+  {                                                                                                             \
+    const int a_next = (a_st + TILE == NSA * TILE) ? 0 : a_st + TILE;                                          \
+    const int wsoff = koff((T) + 2, w_seg_magic, w_seg_extra);                                                 \
+    const int asoff = koff((T) + NSA, a_seg_magic, a_seg_extra);                                               \
+    W4_BAR();                                                                                                   \
+    W4_UNIT0(0, K0, WP, wsoff) W4_UNIT0(1, K0, WP, wsoff) W4_UNIT0(2, K0, WP, wsoff) W4_UNIT0(3, K0, WP, wsoff) \
+    W4_UNIT0(4, K0, WP, wsoff) W4_UNIT0(5, K0, WP, wsoff) W4_UNIT0(6, K0, WP, wsoff) W4_UNIT0(7, K0, WP, wsoff) \
+    if (NSA == 3) W4_VM(16); else W4_VM(8);                                                                     \
+    W4_BAR();                                                                                                   \
+    W4_UNIT1(0, K1, K0, KN, WP) W4_UNIT1(1, K1, K0, KN, WP) W4_UNIT1(2, K1, K0, KN, WP) W4_UNIT1(3, K1, K0, KN, WP) \
+    W4_UNIT1(4, K1, K0, KN, WP) W4_UNIT1(5, K1, K0, KN, WP) W4_UNIT1(6, K1, K0, KN, WP) W4_UNIT1(7, K1, K0, KN, WP) \
+    W4_LGKM0();                                                                                                 \
+    W4_PIN();                                                                                                   \
+    a_st = a_next;                                                                                              \
+  }
+  // one wave per SIMD: nothing else covers an issue slot, so the fillers go BETWEEN single MFMAs (16 cycles of matrix pipe
+  // each = the MFMA's own issue + about three more slots), never bunched behind a group
+#define W4_UNIT0(F, K0, WP, WSOFF)                                                                                 \
+  W4_MMA(F, 0, K0); dma_w(F, (WP) * TILE, WSOFF); W4_PIN();                                                        \
+  W4_MMA(F, 1, K0); W4_MMA(F, 2, K0); W4_MMA(F, 3, K0); W4_MMA(F, 4, K0); W4_MMA(F, 5, K0); W4_MMA(F, 6, K0);      \
+  W4_MMA(F, 7, K0); W4_PIN();
+#define W4_UNIT1(F, K1, K0, KN, WP)                                                                                \
+  W4_MMA(F, 0, K1); dma_a(F, a_st, asoff); W4_PIN();                                                               \
+  W4_MMA(F, 1, K1); W4_PIN();                                                                                      \
+  W4_MMA(F, 2, K1); read_frag(4 * (F) + 0, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 3, K1); read_frag(4 * (F) + 1, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 4, K1); read_frag(4 * (F) + 2, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 5, K1); read_frag(4 * (F) + 3, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 6, K1); W4_MMA(F, 7, K1); W4_PIN();
+
+  const int npairs = ktn >> 1;
+  for (int it = 0; it < npairs; ++it) {
+    const int t = 2 * it;
+    W4_TILE(t, 0, s0, s1, s2)
+    W4_TILE(t + 1, 1, s0, s2, s1)
+  }
+#undef W4_TILE
+#undef W4_UNIT0
+#undef W4_UNIT1
+  W4_VM(0);  // surplus prefetches must retire before the epilogue reuses the LDS
+  W4_LGKM0();
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results -> v_accvgpr_read (hipcc does not see the asm MFMAs)
+  W4_BAR();
+
+  if (partial) {  // split-K tail piece: fp32 slab [wave][f][g][lane] for gemm256w4_reduce
+    float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        *reinterpret_cast<f32x4*>(slab + (((wave * 64 + f * 8 + g) * 64) + lane) * 4) = acc[f][g];
+    return;
+  }
+
+  // ---- epilogue: four passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave = tile rows
+  // wm*128 + p*32 + [0,32)), so that bias / GELU / gated-residual math and the global stores run on 16-B row-contiguous chunks
+  f32x4 bcol[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int n = n0 + wn * 128 + g * 16 + fg * 4;
+    bcol[g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (p > 0) __syncthreads();
+#pragma unroll
+    for (int ff = 0; ff < 2; ++ff) {
+      const int f = 2 * p + ff;
+      float brow = 0.f;
+      if (EPI == EPI_BIAS_ROW) brow = bias[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
+      const int rl = wm * 32 + ff * 16 + fr;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int cl = wn * 128 + g * 16 + fg * 4;
+        f32x4 bv = bcol[g];
+        if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow;
+        const f32x4 v = acc[f][g];
+        const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
+        *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
+      }
+    }
+    __syncthreads();
+    epi_chunks<EPI, 8>(smem, CROW,
+                       [&](int tt, int& rl, int& cc, int& mr) {
+                         const int c = tid + 256 * tt;
+                         rl = c >> 5;
+                         cc = c & 31;
+                         mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
+                       },
+                       m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+  }
+}
+
+// Sums the `split` fp32 slabs of one quadrant (= one wave's 128 x 128 accumulators) of a tail tile and applies the epilogue.
+// grid = 4 x the number of tail tiles, 256 threads: thread (w, lane) takes accumulator rows f = 2w, 2w+1 of the quadrant.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256w4_reduce(bf16* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ gate,
+                                                        const bf16* __restrict__ res, int M, int N, int ldc, int ldres, int gate_rows,
+                                                        int tiles_m, int tiles_n, int t_full, int split, const float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;  // q = producer wave = (wm, wn)
+  int m0, n0;
+  tile_origin_w4(t_full + tile, tiles_m, tiles_n, m0, n0);
+  m0 += (q >> 1) * 128;
+  n0 += (q & 1) * 128;
+  const float* slab = ws + (size_t)tile * split * (BM * BN);
+#pragma unroll
+  for (int ff = 0; ff < 2; ++ff) {
+    const int f = 2 * w + ff;
+    const int rl = f * 16 + fr;
+    float brow = 0.f;
+    if (EPI == EPI_BIAS_ROW) brow = bias[min(m0 + rl, M - 1)];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int cl = g * 16 + fg * 4;
+      f32x4 bv = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n0 + cl, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow;
+      const int e = (((q * 64 + f * 8 + g) * 64) + lane) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
+      for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
+      const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
+      *reinterpret_cast<u32x2*>(smem + rl * QROW + cl * 2) = pk;
+    }
+  }
+  __syncthreads();
+  epi_chunks<EPI, 8>(smem, QROW, [&](int tt, int& rl, int& cc, int& mr) { const int c = tid + 256 * tt; rl = mr = c >> 4; cc = c & 15; }, m0, n0,
+                     C, gate, res, M, N, ldc, ldres, gate_rows);
+}
+
+}  // namespace
+
+extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+
+// nsa: 3 = A ring of three K-tile stages (160 KiB of LDS), 2 = two (128 KiB)
+extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                   const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                   int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n, kt = K / BK;
+  uint32_t a_seg_magic = 0, a_seg_extra = 0, w_seg_magic = 0, w_seg_extra = 0;
+  auto seg = [&](int seg_k, long long seg_stride, uint32_t& magic, uint32_t& extra_out) -> int {
+    if (seg_k <= 0 || seg_k >= K) return CE_OK;
+    if (seg_k % BK) return CE_ERR_SHAPE;
+    const int tps = seg_k / BK;
+    magic = 65536u / (uint32_t)tps + 1u;
+    for (int t = 0; t < kt; ++t)
+      if ((int)(((uint32_t)t * magic) >> 16) != t / tps) return CE_ERR_SHAPE;
+    const long long extra = (seg_stride - seg_k) * 2;
+    if (extra < 0 || extra * (K / seg_k) + (long long)K * 2 >= (1ll << 31)) return CE_ERR_SHAPE;  // the K-tile offset is a signed scalar
+    extra_out = (uint32_t)extra;
+    return CE_OK;
+  };
+  if (int rc = seg(a_seg_k, a_seg_stride, a_seg_magic, a_seg_extra)) return rc;
+  if (int rc = seg(w_seg_k, w_seg_stride, w_seg_magic, w_seg_extra)) return rc;
+  float* g_ws = nullptr;
+  size_t g_ws_bytes = 0;
+  int g_cus = 256;
+  ce_gemm256_workspace(&g_ws, &g_ws_bytes, &g_cus);
+  int tail = nwg % g_cus, split = 1;
+  if (tail > 0 && g_ws != nullptr) {
+    for (int s = std::min(g_cus / tail, 8); s >= 2; --s)
+      if (kt % (2 * s) == 0 && (size_t)tail * s * BM * BN * sizeof(float) <= g_ws_bytes) {
+        split = s;
+        break;
+      }
+  }
+  if (split == 1) tail = 0;
+  const int t_full2 = nwg - tail;
+  dim3 grid(t_full2 + tail * split), block(256);
+  const int lds3 = 5 * TILE, lds2 = 4 * TILE;
+  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
+#define CE_LAUNCH(E)                                                                                                       \
+  do {                                                                                                                     \
+    if (!attr_done[E]) {                                                                                                   \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3) != hipSuccess) return CE_ERR_ARG; \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess) return CE_ERR_ARG; \
+      (void)hipFuncSetAttribute((const void*)gemm256w4_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * QROW); \
+      attr_done[E] = true;                                                                                                 \
+    }                                                                                                                      \
+    if (nsa == 3)                                                                                                          \
+      hipLaunchKernelGGL((gemm_bf16_w4<E, 3>), grid, block, lds3, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+                         (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
+                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((gemm_bf16_w4<E, 2>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+                         (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
+                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
+    if (tail)                                                                                                              \
+      hipLaunchKernelGGL((gemm256w4_reduce<E>), dim3(4 * tail), block, 128 * QROW, stream, (bf16*)C, bias, gate,           \
+                         (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);           \
+  } while (0)
+  switch (epilogue) {
+    case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;
+    case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;
+    case EPI_GATE_RES: CE_LAUNCH(EPI_GATE_RES); break;
+    case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
+    case EPI_BIAS_ROW: CE_LAUNCH(EPI_BIAS_ROW); break;
+    default: return CE_ERR_ARG;
+  }
+#undef CE_LAUNCH
+  return (int)hipGetLastError();
+}

@@ -28,9 +28,9 @@ __device__ __forceinline__ void epi_chunks_impl(const unsigned char* smem, int r
   int ms[NCH], ns[NCH];
 #pragma unroll
   for (int t = 0; t < NCH; ++t) {
-    int rl, cc;
-    rowcol(t, rl, cc);
-    ms[t] = m0 + rl;
+    int rl, cc, mr;
+    rowcol(t, rl, cc, mr);  // staging row, 16-byte chunk, row inside the tile (== rl when a pass stages consecutive tile rows)
+    ms[t] = m0 + mr;
     ns[t] = n0 + cc * 8;
     v[t] = *reinterpret_cast<const u32x4*>(smem + rl * row_bytes + cc * 16);
     if (EPI == EPI_GATE_RES) {

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm_fp8_256(const unsigned char* __restr
         }
       }
     __syncthreads();
-    epi_chunks<EPI, 8>(smem, CROW, [&](int tt, int& rl, int& cc) { const int c = tid + 512 * tt; rl = c >> 5; cc = c & 31; },
+    epi_chunks<EPI, 8>(smem, CROW, [&](int tt, int& rl, int& cc, int& mr) { const int c = tid + 512 * tt; rl = mr = c >> 5; cc = c & 31; },
                        m0 + i * 128, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
   }
 }

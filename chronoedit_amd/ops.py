@@ -23,6 +23,10 @@ def lib():
     global _lib
     if _lib is None:
         _lib = hiplib.load()
+        import os
+        v = os.environ.get("CE_GEMM_VARIANT")  # A/B knob for whole-step runs (bench.py under another main loop): see ce_set_gemm_variant
+        if v is not None:
+            _lib.ce_set_gemm_variant(int(v))
     return _lib
 
 

@@ -79,7 +79,8 @@ int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, i
                      int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
 /* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default), 0 force the 128x128
- * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows.  Host-side test/bench knob. */
+ * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows, 2 the same with the staggered main
+ * loop, 3 / 4 its one-wave-per-SIMD main loop (csrc/ce_gemm256w4.hip; A ring of 3 / 2 stages).  Host-side test/bench knob. */
 int ce_set_gemm_variant(int variant);
 
 /* Scratch for the split-K tail of ce_gemm_bf16's 256-tile kernel: the tiles that would run as a partially filled last

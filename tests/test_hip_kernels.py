@@ -80,7 +80,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["tile128", "tile256", "tile256stag"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["tile128", "tile256", "tile256stag", "tile256w4", "tile256w4_2stage"])
 def gemm_variant(request):
     from chronoedit_amd import ops
     old = ops.set_gemm_variant(request.param)
@@ -151,9 +151,10 @@ def test_gemm_epilogues(gemm_variant):
     assert rel_l2(x, ref) < 5e-3
 
 
+@pytest.mark.parametrize("variant", [1, 3], ids=["tile256", "tile256w4"])
 @pytest.mark.parametrize("M,N,K,epi", [(4352, 4096, 1024, "bias"), (7200, 5120, 5120, "gate"), (1538, 10240, 5120, "gelu"),
                                        (600, 512, 1024, "bias")])
-def test_gemm_split_k_tail(M, N, K, epi):
+def test_gemm_split_k_tail(M, N, K, epi, variant):
     """Tail tiles of the 256-tile kernel are cut along K (fp32 slabs + reduce launch); same result as running whole."""
     from chronoedit_amd import ops
     dev = _dev()
@@ -165,7 +166,7 @@ def test_gemm_split_k_tail(M, N, K, epi):
     gate = torch.randn(N, generator=g).to(dev)
     kw = {"bias": dict(), "gelu": dict(epilogue=ops.EPI_BIAS_GELU),
           "gate": dict(epilogue=ops.EPI_GATE_RES, gate=gate, res=res)}[epi]
-    old_v = ops.set_gemm_variant(1)
+    old_v = ops.set_gemm_variant(variant)
     try:
         old_s = ops.set_gemm_split(False)
         whole = ops.gemm(a, w, bias, **kw)
