@@ -37,6 +37,15 @@ __device__ __forceinline__ float round_bf16(float x) {
   return (float)b;
 }
 
+// r + y * g with BOTH fp32 roundings (x.float() + y * gate of transformer_chronoedit.py:281,293 is a multiply and an add in eager
+// torch).  hipcc compiles HIP with -ffp-contract=fast and __fmul_rn / __fadd_rn are plain `*` / `+` in its headers: without the
+// pragma the pair becomes one v_pk_fma_f32 (a single rounding).
+__device__ __forceinline__ float mul_then_add(float y, float g, float r) {
+#pragma clang fp contract(off)
+  const float t = y * g;
+  return r + t;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

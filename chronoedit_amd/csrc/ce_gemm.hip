@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_128(const bf16* __restrict__ A,
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          v[q] = pack_bf16(bf16lo(rv[q]) + bf16lo(v[q]) * g[2 * q], bf16hi(rv[q]) + bf16hi(v[q]) * g[2 * q + 1]);
+          v[q] = pack_bf16(mul_then_add(bf16lo(v[q]), g[2 * q], bf16lo(rv[q])), mul_then_add(bf16hi(v[q]), g[2 * q + 1], bf16hi(rv[q])));
       }
       *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + n) = v;
     }
@@ -231,9 +231,9 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
                                    const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                    int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream);
 
-// kernel selection: -1 = automatic (256-tile LDS-DMA kernel for large shapes), 0 = always the 128-tile kernel,
-// 1 = the 256-tile kernel whenever the shape allows it, 2 = same with the staggered (two wave groups one barrier apart)
-// main loop, 3 / 4 = the one-wave-per-SIMD main loop of ce_gemm256w4.hip (A ring of 3 / 2 stages) whenever the shape allows it
+// kernel selection: -1 = automatic (256-tile LDS-DMA kernel, one-wave-per-SIMD main loop, for large shapes), 0 = always the
+// 128-tile kernel; whenever the shape allows the 256-tile kernel: 1 = its 8-wave / 8-phase main loop, 2 = the same staggered (two
+// wave groups one barrier apart), 3 / 4 = the one-wave-per-SIMD main loop of ce_gemm256w4.hip with an A ring of 3 / 2 stages, 5 = 3 stages and one barrier per K-tile
 static int g_gemm_variant = -1;
 extern "C" int ce_set_gemm_variant(int v) {
   const int old = g_gemm_variant;
@@ -263,12 +263,15 @@ extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const flo
   if (epilogue != EPI_F32 && epilogue != EPI_MUL) {
     const bool big = (long long)M * N >= 256ll * 256 * 128;  // enough 256x256 tiles to fill half the chip
     const bool want = g_gemm_variant >= 1 || (g_gemm_variant == -1 && big);
-    if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw) && (g_gemm_variant == 3 || g_gemm_variant == 4))
+    if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw)) {
+      // the 256-tile kernel has two main loops: one wave per SIMD (ce_gemm256w4.hip; the default: +3...5 % on the step's shapes,
+      // profiles/r03_gemm_variants_ab.txt) and the 8-wave / 8-phase loop of ce_gemm256.hip (variants 1, 2)
+      if (g_gemm_variant == 1 || g_gemm_variant == 2)
+        return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
+                                 w_seg_k, w_seg_stride, stream);
       return ce_gemm256w4_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
-                                 w_seg_k, w_seg_stride, g_gemm_variant == 3 ? 3 : 2, stream);
-    if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw))
-      return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
-                               w_seg_k, w_seg_stride, stream);
+                                 w_seg_k, w_seg_stride, g_gemm_variant == 3 ? 3 : g_gemm_variant == 5 ? 1 : 2, stream);
+    }
   }
   if (w_seg_k) return CE_ERR_SHAPE;
   const int a_seg_tiles = a_seg_k > 0 ? a_seg_k / BK : 0;

@@ -62,7 +62,7 @@ struct FragSet {
 // loop sits behind explicit wait states.
 #define W4_MMA(F, G, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((S).b[G]), "v"((S).a[F]))
 
-template <int EPI, int NSA>
+template <int EPI, int NSA, bool ONEBAR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4(
     const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ bias,
     const float* __restrict__ gate, const bf16* __restrict__ res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
@@ -148,13 +148,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int p = 0; p < 8; ++p) dma_a(p, TILE, a1);
 #pragma unroll
     for (int p = 0; p < 8; ++p) dma_w(p, TILE, w1);
-    if (NSA == 3) {
+    if (NSA == 3 && !ONEBAR) {
       const int a2 = koff(2, a_seg_magic, a_seg_extra);
 #pragma unroll
       for (int p = 0; p < 8; ++p) dma_a(p, 2 * TILE, a2);
     }
   }
-  if (NSA == 3) W4_VM(24); else W4_VM(16);  // tile 0 has landed
+  if (NSA == 3 && !ONEBAR) W4_VM(24); else W4_VM(16);  // tile 0 has landed
   W4_BAR();
   FragSet s0, s1, s2;
 #pragma unroll
@@ -167,12 +167,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define W4_TILE(T, WP, K0, K1, KN)                                                                              \
   {                                                                                                             \
     const int a_next = (a_st + TILE == NSA * TILE) ? 0 : a_st + TILE;                                          \
+    const int a_nn = (a_next + TILE == NSA * TILE) ? 0 : a_next + TILE;                                        \
     const int wsoff = koff((T) + 2, w_seg_magic, w_seg_extra);                                                 \
-    const int asoff = koff((T) + NSA, a_seg_magic, a_seg_extra);                                               \
-    W4_BAR();                                                                                                   \
+    const int asoff = koff((T) + (ONEBAR ? 2 : NSA), a_seg_magic, a_seg_extra);                                \
+    const int a_dst = ONEBAR ? a_nn : a_st;                                                                     \
+    if (!ONEBAR) W4_BAR();                                                                                      \
     W4_UNIT0(0, K0, WP, wsoff) W4_UNIT0(1, K0, WP, wsoff) W4_UNIT0(2, K0, WP, wsoff) W4_UNIT0(3, K0, WP, wsoff) \
     W4_UNIT0(4, K0, WP, wsoff) W4_UNIT0(5, K0, WP, wsoff) W4_UNIT0(6, K0, WP, wsoff) W4_UNIT0(7, K0, WP, wsoff) \
-    if (NSA == 3) W4_VM(16); else W4_VM(8);                                                                     \
+    if (NSA == 3 && !ONEBAR) W4_VM(16); else W4_VM(8);                                                          \
     W4_BAR();                                                                                                   \
     W4_UNIT1(0, K1, K0, KN, WP) W4_UNIT1(1, K1, K0, KN, WP) W4_UNIT1(2, K1, K0, KN, WP) W4_UNIT1(3, K1, K0, KN, WP) \
     W4_UNIT1(4, K1, K0, KN, WP) W4_UNIT1(5, K1, K0, KN, WP) W4_UNIT1(6, K1, K0, KN, WP) W4_UNIT1(7, K1, K0, KN, WP) \
@@ -183,11 +185,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // one wave per SIMD: nothing else covers an issue slot, so the fillers go BETWEEN single MFMAs (16 cycles of matrix pipe
   // each = the MFMA's own issue + about three more slots), never bunched behind a group
 #define W4_UNIT0(F, K0, WP, WSOFF)                                                                                 \
-  W4_MMA(F, 0, K0); dma_w(F, (WP) * TILE, WSOFF); W4_PIN();                                                        \
+  W4_MMA(F, 0, K0);                                                                                                \
+  if (ONEBAR) dma_a(F, a_dst, asoff); else dma_w(F, (WP) * TILE, WSOFF);                                           \
+  W4_PIN();                                                                                                        \
   W4_MMA(F, 1, K0); W4_MMA(F, 2, K0); W4_MMA(F, 3, K0); W4_MMA(F, 4, K0); W4_MMA(F, 5, K0); W4_MMA(F, 6, K0);      \
   W4_MMA(F, 7, K0); W4_PIN();
 #define W4_UNIT1(F, K1, K0, KN, WP)                                                                                \
-  W4_MMA(F, 0, K1); dma_a(F, a_st, asoff); W4_PIN();                                                               \
+  W4_MMA(F, 0, K1);                                                                                                \
+  if (ONEBAR) dma_w(F, (WP) * TILE, wsoff); else dma_a(F, a_dst, asoff);                                           \
+  W4_PIN();                                                                                                        \
   W4_MMA(F, 1, K1); W4_PIN();                                                                                      \
   W4_MMA(F, 2, K1); read_frag(4 * (F) + 0, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
   W4_MMA(F, 3, K1); read_frag(4 * (F) + 1, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
@@ -227,6 +233,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int n = n0 + wn * 128 + g * 16 + fg * 4;
     bcol[g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // Gated residual: ALL of this thread's residual chunks (4 passes x 8 chunks x 16 B = 128 VGPRs - the fragment registers are
+  // free now) and its gate values are requested HERE, before the first staging pass, so the four passes below run without a
+  // memory round trip each (as per-pass loads the epilogue of a K = 5120 tile cost ~12 us of its ~120 us: four serial HBM
+  // latencies).  The thread that reads a chunk is the thread that stores it (res may alias C).  The gate of a thread is one
+  // column chunk of at most two samples' rows when gate_rows >= the tile height (the engine: tokens per sample); other callers
+  // (gate_rows < 256) take the per-pass path of ce_gemm_epi.h.
+  constexpr bool prefetch = EPI == EPI_GATE_RES;  // (the launcher sends 0 < gate_rows < 256 to the 8-wave kernel)
+  u32x4 rv[4][8];
+  f32x4 gA0, gA1, gB0, gB1;
+  int g_switch = 0x7fffffff;  // first global row that takes the second sample's gate
+  const int my_n = n0 + (tid & 31) * 8, my_nc = min(my_n, N - 8);
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
+  if (EPI == EPI_GATE_RES && prefetch) {
+    gA0 = gA1 = gB0 = gB1 = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (gate != nullptr) {  // first: in-order returns, and the first chunk needs them
+      const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
+      const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
+      const float* ga = gate + (size_t)s0 * N + my_nc;
+      const float* gb = gate + (size_t)s1 * N + my_nc;
+      gA0 = *reinterpret_cast<const f32x4*>(ga);
+      gA1 = *reinterpret_cast<const f32x4*>(ga + 4);
+      gB0 = *reinterpret_cast<const f32x4*>(gb);
+      gB1 = *reinterpret_cast<const f32x4*>(gb + 4);
+      if (s1 != s0) g_switch = s1 * gate_rows;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int rl = (tid + 256 * tt) >> 5;
+        const int m = min(m0 + (rl >> 5) * 128 + p * 32 + (rl & 31), M - 1);
+        rv[p][tt] = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + my_nc);
+      }
+  }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     if (p > 0) __syncthreads();
@@ -247,14 +287,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     __syncthreads();
-    epi_chunks<EPI, 8>(smem, CROW,
-                       [&](int tt, int& rl, int& cc, int& mr) {
-                         const int c = tid + 256 * tt;
-                         rl = c >> 5;
-                         cc = c & 31;
-                         mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
-                       },
-                       m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+    if (EPI == EPI_GATE_RES && prefetch) {
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int rl = (tid + 256 * tt) >> 5;
+        const int m = m0 + (rl >> 5) * 128 + p * 32 + (rl & 31);
+        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + (tid & 31) * 16);
+        const bool second = m >= g_switch;
+        const f32x4 g0 = second ? gB0 : gA0, g1 = second ? gB1 : gA1;
+        const u32x4 r = rv[p][tt];
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
+          // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
+          o[q] = pack_bf16(mul_then_add(bf16lo(y[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(y[q]), gb, bf16hi(r[q])));
+        }
+        // predicated by the buffer's range check, not by a branch: hipcc sinks a chunk's residual load into a branch that holds its
+        // only use (one exposed memory round trip per pass again)
+        const uint32_t coff = (m < M && my_n < N) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)my_n * 2u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
+      }
+    } else if (EPI != EPI_GATE_RES) {
+      epi_chunks<EPI, 8>(smem, CROW,
+                         [&](int tt, int& rl, int& cc, int& mr) {
+                           const int c = tid + 256 * tt;
+                           rl = c >> 5;
+                           cc = c & 31;
+                           mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
+                         },
+                         m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+    }
   }
 }
 
@@ -300,10 +363,19 @@ __global__ __launch_bounds__(256) void gemm256w4_reduce(bf16* __restrict__ C, co
 
 extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
 
-// nsa: 3 = A ring of three K-tile stages (160 KiB of LDS), 2 = two (128 KiB)
+// nsa: 3 = A ring of three K-tile stages (160 KiB of LDS), 2 = two (128 KiB), 1 = three stages and ONE barrier per K-tile
+extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
+
 extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                    const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                    int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream) {
+  // the prefetched gated-residual epilogue holds ONE or TWO samples' gate rows per tile: gate rows shorter than a tile -> 8-wave kernel
+  // ... and stores through a 32-bit-offset buffer descriptor
+  if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32)))
+    return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
+                             w_seg_stride, stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n, kt = K / BK;
   uint32_t a_seg_magic = 0, a_seg_extra = 0, w_seg_magic = 0, w_seg_extra = 0;
@@ -341,17 +413,22 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
 #define CE_LAUNCH(E)                                                                                                       \
   do {                                                                                                                     \
     if (!attr_done[E]) {                                                                                                   \
-      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<E, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3) != hipSuccess) return CE_ERR_ARG; \
-      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess) return CE_ERR_ARG; \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<E, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3) != hipSuccess) return CE_ERR_ARG; \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<E, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3) != hipSuccess) return CE_ERR_ARG; \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<E, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess) return CE_ERR_ARG; \
       (void)hipFuncSetAttribute((const void*)gemm256w4_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * QROW); \
       attr_done[E] = true;                                                                                                 \
     }                                                                                                                      \
-    if (nsa == 3)                                                                                                          \
-      hipLaunchKernelGGL((gemm_bf16_w4<E, 3>), grid, block, lds3, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+    if (nsa == 1)                                                                                                          \
+      hipLaunchKernelGGL((gemm_bf16_w4<E, 3, true>), grid, block, lds3, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+                         (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
+                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
+    else if (nsa == 3)                                                                                                     \
+      hipLaunchKernelGGL((gemm_bf16_w4<E, 3, false>), grid, block, lds3, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
                          (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
                          a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
     else                                                                                                                   \
-      hipLaunchKernelGGL((gemm_bf16_w4<E, 2>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+      hipLaunchKernelGGL((gemm_bf16_w4<E, 2, false>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
                          (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
                          a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
     if (tail)                                                                                                              \

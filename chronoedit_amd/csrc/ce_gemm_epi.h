@@ -58,7 +58,7 @@ __device__ __forceinline__ void epi_chunks_impl(const unsigned char* smem, int r
         const float ga = !HAS_GATE ? 1.0f : q < 2 ? g0[t][2 * q] : g1[t][2 * q - 4];
         const float gb = !HAS_GATE ? 1.0f : q < 2 ? g0[t][2 * q + 1] : g1[t][2 * q - 3];
         // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
-        o[q] = pack_bf16(__fadd_rn(bf16lo(rv[t][q]), __fmul_rn(bf16lo(o[q]), ga)), __fadd_rn(bf16hi(rv[t][q]), __fmul_rn(bf16hi(o[q]), gb)));
+        o[q] = pack_bf16(mul_then_add(bf16lo(o[q]), ga, bf16lo(rv[t][q])), mul_then_add(bf16hi(o[q]), gb, bf16hi(rv[t][q])));
       }
     }
     if (ms[t] < M && ns[t] < N) *reinterpret_cast<u32x4*>(C + (size_t)ms[t] * ldc + ns[t]) = o;

@@ -12,11 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chronoedit_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
-NAMES = {0: "tile128", 1: "w8", 2: "w8stag", 3: "w4", 4: "w4-2st"}
+NAMES = {0: "tile128", 1: "w8", 2: "w8stag", 3: "w4-3st", 4: "w4", 5: "w4-1bar"}
 
 
 def main():
-    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,3,4").split(",")]
+    variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,4,3,5").split(",")]
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
