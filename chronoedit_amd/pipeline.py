@@ -52,10 +52,10 @@ def _token_sharded(transformer) -> bool:
 
 
 def _sharded_batchable(transformer) -> bool:
-    """Can a token-sharded (Ulysses) forward take the guidance pair as ONE batch of two?  Yes on the bf16 V^T attention path (the
-    blocked-layout kernels, chronoedit_amd/parallel.py); the fp8 modes and the register-staged kernel run the passes in sequence."""
-    return (getattr(transformer, "v_transposed", False) and getattr(transformer, "gemm_dtype", "bf16") == "bf16"
-            and getattr(transformer, "attn_dtype", "bf16") == "bf16" and getattr(transformer, "sp_batch_cfg", True))
+    """Can a token-sharded (Ulysses) forward take the guidance pair as ONE batch of two?  Yes on the V^T attention path (the
+    blocked-layout kernels, chronoedit_amd/parallel.py) - with bf16 or fp8 GEMMs; the sharded self-attention itself is always the
+    bf16 kernel (transformer.attention_path()).  The register-staged attention kernel runs the passes in sequence."""
+    return bool(getattr(transformer, "v_transposed", False) and getattr(transformer, "sp_batch_cfg", True))
 
 
 @torch.no_grad()

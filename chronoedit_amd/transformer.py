@@ -267,7 +267,6 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self._sp = Ulysses(self._cfgp.sp_group)
         if self.config.num_attention_heads % self._sp.world:
             raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
-        self._engine = None if self._engine is None else self._engine  # packed weights stay valid; workspaces are per shape
         if self._engine is not None:
             self._engine._ws = {}
         return self
@@ -310,6 +309,13 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
             self._engine.fp8_attn = on
             self._engine._ws = {}
         return self
+
+    def attention_path(self) -> str:
+        """The self-attention arithmetic the next forward will actually run: "mxfp8" only when enable_fp8_attention() is on AND the
+        tokens are not sharded - the sequence-parallel path exchanges bf16 q / k / v and runs the bf16 kernel (bench.py labels
+        its lines from this, not from the flag)."""
+        sharded = self._sp is not None and self._sp.sharded
+        return "mxfp8" if (self.attn_dtype == "mxfp8" and not sharded) else "bf16"
 
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() / .cpu() re-create storages
         self._engine = None
@@ -695,8 +701,13 @@ class DiTEngine:
         cs = self._rope_table(T, Hp, Wp)  # raises AssertionError for unsupported frame counts (:205)
         sp = self.model._sp
         if sp is not None and sp.sharded:
-            if B != 1 and (self.fp8 or not self.v_transposed):
-                raise ValueError("several samples per sequence-parallel forward need the bf16 V^T attention path (enable_transposed_v, no fp8 GEMMs)")
+            if B != 1 and not self.v_transposed:
+                raise ValueError("several samples per sequence-parallel forward need the V^T attention path (enable_transposed_v)")
+            if self.fp8_attn and not getattr(self, "_warned_fp8_attn_sp", False):
+                import warnings
+                warnings.warn("enable_fp8_attention() has no effect while the tokens are sharded (Ulysses / CFG parallel): the exchange "
+                              "carries bf16 q / k / v and the self-attention runs the bf16 V^T kernel; see attention_path()")
+                self._warned_fp8_attn_sp = True
             align = 64 if B > 1 else 1  # B > 1: blocked receive layout, a key tile must not straddle two source ranks' blocks
             Nl = sp.shard(N, align)[0]  # local (zero-padded) token rows
             key = ("sp", T, Hp, Wp, sp.rank, sp.world, Nl)

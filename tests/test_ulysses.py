@@ -306,6 +306,62 @@ def test_denoise_loop_with_cfg_sharded_over_ranks(world, mode):
         assert shape == (1, 16, 2, 8, 12) and finite and err < 5e-3, (rank, shape, err)
 
 
+def _full_width_worker(rank, world, port, q):
+    """The 8-GPU configuration of BASELINE.json configs[3] as far as one GPU can execute it: world 8, the 14B width (40 heads = 5 per
+    rank, D = 5120, F = 13 824), ONE block, the guidance pair batched inside the Ulysses group (blocked receive layout, 64-aligned
+    shards) and the 8 -> 2 latent-frame truncation mid-loop (after which ranks 3..7 hold no valid token at all)."""
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    from chronoedit_amd.pipeline import denoise
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from oracle import dit_oracle as O
+    cfg = O.DiTConfig(num_layers=1)
+    p = O.make_synthetic_params(cfg, seed=7, dtype=BF)
+    m = ChronoEditTransformer3DModel(
+        num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, in_channels=cfg.in_channels,
+        out_channels=cfg.out_channels, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, ffn_dim=cfg.ffn_dim, num_layers=1,
+        image_dim=cfg.image_dim, added_kv_proj_dim=cfg.added_kv_proj_dim, rope_temporal_skip_len=cfg.rope_temporal_skip_len,
+        device="cuda:0", dtype=BF)
+    m.load_synthetic_({k: v.cuda() for k, v in p.items()})
+    del p
+    g = torch.Generator().manual_seed(11 + 0)  # the same inputs on every rank (replicated)
+    lat0 = torch.randn(1, 16, 8, 16, 24, generator=g).cuda()         # 8 latent frames x 8 x 12 tokens = 768
+    cond = torch.randn(1, 20, 8, 16, 24, generator=g).cuda().to(BF)
+    prompt = torch.randn(1, 512, 4096, generator=g).cuda().to(BF)
+    negative = torch.randn(1, 512, 4096, generator=g).cuda().to(BF)
+    img = torch.randn(1, 257, 1280, generator=g).cuda().to(BF)
+    # one batched forward (B = 2) at 8 frames, single process vs sharded
+    x2 = torch.cat([torch.cat([lat0, cond.float()], 1)] * 2).to(BF)
+    ts2 = torch.tensor([900, 900], device="cuda:0")
+    txt2, img2 = torch.cat([prompt, negative]), torch.cat([img, img])
+    ref_fwd = m(x2, ts2, txt2, img2).sample.clone()
+    kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)
+    ref = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, prompt, negative, img, 4, 5.0, **kw).clone()
+    m.enable_sequence_parallel()
+    out_fwd = m(x2, ts2, txt2, img2).sample
+    calls = m._sp.stats["all_to_all_calls"]
+    out = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, prompt, negative, img, 4, 5.0, **kw)
+    e_fwd = float((out_fwd.float() - ref_fwd.float()).norm() / ref_fwd.float().norm())
+    e_loop = float((out - ref).norm() / ref.norm())
+    q.put((rank, m._sp.world, m.config.num_attention_heads // m._sp.world, e_fwd, calls, tuple(out.shape), e_loop, bool(torch.isfinite(out).all())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_world_8_forty_heads_full_width_block_ranks_sharing_one_gpu():
+    """the first 8-GPU run must not be the first time the 8-rank / 5-heads-per-rank path executes.  Eight ranks
+    share cuda:0 (collectives host-staged through gloo); forward B = 2 and the 4-step guidance loop incl. the frame truncation equal the
+    single-process run up to GEMM tile decomposition (row counts differ per rank: rel-L2 <= 5e-3; three collectives per layer)."""
+    res = _spawn(_full_width_worker, 8, timeout=900)
+    assert len(res) == 8
+    for rank, world, heads_per_rank, e_fwd, calls, shape, e_loop, finite in res:
+        assert world == 8 and heads_per_rank == 5
+        assert e_fwd < 5e-3, (rank, e_fwd)
+        assert calls == 3          # one layer: k|v, q, output - for BOTH samples
+        assert shape == (1, 16, 2, 16, 24) and finite and e_loop < 5e-3, (rank, shape, e_loop)
+
+
 def _rccl_one_rank_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
