@@ -74,6 +74,13 @@ def parse():
     ap.add_argument("--full-edit", action="store_true", help="also MEASURE the 50-step configs[1] edit end to end (~20 s)")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the secondary fp8-GEMM-mode timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-only", action="store_true",
+                    help="no GPU: only the CPU legs (cpu_baseline at N = 7200 and BASELINE configs[0] at N = 512; with /root/reference present also "
+                         "the reference's own transformer class) - what profiles/r03_cpu_legs.json holds")
+    ap.add_argument("--reasoning-edit", action="store_true",
+                    help="also MEASURE one temporal-reasoning edit end to end on this GPU (29 pixel frames: 8 latent frames, truncated to 2 after "
+                         "--reasoning-steps steps; two decodes) - minutes at 50 steps")
+    ap.add_argument("--reasoning-steps", type=int, default=10, help="num_temporal_reasoning_steps of --reasoning-edit (50 = never truncates)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the single-GPU / replica legs beside the Ulysses line")
     ap.add_argument("--fp8", action="store_true",
@@ -105,6 +112,16 @@ def build_model(layers: int, dev):
     return m
 
 
+def _median_time(fn, runs=3, warm=1):
+    ts = []
+    for i in range(warm + runs):
+        t0 = time.perf_counter()
+        fn()
+        if i >= warm:
+            ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
+
+
 def cpu_baseline(N: int, steps_fwd: int):
     """Oracle ("port") on the host cores: one full-width transformer block at N tokens, fp32; one warm-up run, then the
     median of three."""
@@ -119,18 +136,69 @@ def cpu_baseline(N: int, steps_fwd: int):
     temb6 = torch.randn(1, 6, cfg.inner_dim, generator=g) * 0.1
     T, hp, wp = 2, 45, N // 90
     rot = O.rope_table(cfg, T, 2 * hp, 2 * wp) if T * hp * wp == N else None
-    times = []
     with torch.no_grad():
-        for i in range(4):
-            t0 = time.perf_counter()
-            O.block_forward(p, 0, cfg, x, enc, temb6, rot)
-            if i:
-                times.append(time.perf_counter() - t0)
-    dt = statistics.median(times)
+        dt, times = _median_time(lambda: O.block_forward(p, 0, cfg, x, enc, temb6, rot))
     per_step = dt * 40 * steps_fwd
     return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
             "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, median of 3 after 1 warm-up = {dt:.2f} s "
                       f"(runs {', '.join(f'{t:.2f}' for t in times)}); x40 blocks x{steps_fwd} forwards/step"}
+
+
+def cpu_config0(with_reference: bool = True):
+    """BASELINE.json configs[0] on the host cores (SURVEY section 8d "Config 1"): the 14B width at 256x256 / 5 pixel frames
+    (latents [1,16,2,32,32], N = 512 tokens), fp32 eager, 4 steps x 2 forwards.  Full depth in fp32 is 61 GiB of weights, so
+    the whole forward (embedders, L blocks, head) is timed at L = 1, 2, 4 and the per-block time is the slope; 40 blocks are
+    composed from it.  "port" = oracle/dit_oracle.py; "reference" = the reference's own ChronoEditTransformer3DModel
+    (chronoedit_diffusers/transformer_chronoedit.py) with oracle/refshim standing in for the diffusers leaf modules - only where
+    /root/reference exists (the build container; not the GPU box)."""
+    from oracle import dit_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg4 = O.DiTConfig(num_layers=4)
+    p4 = O.make_synthetic_params(cfg4, seed=1234)
+    lat, text, image = O.make_synthetic_inputs(cfg4, 2, 32, 32, dtype=torch.float32)
+    ts = torch.tensor([637])
+    out = {"workload": "ChronoEdit-14B width, 256x256 px, 5 pixel frames = 2 latent frames (N = 512), fp32, CPU; 4 steps x 2 forwards per edit",
+           "cores": cores}
+
+    def sub(L):
+        keep = lambda k: (not k.startswith("blocks.")) or int(k.split(".")[1]) < L
+        return {k: v for k, v in p4.items() if keep(k)}
+
+    def fit(times):  # forward(L) = a + b L  (least squares over L = 1, 2, 4)
+        Ls = [1.0, 2.0, 4.0]
+        mL, mt = sum(Ls) / 3, sum(times) / 3
+        b = sum((l - mL) * (t - mt) for l, t in zip(Ls, times)) / sum((l - mL) ** 2 for l in Ls)
+        return mt - b * mL, b
+
+    legs = {}
+    with torch.no_grad():
+        t_port = []
+        for L in (1, 2, 4):
+            cfg = O.DiTConfig(num_layers=L)
+            pl = sub(L)
+            dt, _ = _median_time(lambda: O.dit_forward(pl, cfg, lat, ts, text, image))
+            t_port.append(dt)
+        legs["port"] = t_port
+        ref_py = "/root/reference/chronoedit_diffusers/transformer_chronoedit.py"
+        if with_reference and os.path.exists(ref_py):
+            sys.path.insert(0, os.path.join(ROOT, "oracle", "refshim"))
+            from oracle import gen_golden as G
+            mod = G.load_reference_module()
+            t_ref = []
+            for L in (1, 2, 4):
+                m = G.build_reference_model(mod, O.DiTConfig(num_layers=L), sub(L))
+                dt, _ = _median_time(lambda: m(lat, ts, text, image, return_dict=False))
+                t_ref.append(dt)
+                del m
+            legs["reference"] = t_ref
+    for kind, tl in legs.items():
+        a0, b = fit(tl)
+        fwd40 = a0 + 40 * b
+        out[kind] = {"forward_s_at_L_1_2_4": [round(t, 3) for t in tl], "per_block_s": round(b, 4), "outside_blocks_s": round(max(a0, 0.0), 4),
+                     "forward_40_blocks_s": round(fwd40, 2), "denoising_steps_per_sec": round(1.0 / (2 * fwd40), 5),
+                     "sec_per_4_step_edit_dit_only": round(8 * fwd40, 1), "kind": kind}
+    return out
 
 
 def _pmc_traffic(kernel_label: str):
@@ -180,6 +248,10 @@ class Workload:
 
 def main():
     a = parse()
+    if a.cpu_only:
+        out = {"cpu_baseline": cpu_baseline(7200, 2), "cpu_config0": cpu_config0()}
+        print(json.dumps(out), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -344,15 +416,18 @@ def main():
         sp, cfgp = model._sp, model._cfgp
         model._sp = model._cfgp = None
         model.engine()._ws = {}
-        if rank == 0:
-            s1 = new_sched(3)
+        if rank == 0:  # the denominator of the strong-scaling speed-up: median of three timed steps after one warm step
+            s1 = new_sched(5)
             st1 = make_stepper(wl, s1)
             st1(0)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            st1(1)
-            torch.cuda.synchronize()
-            single_same = round(1.0 / (time.perf_counter() - t0), 4)
+            ts1 = []
+            for i in range(3):
+                t0 = time.perf_counter()
+                st1(1 + i)
+                torch.cuda.synchronize()
+                ts1.append(time.perf_counter() - t0)
+            single_same = round(1.0 / statistics.median(ts1), 4)
         wl2 = Workload(dev, 2, h, w, 42 + rank)
         s2 = new_sched(4)
         dt2 = timed(make_stepper(wl2, s2), 1, 2)
@@ -367,10 +442,14 @@ def main():
         fl = dit_flops_per_forward(N, num_layers=a.layers) * fwd_per_step
         per_gpu = fl * a.steps / dt / 1e12 / (world if ulysses else 1)
         out = {
-            "metric": "denoising-steps/sec", "value": round(steps_per_s, 4), "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})",
+            "metric": "denoising-steps/sec", "value": round(steps_per_s, 4),
+            "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})" + (
+                f"; ONE configs[3] edit (N = {N} tokens) sharded over {world} GPUs - a different workload from the N = 1 line (configs[1], "
+                "N = 7200): read the curve through strong_scaling_speedup_vs_one_gpu" if ulysses else ""),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None,
-            "dtype": ("fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if a.fp8_gemms_only else
+            # from the path actually taken (transformer.attention_path()): under sequence parallelism the self-attention is the bf16 kernel
+            "dtype": ("fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if model.attention_path() == "bf16" else
                       "fp8: e4m3 GEMMs + MXFP8 self-attention on the MX matrix instruction (fp32 accumulate); bf16 cross-attention / norms / residual")
                      if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
@@ -403,6 +482,7 @@ def main():
             "roofline": roofline,
             "roofline_family": roofline_family,
             "kernel_breakdown": breakdown,
+            "sec_per_edit_temporal_reasoning": single.get("edit_reasoning"),
         }
         if a.layers != 40:
             out["invalid"] = "reduced depth (debug run)"
@@ -411,6 +491,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(N, fwd_per_step)
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(e)}
+            try:  # BASELINE.json configs[0] (N = 512, fp32 CPU plumbing): the port here; port + the reference's own class in profiles/r03_cpu_legs.json
+                out["cpu_config0"] = cpu_config0(with_reference=False)
+            except Exception as e:
+                out["cpu_config0"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

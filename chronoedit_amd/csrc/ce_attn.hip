@@ -922,7 +922,8 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
   if (sp) {
 #define CE_ATTN_SP(TWO)                                                                                              \
   do {                                                                                                               \
-    static bool done = false;                                                                                        \
+    static bool done_[CE_MAX_DEVICES] = {};                                                                          \
+    bool& done = done_[ce_device_slot()];                                                                            \
     if (!done) {                                                                                                     \
       (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<TWO>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                 sp_smem_bytes(TWO));                                                                 \
@@ -937,7 +938,8 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
   }
 #define CE_ATTN_LAUNCH(TWO, NW)                                                                                     \
   do {                                                                                                              \
-    static bool done = false;                                                                                       \
+    static bool done_[CE_MAX_DEVICES] = {};                                                                         \
+    bool& done = done_[ce_device_slot()];                                                                           \
     if (!done) {                                                                                                    \
       (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<TWO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                 smem_bytes(NW, TWO));                                                               \
@@ -1015,12 +1017,14 @@ static int attention_vt_launch(const void* Q, const void* K, const void* Vt, int
   }
   const float sl2 = softmax_scale * 1.4426950408889634f;
   const int nqb = (Nq + 8 * QW - 1) / (8 * QW);
-  static bool done = false;
+  static bool done_[CE_MAX_DEVICES] = {};
+  bool& done = done_[ce_device_slot()];
   if (!done) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(false));
     done = true;
   }
-  static int cus = 0;
+  static int cus_[CE_MAX_DEVICES] = {};
+  int& cus = cus_[ce_device_slot()];
   if (cus == 0) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;

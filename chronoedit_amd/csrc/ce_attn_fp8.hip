@@ -805,7 +805,8 @@ extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8
   if (head_dim != HD || Nq <= 0 || Nkv <= 0 || H <= 0 || batch <= 0 || (npad & 63) || npad < Nkv || npad - Nkv >= KVB) return CE_ERR_SHAPE;
   if ((ldq8 & 15) || (ldk8 & 15) || (ldo & 7)) return CE_ERR_ALIGN;
   const int nqb = (Nq + QW * 8 - 1) / (QW * 8);
-  static bool attr = false;
+  static bool attr_[CE_MAX_DEVICES] = {};
+  bool& attr = attr_[ce_device_slot()];
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_SP);

@@ -22,6 +22,14 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #define CE_ERR_SHAPE (-2)
 #define CE_ERR_ALIGN (-3)
 
+// hipFuncSetAttribute applies to the CURRENT device only: launchers remember "attribute set" per device, not per process
+#define CE_MAX_DEVICES 16
+inline int ce_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= CE_MAX_DEVICES) d = 0;
+  return d;
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 __device__ __forceinline__ float bf16lo(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float bf16hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }

@@ -409,7 +409,8 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
   const int t_full2 = nwg - tail;
   dim3 grid(t_full2 + tail * split), block(256);
   const int lds3 = 5 * TILE, lds2 = 4 * TILE;
-  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
+  static bool attr_done_[CE_MAX_DEVICES][8] = {};
+  bool* attr_done = attr_done_[ce_device_slot()];
 #define CE_LAUNCH(E)                                                                                                       \
   do {                                                                                                                     \
     if (!attr_done[E]) {                                                                                                   \

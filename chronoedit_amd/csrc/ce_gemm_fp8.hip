@@ -321,7 +321,8 @@ extern "C" int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float*
   if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(512);
-  static bool attr_done[3] = {false, false, false};
+  static bool attr_done_[CE_MAX_DEVICES][3] = {};
+  bool* attr_done = attr_done_[ce_device_slot()];
 #define F8_LAUNCH(E)                                                                                                        \
   do {                                                                                                                      \
     if (!attr_done[E]) {                                                                                                    \

@@ -35,17 +35,20 @@ __global__ __launch_bounds__(256) void cfg_unipc_kernel(const bf16* __restrict__
       v = round_bf16(u + round_bf16(g * round_bf16(v - u)));
     }
     const float xs = x[i];
-    const float x0 = xs - ((flags & 1) ? round_bf16(sigma * v) : sigma * v);
+    float x0 = xs - ((flags & 1) ? round_bf16(sigma * v) : sigma * v);
+    // flags & 2 = reference-precision trajectory: the reference's latents, x0 prediction and scheduler history are bf16 TENSORS
+    // (pipeline_chronoedit.py:681 passes torch.bfloat16 to prepare_latents), so x0 is rounded before UniC consumes it and the
+    // corrected sample before UniP does; storage stays fp32, the values are bf16
+    if (flags & 2) x0 = round_bf16(x0);
     const float m0o = m0[i], m1o = m1[i];
     float xc = xs;
-    if (use_corr) xc = a0 * x_last[i] + a1 * m0o + a2 * m1o + a3 * x0;
-    float xn = p0 * xc + p1 * x0 + p2 * m0o;
-    float x0s = x0;
-    if (flags & 2) {  // reference-precision trajectory: latents and the scheduler history are bf16 tensors in the reference
-      xn = round_bf16(xn);  // (pipeline_chronoedit.py:681 passes torch.bfloat16 to prepare_latents); keep fp32 storage, bf16 values
-      xc = round_bf16(xc);
-      x0s = round_bf16(x0);
+    if (use_corr) {
+      xc = a0 * x_last[i] + a1 * m0o + a2 * m1o + a3 * x0;
     }
+    if (flags & 2) xc = round_bf16(xc);
+    float xn = p0 * xc + p1 * x0 + p2 * m0o;
+    if (flags & 2) xn = round_bf16(xn);
+    const float x0s = x0;
     x[i] = xn;
     x_last[i] = xc;
     m1[i] = m0o;

@@ -164,7 +164,8 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
             num_inference_steps: int, guidance_scale: float = 5.0, enable_temporal_reasoning: bool = False,
             num_temporal_reasoning_steps: int = 0, use_graph: bool = False, on_step_end=None, interrupted=None):
     """The whole loop, including the temporal-reasoning truncation 8 -> 2 latent frames (pipeline_chronoedit.py:700-709).
-    on_step_end(i, t, latents) -> replacement latents or None (the reference's callback_on_step_end hook, :741-749);
+    on_step_end(i, t, latents) -> replacement latents, a dict with any of latents / prompt_embeds / negative_prompt_embeds, or None
+    (the reference's callback_on_step_end hook, :741-749);
     interrupted() -> True skips the remaining steps (`self.interrupt`, :697-698).  With the tokens sharded over ranks
     (Ulysses) every rank holds the replicated latents and scheduler history, so the truncation is a local slice on every
     rank (the reference all-gathers and re-shards: chronoedit_14b_edit_model.py:168-186) and the next forward simply shards
@@ -203,6 +204,15 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
                                    image_embeds, guidance_scale, batch_cfg=not sharded, cfg_inputs=cfg_inputs)
         if on_step_end is not None:
             new = on_step_end(i, t, latents)
+            if isinstance(new, dict):  # the reference's callback may also replace the conditioning (pipeline_chronoedit.py:747-749)
+                if "prompt_embeds" in new or "negative_prompt_embeds" in new:
+                    prompt_embeds = new.get("prompt_embeds", prompt_embeds)
+                    if negative_prompt_embeds is not None:
+                        negative_prompt_embeds = new.get("negative_prompt_embeds", negative_prompt_embeds)
+                    if cfg_inputs is not None:
+                        cfg_inputs = make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)
+                    graphed = None  # the graph holds the stacked conditioning it was captured with
+                new = new.get("latents")
             if new is not None and new is not latents:
                 graphed = None  # the graph is tied to the latents' storage
                 latents = new.to(torch.float32).contiguous()
@@ -340,7 +350,10 @@ class ChronoEditPipeline:
         return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
     def to(self, device=None, dtype=None):
-        """`pipe.to(device)` (run_inference_diffusers.py:386): moves every nn.Module component."""
+        """`pipe.to(device)` (run_inference_diffusers.py:386): moves every nn.Module component.  The engine computes in bf16 (the
+        reference runner hard-codes it, :344-362): any other `dtype` is refused rather than ignored."""
+        if dtype is not None and dtype != torch.bfloat16:
+            raise ValueError(f"chronoedit_amd components compute in torch.bfloat16; pipe.to(dtype={dtype}) is not supported")
         for m in (self.text_encoder, self.image_encoder, self.transformer, self.vae):
             if m is not None and hasattr(m, "to") and device is not None:
                 m.to(device)
@@ -514,8 +527,9 @@ class ChronoEditPipeline:
     @staticmethod
     def preprocess_image(image, height: int, width: int) -> torch.Tensor:
         """VideoProcessor.preprocess(image, height=, width=): PIL / array / tensor -> [B,3,height,width] in [-1, 1] (fp32, CPU or
-        the tensor's device).  PIL images are resized with Lanczos, arrays / tensors are taken as [0, 1] unless they already
-        carry negative values (diffusers' own rule)."""
+        the tensor's device).  PIL images are resized with Lanczos, arrays / tensors with F.interpolate's default mode (nearest) - both as
+        diffusers' VaeImageProcessor.resize does; arrays / tensors are taken as [0, 1] unless they already carry negative values
+        (diffusers' own rule)."""
         import numpy as np
         if _is_pil(image) or (isinstance(image, (list, tuple)) and all(_is_pil(i) for i in image)):
             from PIL import Image
@@ -532,7 +546,7 @@ class ChronoEditPipeline:
         else:
             raise ValueError(f"`image` has to be of type `torch.Tensor` or `PIL.Image.Image` but is {type(image)}")
         if x.shape[-2:] != (height, width):
-            x = torch.nn.functional.interpolate(x, size=(height, width), mode="bilinear", align_corners=False)
+            x = torch.nn.functional.interpolate(x, size=(height, width))  # arrays / tensors: F.interpolate's default (nearest), as diffusers' VaeImageProcessor.resize
         if x.min() >= 0:
             x = 2.0 * x - 1.0
         return x.contiguous()
@@ -605,22 +619,37 @@ class ChronoEditPipeline:
         img = self.preprocess_image(image, height, width).to(device=device, dtype=torch.bfloat16)
         latents, condition = self.prepare_latents(img, B, self.vae.config.z_dim, height, width, num_frames, torch.bfloat16, device,
                                                   generator, latents)
-        if B > 1:
-            raise NotImplementedError("the engine denoises one edit per call (batch_size * num_videos_per_prompt == 1); loop over prompts")
+        if prompt_embeds.shape[0] != B or (negative_prompt_embeds is not None and negative_prompt_embeds.shape[0] != B):
+            raise ValueError(f"prompt_embeds carry {prompt_embeds.shape[0]} samples, expected batch_size * num_videos_per_prompt = {B}")
+        if image_embeds.shape[0] != B:
+            image_embeds = image_embeds.repeat(B // image_embeds.shape[0], 1, 1)
 
-        def on_step_end(i, t, lat):
-            self._current_timestep = t
-            if callback_on_step_end is None:
-                return None
-            pool = {"latents": lat, "prompt_embeds": prompt_embeds, "negative_prompt_embeds": negative_prompt_embeds}
-            outs = callback_on_step_end(self, i, t, {k: pool[k] for k in callback_on_step_end_tensor_inputs})
-            return outs.pop("latents", lat) if outs else None
-
+        # The engine denoises ONE edit at a time (its batch axis carries the guidance pair); B = batch_size * num_videos_per_prompt
+        # edits (pipeline_chronoedit.py:493,631-637,676-691) run one after the other on the same weights - the reference's batched
+        # loop computes the same per-sample arithmetic.  `callback_on_step_end` is then called per sample and step with that
+        # sample's tensors; returned `latents`, `prompt_embeds`, `negative_prompt_embeds` are honoured (:741-749).
         self._num_timesteps = num_inference_steps
-        latents = denoise(self.transformer, self.scheduler, latents, condition, prompt_embeds,
-                          negative_prompt_embeds if self.do_classifier_free_guidance else None, image_embeds, num_inference_steps,
-                          guidance_scale, enable_temporal_reasoning, num_temporal_reasoning_steps, use_graph=self.use_graph,
-                          on_step_end=on_step_end, interrupted=lambda: self._interrupt)
+        done = []
+        for b in range(B):
+            embeds = {"prompt_embeds": prompt_embeds[b:b + 1], "negative_prompt_embeds": None if negative_prompt_embeds is None else negative_prompt_embeds[b:b + 1]}
+
+            def on_step_end(i, t, lat, embeds=embeds):
+                self._current_timestep = t
+                if callback_on_step_end is None:
+                    return None
+                pool = {"latents": lat, **embeds}
+                outs = callback_on_step_end(self, i, t, {k: pool[k] for k in callback_on_step_end_tensor_inputs})
+                if not outs:
+                    return None
+                new = {k: outs[k] for k in ("latents", "prompt_embeds", "negative_prompt_embeds") if k in outs and outs[k] is not pool[k]}
+                embeds.update({k: v for k, v in new.items() if k != "latents"})
+                return new or None
+
+            done.append(denoise(self.transformer, self.scheduler, latents[b:b + 1], condition[b:b + 1], embeds["prompt_embeds"],
+                                embeds["negative_prompt_embeds"] if self.do_classifier_free_guidance else None, image_embeds[b:b + 1],
+                                num_inference_steps, guidance_scale, enable_temporal_reasoning, num_temporal_reasoning_steps,
+                                use_graph=self.use_graph, on_step_end=on_step_end, interrupted=lambda: self._interrupt))
+        latents = done[0] if B == 1 else torch.cat(done, dim=0)
         if offload_model and self.transformer is not None:
             self.transformer.cpu()
             torch.cuda.empty_cache()

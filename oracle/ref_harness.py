@@ -4,7 +4,9 @@
 `oracle/_ref/pipeline_ref.bin` (a compiled code object generated at build time, never committed) and run them over the chronoedit_amd drop-ins.
 
 Nothing here restates reference logic: these are the un-vendored leaves (diffusers==0.35.2 is not installable here) - a logger,
-a progress bar, `randn_tensor`, `VideoProcessor` pre / post processing, the output dataclass.  Only tests/ may import this."""
+a progress bar, `randn_tensor`, `VideoProcessor` pre / post processing, the output dataclass - each written here on its own (plain
+torch / PIL restatements of the diffusers behaviour), NOT delegated to chronoedit_amd, so that tests/test_ref_loop_gpu.py compares
+the engine pipeline's noise / pre- / post-processing against an independent statement.  Only tests/ may import this."""
 from __future__ import annotations
 
 import contextlib
@@ -61,20 +63,70 @@ class WanPipelineOutput:
 
 
 def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
-    from chronoedit_amd.pipeline import _randn_tensor
-    return _randn_tensor(tuple(shape), generator, device, dtype)
+    """diffusers.utils.torch_utils.randn_tensor restated from its 0.35.2 behaviour (NOT delegated to chronoedit_amd, so that the
+    reference-loop test can see a divergence in how the engine draws its noise): the noise is drawn on the generator's device -
+    a CPU generator with a GPU target draws on the CPU and moves the result; a list of generators draws one sample each."""
+    shape = tuple(shape)
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    draw_on = device
+    gens = generator if isinstance(generator, (list, tuple)) else None
+    first = gens[0] if gens else generator
+    if first is not None:
+        gtype = first.device.type
+        if gtype != device.type:
+            if gtype == "cpu":
+                draw_on = torch.device("cpu")
+            else:
+                raise ValueError(f"Cannot generate a {device.type} tensor from a generator of type {gtype}.")
+    if gens is not None and len(gens) == 1:
+        generator, gens = gens[0], None
+    if gens is not None:
+        one = (1,) + shape[1:]
+        return torch.cat([torch.randn(one, generator=g, device=draw_on, dtype=dtype) for g in gens], dim=0).to(device)
+    return torch.randn(shape, generator=generator, device=draw_on, dtype=dtype).to(device)
 
 
 class _VideoProcessor:
-    """diffusers.video_processor.VideoProcessor: the two calls the reference makes (pipeline_chronoedit.py:673,801)."""
+    """diffusers.video_processor.VideoProcessor restated from its 0.35.2 behaviour for the two calls the reference makes
+    (pipeline_chronoedit.py:673,801) - independently of chronoedit_amd.pipeline's own pre / post processing, which the
+    reference-loop test compares against: PIL images are resized with Lanczos and scaled to [0, 1]; arrays / tensors are resized with
+    F.interpolate's default (nearest); everything is mapped to [-1, 1] unless it already carries negative values."""
 
     def preprocess(self, image, height=None, width=None):
-        from chronoedit_amd.pipeline import ChronoEditPipeline
-        return ChronoEditPipeline.preprocess_image(image, height, width)
+        if isinstance(image, PIL.Image.Image):
+            image = [image]
+        if isinstance(image, (list, tuple)) and isinstance(image[0], PIL.Image.Image):
+            arrs = [np.asarray(im.convert("RGB").resize((width, height), resample=PIL.Image.LANCZOS)).astype(np.float32) / 255.0 for im in image]
+            x = torch.from_numpy(np.stack(arrs, axis=0)).permute(0, 3, 1, 2)
+        elif isinstance(image, np.ndarray):
+            x = torch.from_numpy(image if image.ndim == 4 else image[None]).float().permute(0, 3, 1, 2)
+            if x.shape[-2:] != (height, width):
+                x = torch.nn.functional.interpolate(x, size=(height, width))
+        else:
+            x = image.float()
+            x = x if x.dim() == 4 else x[None]
+            if x.shape[-2:] != (height, width):
+                x = torch.nn.functional.interpolate(x, size=(height, width))
+        if x.min() < 0:  # already in [-1, 1]: diffusers warns and skips the normalisation
+            return x
+        return 2.0 * x - 1.0
 
     def postprocess_video(self, video, output_type="np"):
-        from chronoedit_amd.pipeline import ChronoEditPipeline
-        return ChronoEditPipeline.postprocess_video(video, output_type)
+        outs = []
+        for sample in video:  # [3, F, H, W] -> frames [F, 3, H, W] -> [0, 1]
+            frames = (sample.permute(1, 0, 2, 3).float() / 2 + 0.5).clamp(0, 1)
+            if output_type == "pt":
+                outs.append(frames)
+                continue
+            arr = frames.cpu().permute(0, 2, 3, 1).numpy()
+            outs.append(arr if output_type == "np" else [PIL.Image.fromarray((f * 255).round().astype("uint8")) for f in arr])
+        if output_type == "np":
+            return np.stack(outs)
+        if output_type == "pt":
+            return torch.stack(outs)
+        if output_type == "pil":
+            return outs
+        raise ValueError(f"{output_type} does not exist. Please choose one of ['np', 'pt', 'pil']")
 
 
 class RefHarnessBase:

@@ -48,6 +48,23 @@ def test_gemm_kernels_have_no_spills_and_a_batched_epilogue():
                 assert r[5] <= 8, f"{r[0]}: {r[5]} serialised loads"
 
 
+def test_one_wave_per_simd_gemm_keeps_its_accumulators_in_place():
+    """ce_gemm256w4.hip: 256 accumulator AGPRs + the fragment sets in VGPRs, no scratch; per trip of the K loop (two K-tiles) exactly
+    256 MFMAs, 64 fragment reads, 32 LDS-DMA pieces, 4 barriers (2 in the one-barrier form) and NOT ONE v_accvgpr_* - as builtins the
+    MFMAs came out untied and hipcc shuffled every result through VGPRs (hundreds of v_accvgpr_* per K-tile): the trap this pins."""
+    src = os.path.join(CSRC, "ce_gemm256w4.hip")
+    for r in _rows("ce_gemm256w4.hip"):
+        assert r[3] == 0, f"{r[0]}: scratch"
+        assert r[2] <= 512, r
+    loops = isa_lint.inner_loops(src, "gemm_bf16_w4")
+    assert len(loops) == 15  # 5 epilogues x (3 stages, 3 stages + one barrier, 2 stages)
+    for name, c in loops:
+        assert c.get("v_mfma_f32_16x16x32_bf16", 0) == 256, (name, c)
+        assert c.get("ds_read_b128", 0) == 64 and c.get("buffer_load_dwordx4", 0) == 32, (name, c)
+        assert c.get("s_barrier", 0) == (2 if "ELb1E" in name else 4), (name, c)
+        assert not any(op.startswith("v_accvgpr") or op.startswith("scratch") for op in c), (name, c)
+
+
 def test_row_kernels_issue_their_row_loads_back_to_back():
     rows = _rows("ce_rowops.hip")
     (rr,) = _pick(rows, "rmsnorm_rope_kernel", "ILb1E")  # FULL variant (D = 5120)
