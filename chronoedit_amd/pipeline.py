@@ -101,13 +101,20 @@ class GraphedDenoiser:
     def __init__(self, transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
                  guidance_scale: float, batch_cfg: bool = True):
         assert latents.dtype == torch.float32 and latents.is_contiguous()
-        if _token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None:
-            raise NotImplementedError("hipGraph capture of a step with RCCL exchanges is not built: run the sharded loop eagerly")
+        sp = getattr(transformer, "_sp", None)
+        if (_token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None) and getattr(sp, "backend", "nccl") != "nccl":
+            # RCCL collectives (torch.distributed backend "nccl") are stream operations and are captured with the kernels around them;
+            # the gloo test backend stages through host memory, which a graph cannot hold
+            raise NotImplementedError("hipGraph capture of a sharded step needs the RCCL backend (host-staged gloo exchanges cannot be captured)")
+        self.cfgp = getattr(transformer, "_cfgp", None)
+        if self.cfgp is None and _token_sharded(transformer) and not _sharded_batchable(transformer):
+            batch_cfg = False
         self.tr, self.sch, self.latents, self.condition = transformer, scheduler, latents, condition
         self.prompt, self.negative, self.image, self.g, self.batch_cfg = prompt_embeds, negative_prompt_embeds, image_embeds, guidance_scale, batch_cfg
         dev = latents.device
         self.cfg_inputs = None
-        if guidance_scale > 1.0 and negative_prompt_embeds is not None:
+        self.guided = guidance_scale > 1.0 and negative_prompt_embeds is not None
+        if self.guided and self.cfgp is None and batch_cfg:
             self.cfg_inputs = make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)
         self.t_buf = torch.zeros((), dtype=torch.int64, device=dev)
         self.coef_buf = torch.zeros(10, dtype=torch.float32, device=dev)
@@ -142,10 +149,13 @@ class GraphedDenoiser:
         inp = torch.cat([self.latents.to(torch.bfloat16), self.condition], dim=1)
         B = inp.shape[0]
         ts = self.t_buf.expand(B)
-        if self.cfg_inputs is not None and self.batch_cfg:
+        if self.guided and self.cfgp is not None:  # CFG parallelism: this rank's Ulysses group runs one of the two passes
+            mine = self.tr(inp, ts, self.prompt if self.cfgp.branch == 0 else self.negative, self.image, return_dict=False)[0]
+            c, u = self.cfgp.exchange(mine)
+        elif self.cfg_inputs is not None:
             out = self.tr(torch.cat([inp, inp], 0), torch.cat([ts, ts], 0), self.cfg_inputs[0], self.cfg_inputs[1], return_dict=False)[0]
             c, u = out[:B].contiguous(), out[B:].contiguous()
-        elif self.cfg_inputs is not None:
+        elif self.guided:
             c = self.tr(inp, ts, self.prompt, self.image, return_dict=False)[0]
             u = self.tr(inp, ts, self.negative, self.image, return_dict=False)[0]
         else:
@@ -179,6 +189,9 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
     if hasattr(transformer, "clear_context_cache"):
         transformer.clear_context_cache()  # a new edit: nothing of the previous edit's conditioning may be reused
     graphed = None
+    sp = getattr(transformer, "_sp", None)
+    if use_graph and sp is not None and sp.sharded and sp.backend != "nccl":
+        use_graph = False  # host-staged (gloo) exchanges cannot live in a graph: the test backend runs eagerly
     for i, t in enumerate(scheduler.timesteps):
         if interrupted is not None and interrupted():
             continue
@@ -313,7 +326,13 @@ class ChronoEditPipeline:
         self.guardrail_enabled = not disable_guardrails
         self.text_guardrail_runner = None
         self.video_guardrail_runner = None
-        self.use_graph = False  # replay one hipGraph-captured step per iteration (GraphedDenoiser)
+        # Defaults of the product pipeline (bit-identical to the eager / uncached loop: tests/test_pipeline_gpu.py): every step of the
+        # loop is ONE hipGraph replay (GraphedDenoiser; two graphs when temporal reasoning truncates 8 -> 2 frames), and the
+        # step-invariant text / image context projections are computed once per edit (`denoise` clears them at
+        # the start of every edit).  `pipe.use_graph = False` / `pipe.transformer.cache_context = False` switch either off.
+        self.use_graph = True
+        if transformer is not None and hasattr(transformer, "cache_context"):
+            transformer.cache_context = True
         self._guidance_scale, self._attention_kwargs, self._current_timestep, self._interrupt, self._num_timesteps = 1.0, None, None, False, 0
 
     # -- properties of the reference pipeline (:458-478) ---------------------------------------------------------------

@@ -157,3 +157,73 @@ class RefHarnessBase:
 
     def maybe_free_model_hooks(self):
         pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# scripts/run_inference_diffusers.py: the import names of the reference runner bound to the drop-ins
+# ---------------------------------------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def runner_shims(exported_videos: Optional[list] = None):
+    """While active, the module names scripts/run_inference_diffusers.py imports (:64-80) resolve to the chronoedit_amd drop-ins -
+    the edit INTEGRATION.md section 1 asks a maintainer to make, done here in `sys.modules` so that the reference's script runs
+    UNMODIFIED (its compiled code, oracle/build_ref.build_runner):
+        diffusers.AutoencoderKLWan                      -> chronoedit_amd.vae.AutoencoderKLWan
+        diffusers.schedulers.UniPCMultistepScheduler    -> chronoedit_amd.scheduler.FlowUniPCMultistepScheduler
+        diffusers.utils.export_to_video / load_image    -> frame recorder (appends to `exported_videos`) / PIL loader
+        transformers.CLIPVisionModel                    -> chronoedit_amd.clip_vision.CLIPVisionModel (everything else: the real package)
+        chronoedit_diffusers.pipeline_chronoedit / .transformer_chronoedit -> the chronoedit_amd classes of the same names
+        scripts.prompt_enhancer                         -> refuses (out of scope: SURVEY section 2)"""
+    import sys
+    import types
+
+    import transformers as real_transformers
+
+    from chronoedit_amd.clip_vision import CLIPVisionModel
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from chronoedit_amd.vae import AutoencoderKLWan
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        return m
+
+    def load_image(path):
+        return PIL.Image.open(path).convert("RGB")
+
+    def export_to_video(frames, path, fps=8):
+        if exported_videos is not None:
+            exported_videos.append((path, fps, np.asarray(frames)))
+        return path
+
+    def refuse(*a, **k):
+        raise RuntimeError("the prompt enhancer (Qwen-VL) is outside the hot path (SURVEY.md section 2)")
+
+    class _Transformers(types.ModuleType):
+        def __getattr__(self, name):  # AutoTokenizer, CLIPImageProcessor, ...: the host-side objects stay the reference's
+            return getattr(real_transformers, name)
+
+    tf = _Transformers("transformers")
+    tf.CLIPVisionModel = CLIPVisionModel
+    shims = {
+        "diffusers": mod("diffusers", AutoencoderKLWan=AutoencoderKLWan),
+        "diffusers.schedulers": mod("diffusers.schedulers", UniPCMultistepScheduler=FlowUniPCMultistepScheduler),
+        "diffusers.utils": mod("diffusers.utils", export_to_video=export_to_video, load_image=load_image),
+        "transformers": tf,
+        "chronoedit_diffusers": mod("chronoedit_diffusers"),
+        "chronoedit_diffusers.pipeline_chronoedit": mod("chronoedit_diffusers.pipeline_chronoedit", ChronoEditPipeline=ChronoEditPipeline),
+        "chronoedit_diffusers.transformer_chronoedit": mod("chronoedit_diffusers.transformer_chronoedit", ChronoEditTransformer3DModel=ChronoEditTransformer3DModel),
+        "scripts": mod("scripts"),
+        "scripts.prompt_enhancer": mod("scripts.prompt_enhancer", load_model=refuse, enhance_prompt=refuse),
+    }
+    saved = {k: sys.modules.get(k) for k in shims}
+    sys.modules.update(shims)
+    try:
+        yield shims
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

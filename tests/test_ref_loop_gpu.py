@@ -151,3 +151,41 @@ def test_engine_pipeline_call_contract():
     a = pipe(**dict(base, generator=torch.Generator(device="cuda:0").manual_seed(7), output_type="latent")).frames
     b = pipe(**dict(base, generator=torch.Generator(device="cuda:0").manual_seed(7), output_type="latent")).frames
     assert torch.equal(a, b)
+
+
+def test_engine_pipeline_batch_of_edits_and_callback_returned_embeds():
+    """batch_size * num_videos_per_prompt > 1 (pipeline_chronoedit.py:493,631-637,676-691): the edits run one after the other on the
+    engine and every sample equals its own single call; a callback that returns `prompt_embeds` / `negative_prompt_embeds` replaces
+    the conditioning from the next step on (:747-749)."""
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    m, vae, ie, mk_sched = _components()
+    pipe = ChronoEditPipeline(image_encoder=ie, image_processor=_ImageProcessor(56), transformer=m, vae=vae, scheduler=mk_sched())
+    g = torch.Generator().manual_seed(6)
+    img = torch.rand(1, 3, 64, 96, generator=g)
+    pe = torch.randn(1, 40, 128, generator=g).to(torch.bfloat16).cuda()
+    ne = torch.randn(1, 40, 128, generator=g).to(torch.bfloat16).cuda()
+    lat = torch.randn(2, 16, 2, 8, 12, generator=g)
+    base = dict(image=img, prompt_embeds=pe, negative_prompt_embeds=ne, height=64, width=96, num_frames=5, num_inference_steps=3, output_type="pt")
+    both = pipe(**dict(base, num_videos_per_prompt=2, prompt_embeds=pe.repeat(2, 1, 1), negative_prompt_embeds=ne.repeat(2, 1, 1), latents=lat.clone())).frames
+    assert both.shape == (2, 5, 3, 64, 96)
+    for b in range(2):
+        one = pipe(**dict(base, latents=lat[b:b + 1].clone())).frames
+        assert torch.equal(both[b:b + 1], one), b
+    assert not torch.equal(both[0], both[1])
+    other = torch.randn(1, 40, 128, generator=g).to(torch.bfloat16).cuda()
+    seen = []
+
+    def cb(p, i, t, kwargs):
+        seen.append(i)
+        return {"prompt_embeds": other} if i == 0 else {}
+
+    swapped = pipe(**dict(base, latents=lat[:1].clone(), callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"])).frames
+    plain = pipe(**dict(base, latents=lat[:1].clone())).frames
+    assert seen == [0, 1, 2] and not torch.equal(swapped, plain)
+    # ... and equals running step 0 with `pe`, the rest with `other`: the engine honours the returned tensor
+    from chronoedit_amd.pipeline import denoise, prepare_latents, decode_latents
+    pipe.use_graph = False
+    eager = pipe(**dict(base, latents=lat[:1].clone(), callback_on_step_end=cb, callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"])).frames
+    assert torch.equal(eager, swapped)  # hipGraph replay (default) == eager loop, also across a conditioning swap
+    with pytest.raises(ValueError, match="bfloat16"):
+        pipe.to("cuda", dtype=torch.float32)

@@ -336,15 +336,25 @@ def _full_width_worker(rank, world, port, q):
     ts2 = torch.tensor([900, 900], device="cuda:0")
     txt2, img2 = torch.cat([prompt, negative]), torch.cat([img, img])
     ref_fwd = m(x2, ts2, txt2, img2).sample.clone()
+    x2s = x2[:, :, [0, -1]].contiguous()  # the post-truncation shape: 2 latent frames = 192 tokens -> 64-row shards, ranks 3..7 all padding
+    ref_fwd_s = m(x2s, ts2, txt2, img2).sample.clone()
     kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)
+    from chronoedit_amd import ops
     ref = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, prompt, negative, img, 4, 5.0, **kw).clone()
+    # noise floor of the loop comparison: the SAME single-process loop with another GEMM tile decomposition (128-tile kernel) - four
+    # steps of guidance 5 amplify the bf16 summation-order differences of one forward
+    old = ops.set_gemm_variant(0)
+    alt = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, prompt, negative, img, 4, 5.0, **kw)
+    ops.set_gemm_variant(old)
+    e_noise = float((alt - ref).norm() / ref.norm())
     m.enable_sequence_parallel()
     out_fwd = m(x2, ts2, txt2, img2).sample
     calls = m._sp.stats["all_to_all_calls"]
+    out_fwd_s = m(x2s, ts2, txt2, img2).sample
     out = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, prompt, negative, img, 4, 5.0, **kw)
-    e_fwd = float((out_fwd.float() - ref_fwd.float()).norm() / ref_fwd.float().norm())
-    e_loop = float((out - ref).norm() / ref.norm())
-    q.put((rank, m._sp.world, m.config.num_attention_heads // m._sp.world, e_fwd, calls, tuple(out.shape), e_loop, bool(torch.isfinite(out).all())))
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    q.put((rank, m._sp.world, m.config.num_attention_heads // m._sp.world, rel(out_fwd, ref_fwd), rel(out_fwd_s, ref_fwd_s), calls, tuple(out.shape),
+           rel(out, ref), e_noise, bool(torch.isfinite(out).all())))
     dist.destroy_process_group()
 
 
@@ -352,39 +362,54 @@ def _full_width_worker(rank, world, port, q):
 def test_world_8_forty_heads_full_width_block_ranks_sharing_one_gpu():
     """the first 8-GPU run must not be the first time the 8-rank / 5-heads-per-rank path executes.  Eight ranks
     share cuda:0 (collectives host-staged through gloo); forward B = 2 and the 4-step guidance loop incl. the frame truncation equal the
-    single-process run up to GEMM tile decomposition (row counts differ per rank: rel-L2 <= 5e-3; three collectives per layer)."""
+    single-process run up to GEMM tile decomposition (row counts differ per rank): forwards rel-L2 <= 5e-3 at both latent shapes,
+    the loop within 3 x what the same single-process loop moves when only its GEMM tiling changes; three collectives per layer."""
     res = _spawn(_full_width_worker, 8, timeout=900)
     assert len(res) == 8
-    for rank, world, heads_per_rank, e_fwd, calls, shape, e_loop, finite in res:
+    for rank, world, heads_per_rank, e_fwd, e_fwd_s, calls, shape, e_loop, e_noise, finite in res:
+        if rank == 0:
+            print(f"world 8 / 5 heads per rank: forward (8 frames) {e_fwd:.2e}, forward (2 frames) {e_fwd_s:.2e}, 4-step loop {e_loop:.2e} "
+                  f"(same loop, another GEMM tiling, one process: {e_noise:.2e})")
         assert world == 8 and heads_per_rank == 5
-        assert e_fwd < 5e-3, (rank, e_fwd)
+        assert e_fwd < 5e-3 and e_fwd_s < 5e-3, (rank, e_fwd, e_fwd_s)
         assert calls == 3          # one layer: k|v, q, output - for BOTH samples
-        assert shape == (1, 16, 2, 16, 24) and finite and e_loop < 5e-3, (rank, shape, e_loop)
+        assert shape == (1, 16, 2, 16, 24) and finite
+        assert e_loop <= 3 * e_noise + 5e-3, (rank, e_loop, e_noise)  # within the loop's own bf16 reordering noise
 
 
-def _rccl_one_rank_worker(rank, world, port, q):
+def _rccl_graph_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
+    dist.init_process_group("nccl", rank=rank, world_size=world)
     from chronoedit_amd.pipeline import denoise
     from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
     m, cfg, O = _tiny_model()
-    lat, text, image = O.make_synthetic_inputs(cfg, 2, 18, 22, dtype=BF, text_len=40, real_text=8)
-    ts = torch.tensor([321], device="cuda:0")
-    ref = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample.clone()
-    m.enable_sequence_parallel(force=True)  # the sharded path with every exchange issued through RCCL (async k|v, q, output, gather)
-    out = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample
+    m.enable_sequence_parallel(force=True)
     g = torch.Generator().manual_seed(11)
-    lat0 = torch.randn(1, 16, 2, 8, 12, generator=g).cuda()
-    cond = torch.randn(1, 20, 2, 8, 12, generator=g).cuda().to(BF)
+    lat0 = torch.randn(1, 16, 8, 8, 12, generator=g).cuda()
+    cond = torch.randn(1, 20, 8, 8, 12, generator=g).cuda().to(BF)
     pr, ng = torch.randn(1, 40, 128, generator=g).cuda().to(BF), torch.randn(1, 40, 128, generator=g).cuda().to(BF)
     img = torch.randn(1, 257, 64, generator=g).cuda().to(BF)
-    loop = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 3, 5.0)
+    kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)  # two graphs: 8 and 2 latent frames
+    eager = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, **kw).clone()
+    calls = m._sp.stats["all_to_all_calls"]
+    graphed = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=True, **kw)
     torch.cuda.synchronize()
-    q.put((rank, dist.get_backend(), bool(torch.equal(out, ref)), float((out.float() - ref.float()).abs().max()), m._sp.stats["all_to_all_calls"],
-           bool(torch.isfinite(loop).all())))
+    q.put((rank, bool(torch.equal(eager, graphed)), float((eager - graphed).abs().max()), m._sp.stats["all_to_all_calls"] - calls,
+           bool(torch.isfinite(graphed).all())))
     dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_step_is_hipgraph_capturable_over_rccl():
+    """the sharded denoising step - three RCCL all-to-all per layer (the k|v one asynchronous on the
+    communicator's stream), the all_gather of the head - captured into a hipGraph per latent shape and replayed per step ==
+    the eager sharded loop bit for bit (one rank: the only RCCL group a one-GPU box can form; the collectives are real)."""
+    (rank, equal, err, calls, finite), = _spawn(_rccl_graph_worker, 1, timeout=300)
+    assert finite and equal, (equal, err)
+    # Python-side counters tick at CAPTURE time only: 2 graphs x (1 warm-up + 1 captured) batched forwards x 2 layers x 3 exchanges
+    assert calls == 2 * 2 * 2 * 3, calls
 
 
 @pytest.mark.gpu
