@@ -93,9 +93,14 @@ class CLIPVisionModel(nn.Module):
 
     @classmethod
     def from_pretrained(cls, path: str, subfolder: Optional[str] = None, torch_dtype: torch.dtype = torch.bfloat16, device=None, **unused):
+        """`CLIPVisionModel.from_pretrained(model_path, subfolder="image_encoder", torch_dtype=torch.float32)` is how the reference
+        runner loads it (run_inference_diffusers.py:333-337).  The engine computes in bf16: an fp32 request is honoured as "read the
+        checkpoint, round every parameter to bf16 once" (the pipeline casts the embeddings to the transformer's bf16 anyway,
+        pipeline_chronoedit.py:661); the request is remembered in `requested_dtype`."""
         cfg = weights.read_config(path, subfolder)
         cfg = cfg.get("vision_config", cfg)  # a full CLIP config nests the tower's
-        model = cls(**cfg, device=device, dtype=torch_dtype)
+        model = cls(**cfg, device=device, dtype=torch.bfloat16)
+        model.requested_dtype = torch_dtype
         files = weights.shard_files(path, subfolder, names=("model.safetensors",))
         sd = weights.load_state_dict_files(files)
         sd = {k: v for k, v in sd.items() if k.startswith("vision_model.")}  # a full CLIP checkpoint also carries the text tower

@@ -166,7 +166,7 @@ def test_engine_pipeline_batch_of_edits_and_callback_returned_embeds():
     ne = torch.randn(1, 40, 128, generator=g).to(torch.bfloat16).cuda()
     lat = torch.randn(2, 16, 2, 8, 12, generator=g)
     base = dict(image=img, prompt_embeds=pe, negative_prompt_embeds=ne, height=64, width=96, num_frames=5, num_inference_steps=3, output_type="pt")
-    both = pipe(**dict(base, num_videos_per_prompt=2, prompt_embeds=pe.repeat(2, 1, 1), negative_prompt_embeds=ne.repeat(2, 1, 1), latents=lat.clone())).frames
+    both = pipe(**dict(base, prompt_embeds=pe.repeat(2, 1, 1), negative_prompt_embeds=ne.repeat(2, 1, 1), latents=lat.clone())).frames  # batch_size = 2
     assert both.shape == (2, 5, 3, 64, 96)
     for b in range(2):
         one = pipe(**dict(base, latents=lat[b:b + 1].clone())).frames

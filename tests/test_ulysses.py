@@ -377,6 +377,31 @@ def test_world_8_forty_heads_full_width_block_ranks_sharing_one_gpu():
         assert e_loop <= 3 * e_noise + 5e-3, (rank, e_loop, e_noise)  # within the loop's own bf16 reordering noise
 
 
+def _rccl_one_rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" IS RCCL on ROCm
+    from chronoedit_amd.pipeline import denoise
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    m, cfg, O = _tiny_model()
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 18, 22, dtype=BF, text_len=40, real_text=8)
+    ts = torch.tensor([321], device="cuda:0")
+    ref = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample.clone()
+    m.enable_sequence_parallel(force=True)  # the sharded path with every exchange issued through RCCL (async k|v, q, output, gather)
+    out = m(lat.cuda(), ts, text.cuda(), image.cuda()).sample
+    g = torch.Generator().manual_seed(11)
+    lat0 = torch.randn(1, 16, 2, 8, 12, generator=g).cuda()
+    cond = torch.randn(1, 20, 2, 8, 12, generator=g).cuda().to(BF)
+    pr, ng = torch.randn(1, 40, 128, generator=g).cuda().to(BF), torch.randn(1, 40, 128, generator=g).cuda().to(BF)
+    img = torch.randn(1, 257, 64, generator=g).cuda().to(BF)
+    loop = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 3, 5.0)
+    torch.cuda.synchronize()
+    q.put((rank, dist.get_backend(), bool(torch.equal(out, ref)), float((out.float() - ref.float()).abs().max()), m._sp.stats["all_to_all_calls"],
+           bool(torch.isfinite(loop).all())))
+    dist.destroy_process_group()
+
+
 def _rccl_graph_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
