@@ -304,3 +304,142 @@ extern "C" int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M,
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, stream, scores, (bf16*)probs, n, npad, ld, ldp, scale);
   return (int)hipGetLastError();
 }
+
+// ---- mid-block attention of the Wan VAE as ONE flash-style kernel (wan2pt1.py:223-259: a single head over the h*w positions of a
+// frame, head dim = C = 384 at the shipped width) -----------------------------------------------------------------------------------
+// No [HW, HW] score matrix in memory (0.83 GB fp32 per frame at 720p, 2.7 GB at 1584x1056): scores, online softmax and P.V stay in
+// registers.  4 waves x 16 query rows per workgroup, 64-key tiles staged through LDS (K rows and V^T rows), v_mfma_f32_16x16x32_bf16:
+//   S^T block = K.Q^T   (first operand K: lane (fr, fg) then owns query fr and the four keys 16 kb + 4 fg + j of key block kb)
+//   O^T block = V^T.P^T (first operand V^T rows = output channels; the P operand is taken straight from the S registers: MFMA k-slot
+//                        8 fg + j <-> key 32 h + 4 fg + j, slot 8 fg + 4 + j <-> key 32 h + 16 + 4 fg + j, and V^T is read with the
+//                        same slot -> key map, two 8-byte LDS reads per fragment)
+// so a lane keeps one query's statistics (running maximum, partial row sum) and rescales its own 96 accumulator values.
+// Bound: LDS reads (every wave streams the whole K and V^T tile per 96 MFMAs); the product is ~1.3 TFLOP per 720p edit.
+namespace {
+
+template <int C>
+__global__ __launch_bounds__(256) void attn_1head_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
+                                                         bf16* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, float sl2) {
+  constexpr int KS = C / 32;          // k-steps of the score product
+  constexpr int DB = C / 16;          // 16-channel blocks of the output
+  constexpr int KROW = C * 2 + 16;    // padded K row (bytes)
+  constexpr int VROW = 128 + 16;      // padded V^T row: 64 keys
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + 64 * KROW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  bf16x8 qf[KS];
+  {
+    const bf16* qrow = Q + (size_t)min(q0 + fr, Nq - 1) * ldq + 8 * fg;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks);
+  }
+  f32x4 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -3.0e38f, l_run = 0.f;
+  const int ntiles = (Nk + 63) / 64;
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+    constexpr int KCH = 64 * (C / 8);  // 16-byte chunks of the K tile
+    for (int c = tid; c < KCH; c += 256) {
+      const int r = c / (C / 8), cc = c - r * (C / 8);
+      *reinterpret_cast<u32x4*>(sK + r * KROW + cc * 16) = *reinterpret_cast<const u32x4*>(K + (size_t)min(t * 64 + r, Nk - 1) * ldk + cc * 8);
+    }
+    for (int c = tid; c < C * 8; c += 256) {
+      const int r = c >> 3, cc = c & 7;
+      *reinterpret_cast<u32x4*>(sV + r * VROW + cc * 16) = *reinterpret_cast<const u32x4*>(Vt + (size_t)r * ldvt + t * 64 + cc * 8);
+    }
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 16 + fr) * KROW + (32 * ks + 8 * fg) * 2);
+        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    // online softmax in the exp2 domain; keys past Nk are masked (their K rows were clamped copies)
+    float mt = -3.0e38f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = t * 64 + kb * 16 + 4 * fg + j;
+        s[kb][j] = key < Nk ? s[kb][j] * sl2 : -3.0e38f;
+        mt = fmaxf(mt, s[kb][j]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[kb][j] = __builtin_amdgcn_exp2f(s[kb][j] - m_new);
+        psum += s[kb][j];
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) o[d] *= alpha;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4 pw = {pack_bf16(s[2 * h][0], s[2 * h][1]), pack_bf16(s[2 * h][2], s[2 * h][3]), pack_bf16(s[2 * h + 1][0], s[2 * h + 1][1]),
+                  pack_bf16(s[2 * h + 1][2], s[2 * h + 1][3])};
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const unsigned char* vr = sV + (d * 16 + fr) * VROW + (32 * h + 4 * fg) * 2;
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vr), hi = *reinterpret_cast<const u32x2*>(vr + 32);
+        const u32x4 vw = {lo[0], lo[1], hi[0], hi[1]};
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[d], 0, 0, 0);
+      }
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_run;
+  if (q0 + fr < Nq) {
+    bf16* orow = O + (size_t)(q0 + fr) * ldo + 4 * fg;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const u32x2 pk = {pack_bf16(o[d][0] * inv, o[d][1] * inv), pack_bf16(o[d][2] * inv, o[d][3] * inv)};
+      *reinterpret_cast<u32x2*>(orow + d * 16) = pk;
+    }
+  }
+}
+
+}  // namespace
+
+// O [Nq][ldo] = softmax(Q K^T * scale) V for ONE head of dimension C (128 or 384): Q [Nq][ldq], K [Nk][ldk] bf16 rows, Vt [C][ldvt] =
+// V transposed (keys contiguous; columns [Nk, 64 ceil(Nk / 64)) must be finite - zero them).  Replaces the q.k^T / softmax / .v of the
+// VAE's AttentionBlock (chronoedit/_src/tokenizers/wan2pt1.py:247-255, F.scaled_dot_product_attention on [b t, 1, h w, c]).
+extern "C" int ce_attention_1head_bf16(const void* Q, const void* K, const void* Vt, void* O, int Nq, int Nk, int C, int ldq, int ldk, int ldvt,
+                                       int ldo, float softmax_scale, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O || Nq <= 0 || Nk <= 0) return CE_ERR_ARG;
+  if ((C != 128 && C != 384) || (ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3) || ldvt < (Nk + 63) / 64 * 64) return CE_ERR_SHAPE;
+  const float sl2 = softmax_scale * 1.4426950408889634f;
+  const dim3 grid((Nq + 63) / 64), block(256);
+  static bool done_[CE_MAX_DEVICES] = {};
+  bool& done = done_[ce_device_slot()];
+  const int smem384 = 64 * (384 * 2 + 16) + 384 * 144, smem128 = 64 * (128 * 2 + 16) + 128 * 144;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)attn_1head_kernel<384>, hipFuncAttributeMaxDynamicSharedMemorySize, smem384);
+    (void)hipFuncSetAttribute((const void*)attn_1head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem128);
+    done = true;
+  }
+  if (C == 384)
+    hipLaunchKernelGGL(attn_1head_kernel<384>, grid, block, smem384, stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, Nq, Nk, ldq,
+                       ldk, ldvt, ldo, sl2);
+  else
+    hipLaunchKernelGGL(attn_1head_kernel<128>, grid, block, smem128, stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, Nq, Nk, ldq,
+                       ldk, ldvt, ldo, sl2);
+  return (int)hipGetLastError();
+}

@@ -503,6 +503,25 @@ def softmax_rows(scores: torch.Tensor, probs: torch.Tensor, n: int, scale: float
     return probs
 
 
+def attention_1head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None):
+    """softmax(q k^T * scale) v for one head of dimension C in {128, 384} (the Wan VAE mid-block): q [Nq, C], k [Nk, C] row views,
+    vt [C, >= 64 ceil(Nk / 64)] = v transposed with zero padding columns; flash-style, nothing of size Nq x Nk is materialised."""
+    _dev(q, torch.bfloat16, "q"), _dev(k, torch.bfloat16, "k"), _dev(vt, torch.bfloat16, "vt")
+    Nq, C, ldq = _rows(q, "q")
+    Nk, C2, ldk = _rows(k, "k")
+    Cv, _, ldvt = _rows(vt, "vt")
+    assert C == C2 == Cv, (C, C2, Cv)
+    if out is None:
+        out = torch.empty((Nq, C), dtype=torch.bfloat16, device=q.device)
+    _dev(out, torch.bfloat16, "out")
+    _, _, ldo = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_attention_1head_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), Nq, Nk, C, ldq, ldk, ldvt, ldo, float(scale), _stream()),
+           "ce_attention_1head_bf16")
+    _prof_end(st, f"attention_1head_{Nq}x{Nk}x{C}", 4.0 * Nq * Nk * C)
+    return out
+
+
 def gemm_f32(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None):
     """out[M,N] (fp32) = a[M,K] @ w[N,K]^T, no bias (CE_EPI_F32)."""
     _dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w")

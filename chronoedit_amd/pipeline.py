@@ -129,7 +129,12 @@ class GraphedDenoiser:
         torch.cuda.current_stream().wait_stream(side)
         self._restore(saved)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # A sharded step holds RCCL collectives.  torch's process-group watchdog THREAD polls the events of in-flight collectives
+        # (hipEventQuery); under the default "global" capture mode that call from another thread aborts the capture
+        # (hipErrorStreamCaptureUnsupported - tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt), so a capture that contains
+        # collectives is thread-local: only this thread's unsafe calls are policed.
+        mode = "thread_local" if (_token_sharded(transformer) or self.cfgp is not None) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self._body()
         self._restore(saved)
 

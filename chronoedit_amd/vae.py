@@ -190,32 +190,39 @@ class WanVAEEngine:
         return self._cached_conv(name + ".residual.6", y, caches, res=h)
 
     def _attn(self, name, x: Frames) -> Frames:
-        """Per-frame single-head attention over h*w (wan2pt1.py:240-259): 1x1 qkv conv -> fp32 scores GEMM -> row softmax
-        -> P.V GEMM -> 1x1 proj conv with the identity fused as residual."""
+        """Per-frame single-head attention over h*w (wan2pt1.py:240-259): 1x1 qkv conv -> one flash-style attention kernel
+        (ce_attention_1head_bf16) -> 1x1 proj conv with the identity fused as residual."""
         C, HW = x.C, x.H * x.W
         xn = self._rms_silu(x, name + ".norm.gamma", silu=False)  # bordered
         qkv = torch.empty((x.T, HW, 3 * C), dtype=torch.bfloat16, device=self.dev)
         self._conv(name + ".to_qkv", xn.frame_list(), x.T, x.H, x.W, x.W, in_off=1, rows=qkv)
         hwp = (HW + 63) // 64 * 64
         o = torch.empty((x.T, HW, C), dtype=torch.bfloat16, device=self.dev)
-        # Query rows in chunks: the fp32 score block is [rows, HW] with rows chosen for <= 256 MiB (the whole [HW, HW] matrix is
-        # 0.83 GB per frame at 720p, 2.7 GB at 1584x1056), and the three work buffers live across frames and calls (no allocator
-        # churn on the sec/edit path): scores, probabilities and V^T (its padding columns zeroed once).
-        rows = min(HW, max(256, (1 << 26) // hwp // 64 * 64))
-        ws = getattr(self, "_attn_ws", None)
-        if ws is None or ws[0] != (rows, hwp, C):
-            ws = ((rows, hwp, C), torch.empty((rows, hwp), dtype=torch.float32, device=self.dev),
-                  torch.empty((rows, hwp), dtype=torch.bfloat16, device=self.dev), torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev))
-            self._attn_ws = ws
-        _, s_buf, p_buf, vt = ws
-        for t in range(x.T):
-            q, k, v = qkv[t, :, :C], qkv[t, :, C : 2 * C], qkv[t, :, 2 * C :]
-            vt[:, :HW].copy_(v.t())
-            for r0 in range(0, HW, rows):
-                n = min(rows, HW - r0)
-                ops.gemm_f32(q[r0:r0 + n], k, out=s_buf[:n, :HW])  # [n, HW] fp32
-                ops.softmax_rows(s_buf[:n, :HW], p_buf[:n], HW, C ** -0.5)
-                ops.gemm(p_buf[:n], vt, None, out=o[t, r0:r0 + n])
+        if C in (128, 384):  # the shipped width (384) and the dim-32 test width: one flash-style kernel per frame, nothing [HW, HW]-sized
+            vt = getattr(self, "_attn_vt", None)
+            if vt is None or vt.shape != (C, hwp):
+                vt = self._attn_vt = torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev)  # padding columns stay zero
+            for t in range(x.T):
+                vt[:, :HW].copy_(qkv[t, :, 2 * C :].t())
+                ops.attention_1head(qkv[t, :, :C], qkv[t, :, C : 2 * C], vt, C ** -0.5, out=o[t])
+        else:
+            # other widths: query rows in chunks - the fp32 score block is [rows, HW] with rows chosen for <= 256 MiB, and the work
+            # buffers live across frames and calls (scores, probabilities, V^T with its padding columns zeroed once)
+            rows = min(HW, max(256, (1 << 26) // hwp // 64 * 64))
+            ws = getattr(self, "_attn_ws", None)
+            if ws is None or ws[0] != (rows, hwp, C):
+                ws = ((rows, hwp, C), torch.empty((rows, hwp), dtype=torch.float32, device=self.dev),
+                      torch.empty((rows, hwp), dtype=torch.bfloat16, device=self.dev), torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev))
+                self._attn_ws = ws
+            _, s_buf, p_buf, vt = ws
+            for t in range(x.T):
+                q, k, v = qkv[t, :, :C], qkv[t, :, C : 2 * C], qkv[t, :, 2 * C :]
+                vt[:, :HW].copy_(v.t())
+                for r0 in range(0, HW, rows):
+                    n = min(rows, HW - r0)
+                    ops.gemm_f32(q[r0:r0 + n], k, out=s_buf[:n, :HW])  # [n, HW] fp32
+                    ops.softmax_rows(s_buf[:n, :HW], p_buf[:n], HW, C ** -0.5)
+                    ops.gemm(p_buf[:n], vt, None, out=o[t, r0:r0 + n])
         # proj (1x1) on the un-bordered rows, + identity, into a bordered stack
         out = Frames(x.T, x.H, x.W, C, self.dev)
         pk = self.packs[name + ".proj"]

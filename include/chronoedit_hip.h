@@ -218,6 +218,13 @@ int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix,
 /* nearest-exact 2x spatial upsample of T bordered frames [H+2][W+2][C] -> [2H+2][2W+2][C] (wan2pt1.py:78-83,99-104). */
 int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipStream_t stream);
 
+/* O [Nq][ldo] = softmax(Q K^T * softmax_scale) V for ONE attention head of dimension C (128 or 384) as a single flash-style kernel
+ * (no [Nq, Nk] score matrix in memory): Q [Nq][ldq], K [Nk][ldk] bf16 rows; Vt [C][ldvt] = V transposed, keys contiguous, ldvt >=
+ * 64 ceil(Nk / 64) with the padding columns finite (zero).  Replaces the scaled_dot_product_attention of the Wan VAE's mid-block
+ * AttentionBlock (chronoedit/_src/tokenizers/wan2pt1.py:247-255: one head over the h*w positions of a frame). */
+int ce_attention_1head_bf16(const void* Q, const void* K, const void* Vt, void* O, int Nq, int Nk, int C, int ldq, int ldk, int ldvt,
+                            int ldo, float softmax_scale, hipStream_t stream);
+
 /* probs[m][0:npad] = bf16(softmax(scale * scores[m][0:n])) (zeros beyond n); scores fp32.  Mid-block attention
  * (wan2pt1.py:247-252) runs as GEMM (CE_EPI_F32) -> this -> GEMM. */
 int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int npad, int ld, int ldp, float scale,

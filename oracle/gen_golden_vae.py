@@ -36,6 +36,11 @@ CASES = {
     # the real Wan 2.1 widths (dim 96 -> 96 / 192 / 384 / 384 channels): the MFMA and the HBM-bound conv paths, the Cin padding
     # and the 384-channel mid-block attention at the channel counts the 14B pipeline runs (round-1 VERDICT: toy width only)
     "full_5f": (dict(dim=96, z_dim=16), 5, 64, 96),
+    # round 3: a larger frame at the real widths (128 x 192 px: 16 x 24 = 384 mid-block attention tokens, several
+    # 128-pixel tiles per conv row) and the temporal-reasoning encode length (29 pixel frames = chunks 1 + 4 x 7 through feat_cache ->
+    # 8 latent frames; decode of 8 latent frames frame by frame)
+    "full_5f_128x192": (dict(dim=96, z_dim=16), 5, 128, 192),
+    "full_29f": (dict(dim=96, z_dim=16), 29, 32, 48),
 }
 
 

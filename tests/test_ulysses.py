@@ -269,6 +269,41 @@ def test_ulysses_hip_forward_ranks_sharing_one_gpu(world):
         assert calls == 3 * 2 and calls2 == 3 * 2  # per layer: k|v, q, output - the same number of collectives for two samples
 
 
+def _fp8_sp_worker(rank, world, port, q):
+    """fp8 GEMMs under sequence parallelism with the guidance pair batched: the six large Linears of every block
+    run on the e4m3 path with per-row scales of the LOCAL rows, the exchange and the self-attention stay bf16 (attention_path())."""
+    _init(rank, world, port)
+    torch.cuda.set_device(0)
+    import warnings
+    m, cfg, O = _tiny_model()
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 18, 22, dtype=BF, text_len=40, real_text=8)
+    g = torch.Generator().manual_seed(5)
+    lat2 = torch.cat([lat, torch.randn(lat.shape, generator=g).to(BF)], 0).cuda()
+    text2 = torch.cat([text, torch.randn(text.shape, generator=g).to(BF)], 0).cuda()
+    image2 = torch.cat([image, image], 0).cuda()
+    ts2 = torch.tensor([321, 777], device="cuda:0")
+    m.enable_fp8_gemms()
+    ref2 = m(lat2, ts2, text2, image2).sample.clone()        # single process, fp8 GEMMs, bf16 attention
+    m.enable_fp8_attention()
+    assert m.attention_path() == "mxfp8"
+    m.enable_sequence_parallel()
+    assert m.attention_path() == "bf16"                        # the sharded path exchanges bf16 q / k / v
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out2 = m(lat2, ts2, text2, image2).sample
+    warned = any("no effect while the tokens are sharded" in str(x.message) for x in w)
+    q.put((rank, float((out2.float() - ref2.float()).norm() / ref2.float().norm()), warned, m._sp.stats["all_to_all_calls"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_fp8_gemms_with_the_batched_pair_under_sequence_parallelism(world):
+    for rank, err, warned, calls in _spawn(_fp8_sp_worker, world):
+        assert err < 2e-2, (rank, err)   # row scales are per token row: sharding the rows does not change them; GEMM tilings differ
+        assert warned and calls == 3 * 2  # ADVICE r2: fp8 attention + sharding is announced, not silently dropped
+
+
 def _loop_worker(rank, world, port, q, mode):
     """denoise() with guidance 5: single process (batched CFG) vs sharded (the pair batched inside one Ulysses group - blocked receive
     layout, 64-aligned shards, a rank with NO valid token after the frame truncation at world 4 - or the 2 x (world/2) CFG-parallel

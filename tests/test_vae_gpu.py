@@ -38,7 +38,29 @@ def test_conv_igemm_matches_conv3d():
     assert float(out.data[:, 0].abs().max()) == 0.0 and float(out.data[:, :, 0].abs().max()) == 0.0  # border untouched
 
 
-@pytest.mark.parametrize("name", ["small_5f", "small_9f", "full_5f"])
+@pytest.mark.parametrize("N,C", [(384, 384), (1000, 384), (100, 128), (3600, 384), (14400, 384)])
+def test_single_head_attention_kernel_vs_fp32(N, C):
+    """ce_attention_1head_bf16 (the VAE mid-block attention as one flash-style kernel, head dim 384 / 128) vs fp32 softmax(q k^T) v;
+    14 400 = the 90 x 160 positions of a 720p frame (the score matrix this kernel never materialises is 0.83 GB in fp32)."""
+    from chronoedit_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    qkv = torch.randn(N, 3 * C, generator=g).to(torch.bfloat16).to(dev)
+    qkv[:, 2 * C:].mul_(torch.linspace(0.5, 1.5, C, device=dev).to(torch.bfloat16))           # channel- and ...
+    qkv[:, 2 * C:].add_((torch.arange(N, device=dev) % 7).to(torch.bfloat16)[:, None] * 0.25)  # ... key-dependent v: a permuted P.V shows up
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    hwp = (N + 63) // 64 * 64
+    vt = torch.zeros((C, hwp), dtype=torch.bfloat16, device=dev)
+    vt[:, :N] = v.t()
+    out = ops.attention_1head(q, k, vt, C ** -0.5)
+    worst = 0.0
+    for r0 in range(0, N, 2048):
+        s = torch.softmax(q[r0:r0 + 2048].float() @ k.float().t() * C ** -0.5, dim=-1)
+        worst = max(worst, rel_l2(out[r0:r0 + 2048], s @ v.float()))
+    assert worst < 1e-2, worst
+
+
+@pytest.mark.parametrize("name", ["small_5f", "small_9f", "full_5f", "full_5f_128x192", "full_29f"])
 def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
     from chronoedit_amd.vae import AutoencoderKLWan
     fx = torch.load(os.path.join(golden_dir, f"vae_{name}.pt"))
@@ -50,13 +72,16 @@ def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
     mu = vae.encode(x.cuda().to(torch.bfloat16)).latent_dist.mode()
     rec = vae.decode(z.cuda().to(torch.bfloat16), return_dict=False)[0]
     assert mu.shape == fx["mu"].shape and rec.shape == fx["rec"].shape
+    e_mu, e_rec = rel_l2(mu, fx["mu"]), rel_l2(rec, fx["rec"])
+    assert e_mu < 5e-2 and e_rec < 5e-2, (e_mu, e_rec)
+    if name in ("full_5f_128x192", "full_29f"):  # the bf16 CPU oracle at these sizes costs minutes of host time: fp32 golden only
+        print(f"{name}: encode hip {e_mu:.3e}  decode hip {e_rec:.3e}")
+        return
     # the bf16 eager error of the reference arithmetic itself, for scale
     pb = {k: v.to(torch.bfloat16) for k, v in p.items()}
     with torch.no_grad():
         mu_b = V.encode(pb, cfg, x.to(torch.bfloat16))
         rec_b = V.decode(pb, cfg, z.to(torch.bfloat16))
-    e_mu, e_rec = rel_l2(mu, fx["mu"]), rel_l2(rec, fx["rec"])
     b_mu, b_rec = rel_l2(mu_b, fx["mu"]), rel_l2(rec_b, fx["rec"])
     print(f"{name}: encode hip {e_mu:.3e} (bf16 eager {b_mu:.3e})  decode hip {e_rec:.3e} (bf16 eager {b_rec:.3e})")
-    assert e_mu < 5e-2 and e_rec < 5e-2
     assert e_mu < 3 * b_mu + 5e-3 and e_rec < 3 * b_rec + 5e-3

@@ -7,7 +7,7 @@ import torch
 from oracle import vae_oracle as V
 
 
-@pytest.mark.parametrize("name", ["small_5f", "small_9f", "full_5f"])
+@pytest.mark.parametrize("name", ["small_5f", "small_9f", "full_5f", "full_5f_128x192", "full_29f"])
 def test_vae_oracle_matches_reference_golden(golden_dir, name):
     fx = torch.load(os.path.join(golden_dir, f"vae_{name}.pt"))
     cfg = V.VAEConfig(**fx["cfg"])

@@ -9,6 +9,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 stage_max = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+MODE = sys.argv[2] if len(sys.argv) > 2 else "global"  # capture_error_mode of torch.cuda.graph
 
 
 def say(*a):
@@ -21,6 +22,7 @@ dist.init_process_group("nccl", rank=0, world_size=1)
 dev = torch.device("cuda:0")
 a = torch.arange(1 << 20, device=dev, dtype=torch.bfloat16).view(1, -1)
 b = torch.empty_like(a)
+say("capture_error_mode =", MODE)
 say("stage 1: eager all_to_all_single")
 dist.all_to_all_single(b, a)
 torch.cuda.synchronize()
@@ -34,7 +36,7 @@ if stage_max >= 2:
     with torch.cuda.stream(s):
         dist.all_to_all_single(b, a)  # warm-up on the side stream, as torch recommends before capture
     torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode=MODE):
         dist.all_to_all_single(b, a)
     b.zero_()
     g.replay()
@@ -44,7 +46,7 @@ if stage_max >= 3:
     say("stage 3: capture async_op=True + work.wait() with a kernel in between")
     g2 = torch.cuda.CUDAGraph()
     c = torch.empty_like(a)
-    with torch.cuda.graph(g2):
+    with torch.cuda.graph(g2, capture_error_mode=MODE):
         w = dist.all_to_all_single(b, a, async_op=True)
         c.copy_(a).mul_(2)
         w.wait()
@@ -57,7 +59,7 @@ if stage_max >= 4:
     say("stage 4: all_gather_into_tensor captured")
     g3 = torch.cuda.CUDAGraph()
     o = torch.empty_like(a)
-    with torch.cuda.graph(g3):
+    with torch.cuda.graph(g3, capture_error_mode=MODE):
         dist.all_gather_into_tensor(o, a)
     o.zero_()
     g3.replay()
