@@ -133,7 +133,10 @@ class GraphedDenoiser:
         # (hipEventQuery); under the default "global" capture mode that call from another thread aborts the capture
         # (hipErrorStreamCaptureUnsupported - tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt), so a capture that contains
         # collectives is thread-local: only this thread's unsafe calls are policed.
-        mode = "thread_local" if (_token_sharded(transformer) or self.cfgp is not None) else "global"
+        mode = "global"
+        if _token_sharded(transformer) or self.cfgp is not None:
+            mode = "thread_local"
+            torch.cuda.synchronize()  # the warm-up's collectives have retired: nothing of them is left for the watchdog to poll
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self._body()
         self._restore(saved)

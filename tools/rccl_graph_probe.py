@@ -43,18 +43,31 @@ if stage_max >= 2:
     torch.cuda.synchronize()
     say("  replay ok", bool(torch.equal(a, b)))
 if stage_max >= 3:
-    say("stage 3: capture async_op=True + work.wait() with a kernel in between")
+    say("stage 3: fork / join on a side stream (synchronous collective there, a kernel on the main stream meanwhile)")
     g2 = torch.cuda.CUDAGraph()
     c = torch.empty_like(a)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
     with torch.cuda.graph(g2, capture_error_mode=MODE):
-        w = dist.all_to_all_single(b, a, async_op=True)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_to_all_single(b, a)
         c.copy_(a).mul_(2)
-        w.wait()
+        torch.cuda.current_stream().wait_stream(side)
         c.add_(b)
     b.zero_()
     g2.replay()
     torch.cuda.synchronize()
     say("  replay ok", bool(torch.equal(c, a * 2 + a)))
+if stage_max >= 6:
+    say("stage 6: async_op=True + work.wait() under capture (known to crash this stack: run last, on its own)")
+    g4 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g4, capture_error_mode=MODE):
+        w = dist.all_to_all_single(b, a, async_op=True)
+        w.wait()
+    g4.replay()
+    torch.cuda.synchronize()
+    say("  replay ok")
 if stage_max >= 4:
     say("stage 4: all_gather_into_tensor captured")
     g3 = torch.cuda.CUDAGraph()
