@@ -351,7 +351,7 @@ def main():
             dt_ = float(tt.item())
         return dt_
 
-    total = a.warmup + a.steps + (0 if a.no_profile else 1)
+    total = a.warmup + a.steps + (0 if a.no_profile else 2)
     sched = new_sched(total)
     one_step = make_stepper(wl, sched, graph=a.graph, sequential=a.sequential_cfg)
     eager_step = one_step if not a.graph else make_stepper(wl, sched, graph=False, sequential=a.sequential_cfg)
@@ -359,6 +359,15 @@ def main():
         model._sp.stats.update(all_to_all_calls=0, all_to_all_bytes_sent_off_rank=0)
     dt = timed(one_step, a.warmup, a.steps)
     finite = bool(torch.isfinite(wl.latents).all().item())
+    # how long the host needs to ISSUE one eager step (no wait): the margin by which a launch-per-kernel loop stays GPU-bound
+    # (why the sharded loop, which cannot be hipGraph-captured on this stack, loses nothing by running eagerly)
+    host_enqueue_ms = None
+    if not a.no_profile:
+        sync_all()
+        t0h = time.perf_counter()
+        eager_step(a.warmup + a.steps)
+        host_enqueue_ms = round((time.perf_counter() - t0h) * 1e3, 2)
+        sync_all()
     rccl = None
     if ulysses:
         st = model._sp.stats
@@ -375,10 +384,10 @@ def main():
     # ---- per-kernel HIP-event profile of ONE more step (outside the timed region) -> roofline of the dominant kernel
     roofline = roofline_family = breakdown = None
     if not a.no_profile and ulysses and rank != 0:
-        eager_step(a.warmup + a.steps)  # the step has collectives: every rank must take part
+        eager_step(a.warmup + a.steps + 1)  # the step has collectives: every rank must take part
     if not a.no_profile and rank == 0:
         with ops.profile() as prof:
-            eager_step(a.warmup + a.steps)
+            eager_step(a.warmup + a.steps + 1)
         summ = prof.summary()
         tot = sum(d["total_ms"] for d in summ.values())
         breakdown = {k: {"n": d["n"], "avg_ms": round(d["avg_ms"], 4), "share": round(d["total_ms"] / tot, 4),
@@ -467,6 +476,7 @@ def main():
             "finite": finite,
             **({"TEST_ONLY": f"ranks share one GPU, collectives host-staged over {test_backend}: exercises the code path, measures nothing"} if test_backend else {}),
             "launch": "hipGraph replay" if a.graph else "eager",
+            "host_enqueue_ms_per_step": host_enqueue_ms,
             "rccl": rccl,
             "single_gpu_same_workload_steps_per_sec": single_same,
             "strong_scaling_speedup_vs_one_gpu": None if not single_same else round(steps_per_s / single_same, 3),

@@ -45,18 +45,6 @@ class _Done:
         return True
 
 
-class _Joined:
-    """Handle of an exchange issued on the communicator side stream: wait() orders the CURRENT stream behind it (a stream-level
-    dependency, the host does not block) - in eager mode and, captured, as the join of a fork in the hipGraph."""
-
-    def __init__(self, side):
-        self.side = side
-
-    def wait(self):
-        torch.cuda.current_stream().wait_stream(self.side)
-        return True
-
-
 class Ulysses:
     @property
     def sharded(self) -> bool:
@@ -114,24 +102,8 @@ class Ulysses:
             dist.all_to_all_single(rc, sc, group=self.group)
             recv.copy_(rc)
             return recv, _Done()
-        if async_op and send.is_cuda:
-            # Overlap WITHOUT torch's asynchronous Work objects: the exchange is issued (synchronously with respect to its own stream)
-            # on a side stream that forks off the compute stream here and is joined by wait().  Same overlap as async_op=True in the
-            # eager loop, and - unlike it - capturable: a Work created under stream capture crashes this ROCm / RCCL stack (the
-            # process-group watchdog polls its event from another thread: tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt).
-            side = self._side_stream(send.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                dist.all_to_all_single(recv, send, group=self.group)
-            return recv, _Joined(side)
-        dist.all_to_all_single(recv, send, group=self.group)
-        return recv, _Done()
-
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = self._side = torch.cuda.Stream(device=device)
-        return st
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=async_op)
+        return recv, (work if async_op else _Done())
 
     def all_gather_rows(self, x_local: torch.Tensor) -> torch.Tensor:
         """[n_local, C] -> [W*n_local, C] in rank order."""

@@ -101,14 +101,15 @@ class GraphedDenoiser:
     def __init__(self, transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
                  guidance_scale: float, batch_cfg: bool = True):
         assert latents.dtype == torch.float32 and latents.is_contiguous()
-        sp = getattr(transformer, "_sp", None)
-        if (_token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None) and getattr(sp, "backend", "nccl") != "nccl":
-            # RCCL collectives (torch.distributed backend "nccl") are stream operations and are captured with the kernels around them;
-            # the gloo test backend stages through host memory, which a graph cannot hold
-            raise NotImplementedError("hipGraph capture of a sharded step needs the RCCL backend (host-staged gloo exchanges cannot be captured)")
-        self.cfgp = getattr(transformer, "_cfgp", None)
-        if self.cfgp is None and _token_sharded(transformer) and not _sharded_batchable(transformer):
-            batch_cfg = False
+        if _token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None:
+            # Measured on this stack (ROCm 7.0 / RCCL 2.26 / torch 2.10: tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt): ONE
+            # collective of torch.distributed's "nccl" backend can be captured and replayed, but the process-group watchdog thread keeps
+            # polling the event of every Work created under capture - the next capture (or any later poll) kills the process
+            # (hipErrorStreamCaptureUnsupported in "global" capture mode, a segmentation fault in "thread_local" / "relaxed"), with
+            # synchronous collectives, async_op=True and side-stream fork / join alike.  A sharded loop needs two graphs (8 -> 2 frames), so it
+            # runs eagerly; DESIGN.md section 6 has the measurement of why that costs nothing at the per-rank kernel times of 4 / 8 GPUs.
+            raise NotImplementedError("hipGraph capture of a step with RCCL exchanges is not usable on this torch / RCCL build: the sharded loop runs eagerly")
+        self.cfgp = None
         self.tr, self.sch, self.latents, self.condition = transformer, scheduler, latents, condition
         self.prompt, self.negative, self.image, self.g, self.batch_cfg = prompt_embeds, negative_prompt_embeds, image_embeds, guidance_scale, batch_cfg
         dev = latents.device
@@ -129,15 +130,7 @@ class GraphedDenoiser:
         torch.cuda.current_stream().wait_stream(side)
         self._restore(saved)
         self.graph = torch.cuda.CUDAGraph()
-        # A sharded step holds RCCL collectives.  torch's process-group watchdog THREAD polls the events of in-flight collectives
-        # (hipEventQuery); under the default "global" capture mode that call from another thread aborts the capture
-        # (hipErrorStreamCaptureUnsupported - tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt), so a capture that contains
-        # collectives is thread-local: only this thread's unsafe calls are policed.
-        mode = "global"
-        if _token_sharded(transformer) or self.cfgp is not None:
-            mode = "thread_local"
-            torch.cuda.synchronize()  # the warm-up's collectives have retired: nothing of them is left for the watchdog to poll
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+        with torch.cuda.graph(self.graph):
             self._body()
         self._restore(saved)
 
@@ -197,9 +190,8 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
     if hasattr(transformer, "clear_context_cache"):
         transformer.clear_context_cache()  # a new edit: nothing of the previous edit's conditioning may be reused
     graphed = None
-    sp = getattr(transformer, "_sp", None)
-    if use_graph and sp is not None and sp.sharded and sp.backend != "nccl":
-        use_graph = False  # host-staged (gloo) exchanges cannot live in a graph: the test backend runs eagerly
+    if use_graph and (_token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None):
+        use_graph = False  # a step with RCCL exchanges runs eagerly (GraphedDenoiser says why); the pipeline default stays use_graph=True
     for i, t in enumerate(scheduler.timesteps):
         if interrupted is not None and interrupted():
             continue

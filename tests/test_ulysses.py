@@ -437,39 +437,41 @@ def _rccl_one_rank_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _rccl_graph_worker(rank, world, port, q):
+def _rccl_eager_default_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world)
-    from chronoedit_amd.pipeline import denoise
+    from chronoedit_amd.pipeline import GraphedDenoiser, denoise
     from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
     m, cfg, O = _tiny_model()
-    m.enable_sequence_parallel(force=True)
     g = torch.Generator().manual_seed(11)
     lat0 = torch.randn(1, 16, 8, 8, 12, generator=g).cuda()
     cond = torch.randn(1, 20, 8, 8, 12, generator=g).cuda().to(BF)
     pr, ng = torch.randn(1, 40, 128, generator=g).cuda().to(BF), torch.randn(1, 40, 128, generator=g).cuda().to(BF)
     img = torch.randn(1, 257, 64, generator=g).cuda().to(BF)
-    kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)  # two graphs: 8 and 2 latent frames
-    eager = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, **kw).clone()
-    calls = m._sp.stats["all_to_all_calls"]
-    graphed = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=True, **kw)
+    kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)
+    ref = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=True, **kw).clone()  # un-sharded: graphs
+    m.enable_sequence_parallel(force=True)
+    refused = False
+    try:
+        GraphedDenoiser(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0[:, :, :2].clone().contiguous(), cond[:, :, :2].contiguous(), pr, ng, img, 5.0)
+    except NotImplementedError:
+        refused = True
+    out = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=True, **kw)  # the pipeline default
     torch.cuda.synchronize()
-    q.put((rank, bool(torch.equal(eager, graphed)), float((eager - graphed).abs().max()), m._sp.stats["all_to_all_calls"] - calls,
-           bool(torch.isfinite(graphed).all())))
+    q.put((rank, refused, float((out - ref).norm() / ref.norm()), bool(torch.isfinite(out).all())))
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_sharded_step_is_hipgraph_capturable_over_rccl():
-    """the sharded denoising step - three RCCL all-to-all per layer (the k|v one asynchronous on the
-    communicator's stream), the all_gather of the head - captured into a hipGraph per latent shape and replayed per step ==
-    the eager sharded loop bit for bit (one rank: the only RCCL group a one-GPU box can form; the collectives are real)."""
-    (rank, equal, err, calls, finite), = _spawn(_rccl_graph_worker, 1, timeout=300)
-    assert finite and equal, (equal, err)
-    # Python-side counters tick at CAPTURE time only: 2 graphs x (1 warm-up + 1 captured) batched forwards x 2 layers x 3 exchanges
-    assert calls == 2 * 2 * 2 * 3, calls
+def test_sharded_loop_runs_eagerly_under_the_graph_default():
+    """`use_graph=True` is the pipeline default; a step that holds RCCL exchanges cannot be captured on this torch / RCCL build
+    (tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt: the process-group watchdog polls the events of Works created under
+    capture and takes the process down), so GraphedDenoiser refuses it and `denoise` runs that loop eagerly - same result as the
+    graphed un-sharded loop."""
+    (rank, refused, err, finite), = _spawn(_rccl_eager_default_worker, 1, timeout=300)
+    assert refused and finite and err < 5e-3, (refused, err)
 
 
 @pytest.mark.gpu
