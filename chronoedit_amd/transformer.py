@@ -275,6 +275,13 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         if self._engine is not None:
             self._engine.clear_context_cache()
 
+    @torch.no_grad()
+    def prime_context(self, encoder_hidden_states: torch.Tensor, encoder_hidden_states_image: Optional[torch.Tensor]):
+        """Compute the step-invariant conditioning work for exactly these tensors now, so that the next forward
+        that receives them - e.g. the one a hipGraph capture records - finds the cache entry (only with `cache_context`)."""
+        if self.cache_context:
+            self.engine()._context(encoder_hidden_states, encoder_hidden_states_image)
+
     def invalidate(self):
         """Call after changing parameters in place (LoRA fuse, load_state_dict): re-packs on next forward."""
         self._engine = None
@@ -601,7 +608,10 @@ class DiTEngine:
                 ws.send_kv, ws.recv_kv = e(W, N, 2, Dl), e(W, N, 2, Dl)
                 ws.send_q, ws.recv_q = e(W, N, 1, Dl), e(W, N, 1, Dl)
                 ws.att_g, ws.att_seg = e(W * N, Dl), e(W, N, Dl)
-            self._ws = {N: ws}  # keep one shape resident
+            # keep the two most recent shapes resident: a temporal-reasoning edit alternates between its 8-frame and 2-frame shapes, and a
+            # hipGraph capture of a shape seen before must find its workspace (nothing may be allocated for the engine under capture)
+            keep = list(self._ws.items())[-1:]
+            self._ws = dict(keep + [(N, ws)])
         return ws
 
     def _rope_table(self, T, Hp, Wp):
@@ -609,9 +619,18 @@ class DiTEngine:
         key = (T, Hp, Wp, plain)
         if key not in self._rope:
             c = self.cfg
-            self._rope = {key: rope_cos_sin(c.attention_head_dim, c.rope_max_seq_len, c.rope_temporal_skip_len, T, Hp, Wp,
-                                            plain_temporal=plain).to(self.dev)}
+            if len(self._rope) >= 4:  # a handful of latent shapes per process (8 / 2 frames, + their sharded slices)
+                self._rope.pop(next(iter(self._rope)))
+            self._rope[key] = rope_cos_sin(c.attention_head_dim, c.rope_max_seq_len, c.rope_temporal_skip_len, T, Hp, Wp,
+                                           plain_temporal=plain).to(self.dev)
         return self._rope[key]
+
+    def is_warm(self, B: int, T: int, Hh: int, Ww: int) -> bool:
+        """Has a forward of exactly this shape already run through this engine (workspace and RoPE table resident)?  What a hipGraph
+        capture without a warm-up step requires (pipeline.GraphedDenoiser)."""
+        plain = bool(getattr(self.model, "rope_plain_temporal", False))
+        N = T * (Hh // 2) * (Ww // 2)
+        return (B * N) in self._ws and (T, Hh // 2, Ww // 2, plain) in self._rope
 
     # -- K3 + K13: conditioning-side work (step-invariant) -------------------------------
     def _context(self, text: torch.Tensor, image: Optional[torch.Tensor]):
