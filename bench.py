@@ -24,7 +24,7 @@ The JSON line carries:
   roofline         the single largest kernel launch shape (the batched self-attention at 7200 tokens), algorithmic FLOPs / mean
                    launch duration measured with HIP events on the launch stream in one extra profiled step after the timed
                    region, vs 2.5 PFLOP/s dense bf16; `traffic` from the committed rocprofv3 --pmc passes under profiles/;
-  roofline_family  the same accounting for ALL launches of the 256x256x64 GEMM kernel together (68 % of a step);
+  roofline_family  the same accounting for ALL launches of the 256x256x64 GEMM kernel together (72 % of a step);
   cpu_baseline     the CPU oracle (oracle/dit_oracle.py, "port") timed on this host's cores on ONE transformer block at the
                    same token count (rank 0, N=1 only; one warm-up + median of three), extrapolated to steps/sec;
   sec_per_edit     MEASURED end to end through ChronoEditPipeline for configs[2] (8-step distilled schedule, guidance 1) and,
@@ -112,6 +112,24 @@ def build_model(layers: int, dev):
     return m
 
 
+def _host_cores() -> int:
+    """Cores this process may actually use: os.cpu_count() reports the HOST's (256 on the GPU boxes) even when the container's cgroup
+    quota or affinity mask grants far fewer - 256 torch threads on a few granted cores made the round-3 CPU legs 20x slower than 8
+    threads on 8 cores."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _median_time(fn, runs=3, warm=1):
     ts = []
     for i in range(warm + runs):
@@ -126,7 +144,7 @@ def cpu_baseline(N: int, steps_fwd: int):
     """Oracle ("port") on the host cores: one full-width transformer block at N tokens, fp32; one warm-up run, then the
     median of three."""
     from oracle import dit_oracle as O
-    cores = os.cpu_count() or 1
+    cores = _host_cores()
     torch.set_num_threads(cores)
     cfg = O.DiTConfig(num_layers=1)
     g = torch.Generator().manual_seed(1)
@@ -139,22 +157,22 @@ def cpu_baseline(N: int, steps_fwd: int):
     with torch.no_grad():
         dt, times = _median_time(lambda: O.block_forward(p, 0, cfg, x, enc, temb6, rot))
     per_step = dt * 40 * steps_fwd
-    return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
+    return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, median of 3 after 1 warm-up = {dt:.2f} s "
                       f"(runs {', '.join(f'{t:.2f}' for t in times)}); x40 blocks x{steps_fwd} forwards/step"}
 
 
-def cpu_config0(with_reference: bool = True):
+def cpu_config0(with_reference: bool = True, depths=(1, 2, 4)):
     """BASELINE.json configs[0] on the host cores (SURVEY section 8d "Config 1"): the 14B width at 256x256 / 5 pixel frames
     (latents [1,16,2,32,32], N = 512 tokens), fp32 eager, 4 steps x 2 forwards.  Full depth in fp32 is 61 GiB of weights, so
-    the whole forward (embedders, L blocks, head) is timed at L = 1, 2, 4 and the per-block time is the slope; 40 blocks are
-    composed from it.  "port" = oracle/dit_oracle.py; "reference" = the reference's own ChronoEditTransformer3DModel
+    the whole forward (embedders, L blocks, head) is timed at L = 1, 2 (inside the default bench run) or 1, 2, 4 (`--cpu-only`) and the
+    per-block time is the slope; 40 blocks are composed from it.  "port" = oracle/dit_oracle.py; "reference" = the reference's own ChronoEditTransformer3DModel
     (chronoedit_diffusers/transformer_chronoedit.py) with oracle/refshim standing in for the diffusers leaf modules - only where
     /root/reference exists (the build container; not the GPU box)."""
     from oracle import dit_oracle as O
-    cores = os.cpu_count() or 1
+    cores = _host_cores()
     torch.set_num_threads(cores)
-    cfg4 = O.DiTConfig(num_layers=4)
+    cfg4 = O.DiTConfig(num_layers=max(depths))
     p4 = O.make_synthetic_params(cfg4, seed=1234)
     lat, text, image = O.make_synthetic_inputs(cfg4, 2, 32, 32, dtype=torch.float32)
     ts = torch.tensor([637])
@@ -165,37 +183,42 @@ def cpu_config0(with_reference: bool = True):
         keep = lambda k: (not k.startswith("blocks.")) or int(k.split(".")[1]) < L
         return {k: v for k, v in p4.items() if keep(k)}
 
-    def fit(times):  # forward(L) = a + b L  (least squares over L = 1, 2, 4)
-        Ls = [1.0, 2.0, 4.0]
-        mL, mt = sum(Ls) / 3, sum(times) / 3
+    def fit(Ls, times):  # forward(L) = a + b L  (least squares over the depths timed)
+        n = len(Ls)
+        mL, mt = sum(Ls) / n, sum(times) / n
         b = sum((l - mL) * (t - mt) for l, t in zip(Ls, times)) / sum((l - mL) ** 2 for l in Ls)
         return mt - b * mL, b
 
     legs = {}
+    t_start = time.perf_counter()
+    budget_s = 120.0  # the whole bench must stay within minutes on any host: depths beyond the budget are dropped (>= 2 are needed for the slope)
     with torch.no_grad():
-        t_port = []
-        for L in (1, 2, 4):
+        t_port, Ls_port = [], []
+        for L in depths:
+            if Ls_port and len(Ls_port) >= 2 and time.perf_counter() - t_start > budget_s:
+                break
             cfg = O.DiTConfig(num_layers=L)
             pl = sub(L)
-            dt, _ = _median_time(lambda: O.dit_forward(pl, cfg, lat, ts, text, image))
+            dt, _ = _median_time(lambda: O.dit_forward(pl, cfg, lat, ts, text, image), runs=2, warm=0 if Ls_port else 1)
             t_port.append(dt)
-        legs["port"] = t_port
+            Ls_port.append(L)
+        legs["port"] = (Ls_port, t_port)
         ref_py = "/root/reference/chronoedit_diffusers/transformer_chronoedit.py"
         if with_reference and os.path.exists(ref_py):
             sys.path.insert(0, os.path.join(ROOT, "oracle", "refshim"))
             from oracle import gen_golden as G
             mod = G.load_reference_module()
             t_ref = []
-            for L in (1, 2, 4):
+            for L in Ls_port:
                 m = G.build_reference_model(mod, O.DiTConfig(num_layers=L), sub(L))
-                dt, _ = _median_time(lambda: m(lat, ts, text, image, return_dict=False))
+                dt, _ = _median_time(lambda: m(lat, ts, text, image, return_dict=False), runs=2, warm=0 if t_ref else 1)
                 t_ref.append(dt)
                 del m
-            legs["reference"] = t_ref
-    for kind, tl in legs.items():
-        a0, b = fit(tl)
+            legs["reference"] = (Ls_port, t_ref)
+    for kind, (Ls, tl) in legs.items():
+        a0, b = fit([float(l) for l in Ls], tl)
         fwd40 = a0 + 40 * b
-        out[kind] = {"forward_s_at_L_1_2_4": [round(t, 3) for t in tl], "per_block_s": round(b, 4), "outside_blocks_s": round(max(a0, 0.0), 4),
+        out[kind] = {"depths": list(Ls), "forward_s_at_depths": [round(t, 3) for t in tl], "per_block_s": round(b, 4), "outside_blocks_s": round(max(a0, 0.0), 4),
                      "forward_40_blocks_s": round(fwd40, 2), "denoising_steps_per_sec": round(1.0 / (2 * fwd40), 5),
                      "sec_per_4_step_edit_dit_only": round(8 * fwd40, 1), "kind": kind}
     return out
@@ -411,7 +434,7 @@ def main():
             fam_ms = sum(d["total_ms"] for d in big.values())
             fam_fl = sum(d["work"] * d["n"] for d in big.values())
             fam = fam_fl / (fam_ms * 1e-3) / 1e12
-            roofline_family = {"kernel": "gemm_bf16_256 (every launch of the 256x256x64 LDS-DMA GEMM in the step, all epilogues)", "bound": "mfma",
+            roofline_family = {"kernel": "gemm_bf16_w4 (every launch of the 256x256x64 LDS-DMA GEMM in the step - one-wave-per-SIMD main loop, all epilogues)", "bound": "mfma",
                                "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
                                "launches": sum(d["n"] for d in big.values()), "total_ms": round(fam_ms, 3), "share_of_step": round(fam_ms / tot, 4)}
 
@@ -503,7 +526,7 @@ def main():
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(e)}
             try:  # BASELINE.json configs[0] (N = 512, fp32 CPU plumbing): the port here; port + the reference's own class in profiles/r03_cpu_legs.json
-                out["cpu_config0"] = cpu_config0(with_reference=False)
+                out["cpu_config0"] = cpu_config0(with_reference=False, depths=(1, 2))  # (1, 2, 4) + the reference class: bench.py --cpu-only
             except Exception as e:
                 out["cpu_config0"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
