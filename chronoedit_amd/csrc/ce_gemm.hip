@@ -227,13 +227,18 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
                                  int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
 extern "C" void ce_gemm256_set_staggered(int on);
+extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
 extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                    const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                    int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream);
 
-// kernel selection: -1 = automatic (256-tile LDS-DMA kernel, one-wave-per-SIMD main loop, for large shapes), 0 = always the
+// kernel selection: -1 = automatic (for large shapes the one-wave-per-SIMD LDS-DMA kernels, macro tile 384 x 256 or 256 x 256 by
+// the round count of the shape: prefer_tile384), 0 = always the
 // 128-tile kernel; whenever the shape allows the 256-tile kernel: 1 = its 8-wave / 8-phase main loop, 2 = the same staggered (two
-// wave groups one barrier apart), 3 / 4 = the one-wave-per-SIMD main loop of ce_gemm256w4.hip with an A ring of 3 / 2 stages, 5 = 3 stages and one barrier per K-tile
+// wave groups one barrier apart), 3 / 4 = the one-wave-per-SIMD main loop of ce_gemm256w4.hip with an A ring of 3 / 2 stages, 5 = 3 stages and one barrier per K-tile,
+// 6 = the 384 x 256 macro tile of ce_gemm384.hip (4 waves, 192 x 128 wave tiles, one barrier per K-tile)
 static int g_gemm_variant = -1;
 extern "C" int ce_set_gemm_variant(int v) {
   const int old = g_gemm_variant;
@@ -248,6 +253,40 @@ extern "C" int ce_set_gemm_variant(int v) {
 // ... and the same for W (w_seg_k, w_seg_stride): weights re-packed K-slab-major ([K/64][N][64]) so that every 16 KiB
 // half-tile of the LDS-DMA stream is one contiguous block (tools/probes/l2_pattern_probe.hip: 21.7 vs 18.3 TB/s for the
 // row-strided form).  Segmented W needs the 256-tile kernel (CE_ERR_SHAPE otherwise).
+extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+
+// Which macro tile for a large GEMM: 384 x 256 (ce_gemm384.hip) or 256 x 256 (ce_gemm256w4.hip)?  Their main loops run at the same
+// rate per flop within 1 % (profiles/r03_gemm_variants_ab.txt); what differs is how the tile count falls on the 256 CUs.  Cost model:
+// full rounds of workgroups, plus the last partial round - a whole round if it cannot be cut along K, 1 / split + an eighth of a
+// round (slab write, reduce launch) if it can - times the tile area.  M = 14400 at N = 5120: 1140 tiles of 256 x 256 = 4 rounds + a
+// half round + reduce against 760 tiles of 384 x 256 = 2.97 rounds (measured +3 ... +4 %); N = 13824: 12.02 against 8.02 rounds
+// (256 x 256 wins by 2.6 %); the V^T product (M = 5120 = 13.3 tiles of 384 rows: 5 % of padding) stays on 256 x 256.
+static bool prefer_tile384(int M, int N, int K) {
+  float* ws = nullptr;
+  size_t ws_bytes = 0;
+  int cus = 256;
+  ce_gemm256_workspace(&ws, &ws_bytes, &cus);
+  const int kt = K / 64;
+  auto cost = [&](int bm) -> double {
+    const long long nwg = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
+    const long long full = nwg / cus;
+    const int tail = (int)(nwg % cus);
+    double last = 0.0;
+    if (tail > 0) {
+      int split = 1;
+      if (ws != nullptr)
+        for (int sp = cus / tail < 8 ? cus / tail : 8; sp >= 2; --sp)
+          if (kt % (2 * sp) == 0 && (size_t)tail * sp * bm * 256 * sizeof(float) <= ws_bytes) {
+            split = sp;
+            break;
+          }
+      last = split > 1 ? 1.0 / split + 0.125 : 1.0;
+    }
+    return ((double)full + last) * bm * 256.0;
+  };
+  return cost(384) <= cost(256);
+}
+
 extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
@@ -266,6 +305,9 @@ extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const flo
     if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw)) {
       // the 256-tile kernel has two main loops: one wave per SIMD (ce_gemm256w4.hip; the default: +3...5 % on the step's shapes,
       // profiles/r03_gemm_variants_ab.txt) and the 8-wave / 8-phase loop of ce_gemm256.hip (variants 1, 2)
+      if (g_gemm_variant == 6 || (g_gemm_variant == -1 && prefer_tile384(M, N, K)))  // the 384 x 256 macro tile (ce_gemm384.hip)
+        return ce_gemm384_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
+                                 w_seg_k, w_seg_stride, stream);
       if (g_gemm_variant == 1 || g_gemm_variant == 2)
         return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
                                  w_seg_k, w_seg_stride, stream);

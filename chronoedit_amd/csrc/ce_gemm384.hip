@@ -1,0 +1,420 @@
+// 384x256x64 bf16 GEMM, one wave per SIMD: 4 waves (2 x 2), wave tile 192 x 128 - the macro tile the register file allows at most.
+// Same contract, epilogues, split-K tail and segmented operands as ce_gemm256.hip / ce_gemm256w4.hip (`ce_set_gemm_variant(6)`).
+//
+// Why: ce_gemm256w4.hip is bounded by energy per flop (76 % MFMA busy at a power-limited 1.78 GHz); what is
+// left is the bytes moved per flop.  A 384 x 256 tile needs (384 + 256) operand rows per 384 * 256 outputs: -17 % LDS-DMA / L2 /
+// fabric bytes per flop against 256 x 256, 12 + 8 fragment reads per 96 MFMAs and k-step instead of 8 + 8 per 64 (-17 %), and ONE
+// workgroup barrier per K-tile of 192 MFMAs per wave.
+//  * Accumulators: 12 x 8 tiles of v_mfma_f32_16x16x32_bf16 = 384 registers per lane: row fragments 0..7 in the 256 AGPRs, 8..11
+//    in 128 VGPRs (asm MFMAs, "+a" / "+v": D tied to C in place).  The other 128 VGPRs: TWO W fragment sets (k-step 0 / 1: 64), a
+//    ring of FOUR A fragments read from LDS three MFMA groups ahead of their use (16), addresses.
+//  * LDS: two stages of [A 384 rows | W 256 rows] x 128 B = 160 KiB; 16-byte chunk c of row r in slot c ^ ((r >> 1) & 7) on the
+//    source side of the LDS-DMA and on the read side.  Tile t computes from stage t % 2 while tile t + 1 ... t + 2 arrive.
+//  * A K-tile = 24 groups of 8 MFMAs (k-step G / 12, row fragment G % 12 against the 8 W fragments of the k-step).  Group G issues,
+//    between its MFMAs: the A fragment of group G + 3 (ring slot (G + 3) % 4), one W fragment of the tile's second k-step
+//    (groups 1..8) or of the NEXT tile's first k-step (groups 21..23), and LDS-DMA pieces of tile t + 2 (groups 21..23 and, in the
+//    next tile, 0..13: 12 A + 8 W pieces of 1 KiB per wave).
+//    The ONE barrier of a tile sits between groups 20 and 21, behind `vmcnt(0)` + `lgkmcnt(0)`: every fragment read of tile t has
+//    been issued and has completed by then (=> stage t % 2 may be overwritten by tile t + 2 from here on), and tile t + 1 has landed
+//    (its last piece was issued seven groups = ~900 MFMA cycles earlier) (=> its fragments may be read from here on).
+#include <algorithm>
+
+#include "ce_common.h"
+#include "ce_gemm_epi.h"
+
+namespace {
+
+constexpr int BM = 384, BN = 256, BK = 64;
+constexpr int A_TILE = BM * BK * 2;       // 48 KiB
+constexpr int W_TILE = BN * BK * 2;       // 32 KiB
+constexpr int STAGE = A_TILE + W_TILE;    // 80 KiB
+constexpr int CROW = BN * 2 + 16;         // padded epilogue staging row (528 B)
+constexpr int QROW = 128 * 2 + 16;        // padded staging row of a quadrant (split-K reduce)
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+#define X_BAR() __builtin_amdgcn_s_barrier()
+#define X_PIN() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ void tile_origin_384(int wg, int tiles_m, int tiles_n, int& m0, int& n0) {
+  constexpr int GROUP = 4;
+  const int group_sz = GROUP * tiles_n;
+  const int gid = wg / group_sz;
+  const int first_m = gid * GROUP;
+  const int gm = min(tiles_m - first_m, GROUP);
+  m0 = (first_m + (wg % group_sz) % gm) * BM;
+  n0 = ((wg % group_sz) / gm) * BN;
+}
+
+// one MFMA: row fragment F (operand a) against column fragment G (operand b); rows 0..7 accumulate in AGPRs, 8..11 in VGPRs
+template <int F>
+__device__ __forceinline__ void mma1(f32x4& acc, const bf16x8& b, const bf16x8& a) {
+  if constexpr (F < 8)
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+  else
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(b), "v"(a));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_384(
+    const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ bias,
+    const float* __restrict__ gate, const bf16* __restrict__ res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
+    int gate_rows, int tiles_m, int tiles_n, int t_full, int split, float* __restrict__ ws, uint32_t a_seg_magic,
+    uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  const bool partial = (int)blockIdx.x >= t_full;
+  int wg, kt0 = 0, ktn = K / BK;
+  if (!partial) {
+    wg = xcd_remap(blockIdx.x, t_full);
+  } else {
+    const int tb = blockIdx.x - t_full;
+    wg = t_full + tb / split;
+    ktn = ktn / split;
+    kt0 = (tb % split) * ktn;
+  }
+  int m0, n0;
+  tile_origin_384(wg, tiles_m, tiles_n, m0, n0);
+  const int kt_last = ktn - 1;
+
+  // LDS-DMA sources.  Piece p of this wave = rows 8 (wave + 4 p) .. + 8 of the operand tile (lane l: row + (l >> 3), slot l & 7 <- chunk
+  // slot ^ ((row >> 1) & 7), the same for every p).  The per-lane byte offset of piece p is min(off0 + p * 32 rows, last row): two
+  // VALU ops per piece instead of 20 resident offset registers (rows past the operand's end re-read its last row; never stored).
+  const int prow = 8 * wave + (lane >> 3);
+  const uint32_t pchunk = (uint32_t)(((lane & 7) ^ ((prow >> 1) & 7)) << 4);
+  const uint32_t a_off0 = (uint32_t)(m0 + prow) * (uint32_t)(lda * 2) + pchunk, a_lim = (uint32_t)(M - 1) * (uint32_t)(lda * 2) + pchunk;
+  const uint32_t w_off0 = (uint32_t)(n0 + prow) * (uint32_t)(ldw * 2) + pchunk, w_lim = (uint32_t)(N - 1) * (uint32_t)(ldw * 2) + pchunk;
+  const uint32_t a_pstride = (uint32_t)(32 * lda * 2), w_pstride = (uint32_t)(32 * ldw * 2);
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xffffffffu, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xffffffffu, 0x00020000);
+  auto koff = [&](int t, uint32_t magic, uint32_t extra) __attribute__((always_inline)) -> int {
+    const int ta = kt0 + min(t, kt_last);
+    return ta * (BK * 2) + (int)((((uint32_t)ta * magic) >> 16) * extra);
+  };
+  // piece q of a tile's 20 per wave: 0..11 = A pieces, 12..19 = W pieces
+  auto dma = [&](int q, int stage_bytes, int a_soff, int w_soff) __attribute__((always_inline)) {
+    if (q < 12) {
+      const uint32_t v = min(a_off0 + (uint32_t)q * a_pstride, a_lim);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + stage_bytes + (wave + 4 * q) * 1024), 16, v, a_soff, 0, 0);
+    } else {
+      const uint32_t v = min(w_off0 + (uint32_t)(q - 12) * w_pstride, w_lim);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + stage_bytes + A_TILE + (wave + 4 * (q - 12)) * 1024), 16, v, w_soff, 0, 0);
+    }
+  };
+
+  // fragment read addresses [stage parity][k-step]: row (wm*192 | wn*128) + f*16 + fr, chunk (fg + 4 ks) ^ (fr >> 1);  + f*2048
+  int a_rd[2][2], w_rd[2][2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      a_rd[par][ks] = par * STAGE + (wm * 192 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
+      w_rd[par][ks] = par * STAGE + A_TILE + (wn * 128 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
+    }
+
+  f32x4 acc[12][8];
+#pragma unroll
+  for (int f = 0; f < 12; ++f)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: tile 0 and the first three pieces of tile 1 on their way; tile 0 landed; W fragments of its first k-step and the A fragments of its groups 0..2 read
+  {
+    const int a0 = koff(0, a_seg_magic, a_seg_extra), w0 = koff(0, w_seg_magic, w_seg_extra);
+    const int a1 = koff(1, a_seg_magic, a_seg_extra), w1 = koff(1, w_seg_magic, w_seg_extra);
+#pragma unroll
+    for (int q = 0; q < 20; ++q) dma(q, 0, a0, w0);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dma(q, STAGE, a1, w1);  // (pieces 3..19 of tile 1 follow in groups 0..13 of tile 0, as in steady state)
+  }
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  X_BAR();
+  bf16x8 ring[4], bx[8], by[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bx[g] = *reinterpret_cast<const bf16x8*>(smem + w_rd[0][0] + g * 2048);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) ring[f] = *reinterpret_cast<const bf16x8*>(smem + a_rd[0][0] + f * 2048);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  X_PIN();
+
+  // group G (0..23) of the tile in stage PAR; T = index of that tile (runtime); fillers between the MFMAs, one scheduling region each
+#define X_GROUP(G, PAR, T)                                                                                                       \
+  {                                                                                                                              \
+    constexpr int ks_ = (G) / 12, f_ = (G) % 12;                                                                                 \
+    constexpr int gn_ = (G) + 3;                          /* the group whose A fragment is fetched now */                        \
+    constexpr bool nxt_ = gn_ >= 24;                      /* ... in the next tile (other stage; legal: G >= 21 is behind the barrier) */ \
+    constexpr int ksn_ = (nxt_ ? gn_ - 24 : gn_) / 12, fn_ = (nxt_ ? gn_ - 24 : gn_) % 12;                                       \
+    if ((G) == 21) {                                                                                                             \
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+      X_BAR();                                                                                                                   \
+      X_PIN();                                                                                                                   \
+    }                                                                                                                            \
+    bf16x8(&bb_)[8] = ks_ ? by : bx;                                                                                             \
+    mma1<f_>(acc[f_][0], bb_[0], ring[(G) % 4]);                                                                                 \
+    ring[gn_ % 4] = *reinterpret_cast<const bf16x8*>(smem + a_rd[nxt_ ? 1 - (PAR) : (PAR)][ksn_] + fn_ * 2048);                  \
+    X_PIN();                                                                                                                     \
+    mma1<f_>(acc[f_][1], bb_[1], ring[(G) % 4]);                                                                                 \
+    if ((G) >= 1 && (G) <= 8) by[((G) >= 1 && (G) <= 8) ? (G) - 1 : 0] = *reinterpret_cast<const bf16x8*>(smem + w_rd[(PAR)][1] + ((G) - 1) * 2048);          \
+    if ((G) == 21) { bx[0] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 0 * 2048);                              \
+                     bx[1] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 1 * 2048);                              \
+                     bx[2] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 2 * 2048); }                            \
+    if ((G) == 22) { bx[3] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 3 * 2048);                              \
+                     bx[4] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 4 * 2048);                              \
+                     bx[5] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 5 * 2048); }                            \
+    X_PIN();                                                                                                                     \
+    mma1<f_>(acc[f_][2], bb_[2], ring[(G) % 4]);                                                                                 \
+    if ((G) == 23) { bx[6] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 6 * 2048);                              \
+                     bx[7] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 7 * 2048); }                            \
+    X_PIN();                                                                                                                     \
+    mma1<f_>(acc[f_][3], bb_[3], ring[(G) % 4]);                                                                                 \
+    /* LDS-DMA of the tile two ahead of the one whose stage is being overwritten: pieces 0..2 in groups 21..23 (into THIS tile's   \
+       stage, free behind the barrier), pieces 3..19 in groups 0..13 of the next tile (= into the other stage, seen from there) */ \
+    if ((G) >= 21) dma((G) - 21, (PAR) * STAGE, a_soff_next, w_soff_next);                                                       \
+    if ((G) <= 2) { dma(3 + 2 * (G), (1 - (PAR)) * STAGE, a_soff_prev, w_soff_prev); }                                            \
+    if ((G) >= 3 && (G) <= 13) dma(6 + (G), (1 - (PAR)) * STAGE, a_soff_prev, w_soff_prev);                                        \
+    X_PIN();                                                                                                                     \
+    mma1<f_>(acc[f_][4], bb_[4], ring[(G) % 4]);                                                                                 \
+    if ((G) <= 2) { dma(4 + 2 * (G), (1 - (PAR)) * STAGE, a_soff_prev, w_soff_prev); }                                            \
+    X_PIN();                                                                                                                     \
+    mma1<f_>(acc[f_][5], bb_[5], ring[(G) % 4]);                                                                                 \
+    mma1<f_>(acc[f_][6], bb_[6], ring[(G) % 4]);                                                                                 \
+    mma1<f_>(acc[f_][7], bb_[7], ring[(G) % 4]);                                                                                 \
+    X_PIN();                                                                                                                     \
+  }
+  // pieces of groups 0..13: 3,4 | 5,6 | 7,8 | 9 .. 19  (two per group in groups 0..2, one per group in 3..13: 6 + 11 = 17)
+#define X_TILE(PAR, T)                                                                                                           \
+  {                                                                                                                              \
+    /* groups 0..13 finish the transfer of tile T + 1 (started in groups 21..23 of tile T - 1, into stage 1 - PAR);              \
+       groups 21..23 start the transfer of tile T + 2 (into stage PAR) */                                                       \
+    const int a_soff_prev = koff((T) + 1, a_seg_magic, a_seg_extra), w_soff_prev = koff((T) + 1, w_seg_magic, w_seg_extra);       \
+    const int a_soff_next = koff((T) + 2, a_seg_magic, a_seg_extra), w_soff_next = koff((T) + 2, w_seg_magic, w_seg_extra);       \
+    X_GROUP(0, PAR, T) X_GROUP(1, PAR, T) X_GROUP(2, PAR, T) X_GROUP(3, PAR, T) X_GROUP(4, PAR, T) X_GROUP(5, PAR, T)             \
+    X_GROUP(6, PAR, T) X_GROUP(7, PAR, T) X_GROUP(8, PAR, T) X_GROUP(9, PAR, T) X_GROUP(10, PAR, T) X_GROUP(11, PAR, T)           \
+    X_GROUP(12, PAR, T) X_GROUP(13, PAR, T) X_GROUP(14, PAR, T) X_GROUP(15, PAR, T) X_GROUP(16, PAR, T) X_GROUP(17, PAR, T)       \
+    X_GROUP(18, PAR, T) X_GROUP(19, PAR, T) X_GROUP(20, PAR, T) X_GROUP(21, PAR, T) X_GROUP(22, PAR, T) X_GROUP(23, PAR, T)       \
+  }
+
+  const int npairs = ktn >> 1;
+  for (int it = 0; it < npairs; ++it) {
+    const int t = 2 * it;
+    X_TILE(0, t)
+    X_TILE(1, t + 1)
+  }
+#undef X_TILE
+#undef X_GROUP
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  X_BAR();
+
+  if (partial) {  // split-K tail piece: fp32 slab [wave][f][g][lane] for gemm384_reduce
+    float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
+#pragma unroll
+    for (int f = 0; f < 12; ++f)
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        *reinterpret_cast<f32x4*>(slab + (((wave * 96 + f * 8 + g) * 64) + lane) * 4) = acc[f][g];
+    return;
+  }
+
+  // ---- epilogue: six passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave = tile rows wm*192 + p*32 + [0,32))
+  f32x4 bcol[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int n = n0 + wn * 128 + g * 16 + fg * 4;
+    bcol[g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  constexpr bool prefetch = EPI == EPI_GATE_RES;  // (the launcher sends 0 < gate_rows < BM to the 8-wave kernel)
+  u32x4 rv[3][8];
+  f32x4 gA0, gA1, gB0, gB1;
+  int g_switch = 0x7fffffff;
+  const int my_n = n0 + (tid & 31) * 8, my_nc = min(my_n, N - 8);
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
+  if (EPI == EPI_GATE_RES && prefetch) {
+    gA0 = gA1 = gB0 = gB1 = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (gate != nullptr) {
+      const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
+      const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
+      const float* ga = gate + (size_t)s0 * N + my_nc;
+      const float* gb = gate + (size_t)s1 * N + my_nc;
+      gA0 = *reinterpret_cast<const f32x4*>(ga);
+      gA1 = *reinterpret_cast<const f32x4*>(ga + 4);
+      gB0 = *reinterpret_cast<const f32x4*>(gb);
+      gB1 = *reinterpret_cast<const f32x4*>(gb + 4);
+      if (s1 != s0) g_switch = s1 * gate_rows;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    if (EPI == EPI_GATE_RES && prefetch && (p == 0 || p == 3)) {  // the residual chunks of three passes at a time (96 registers)
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const int rl = (tid + 256 * tt) >> 5;
+          const int m = min(m0 + (rl >> 5) * 192 + (p + pp) * 32 + (rl & 31), M - 1);
+          rv[pp][tt] = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + my_nc);
+        }
+    }
+    if (p > 0) __syncthreads();
+#pragma unroll
+    for (int ff = 0; ff < 2; ++ff) {
+      const int f = 2 * p + ff;
+      float brow = 0.f;
+      if (EPI == EPI_BIAS_ROW) brow = bias[min(m0 + wm * 192 + f * 16 + fr, M - 1)];
+      const int rl = wm * 32 + ff * 16 + fr;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int cl = wn * 128 + g * 16 + fg * 4;
+        f32x4 bv = bcol[g];
+        if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow;
+        const f32x4 v = acc[f][g];
+        const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
+        *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
+      }
+    }
+    __syncthreads();
+    if (EPI == EPI_GATE_RES && prefetch) {
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int rl = (tid + 256 * tt) >> 5;
+        const int m = m0 + (rl >> 5) * 192 + p * 32 + (rl & 31);
+        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + (tid & 31) * 16);
+        const bool second = m >= g_switch;
+        const f32x4 g0 = second ? gB0 : gA0, g1 = second ? gB1 : gA1;
+        const u32x4 r = rv[p % 3][tt];
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
+          o[q] = pack_bf16(mul_then_add(bf16lo(y[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(y[q]), gb, bf16hi(r[q])));
+        }
+        const uint32_t coff = (m < M && my_n < N) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)my_n * 2u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
+      }
+    } else if (EPI != EPI_GATE_RES) {
+      epi_chunks<EPI, 8>(smem, CROW,
+                         [&](int tt, int& rl, int& cc, int& mr) {
+                           const int c = tid + 256 * tt;
+                           rl = c >> 5;
+                           cc = c & 31;
+                           mr = (rl >> 5) * 192 + p * 32 + (rl & 31);
+                         },
+                         m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+    }
+  }
+}
+
+// Sums the `split` fp32 slabs of one wave quadrant (192 x 128 accumulators) of a tail tile and applies the epilogue.
+// grid = 4 x the number of tail tiles, 256 threads: thread (w, lane) takes accumulator rows f = 3w .. 3w + 2 of the quadrant.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm384_reduce(bf16* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ gate,
+                                                      const bf16* __restrict__ res, int M, int N, int ldc, int ldres, int gate_rows,
+                                                      int tiles_m, int tiles_n, int t_full, int split, const float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;  // q = producer wave = (wm, wn)
+  int m0, n0;
+  tile_origin_384(t_full + tile, tiles_m, tiles_n, m0, n0);
+  m0 += (q >> 1) * 192;
+  n0 += (q & 1) * 128;
+  const float* slab = ws + (size_t)tile * split * (BM * BN);
+#pragma unroll
+  for (int ff = 0; ff < 3; ++ff) {
+    const int f = 3 * w + ff;
+    const int rl = f * 16 + fr;
+    float brow = 0.f;
+    if (EPI == EPI_BIAS_ROW) brow = bias[min(m0 + rl, M - 1)];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int cl = g * 16 + fg * 4;
+      f32x4 bv = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n0 + cl, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow;
+      const int e = (((q * 96 + f * 8 + g) * 64) + lane) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
+      for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
+      const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
+      *reinterpret_cast<u32x2*>(smem + rl * QROW + cl * 2) = pk;
+    }
+  }
+  __syncthreads();
+  epi_chunks<EPI, 12>(smem, QROW, [&](int tt, int& rl, int& cc, int& mr) { const int c = tid + 256 * tt; rl = mr = c >> 4; cc = c & 15; }, m0, n0,
+                      C, gate, res, M, N, ldc, ldres, gate_rows);
+}
+
+}  // namespace
+
+extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
+
+extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
+  if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32)))
+    return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
+                             w_seg_stride, stream);
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n, kt = K / BK;
+  uint32_t a_seg_magic = 0, a_seg_extra = 0, w_seg_magic = 0, w_seg_extra = 0;
+  auto seg = [&](int seg_k, long long seg_stride, uint32_t& magic, uint32_t& extra_out) -> int {
+    if (seg_k <= 0 || seg_k >= K) return CE_OK;
+    if (seg_k % BK) return CE_ERR_SHAPE;
+    const int tps = seg_k / BK;
+    magic = 65536u / (uint32_t)tps + 1u;
+    for (int t = 0; t < kt; ++t)
+      if ((int)(((uint32_t)t * magic) >> 16) != t / tps) return CE_ERR_SHAPE;
+    const long long extra = (seg_stride - seg_k) * 2;
+    if (extra < 0 || extra * (K / seg_k) + (long long)K * 2 >= (1ll << 31)) return CE_ERR_SHAPE;
+    extra_out = (uint32_t)extra;
+    return CE_OK;
+  };
+  if (int rc = seg(a_seg_k, a_seg_stride, a_seg_magic, a_seg_extra)) return rc;
+  if (int rc = seg(w_seg_k, w_seg_stride, w_seg_magic, w_seg_extra)) return rc;
+  float* g_ws = nullptr;
+  size_t g_ws_bytes = 0;
+  int g_cus = 256;
+  ce_gemm256_workspace(&g_ws, &g_ws_bytes, &g_cus);
+  int tail = nwg % g_cus, split = 1;
+  if (tail > 0 && g_ws != nullptr) {
+    for (int s = std::min(g_cus / tail, 8); s >= 2; --s)
+      if (kt % (2 * s) == 0 && (size_t)tail * s * BM * BN * sizeof(float) <= g_ws_bytes) {
+        split = s;
+        break;
+      }
+  }
+  if (split == 1) tail = 0;
+  const int t_full2 = nwg - tail;
+  dim3 grid(t_full2 + tail * split), block(256);
+  const int lds = 2 * STAGE;
+  static bool attr_done_[CE_MAX_DEVICES][8] = {};
+  bool* attr_done = attr_done_[ce_device_slot()];
+#define CE_LAUNCH(E)                                                                                                       \
+  do {                                                                                                                     \
+    if (!attr_done[E]) {                                                                                                   \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_384<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
+      (void)hipFuncSetAttribute((const void*)gemm384_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 192 * QROW);   \
+      attr_done[E] = true;                                                                                                 \
+    }                                                                                                                      \
+    hipLaunchKernelGGL((gemm_bf16_384<E>), grid, block, lds, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+                       (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
+                       a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                                \
+    if (tail)                                                                                                              \
+      hipLaunchKernelGGL((gemm384_reduce<E>), dim3(4 * tail), block, 192 * QROW, stream, (bf16*)C, bias, gate,             \
+                         (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);           \
+  } while (0)
+  switch (epilogue) {
+    case EPI_BIAS: CE_LAUNCH(EPI_BIAS); break;
+    case EPI_BIAS_GELU: CE_LAUNCH(EPI_BIAS_GELU); break;
+    case EPI_GATE_RES: CE_LAUNCH(EPI_GATE_RES); break;
+    case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
+    case EPI_BIAS_ROW: CE_LAUNCH(EPI_BIAS_ROW); break;
+    default: return CE_ERR_ARG;
+  }
+#undef CE_LAUNCH
+  return (int)hipGetLastError();
+}

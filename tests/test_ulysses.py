@@ -201,7 +201,7 @@ def test_gemm_with_k_segmented_operand(M, N, K, S, epi):
     want = ops.gemm(a, w, b, **kw)
     got = ops.gemm(seg, w, b, **kw)
     assert torch.equal(got, want), (got.float() - want.float()).abs().max()
-    for variant in (0, 1):  # both kernels explicitly
+    for variant in (0, 1, 4, 6):  # every kernel / main loop explicitly
         ops.set_gemm_variant(variant)
         try:
             assert torch.equal(ops.gemm(seg, w, b, **kw), ops.gemm(a, w, b, **kw))

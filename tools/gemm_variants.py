@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chronoedit_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
-NAMES = {0: "tile128", 1: "w8", 2: "w8stag", 3: "w4-3st", 4: "w4", 5: "w4-1bar"}
+NAMES = {0: "tile128", 1: "w8", 2: "w8stag", 3: "w4-3st", 4: "w4", 5: "w4-1bar", 6: "384x256"}
 
 
 def main():
