@@ -65,6 +65,24 @@ def test_one_wave_per_simd_gemm_keeps_its_accumulators_in_place():
         assert not any(op.startswith("v_accvgpr") or op.startswith("scratch") for op in c), (name, c)
 
 
+def test_tile384_gemm_keeps_its_384_accumulators_in_place():
+    """ce_gemm384.hip: 384 accumulator registers per lane (256 AGPRs + 128 VGPRs) out of 512; per trip of the K loop (two K-tiles of
+    a 192x128 wave tile) exactly 384 MFMAs, 80 fragment reads (48 A through the ring + 32 W), 40 LDS-DMA pieces and ONE barrier per
+    K-tile; nothing moves between register files and nothing spills inside the loop (the gate + residual epilogue parks a few
+    registers in scratch AFTER the loop: bounded here)."""
+    src = os.path.join(CSRC, "ce_gemm384.hip")
+    for r in _pick(_rows("ce_gemm384.hip"), "gemm_bf16_384"):
+        assert r[2] <= 512 and r[4] == 384, r
+        assert r[3] <= (128 if "ILi2E" in r[0] else 0), f"{r[0]}: scratch"
+    loops = isa_lint.inner_loops(src, "gemm_bf16_384")
+    assert len(loops) == 5
+    for name, c in loops:
+        assert c.get("v_mfma_f32_16x16x32_bf16", 0) == 384, (name, c)
+        assert c.get("ds_read_b128", 0) == 80 and c.get("buffer_load_dwordx4", 0) == 40, (name, c)
+        assert c.get("s_barrier", 0) == 2, (name, c)
+        assert not any(op.startswith("v_accvgpr") or op.startswith("scratch") for op in c), (name, c)
+
+
 def test_row_kernels_issue_their_row_loads_back_to_back():
     rows = _rows("ce_rowops.hip")
     (rr,) = _pick(rows, "rmsnorm_rope_kernel", "ILb1E")  # FULL variant (D = 5120)

@@ -44,8 +44,9 @@ def loop_scratch_free(path, kernel_substr):
 
 
 def inner_loops(path, kernel_substr):
-    """[(kernel, {mnemonic: count})] for the innermost loop (the block chain from the `Inner Loop Header` label to the backward
-    branch) of every kernel whose mangled name contains `kernel_substr`: what the K loop of a GEMM actually issues per trip."""
+    """[(kernel, {mnemonic: count})] for the first innermost loop (its header block plus every block the assembler annotates as
+    `in Loop: Header=<that block>` - hipcc rotates loops, so part of the body may sit in front of the header) of every kernel whose
+    mangled name contains `kernel_substr`: what the K loop of a GEMM actually issues per trip."""
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-S", "--cuda-device-only", path, "-o", asm],
@@ -54,17 +55,18 @@ def inner_loops(path, kernel_substr):
     out = []
     for m in re.finditer(r"^(\S*" + re.escape(kernel_substr) + r"\S*):\s*; @\1$", text, flags=re.M):
         body = text[m.end():text.index(".Lfunc_end", m.end())]
-        h = re.search(r"^(\.LBB[0-9_]+):\s*; =>This Inner Loop Header", body, flags=re.M)
+        h = re.search(r"^\.L(BB[0-9_]+):\s*; =>This Inner Loop Header", body, flags=re.M)
         if not h:
             continue
-        rest = body[h.end():]
-        back = re.search(r"s_cbranch_\w+ " + re.escape(h.group(1)) + r"\b", rest)
-        loop = rest[:back.end()] if back else rest
-        counts = {}
-        for l in loop.split("\n"):
-            l = l.strip()
-            if l and l[0] not in ";." and not l.endswith(":"):
-                op = l.split()[0]
+        hdr = h.group(1)
+        counts, inside = {}, False
+        for l in body.split("\n"):
+            s = l.strip()
+            if re.match(r"^(\.LBB[0-9_]+:|; %bb\.[0-9]+:)", s):  # a block starts: does it belong to the loop?
+                inside = s.startswith(".L" + hdr + ":") or ("in Loop: Header=" + hdr + " ") in s
+                continue
+            if inside and s and s[0] not in ";." and not s.endswith(":"):
+                op = s.split()[0]
                 counts[op] = counts.get(op, 0) + 1
         out.append((m.group(1), counts))
     return out
