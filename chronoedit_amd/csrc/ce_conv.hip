@@ -281,6 +281,61 @@ extern "C" int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames,
   return (int)hipGetLastError();
 }
 
+// ---- 3 x 3 (x 3) stride-1 convolutions of >= 128 output channels on the 256 x 256 x 64 LDS-DMA GEMM (ce_gemm256w4.hip) -------------
+// On bordered channels-last frames a stride-1 3 x 3 x 3 convolution IS a GEMM whose A rows are linear in memory: count output
+// positions on the PADDED grid, p = (t Hp + hp) Wp + wp, and tap (kt, kh, kw) of output position p reads input position
+// p + kt Hp Wp + (kh - 1) Wp + (kw - 1) of a stack of frames - a constant offset.  So A = the input stack itself with lda = Cin, row
+// r <-> position r + Wp + 1 (the first interior pixel; every address is then >= the stack's base), K = 27 Cin walked tap by tap: kw runs
+// on contiguously (the next pixel), kh jumps a pixel row, kt a frame - a K-segmented operand on two nested levels, one scalar offset
+// per K-tile.  C = the output stack, linear in the same row index.  Rows that fall on border positions (under 1 % of them) are computed
+// and then zeroed again by zero_border_kernel: the border is the next layer's padding.  K-tiles are consumed in pairs: an odd count is
+// padded by one tile whose weight columns are zero and whose A tile lies three frames (KT = 3) or three pixel rows plus one frame
+// (KT = 1) further on - the caller keeps one zeroed slack frame behind the last input frame.
+// Reference: CausalConv3d, wan2pt1.py:42-60 (the two front frames of the stack are its causal padding / feat_cache).
+namespace {
+__global__ __launch_bounds__(256) void zero_border_kernel(bf16* __restrict__ y, int T, int Hp, int Wp, int C8, int ld8) {
+  // border pixels of a frame: rows 0 and Hp-1 (Wp each), columns 0 and Wp-1 of the rows between (2 (Hp - 2))
+  const int per = 2 * Wp + 2 * (Hp - 2);
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)T * per * C8) return;
+  const int c = (int)(idx % C8);
+  const long long r = idx / C8;
+  const int t = (int)(r / per), b = (int)(r % per);
+  int hp, wp;
+  if (b < Wp) { hp = 0; wp = b; }
+  else if (b < 2 * Wp) { hp = Hp - 1; wp = b - Wp; }
+  else { const int q = b - 2 * Wp; hp = 1 + (q >> 1); wp = (q & 1) ? Wp - 1 : 0; }
+  *reinterpret_cast<u32x4*>(y + ((((size_t)t * Hp + hp) * Wp + wp) * ld8 + c) * 8) = u32x4{0u, 0u, 0u, 0u};
+}
+}  // namespace
+
+extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const void* res, int M, int N,
+                                        int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
+                                        long long a_seg2_stride, hipStream_t stream);
+
+extern "C" int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
+                                   int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, hipStream_t stream) {
+  if (!in_stack || !weight || !out_stack) return CE_ERR_ARG;
+  if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3)) return CE_ERR_SHAPE;
+  if ((Cin % 64) || (Cout & 7) || (out_cstride & 7) || out_cstride < Cout) return CE_ERR_SHAPE;
+  const int Hp = H + 2, Wp = W + 2;
+  const int ktiles = KT * 9 * (Cin / 64), kpad = (ktiles + 1) / 2 * 2 * 64;
+  if (ldw < kpad || (ldw & 7)) return CE_ERR_SHAPE;
+  const long long rows = (long long)T_out * Hp * Wp - 2ll * (Wp + 1);
+  if (rows <= 0 || rows * Cin * 2 >= (1ll << 32) || rows * out_cstride * 2 >= (1ll << 32)) return CE_ERR_SHAPE;
+  const size_t shift = (size_t)(Wp + 1);
+  bf16* c0 = (bf16*)out_stack + shift * out_cstride;
+  const bf16* r0 = res_stack ? (const bf16*)res_stack + shift * out_cstride : nullptr;
+  const int rc = ce_gemm256w4_seg2_launch(in_stack, weight, c0, bias, res_stack ? 2 /* EPI_GATE_RES, no gate: bf16(res + bf16(acc + bias)) */ : 0,
+                                          r0, (int)rows, Cout, kpad, Cin, ldw, out_cstride, out_cstride, 3 * Cin, (long long)Wp * Cin, 9 * Cin,
+                                          (long long)Hp * Wp * Cin, stream);
+  if (rc != CE_OK) return rc;
+  const long long n = (long long)T_out * (2 * Wp + 2 * (Hp - 2)) * (Cout / 8);
+  hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16*)out_stack, T_out, Hp, Wp, Cout / 8,
+                     out_cstride / 8);
+  return (int)hipGetLastError();
+}
+
 extern "C" int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,
                                 int out_border, int apply_silu, hipStream_t stream) {
   if (!x || !y || !gamma || npix <= 0) return CE_ERR_ARG;

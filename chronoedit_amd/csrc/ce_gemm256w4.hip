@@ -62,12 +62,14 @@ struct FragSet {
 // loop sits behind explicit wait states.
 #define W4_MMA(F, G, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((S).b[G]), "v"((S).a[F]))
 
-template <int EPI, int NSA, bool ONEBAR>
+// SEG2: the A operand is K-segmented on TWO nested levels (`ce_gemm256w4_seg2_launch`: the taps of a 3 x 3 x 3 convolution over
+// channels-last frames - kw runs on contiguously, kh jumps a pixel row, kt a frame; ce_conv.hip) - one more scalar multiply per K-tile.
+template <int EPI, int NSA, bool ONEBAR, bool SEG2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4(
     const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ bias,
     const float* __restrict__ gate, const bf16* __restrict__ res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
     int gate_rows, int tiles_m, int tiles_n, int t_full, int split, float* __restrict__ ws, uint32_t a_seg_magic,
-    uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra) {
+    uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra, uint32_t a_seg2_magic, uint32_t a_seg2_extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int W_RING = NSA * TILE;
   constexpr int VMW = 8 * (NSA - 1);
@@ -106,6 +108,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ta = kt0 + min(t, kt_last);
     return ta * (BK * 2) + (int)((((uint32_t)ta * magic) >> 16) * extra);
   };
+  auto koff_a = [&](int t) __attribute__((always_inline)) -> int {
+    int o = koff(t, a_seg_magic, a_seg_extra);
+    if (SEG2) o += (int)((((uint32_t)(kt0 + min(t, kt_last)) * a_seg2_magic) >> 16) * a_seg2_extra);
+    return o;
+  };
   auto dma_a = [&](int p, int stage_bytes, int soff) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + stage_bytes + (wave + 4 * p) * 1024), 16, a_voff[p], soff, 0, 0);
   };
@@ -138,8 +145,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // prologue: tiles 0, 1 (and A of tile 2)
   {
-    const int a0 = koff(0, a_seg_magic, a_seg_extra), w0 = koff(0, w_seg_magic, w_seg_extra);
-    const int a1 = koff(1, a_seg_magic, a_seg_extra), w1 = koff(1, w_seg_magic, w_seg_extra);
+    const int a0 = koff_a(0), w0 = koff(0, w_seg_magic, w_seg_extra);
+    const int a1 = koff_a(1), w1 = koff(1, w_seg_magic, w_seg_extra);
 #pragma unroll
     for (int p = 0; p < 8; ++p) dma_a(p, 0, a0);
 #pragma unroll
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int p = 0; p < 8; ++p) dma_w(p, TILE, w1);
     if (NSA == 3 && !ONEBAR) {
-      const int a2 = koff(2, a_seg_magic, a_seg_extra);
+      const int a2 = koff_a(2);
 #pragma unroll
       for (int p = 0; p < 8; ++p) dma_a(p, 2 * TILE, a2);
     }
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int a_next = (a_st + TILE == NSA * TILE) ? 0 : a_st + TILE;                                          \
     const int a_nn = (a_next + TILE == NSA * TILE) ? 0 : a_next + TILE;                                        \
     const int wsoff = koff((T) + 2, w_seg_magic, w_seg_extra);                                                 \
-    const int asoff = koff((T) + (ONEBAR ? 2 : NSA), a_seg_magic, a_seg_extra);                                \
+    const int asoff = koff_a((T) + (ONEBAR ? 2 : NSA));                                                        \
     const int a_dst = ONEBAR ? a_nn : a_st;                                                                     \
     if (!ONEBAR) W4_BAR();                                                                                      \
     W4_UNIT0(0, K0, WP, wsoff) W4_UNIT0(1, K0, WP, wsoff) W4_UNIT0(2, K0, WP, wsoff) W4_UNIT0(3, K0, WP, wsoff) \
@@ -368,9 +375,13 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
-extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
-                                   const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                   int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream) {
+static int w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res, int M, int N,
+                     int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride, int w_seg_k,
+                     long long w_seg_stride, int a_seg2_k, long long a_seg2_stride, int nsa, hipStream_t stream) {
+  const bool seg2 = a_seg2_k > 0;
+  if (seg2 && (a_seg_k <= 0 || a_seg2_k % a_seg_k || (epilogue != EPI_BIAS && epilogue != EPI_GATE_RES) || nsa != 2 ||
+               (epilogue == EPI_GATE_RES && gate != nullptr)))
+    return CE_ERR_ARG;
   // the prefetched gated-residual epilogue holds ONE or TWO samples' gate rows per tile: gate rows shorter than a tile -> 8-wave kernel
   // ... and stores through a 32-bit-offset buffer descriptor
   if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32)))
@@ -393,12 +404,24 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
   };
   if (int rc = seg(a_seg_k, a_seg_stride, a_seg_magic, a_seg_extra)) return rc;
   if (int rc = seg(w_seg_k, w_seg_stride, w_seg_magic, w_seg_extra)) return rc;
+  uint32_t a_seg2_magic = 0, a_seg2_extra = 0;
+  if (seg2 && a_seg2_k < K) {  // second level: every a_seg2_k columns the source jumps to a_seg2_stride (both in elements), nested in the first
+    if (a_seg2_k % BK) return CE_ERR_SHAPE;
+    const int tps = a_seg2_k / BK;
+    a_seg2_magic = 65536u / (uint32_t)tps + 1u;
+    for (int t = 0; t < kt; ++t)
+      if ((int)(((uint32_t)t * a_seg2_magic) >> 16) != t / tps) return CE_ERR_SHAPE;
+    const long long extra = (a_seg2_stride - (long long)(a_seg2_k / a_seg_k) * a_seg_stride) * 2;
+    const long long reach = ((long long)(K - 1) / a_seg2_k) * a_seg2_stride * 2 + (long long)(a_seg2_k / a_seg_k) * a_seg_stride * 2 + (long long)a_seg_k * 2;
+    if (extra < 0 || reach >= (1ll << 31)) return CE_ERR_SHAPE;
+    a_seg2_extra = (uint32_t)extra;
+  }
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
   int g_cus = 256;
   ce_gemm256_workspace(&g_ws, &g_ws_bytes, &g_cus);
   int tail = nwg % g_cus, split = 1;
-  if (tail > 0 && g_ws != nullptr) {
+  if (tail > 0 && g_ws != nullptr && !seg2) {
     for (int s = std::min(g_cus / tail, 8); s >= 2; --s)
       if (kt % (2 * s) == 0 && (size_t)tail * s * BM * BN * sizeof(float) <= g_ws_bytes) {
         split = s;
@@ -409,6 +432,25 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
   const int t_full2 = nwg - tail;
   dim3 grid(t_full2 + tail * split), block(256);
   const int lds3 = 5 * TILE, lds2 = 4 * TILE;
+  if (seg2) {
+    static bool seg2_done_[CE_MAX_DEVICES] = {};
+    bool& seg2_done = seg2_done_[ce_device_slot()];
+    if (!seg2_done) {
+      if (hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_BIAS, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess)
+        return CE_ERR_ARG;
+      seg2_done = true;
+    }
+    if (epilogue == EPI_BIAS)
+      hipLaunchKernelGGL((gemm_bf16_w4<EPI_BIAS, 2, false, true>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate,
+                         (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, a_seg_magic,
+                         a_seg_extra, w_seg_magic, w_seg_extra, a_seg2_magic, a_seg2_extra);
+    else
+      hipLaunchKernelGGL((gemm_bf16_w4<EPI_GATE_RES, 2, false, true>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias,
+                         gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, a_seg_magic,
+                         a_seg_extra, w_seg_magic, w_seg_extra, a_seg2_magic, a_seg2_extra);
+    return (int)hipGetLastError();
+  }
   static bool attr_done_[CE_MAX_DEVICES][8] = {};
   bool* attr_done = attr_done_[ce_device_slot()];
 #define CE_LAUNCH(E)                                                                                                       \
@@ -423,15 +465,15 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
     if (nsa == 1)                                                                                                          \
       hipLaunchKernelGGL((gemm_bf16_w4<E, 3, true>), grid, block, lds3, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
                          (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
-                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
+                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra, 0u, 0u);                                      \
     else if (nsa == 3)                                                                                                     \
       hipLaunchKernelGGL((gemm_bf16_w4<E, 3, false>), grid, block, lds3, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
                          (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
-                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
+                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra, 0u, 0u);                                      \
     else                                                                                                                   \
       hipLaunchKernelGGL((gemm_bf16_w4<E, 2, false>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
                          (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
-                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                              \
+                         a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra, 0u, 0u);                                      \
     if (tail)                                                                                                              \
       hipLaunchKernelGGL((gemm256w4_reduce<E>), dim3(4 * tail), block, 128 * QROW, stream, (bf16*)C, bias, gate,           \
                          (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);           \
@@ -446,4 +488,20 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
   }
 #undef CE_LAUNCH
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                   const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                   int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream) {
+  return w4_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k, w_seg_stride,
+                   0, 0, nsa, stream);
+}
+
+// A with TWO nested segment levels: column k of row m lives at A + (k / a_seg2_k) a_seg2_stride + ((k % a_seg2_k) / a_seg_k) a_seg_stride +
+// m lda + k % a_seg_k (elements).  EPI_BIAS or the plain residual add (EPI_GATE_RES without a gate); no split-K.
+extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const void* res, int M, int N,
+                                        int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
+                                        long long a_seg2_stride, hipStream_t stream) {
+  return w4_launch(A, W, C, bias, epilogue, nullptr, res, M, N, K, lda, ldw, ldc, ldres, 0, a_seg_k, a_seg_stride, 0, 0, a_seg2_k, a_seg2_stride,
+                   2, stream);
 }

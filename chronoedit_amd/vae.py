@@ -34,10 +34,17 @@ def _pad32(c):
 
 
 class Frames:
-    """T channels-last frames with a zero border: data [T, H+2, W+2, C] bf16."""
+    """T channels-last frames with a zero border: data [T, H+2, W+2, C] bf16.  front >= 0 / slack: the frames live inside a larger
+    contiguous `stack` [front + T + 1] with `front` frames of room before them (the causal padding / cache frames of the conv that
+    reads them) and one zeroed slack frame behind - the operand layout of ce_conv3d_gemm_bf16."""
 
-    def __init__(self, T, H, W, C, device, data=None):
+    def __init__(self, T, H, W, C, device, data=None, front=None):
         self.T, self.H, self.W, self.C = T, H, W, C
+        self.stack, self.front = None, 0
+        if front is not None:
+            self.stack = torch.zeros((front + T + 1, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
+            self.front = front
+            data = self.stack[front : front + T]
         self.data = data if data is not None else torch.zeros((T, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
 
     def frame_list(self):
@@ -63,6 +70,17 @@ class _ConvPack:
             self.b = torch.zeros(cout_p, dtype=torch.float32, device=w.device)
             self.b[:Cout] = b.float()
         self.Cout, self.Cout_p, self.Cin_p, self.k = Cout, cout_p, cin_p, (KT, KH, KW)
+        self._w_gemm = None
+
+    def gemm_weight(self) -> torch.Tensor:
+        """[Cout_pad8][K-tiles rounded up to even x 64]: the same taps-major rows, zero columns behind them (ce_conv3d_gemm_bf16)."""
+        if self._w_gemm is None:
+            k = self.w.shape[1] * self.w.shape[2]
+            kpad = ((k // 64) + 1) // 2 * 2 * 64
+            wg = torch.zeros((self.w.shape[0], kpad), dtype=torch.bfloat16, device=self.w.device)
+            wg[:, :k] = self.w.reshape(self.w.shape[0], k)
+            self._w_gemm = wg
+        return self._w_gemm
 
 
 class WanVAEEngine:
@@ -84,6 +102,7 @@ class WanVAEEngine:
             elif k.endswith("gamma"):
                 self.gammas[k] = v.float().reshape(-1).contiguous()
         self._zero: Dict[tuple, torch.Tensor] = {}
+        self.use_gemm_conv = True  # wide stride-1 3x3(x3) convs on the large-tile GEMM (False: every conv on the implicit-GEMM kernel)
         self._layers()
 
     # -- architecture (wan2pt1.py:283-305, 384-415) ------------------------------------------------
@@ -149,6 +168,30 @@ class WanVAEEngine:
                        out_cstride=oC)
         return out
 
+    def _gemm_ok(self, name, C_in) -> bool:
+        """Does conv `name` run on the large-tile GEMM (ce_conv3d_gemm_bf16)?  Stride-1 3x3(x3), Cin a multiple of 64, >= 128 outputs."""
+        pk = self.packs[name]
+        return self.use_gemm_conv and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and C_in % 64 == 0 and pk.Cout_p >= 128
+
+    def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None) -> Frames:
+        pk = self.packs[name]
+        KT = pk.k[0]
+        need = KT - 1
+        if x.stack is None or x.front != need:  # the producer did not leave room: one copy of the chunk into a stack
+            st = Frames(x.T, x.H, x.W, x.C, self.dev, front=need)
+            st.data.copy_(x.data)
+            x = st
+        zero = self._zero.get((x.H, x.W, x.C))
+        for j, f in enumerate(front_frames):
+            if f is zero:
+                x.stack[j].zero_()
+            else:
+                x.stack[j].copy_(f)
+        out = Frames(x.T, x.H, x.W, out_C or pk.Cout_p, self.dev)
+        ops.conv3d_gemm(x.stack, pk.gemm_weight(), pk.b, out.data, res.data if res is not None else None, T_out=x.T, H=x.H, W=x.W,
+                        Cin=pk.Cin_p, Cout=pk.Cout_p, KT=KT)
+        return out
+
     def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None) -> Frames:
         """3x3x3 causal conv with the chunk-to-chunk frame cache (wan2pt1.py:200-210): two frames in front of the chunk."""
         i = caches["i"]
@@ -167,12 +210,15 @@ class WanVAEEngine:
             keep = torch.cat([prev[-1:], x.data], 0)
         else:
             keep = x.data.clone()
-        out = self._conv(name, front + x.frame_list(), x.T, x.H, x.W, x.W, res=res, out_C=out_C)
+        if self._gemm_ok(name, x.C):
+            out = self._conv_gemm(name, x, front, res, out_C)
+        else:
+            out = self._conv(name, front + x.frame_list(), x.T, x.H, x.W, x.W, res=res, out_C=out_C)
         caches["slots"][i] = keep
         return out
 
-    def _rms_silu(self, x: Frames, gname, silu=True, border=1) -> Frames:
-        out = Frames(x.T, x.H, x.W, x.C, self.dev) if border else None
+    def _rms_silu(self, x: Frames, gname, silu=True, border=1, front=None) -> Frames:
+        out = Frames(x.T, x.H, x.W, x.C, self.dev, front=front) if border else None
         if border:
             ops.rms_silu(x.data, self.gammas[gname], out.data, x.T, x.C, x.H, x.W, 1, 1, silu)
             return out
@@ -184,9 +230,9 @@ class WanVAEEngine:
         h = x
         if (name + ".shortcut") in self.packs:
             h = self._conv(name + ".shortcut", x.frame_list(), x.T, x.H, x.W, x.W, in_off=1)
-        y = self._rms_silu(x, name + ".residual.0.gamma")
+        y = self._rms_silu(x, name + ".residual.0.gamma", front=2 if self._gemm_ok(name + ".residual.2", x.C) else None)
         y = self._cached_conv(name + ".residual.2", y, caches)
-        y = self._rms_silu(y, name + ".residual.3.gamma")
+        y = self._rms_silu(y, name + ".residual.3.gamma", front=2 if self._gemm_ok(name + ".residual.6", y.C) else None)
         return self._cached_conv(name + ".residual.6", y, caches, res=h)
 
     def _attn(self, name, x: Frames) -> Frames:
@@ -277,8 +323,11 @@ class WanVAEEngine:
                 self._conv(name + ".time_conv", ins, x.T, x.H, x.W, x.W, in_off=1, out_frames=fl[1::2], cout_slice=(C, 2 * C), out_C=C)
                 caches["slots"][i] = keep
                 x = y
-        u = Frames(x.T, 2 * x.H, 2 * x.W, C, self.dev)
+        gemm = self._gemm_ok(name + ".resample.1", C)
+        u = Frames(x.T, 2 * x.H, 2 * x.W, C, self.dev, front=0 if gemm else None)
         ops.upsample2x(x.data, u.data, x.T, C, x.H, x.W)
+        if gemm:
+            return self._conv_gemm(name + ".resample.1", u, [], None)
         return self._conv(name + ".resample.1", u.frame_list(), u.T, u.H, u.W, u.W)
 
     def _run(self, layers, x, caches):

@@ -210,6 +210,18 @@ int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames, const void
                        int KH, int KW, int st, int ss, int H_out, int W_out, int in_Wp, int in_off_h, int in_off_w, int out_Wp,
                        int out_border, int out_cstride, int out_coff, hipStream_t stream);
 
+/* The stride-1 3 x 3 (KT = 1) / 3 x 3 x 3 (KT = 3) convolutions of wide layers on the 256 x 256 x 64 LDS-DMA GEMM (same result as
+ * ce_conv_igemm_bf16 with st = ss = 1, in_off = 0, out_border = 1): on bordered frames of one contiguous stack the A rows of the
+ * implicit GEMM are linear in memory and the taps are constant offsets, so the product runs on the large-tile kernel and the border
+ * positions it computes along the way are zeroed again.
+ *   in_stack  [T_out + KT - 1 frames + ONE zeroed slack frame][H+2][W+2][Cin] bf16: for KT = 3 the first two frames are the causal
+ *             padding / cache frames (CausalConv3d, wan2pt1.py:42-60), frame t of the output reads frames t .. t + KT - 1
+ *   weight    [Cout][ldw] bf16, column (kt*9 + kh*3 + kw) * Cin + ci, zero from KT*9*Cin up to ldw >= the K-tile count rounded up to even x 64
+ *   out_stack [T_out][H+2][W+2][out_cstride] (channels [0, Cout) written, borders zeroed); res_stack: same geometry, added, or NULL
+ * Cin % 64 == 0, Cout % 8 == 0 (worth it from 128 output channels up: the N tile is 256 wide). */
+int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
+                        int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, hipStream_t stream);
+
 /* y = [silu]( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ) per pixel over C channels; x, y are stacks of npix/(H*W) frames
  * with in_border / out_border zero borders.  Replaces RMS_norm (+ nn.SiLU) (wan2pt1.py:63-75,193-200). */
 int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,

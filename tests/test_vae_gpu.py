@@ -38,6 +38,46 @@ def test_conv_igemm_matches_conv3d():
     assert float(out.data[:, 0].abs().max()) == 0.0 and float(out.data[:, :, 0].abs().max()) == 0.0  # border untouched
 
 
+@pytest.mark.parametrize("KT,Cin,Cout,T,H,W,with_res", [(3, 192, 192, 2, 24, 40, False), (3, 384, 384, 1, 22, 30, True),
+                                                        (1, 384, 192, 3, 16, 24, False), (3, 192, 384, 4, 45, 80, True)])
+def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, T, H, W, with_res):
+    """ce_conv3d_gemm_bf16 (wide stride-1 3x3 / 3x3x3 convs as one large-tile GEMM over a contiguous stack of bordered frames) vs fp32
+    conv3d with causal front frames, and vs ce_conv_igemm_bf16 on the same operands; borders come back zero; odd and even K-tile
+    counts (81 / 162 / 54 / 81), one and two N tiles, several M tiles (4 x 47 x 82 rows = 61 tiles)."""
+    from chronoedit_amd import ops
+    from chronoedit_amd.vae import Frames, _ConvPack
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(KT * 1000 + Cin + T)
+    n_in = T + KT - 1
+    x = torch.randn(Cin, n_in, H, W, generator=g).to(torch.bfloat16)  # the first KT - 1 frames play the cache frames
+    shape = (Cout, Cin, KT, 3, 3)
+    w = (torch.randn(shape, generator=g) / (9 * KT * Cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(Cout, T, H, W, generator=g).to(torch.bfloat16) if with_res else None
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(x.float()[None], (1, 1, 1, 1, 0, 0)), w.float(), b)[0]  # [Cout, T, H, W]
+    f = Frames(T, H, W, Cin, dev, front=KT - 1)
+    f.stack[:n_in, 1:-1, 1:-1] = x.permute(1, 2, 3, 0).to(dev)
+    pk = _ConvPack(w.to(dev), b.to(dev))
+    res = None
+    if with_res:
+        res = Frames(T, H, W, Cout, dev)
+        res.data[:, 1:-1, 1:-1] = r.permute(1, 2, 3, 0).to(dev)
+        ref = ref + r.float()
+    out = Frames(T, H, W, Cout, dev)
+    out.data.fill_(7.0)  # whatever the buffer held: borders must come back zero
+    ops.conv3d_gemm(f.stack, pk.gemm_weight(), pk.b, out.data, res.data if res is not None else None, T_out=T, H=H, W=W, Cin=Cin, Cout=Cout,
+                    KT=KT)
+    got = out.data[:, 1:-1, 1:-1].permute(3, 0, 1, 2)
+    assert rel_l2(got, ref) < 6e-3, rel_l2(got, ref)
+    for border in (out.data[:, 0], out.data[:, -1], out.data[:, :, 0], out.data[:, :, -1]):
+        assert float(border.abs().max()) == 0.0
+    old = Frames(T, H, W, Cout, dev)
+    ops.conv_igemm([f.stack[i] for i in range(n_in)], pk.w, pk.b, old.frame_list(), res.frame_list() if res is not None else None, Cin=Cin,
+                   Cout=Cout, KT=KT, KH=3, KW=3, st=1, ss=1, H_out=H, W_out=W, in_Wp=W + 2, in_off=0, out_Wp=W + 2, out_border=1,
+                   out_cstride=Cout)
+    assert rel_l2(out.data, old.data) < 3e-3, rel_l2(out.data, old.data)  # same products, another summation order, one bf16 rounding
+
+
 @pytest.mark.parametrize("N,C", [(384, 384), (1000, 384), (100, 128), (3600, 384), (14400, 384)])
 def test_single_head_attention_kernel_vs_fp32(N, C):
     """ce_attention_1head_bf16 (the VAE mid-block attention as one flash-style kernel, head dim 384 / 128) vs fp32 softmax(q k^T) v;

@@ -12,6 +12,8 @@ from chronoedit_amd.vae import AutoencoderKLWan  # noqa: E402
 
 H, W, T = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (720, 1280, 5)))
 vae = AutoencoderKLWan.random_init(torch.device("cuda:0"), seed=4321)
+if os.environ.get("CE_VAE_GEMM_CONV") == "0":  # A/B: every conv on the implicit-GEMM kernel (the wide 3x3(x3) ones not on the large-tile GEMM)
+    vae.engine().use_gemm_conv = False
 x = (torch.rand(1, 3, T, H, W, device="cuda") * 2 - 1).to(torch.bfloat16)
 res = {}
 for name, fn in (("encode", lambda: vae.encode(x).latent_dist.mode()),):
