@@ -290,7 +290,8 @@ extern "C" int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames,
 // per K-tile.  C = the output stack, linear in the same row index.  Rows that fall on border positions (under 1 % of them) are computed
 // and then zeroed again by zero_border_kernel: the border is the next layer's padding.  K-tiles are consumed in pairs: an odd count is
 // padded by one tile whose weight columns are zero and whose A tile lies three frames (KT = 3) or three pixel rows plus one frame
-// (KT = 1) further on - the caller keeps one zeroed slack frame behind the last input frame.
+// (KT = 1) further on - the caller keeps one zeroed slack frame behind the last input frame.  Cin = 96 (three pixels = 288 channels = 4.5
+// K-tiles): every (kt, kh) run is rounded up to 5 tiles whose last 32 columns carry zero weights.
 // Reference: CausalConv3d, wan2pt1.py:42-60 (the two front frames of the stack are its causal padding / feat_cache).
 namespace {
 __global__ __launch_bounds__(256) void zero_border_kernel(bf16* __restrict__ y, int T, int Hp, int Wp, int C8, int ld8) {
@@ -311,24 +312,31 @@ __global__ __launch_bounds__(256) void zero_border_kernel(bf16* __restrict__ y, 
 
 extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const void* res, int M, int N,
                                         int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
-                                        long long a_seg2_stride, hipStream_t stream);
+                                        long long a_seg2_stride, int n_tile, hipStream_t stream);
 
 extern "C" int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
-                                   int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, hipStream_t stream) {
+                                   int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream) {
   if (!in_stack || !weight || !out_stack) return CE_ERR_ARG;
-  if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3)) return CE_ERR_SHAPE;
-  if ((Cin % 64) || (Cout & 7) || (out_cstride & 7) || out_cstride < Cout) return CE_ERR_SHAPE;
+  if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3) || (n_tile != 0 && n_tile != 128 && n_tile != 256)) return CE_ERR_SHAPE;
+  if ((Cin % 32) || (Cout & 7) || (out_cstride & 7) || out_cstride < Cout) return CE_ERR_SHAPE;
   const int Hp = H + 2, Wp = W + 2;
-  const int ktiles = KT * 9 * (Cin / 64), kpad = (ktiles + 1) / 2 * 2 * 64;
+  // one (kt, kh) run of the K axis = the 3 Cin channels of three neighbouring pixels, rounded up to whole 64-wide K-tiles (Cin = 96: 288
+  // -> 320; the 32 surplus columns read the next pixel's first channels against zero weights)
+  const int seg = (3 * Cin + 63) / 64 * 64;
+  const int ktiles = KT * 3 * (seg / 64), kpad = (ktiles + 1) / 2 * 2 * 64;
   if (ldw < kpad || (ldw & 7)) return CE_ERR_SHAPE;
   const long long rows = (long long)T_out * Hp * Wp - 2ll * (Wp + 1);
   if (rows <= 0 || rows * Cin * 2 >= (1ll << 32) || rows * out_cstride * 2 >= (1ll << 32)) return CE_ERR_SHAPE;
+  if (n_tile == 0) {  // the narrower tile where it wastes less of the N axis (its loop reads 1.5 x the LDS bytes per MFMA)
+    const int w256 = (Cout + 255) / 256 * 256, w128 = (Cout + 127) / 128 * 128;
+    n_tile = w128 * 9 < w256 * 8 ? 128 : 256;
+  }
   const size_t shift = (size_t)(Wp + 1);
   bf16* c0 = (bf16*)out_stack + shift * out_cstride;
   const bf16* r0 = res_stack ? (const bf16*)res_stack + shift * out_cstride : nullptr;
   const int rc = ce_gemm256w4_seg2_launch(in_stack, weight, c0, bias, res_stack ? 2 /* EPI_GATE_RES, no gate: bf16(res + bf16(acc + bias)) */ : 0,
-                                          r0, (int)rows, Cout, kpad, Cin, ldw, out_cstride, out_cstride, 3 * Cin, (long long)Wp * Cin, 9 * Cin,
-                                          (long long)Hp * Wp * Cin, stream);
+                                          r0, (int)rows, Cout, kpad, Cin, ldw, out_cstride, out_cstride, seg, (long long)Wp * Cin, 3 * seg,
+                                          (long long)Hp * Wp * Cin, n_tile, stream);
   if (rc != CE_OK) return rc;
   const long long n = (long long)T_out * (2 * Wp + 2 * (Hp - 2)) * (Cout / 8);
   hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16*)out_stack, T_out, Hp, Wp, Cout / 8,

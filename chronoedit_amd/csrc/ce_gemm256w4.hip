@@ -40,18 +40,19 @@ typedef __attribute__((address_space(3))) void lds_void;
 #define W4_BAR() __builtin_amdgcn_s_barrier()
 #define W4_PIN() __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ void tile_origin_w4(int wg, int tiles_m, int tiles_n, int& m0, int& n0) {
+__device__ __forceinline__ void tile_origin_w4(int wg, int tiles_m, int tiles_n, int bn, int& m0, int& n0) {
   constexpr int GROUP = 4;  // same raster as ce_gemm256.hip (the split-K reduce of either kernel must agree with its producer)
   const int group_sz = GROUP * tiles_n;
   const int gid = wg / group_sz;
   const int first_m = gid * GROUP;
   const int gm = min(tiles_m - first_m, GROUP);
   m0 = (first_m + (wg % group_sz) % gm) * BM;
-  n0 = ((wg % group_sz) / gm) * BN;
+  n0 = ((wg % group_sz) / gm) * bn;
 }
 
+template <int NG>
 struct FragSet {
-  bf16x8 a[8], b[8];  // one k-step (32 deep) of a 128 x 128 wave tile: 8 row fragments, 8 column fragments (64 VGPRs)
+  bf16x8 a[8], b[NG];  // one k-step (32 deep) of a 128 x 16 NG wave tile: 8 row fragments, NG column fragments (64 VGPRs at NG = 8)
 };
 
 // One MFMA of row fragment F against column fragment G.  The W fragment is the first operand, so the accumulator holds C^T:
@@ -60,19 +61,25 @@ struct FragSet {
 // accumulators, shuffles every result back through VGPRs (hundreds of v_accvgpr_* per K-tile).  Hazards: the operands come from
 // ds_reads the compiler waits for; consecutive MFMAs never share an accumulator; the first reader of the accumulators after the
 // loop sits behind explicit wait states.
-#define W4_MMA(F, G, S) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((S).b[G]), "v"((S).a[F]))
+#define W4_MMA(F, G, S)                                                                                                      \
+  if ((G) < NG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][(G) < NG ? (G) : 0]) : "v"((S).b[(G) < NG ? (G) : 0]), "v"((S).a[F]))
 
 // SEG2: the A operand is K-segmented on TWO nested levels (`ce_gemm256w4_seg2_launch`: the taps of a 3 x 3 x 3 convolution over
 // channels-last frames - kw runs on contiguously, kh jumps a pixel row, kt a frame; ce_conv.hip) - one more scalar multiply per K-tile.
-template <int EPI, int NSA, bool ONEBAR, bool SEG2 = false>
+// NG: column fragments per wave - 8 = the 256 x 256 tile; 4 = a 256 x 128 tile (wave tile 128 x 64, W stages of 16 KiB) for
+// products whose N is a small multiple of 128 or below it (the 96-channel convolutions of the VAE).
+template <int EPI, int NSA, bool ONEBAR, bool SEG2 = false, int NG = 8>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_w4(
     const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ bias,
     const float* __restrict__ gate, const bf16* __restrict__ res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
     int gate_rows, int tiles_m, int tiles_n, int t_full, int split, float* __restrict__ ws, uint32_t a_seg_magic,
     uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra, uint32_t a_seg2_magic, uint32_t a_seg2_extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BN = 32 * NG;          // tile width
+  constexpr int NW = NG;               // W pieces (32 rows each) per K-tile and wave
+  constexpr int WTILE = BN * BK * 2;   // one W K-tile stage
+  constexpr int CROW = BN * 2 + 16;    // padded epilogue staging row
   constexpr int W_RING = NSA * TILE;
-  constexpr int VMW = 8 * (NSA - 1);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     kt0 = (tb % split) * ktn;
   }
   int m0, n0;
-  tile_origin_w4(wg, tiles_m, tiles_n, m0, n0);
+  tile_origin_w4(wg, tiles_m, tiles_n, BN, m0, n0);
   const int kt_last = ktn - 1;
 
   // LDS-DMA sources: piece p of this wave = rows 8 (wave + 4 p) .. + 8 of the operand tile, lane l -> row + (l >> 3), slot l & 7
@@ -117,7 +124,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + stage_bytes + (wave + 4 * p) * 1024), 16, a_voff[p], soff, 0, 0);
   };
   auto dma_w = [&](int p, int stage_bytes, int soff) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + W_RING + stage_bytes + (wave + 4 * p) * 1024), 16, w_voff[p], soff, 0, 0);
+    if (p < NW)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + W_RING + stage_bytes + (wave + 4 * p) * 1024), 16, w_voff[p < NW ? p : 0], soff, 0, 0);
   };
 
   // fragment read addresses: row (wm|wn)*128 + f*16 + fr, chunk (fg + 4 ks) ^ ((row >> 1) & 7) = (fg + 4 ks) ^ (fr >> 1);  + stage + f*2048
@@ -125,23 +133,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     a_rd[ks] = (wm * 128 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
-    w_rd[ks] = W_RING + (wn * 128 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
+    w_rd[ks] = W_RING + (wn * (BN / 2) + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
   }
   // read number r (0..31) of a tile: k-step r >> 4, operand (r >> 3) & 1 (A, then W), fragment r & 7
-  auto read_frag = [&](int r, int a_stage_bytes, int w_stage_bytes, FragSet& k0, FragSet& k1) __attribute__((always_inline)) {
-    FragSet& s = (r >> 4) ? k1 : k0;
+  auto read_frag = [&](int r, int a_stage_bytes, int w_stage_bytes, FragSet<NG>& k0, FragSet<NG>& k1) __attribute__((always_inline)) {
+    FragSet<NG>& s = (r >> 4) ? k1 : k0;
     const int ks = r >> 4, f = r & 7;
     if (((r >> 3) & 1) == 0)
       s.a[f] = *reinterpret_cast<const bf16x8*>(smem + a_rd[ks] + a_stage_bytes + f * 2048);
-    else
-      s.b[f] = *reinterpret_cast<const bf16x8*>(smem + w_rd[ks] + w_stage_bytes + f * 2048);
+    else if (f < NG)
+      s.b[f < NG ? f : 0] = *reinterpret_cast<const bf16x8*>(smem + w_rd[ks] + w_stage_bytes + f * 2048);
   };
 
-  f32x4 acc[8][8];
+  f32x4 acc[8][NG];
 #pragma unroll
   for (int f = 0; f < 8; ++f)
 #pragma unroll
-    for (int g = 0; g < 8; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < NG; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // prologue: tiles 0, 1 (and A of tile 2)
   {
@@ -154,16 +162,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int p = 0; p < 8; ++p) dma_a(p, TILE, a1);
 #pragma unroll
-    for (int p = 0; p < 8; ++p) dma_w(p, TILE, w1);
+    for (int p = 0; p < 8; ++p) dma_w(p, WTILE, w1);
     if (NSA == 3 && !ONEBAR) {
       const int a2 = koff_a(2);
 #pragma unroll
       for (int p = 0; p < 8; ++p) dma_a(p, 2 * TILE, a2);
     }
   }
-  if (NSA == 3 && !ONEBAR) W4_VM(24); else W4_VM(16);  // tile 0 has landed
+  if (NSA == 3 && !ONEBAR) W4_VM(24); else if (NG == 8) W4_VM(16); else W4_VM(12);  // tile 0 has landed
   W4_BAR();
-  FragSet s0, s1, s2;
+  FragSet<NG> s0, s1, s2;
 #pragma unroll
   for (int r = 0; r < 32; ++r) read_frag(r, 0, 0, s0, s1);
   W4_LGKM0();
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (!ONEBAR) W4_BAR();                                                                                      \
     W4_UNIT0(0, K0, WP, wsoff) W4_UNIT0(1, K0, WP, wsoff) W4_UNIT0(2, K0, WP, wsoff) W4_UNIT0(3, K0, WP, wsoff) \
     W4_UNIT0(4, K0, WP, wsoff) W4_UNIT0(5, K0, WP, wsoff) W4_UNIT0(6, K0, WP, wsoff) W4_UNIT0(7, K0, WP, wsoff) \
-    if (NSA == 3 && !ONEBAR) W4_VM(16); else W4_VM(8);                                                          \
+    if (NSA == 3 && !ONEBAR) W4_VM(16); else if (NG == 8) W4_VM(8); else W4_VM(4);                              \
     W4_BAR();                                                                                                   \
     W4_UNIT1(0, K1, K0, KN, WP) W4_UNIT1(1, K1, K0, KN, WP) W4_UNIT1(2, K1, K0, KN, WP) W4_UNIT1(3, K1, K0, KN, WP) \
     W4_UNIT1(4, K1, K0, KN, WP) W4_UNIT1(5, K1, K0, KN, WP) W4_UNIT1(6, K1, K0, KN, WP) W4_UNIT1(7, K1, K0, KN, WP) \
@@ -193,19 +201,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // each = the MFMA's own issue + about three more slots), never bunched behind a group
 #define W4_UNIT0(F, K0, WP, WSOFF)                                                                                 \
   W4_MMA(F, 0, K0);                                                                                                \
-  if (ONEBAR) dma_a(F, a_dst, asoff); else dma_w(F, (WP) * TILE, WSOFF);                                           \
+  if (ONEBAR) dma_a(F, a_dst, asoff); else dma_w(F, (WP) * WTILE, WSOFF);                                          \
   W4_PIN();                                                                                                        \
   W4_MMA(F, 1, K0); W4_MMA(F, 2, K0); W4_MMA(F, 3, K0); W4_MMA(F, 4, K0); W4_MMA(F, 5, K0); W4_MMA(F, 6, K0);      \
   W4_MMA(F, 7, K0); W4_PIN();
 #define W4_UNIT1(F, K1, K0, KN, WP)                                                                                \
   W4_MMA(F, 0, K1);                                                                                                \
-  if (ONEBAR) dma_w(F, (WP) * TILE, wsoff); else dma_a(F, a_dst, asoff);                                           \
+  if (ONEBAR) dma_w(F, (WP) * WTILE, wsoff); else dma_a(F, a_dst, asoff);                                          \
   W4_PIN();                                                                                                        \
   W4_MMA(F, 1, K1); W4_PIN();                                                                                      \
-  W4_MMA(F, 2, K1); read_frag(4 * (F) + 0, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
-  W4_MMA(F, 3, K1); read_frag(4 * (F) + 1, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
-  W4_MMA(F, 4, K1); read_frag(4 * (F) + 2, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
-  W4_MMA(F, 5, K1); read_frag(4 * (F) + 3, a_next, (1 - (WP)) * TILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 2, K1); read_frag(4 * (F) + 0, a_next, (1 - (WP)) * WTILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 3, K1); read_frag(4 * (F) + 1, a_next, (1 - (WP)) * WTILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 4, K1); read_frag(4 * (F) + 2, a_next, (1 - (WP)) * WTILE, K0, KN); W4_PIN();                           \
+  W4_MMA(F, 5, K1); read_frag(4 * (F) + 3, a_next, (1 - (WP)) * WTILE, K0, KN); W4_PIN();                           \
   W4_MMA(F, 6, K1); W4_MMA(F, 7, K1); W4_PIN();
 
   const int npairs = ktn >> 1;
@@ -222,22 +230,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results -> v_accvgpr_read (hipcc does not see the asm MFMAs)
   W4_BAR();
 
-  if (partial) {  // split-K tail piece: fp32 slab [wave][f][g][lane] for gemm256w4_reduce
+  static_assert(NG == 8 || (NG == 4 && NSA == 2 && !ONEBAR), "the 256 x 128 tile exists for the two-stage loop only");
+  if (partial) {  // split-K tail piece: fp32 slab [wave][f][g][lane] for gemm256w4_reduce (the launcher splits 256 x 256 tiles only)
     float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
 #pragma unroll
     for (int f = 0; f < 8; ++f)
 #pragma unroll
-      for (int g = 0; g < 8; ++g)
+      for (int g = 0; g < NG; ++g)
         *reinterpret_cast<f32x4*>(slab + (((wave * 64 + f * 8 + g) * 64) + lane) * 4) = acc[f][g];
     return;
   }
+  constexpr int CPR = BN / 8;        // 16-byte chunks per staged row (32 | 16)
+  constexpr int CH = 64 * CPR / 256;  // chunks per thread and pass (8 | 4)
 
   // ---- epilogue: four passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave = tile rows
   // wm*128 + p*32 + [0,32)), so that bias / GELU / gated-residual math and the global stores run on 16-B row-contiguous chunks
-  f32x4 bcol[8];
+  f32x4 bcol[NG];
 #pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    const int n = n0 + wn * 128 + g * 16 + fg * 4;
+  for (int g = 0; g < NG; ++g) {
+    const int n = n0 + wn * (BN / 2) + g * 16 + fg * 4;
     bcol[g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // Gated residual: ALL of this thread's residual chunks (4 passes x 8 chunks x 16 B = 128 VGPRs - the fragment registers are
@@ -247,10 +258,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // column chunk of at most two samples' rows when gate_rows >= the tile height (the engine: tokens per sample); other callers
   // (gate_rows < 256) take the per-pass path of ce_gemm_epi.h.
   constexpr bool prefetch = EPI == EPI_GATE_RES;  // (the launcher sends 0 < gate_rows < 256 to the 8-wave kernel)
-  u32x4 rv[4][8];
+  u32x4 rv[4][CH];
   f32x4 gA0, gA1, gB0, gB1;
   int g_switch = 0x7fffffff;  // first global row that takes the second sample's gate
-  const int my_n = n0 + (tid & 31) * 8, my_nc = min(my_n, N - 8);
+  const int my_n = n0 + (tid & (CPR - 1)) * 8, my_nc = min(my_n, N - 8);
   const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
   if (EPI == EPI_GATE_RES && prefetch) {
     gA0 = gA1 = gB0 = gB1 = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -268,8 +279,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
-        const int rl = (tid + 256 * tt) >> 5;
+      for (int tt = 0; tt < CH; ++tt) {
+        const int rl = (tid + 256 * tt) / CPR;
         const int m = min(m0 + (rl >> 5) * 128 + p * 32 + (rl & 31), M - 1);
         rv[p][tt] = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + my_nc);
       }
@@ -284,8 +295,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (EPI == EPI_BIAS_ROW) brow = bias[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
       const int rl = wm * 32 + ff * 16 + fr;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int cl = wn * 128 + g * 16 + fg * 4;
+      for (int g = 0; g < NG; ++g) {
+        const int cl = wn * (BN / 2) + g * 16 + fg * 4;
         f32x4 bv = bcol[g];
         if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow;
         const f32x4 v = acc[f][g];
@@ -296,10 +307,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     if (EPI == EPI_GATE_RES && prefetch) {
 #pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
-        const int rl = (tid + 256 * tt) >> 5;
+      for (int tt = 0; tt < CH; ++tt) {
+        const int rl = (tid + 256 * tt) / CPR;
         const int m = m0 + (rl >> 5) * 128 + p * 32 + (rl & 31);
-        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + (tid & 31) * 16);
+        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + (tid & (CPR - 1)) * 16);
         const bool second = m >= g_switch;
         const f32x4 g0 = second ? gB0 : gA0, g1 = second ? gB1 : gA1;
         const u32x4 r = rv[p][tt];
@@ -316,11 +327,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
       }
     } else if (EPI != EPI_GATE_RES) {
-      epi_chunks<EPI, 8>(smem, CROW,
+      epi_chunks<EPI, CH>(smem, CROW,
                          [&](int tt, int& rl, int& cc, int& mr) {
                            const int c = tid + 256 * tt;
-                           rl = c >> 5;
-                           cc = c & 31;
+                           rl = c / CPR;
+                           cc = c & (CPR - 1);
                            mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
                          },
                          m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm256w4_reduce(bf16* __restrict__ C, co
   const int fr = lane & 15, fg = lane >> 4;
   const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;  // q = producer wave = (wm, wn)
   int m0, n0;
-  tile_origin_w4(t_full + tile, tiles_m, tiles_n, m0, n0);
+  tile_origin_w4(t_full + tile, tiles_m, tiles_n, BN, m0, n0);
   m0 += (q >> 1) * 128;
   n0 += (q & 1) * 128;
   const float* slab = ws + (size_t)tile * split * (BM * BN);
@@ -377,8 +388,9 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
 
 static int w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res, int M, int N,
                      int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride, int w_seg_k,
-                     long long w_seg_stride, int a_seg2_k, long long a_seg2_stride, int nsa, hipStream_t stream) {
+                     long long w_seg_stride, int a_seg2_k, long long a_seg2_stride, int nsa, int ng, hipStream_t stream) {
   const bool seg2 = a_seg2_k > 0;
+  if ((ng != 8 && ng != 4) || (ng == 4 && !seg2)) return CE_ERR_ARG;
   if (seg2 && (a_seg_k <= 0 || a_seg2_k % a_seg_k || (epilogue != EPI_BIAS && epilogue != EPI_GATE_RES) || nsa != 2 ||
                (epilogue == EPI_GATE_RES && gate != nullptr)))
     return CE_ERR_ARG;
@@ -387,7 +399,8 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
   if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32)))
     return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
                              w_seg_stride, stream);
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int bn = 32 * ng;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + bn - 1) / bn;
   const int nwg = tiles_m * tiles_n, kt = K / BK;
   uint32_t a_seg_magic = 0, a_seg_extra = 0, w_seg_magic = 0, w_seg_extra = 0;
   auto seg = [&](int seg_k, long long seg_stride, uint32_t& magic, uint32_t& extra_out) -> int {
@@ -398,7 +411,7 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
     for (int t = 0; t < kt; ++t)
       if ((int)(((uint32_t)t * magic) >> 16) != t / tps) return CE_ERR_SHAPE;
     const long long extra = (seg_stride - seg_k) * 2;
-    if (extra < 0 || extra * (K / seg_k) + (long long)K * 2 >= (1ll << 31)) return CE_ERR_SHAPE;  // the K-tile offset is a signed scalar
+    if (extra < 0 || extra * ((K + seg_k - 1) / seg_k) + (long long)K * 2 >= (1ll << 31)) return CE_ERR_SHAPE;  // the K-tile offset is a signed scalar
     extra_out = (uint32_t)extra;
     return CE_OK;
   };
@@ -433,22 +446,27 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
   dim3 grid(t_full2 + tail * split), block(256);
   const int lds3 = 5 * TILE, lds2 = 4 * TILE;
   if (seg2) {
+    const int lds2n = 2 * TILE + 2 * (128 * BK * 2);  // 256 x 128 tile: W stages of 16 KiB
     static bool seg2_done_[CE_MAX_DEVICES] = {};
     bool& seg2_done = seg2_done_[ce_device_slot()];
     if (!seg2_done) {
       if (hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_BIAS, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess ||
-          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess)
+          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_BIAS, 2, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2n) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2n) != hipSuccess)
         return CE_ERR_ARG;
       seg2_done = true;
     }
-    if (epilogue == EPI_BIAS)
-      hipLaunchKernelGGL((gemm_bf16_w4<EPI_BIAS, 2, false, true>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate,
-                         (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, a_seg_magic,
-                         a_seg_extra, w_seg_magic, w_seg_extra, a_seg2_magic, a_seg2_extra);
-    else
-      hipLaunchKernelGGL((gemm_bf16_w4<EPI_GATE_RES, 2, false, true>), grid, block, lds2, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias,
-                         gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, a_seg_magic,
-                         a_seg_extra, w_seg_magic, w_seg_extra, a_seg2_magic, a_seg2_extra);
+#define CE_LAUNCH_SEG2(E, NGV, LDS)                                                                                                     \
+  hipLaunchKernelGGL((gemm_bf16_w4<E, 2, false, true, NGV>), grid, block, LDS, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+                     (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, a_seg_magic,   \
+                     a_seg_extra, w_seg_magic, w_seg_extra, a_seg2_magic, a_seg2_extra)
+    if (epilogue == EPI_BIAS) {
+      if (ng == 8) CE_LAUNCH_SEG2(EPI_BIAS, 8, lds2); else CE_LAUNCH_SEG2(EPI_BIAS, 4, lds2n);
+    } else {
+      if (ng == 8) CE_LAUNCH_SEG2(EPI_GATE_RES, 8, lds2); else CE_LAUNCH_SEG2(EPI_GATE_RES, 4, lds2n);
+    }
+#undef CE_LAUNCH_SEG2
     return (int)hipGetLastError();
   }
   static bool attr_done_[CE_MAX_DEVICES][8] = {};
@@ -494,14 +512,15 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
                                    const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                    int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream) {
   return w4_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k, w_seg_stride,
-                   0, 0, nsa, stream);
+                   0, 0, nsa, 8, stream);
 }
 
 // A with TWO nested segment levels: column k of row m lives at A + (k / a_seg2_k) a_seg2_stride + ((k % a_seg2_k) / a_seg_k) a_seg_stride +
 // m lda + k % a_seg_k (elements).  EPI_BIAS or the plain residual add (EPI_GATE_RES without a gate); no split-K.
+// n_tile: 256 or 128 (the 256 x 128 macro tile: wave tiles 128 x 64).
 extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const void* res, int M, int N,
                                         int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
-                                        long long a_seg2_stride, hipStream_t stream) {
+                                        long long a_seg2_stride, int n_tile, hipStream_t stream) {
   return w4_launch(A, W, C, bias, epilogue, nullptr, res, M, N, K, lda, ldw, ldc, ldres, 0, a_seg_k, a_seg_stride, 0, 0, a_seg2_k, a_seg2_stride,
-                   2, stream);
+                   2, n_tile / 32, stream);
 }

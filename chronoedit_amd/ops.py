@@ -456,7 +456,7 @@ def cfg_unipc_step(v_cond: torch.Tensor, v_uncond: Optional[torch.Tensor], x: to
 
 # ---- Wan VAE ------------------------------------------------------------------------------------------------------
 def conv3d_gemm(in_stack: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out_stack: torch.Tensor,
-                res_stack: Optional[torch.Tensor], *, T_out: int, H: int, W: int, Cin: int, Cout: int, KT: int):
+                res_stack: Optional[torch.Tensor], *, T_out: int, H: int, W: int, Cin: int, Cout: int, KT: int, n_tile: int = 0):
     """Stride-1 3x3 / 3x3x3 conv of a wide layer as ONE large-tile GEMM over a contiguous stack of bordered frames (see
     include/chronoedit_hip.h: in_stack holds T_out + KT - 1 frames plus one zeroed slack frame)."""
     _dev(in_stack, torch.bfloat16, "in_stack")
@@ -470,7 +470,7 @@ def conv3d_gemm(in_stack: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
         assert res_stack.is_contiguous() and res_stack.shape[1:] == out_stack.shape[1:] and res_stack.shape[0] >= T_out
     st_ev = _prof_begin()
     _check(lib().ce_conv3d_gemm_bf16(_ptr(in_stack), _ptr(weight), weight.shape[1], _ptr(bias), _ptr(out_stack), _ptr(res_stack), T_out, H, W,
-                                     Cin, Cout, KT, out_stack.shape[3], _stream()), "ce_conv3d_gemm_bf16")
+                                     Cin, Cout, KT, out_stack.shape[3], n_tile, _stream()), "ce_conv3d_gemm_bf16")
     _prof_end(st_ev, f"conv_{KT}x3x3_{Cin}->{Cout}_{T_out}x{H}x{W}", 2.0 * T_out * H * W * Cout * Cin * KT * 9)
 
 

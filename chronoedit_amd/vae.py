@@ -75,10 +75,13 @@ class _ConvPack:
     def gemm_weight(self) -> torch.Tensor:
         """[Cout_pad8][K-tiles rounded up to even x 64]: the same taps-major rows, zero columns behind them (ce_conv3d_gemm_bf16)."""
         if self._w_gemm is None:
-            k = self.w.shape[1] * self.w.shape[2]
+            KT, KH, KW = self.k
+            cout, cin = self.w.shape[0], self.w.shape[2]
+            seg = (KW * cin + 63) // 64 * 64  # one (kt, kh) run: three pixels' channels, whole K-tiles (Cin = 96: 288 -> 320)
+            k = KT * KH * seg
             kpad = ((k // 64) + 1) // 2 * 2 * 64
-            wg = torch.zeros((self.w.shape[0], kpad), dtype=torch.bfloat16, device=self.w.device)
-            wg[:, :k] = self.w.reshape(self.w.shape[0], k)
+            wg = torch.zeros((cout, kpad), dtype=torch.bfloat16, device=self.w.device)
+            wg[:, :k].view(cout, KT * KH, seg)[:, :, : KW * cin] = self.w.reshape(cout, KT * KH, KW * cin)
             self._w_gemm = wg
         return self._w_gemm
 
@@ -169,9 +172,9 @@ class WanVAEEngine:
         return out
 
     def _gemm_ok(self, name, C_in) -> bool:
-        """Does conv `name` run on the large-tile GEMM (ce_conv3d_gemm_bf16)?  Stride-1 3x3(x3), Cin a multiple of 64, >= 128 outputs."""
+        """Does conv `name` run on the large-tile GEMM (ce_conv3d_gemm_bf16)?  Stride-1 3x3(x3), at least 96 channels in and out."""
         pk = self.packs[name]
-        return self.use_gemm_conv and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and C_in % 64 == 0 and pk.Cout_p >= 128
+        return self.use_gemm_conv and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and C_in >= 96 and pk.Cout_p >= 96
 
     def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None) -> Frames:
         pk = self.packs[name]

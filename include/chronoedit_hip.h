@@ -216,11 +216,14 @@ int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames, const void
  * positions it computes along the way are zeroed again.
  *   in_stack  [T_out + KT - 1 frames + ONE zeroed slack frame][H+2][W+2][Cin] bf16: for KT = 3 the first two frames are the causal
  *             padding / cache frames (CausalConv3d, wan2pt1.py:42-60), frame t of the output reads frames t .. t + KT - 1
- *   weight    [Cout][ldw] bf16, column (kt*9 + kh*3 + kw) * Cin + ci, zero from KT*9*Cin up to ldw >= the K-tile count rounded up to even x 64
+ *   weight    [Cout][ldw] bf16: column ((kt*3 + kh) * S + kw * Cin + ci), S = 3*Cin rounded up to a multiple of 64 (zero columns in
+ *             between when Cin = 96), zero from KT*3*S up to ldw >= the K-tile count rounded up to even x 64
  *   out_stack [T_out][H+2][W+2][out_cstride] (channels [0, Cout) written, borders zeroed); res_stack: same geometry, added, or NULL
- * Cin % 64 == 0, Cout % 8 == 0 (worth it from 128 output channels up: the N tile is 256 wide). */
+ *   n_tile    256 or 128: width of the macro tile (256 x 256 with 128 x 128 wave tiles | 256 x 128 with 128 x 64); 0 = whichever wastes
+ *             less of Cout
+ * Cin % 32 == 0, Cout % 8 == 0. */
 int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
-                        int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, hipStream_t stream);
+                        int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream);
 
 /* y = [silu]( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ) per pixel over C channels; x, y are stacks of npix/(H*W) frames
  * with in_border / out_border zero borders.  Replaces RMS_norm (+ nn.SiLU) (wan2pt1.py:63-75,193-200). */

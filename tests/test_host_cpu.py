@@ -128,12 +128,14 @@ def test_blocked_layout_tile_to_block_magic_is_exact():
         assert np.array_equal((t * magic) >> np.uint64(32), t // np.uint64(tps)), tps
 
 
-@pytest.mark.parametrize("KT,T_out,H,W,Cin,Cout", [(3, 2, 5, 6, 64, 16), (1, 3, 4, 7, 128, 8), (3, 1, 3, 3, 192, 8)])
+@pytest.mark.parametrize("KT,T_out,H,W,Cin,Cout", [(3, 2, 5, 6, 64, 16), (1, 3, 4, 7, 128, 8), (3, 1, 3, 3, 192, 8), (3, 2, 4, 5, 96, 8),
+                                                   (1, 1, 3, 4, 96, 8)])
 def test_conv3d_gemm_address_map_reproduces_the_convolution(KT, T_out, H, W, Cin, Cout):
     """ce_conv3d_gemm_bf16 hands a stride-1 3x3(x3) convolution to the GEMM as: A row r = the input stack read linearly from position r
-    (lda = Cin), K walked in 64-wide tiles whose source offset is t*64 + (t // tiles(3 Cin)) * extra1 + (t // tiles(9 Cin)) * extra2
-    elements, C row r = padded output position r + Wp + 1, an odd tile count padded by one tile of zero weights, borders zeroed
-    afterwards.  This replays exactly that arithmetic on the CPU (gather + matmul) against torch's conv3d."""
+    (lda = Cin), K walked in 64-wide tiles whose source offset is t*64 + (t // tiles(S)) * extra1 + (t // tiles(3 S)) * extra2 elements
+    (S = one (kt, kh) run = 3 Cin rounded up to whole tiles: Cin = 96 reads 32 channels of the next pixel against zero weights), C row
+    r = padded output position r + Wp + 1, an odd tile count padded by one tile of zero weights, borders zeroed afterwards.  This
+    replays exactly that arithmetic on the CPU (gather + matmul) against torch's conv3d."""
     import torch.nn.functional as F
 
     g = torch.Generator().manual_seed(KT * 100 + Cin)
@@ -141,16 +143,18 @@ def test_conv3d_gemm_address_map_reproduces_the_convolution(KT, T_out, H, W, Cin
     n_in = T_out + KT - 1
     stack = torch.zeros(n_in + 1, Hp, Wp, Cin, dtype=torch.float64)  # + one zeroed slack frame
     stack[:n_in, 1:-1, 1:-1] = torch.randn(n_in, H, W, Cin, generator=g, dtype=torch.float64)
-    w = torch.randn(Cout, Cin, KT, 3, 3, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, KT, 3, 3, generator=g, dtype=torch.float64).to(torch.bfloat16).double()
     # what conv3d computes on those frames (zero spatial padding = the border; the front frames are IN the stack already)
     x = stack[:n_in, 1:-1, 1:-1].permute(3, 0, 1, 2)[None]  # [1, Cin, n_in, H, W]
     want = F.conv3d(x, w, padding=(0, 1, 1))[0].permute(1, 2, 3, 0)  # [T_out, H, W, Cout]
 
-    k = KT * 9 * Cin
+    seg1 = (3 * Cin + 63) // 64 * 64
+    k = KT * 3 * seg1
     kpad = ((k // 64) + 1) // 2 * 2 * 64
-    wg = torch.zeros(Cout, kpad, dtype=torch.float64)
-    wg[:, :k] = w.permute(0, 2, 3, 4, 1).reshape(Cout, k)  # [Cout][(kt, kh, kw)][ci]: _ConvPack.gemm_weight
-    seg1, stride1, seg2, stride2 = 3 * Cin, Wp * Cin, 9 * Cin, Hp * Wp * Cin
+    from chronoedit_amd.vae import _ConvPack
+    wg = _ConvPack(w.to(torch.bfloat16), None).gemm_weight().double()  # the host-side packing the engine hands to the kernel
+    assert wg.shape == (Cout, kpad)
+    stride1, seg2, stride2 = Wp * Cin, 3 * seg1, Hp * Wp * Cin
     t = torch.arange(kpad // 64)
     tile_off = t * 64 + (t // (seg1 // 64)) * (stride1 - seg1) + (t // (seg2 // 64)) * (stride2 - (seg2 // seg1) * stride1)
     koff = (tile_off[:, None] + torch.arange(64)[None]).reshape(-1)  # element offset of GEMM column k from the row's base

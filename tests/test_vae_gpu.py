@@ -38,12 +38,15 @@ def test_conv_igemm_matches_conv3d():
     assert float(out.data[:, 0].abs().max()) == 0.0 and float(out.data[:, :, 0].abs().max()) == 0.0  # border untouched
 
 
-@pytest.mark.parametrize("KT,Cin,Cout,T,H,W,with_res", [(3, 192, 192, 2, 24, 40, False), (3, 384, 384, 1, 22, 30, True),
-                                                        (1, 384, 192, 3, 16, 24, False), (3, 192, 384, 4, 45, 80, True)])
-def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, T, H, W, with_res):
-    """ce_conv3d_gemm_bf16 (wide stride-1 3x3 / 3x3x3 convs as one large-tile GEMM over a contiguous stack of bordered frames) vs fp32
+@pytest.mark.parametrize("KT,Cin,Cout,T,H,W,with_res,n_tile", [(3, 192, 192, 2, 24, 40, False, 0), (3, 384, 384, 1, 22, 30, True, 256),
+                                                               (1, 384, 192, 3, 16, 24, False, 256), (3, 192, 384, 4, 45, 80, True, 128),
+                                                               (3, 96, 96, 2, 40, 64, True, 0), (1, 192, 96, 3, 30, 44, False, 0),
+                                                               (3, 96, 192, 1, 20, 28, False, 128), (3, 384, 384, 2, 30, 50, True, 0)])
+def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, T, H, W, with_res, n_tile):
+    """ce_conv3d_gemm_bf16 (stride-1 3x3 / 3x3x3 convs as one large-tile GEMM over a contiguous stack of bordered frames) vs fp32
     conv3d with causal front frames, and vs ce_conv_igemm_bf16 on the same operands; borders come back zero; odd and even K-tile
-    counts (81 / 162 / 54 / 81), one and two N tiles, several M tiles (4 x 47 x 82 rows = 61 tiles)."""
+    counts, both macro tiles (256 x 256, 256 x 128), one to three N tiles, several M tiles, and Cin = 96 (a (kt, kh) run of 4.5 K-tiles
+    rounded up to 5 against zero weights)."""
     from chronoedit_amd import ops
     from chronoedit_amd.vae import Frames, _ConvPack
     dev = torch.device("cuda:0")
@@ -66,7 +69,7 @@ def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, 
     out = Frames(T, H, W, Cout, dev)
     out.data.fill_(7.0)  # whatever the buffer held: borders must come back zero
     ops.conv3d_gemm(f.stack, pk.gemm_weight(), pk.b, out.data, res.data if res is not None else None, T_out=T, H=H, W=W, Cin=Cin, Cout=Cout,
-                    KT=KT)
+                    KT=KT, n_tile=n_tile)
     got = out.data[:, 1:-1, 1:-1].permute(3, 0, 1, 2)
     assert rel_l2(got, ref) < 6e-3, rel_l2(got, ref)
     for border in (out.data[:, 0], out.data[:, -1], out.data[:, :, 0], out.data[:, :, -1]):
