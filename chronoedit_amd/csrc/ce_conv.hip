@@ -177,37 +177,70 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
 // ---- RMS_norm over channels (+ SiLU), channels-last, in -> out (both bordered frames or plain rows) ---------------
 // y = silu( x / max(||x||_2, 1e-12) * sqrt(C) * gamma )     (F.normalize semantics, wan2pt1.py:74)
-// 16 lanes per pixel, each lane C/16 channels (C % 16 == 0, C <= 512)
+// HBM-bound (one read, one write of the activation): 16 lanes per pixel, LPA of them active, each holding PER 16-byte chunks (8
+// channels) of the pixel in registers - chunk i * LPA + sub - so a pixel is read ONCE, in 16-byte accesses; a workgroup takes 16 PPG
+// consecutive pixels of ONE image row (blockIdx.x = frame * H + row: no per-pixel division), every lane with PPG loads in flight.
+// (The first version read every pixel twice in 4-byte accesses behind two 64-bit divisions: 2.0 TB/s on the full-resolution frames,
+// 15 % of a 720p decode.)
+template <int PER, int PPG>
 __global__ __launch_bounds__(256) void rms_silu_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
-                                                        const float* __restrict__ gamma, long long npix, int C, int H, int W,
-                                                        int in_Wp, int in_border, int out_Wp, int out_border, int apply_silu) {
-  const int sub = threadIdx.x & 15;
-  const long long pix = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (pix >= npix) return;
-  const long long HW = (long long)H * W;
-  const long long t = pix / HW;
-  const int rem = (int)(pix - t * HW);
-  const int h = rem / W, w = rem - h * W;
-  const bf16* xp = x + ((t * (H + 2 * in_border) + h + in_border) * in_Wp + (w + in_border)) * C;
-  bf16* yp = y + ((t * (H + 2 * out_border) + h + out_border) * out_Wp + (w + out_border)) * C;
-  const int per = C >> 4;  // channels per lane (multiple of 2)
-  float ss = 0.f;
-  for (int i = 0; i < per; i += 2) {
-    const uint32_t pk = *reinterpret_cast<const uint32_t*>(xp + sub * per + i);
-    ss += bf16lo(pk) * bf16lo(pk) + bf16hi(pk) * bf16hi(pk);
+                                                        const float* __restrict__ gamma, int C, int LPA, int H, int W, int in_Wp,
+                                                        int in_border, int out_Wp, int out_border, int apply_silu) {
+  const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int t = blockIdx.x / H, h = blockIdx.x - t * H;
+  const size_t in_row = ((size_t)t * (H + 2 * in_border) + h + in_border) * in_Wp + in_border;
+  const size_t out_row = ((size_t)t * (H + 2 * out_border) + h + out_border) * out_Wp + out_border;
+  const int w0 = blockIdx.y * (16 * PPG) + grp;
+  u32x4 v[PPG][PER];
+  float ss[PPG];
+#pragma unroll
+  for (int j = 0; j < PPG; ++j) {
+    const int w = w0 + 16 * j;
+    const bool on = w < W && sub < LPA;
+    const bf16* xp = x + (in_row + min(w, W - 1)) * C;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[j][i] = on ? *reinterpret_cast<const u32x4*>(xp + (i * LPA + sub) * 8) : u32x4{0u, 0u, 0u, 0u};
   }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
-  const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
-  for (int i = 0; i < per; i += 2) {  // second pass re-reads the pixel (L1 hit) instead of holding it in an indexed array
-    const int c = sub * per + i;
-    const uint32_t pk = *reinterpret_cast<const uint32_t*>(xp + c);
-    float a = bf16lo(pk) * scale * gamma[c], b = bf16hi(pk) * scale * gamma[c + 1];
-    if (apply_silu) {
-      a = silu(a);
-      b = silu(b);
+  for (int j = 0; j < PPG; ++j) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a += bf16lo(v[j][i][q]) * bf16lo(v[j][i][q]) + bf16hi(v[j][i][q]) * bf16hi(v[j][i][q]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 16);
+    ss[j] = a;
+  }
+  if (sub >= LPA) return;
+  f32x4 g0[PER], g1[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int c = (i * LPA + sub) * 8;
+    g0[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+    g1[i] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+  }
+#pragma unroll
+  for (int j = 0; j < PPG; ++j) {
+    const int w = w0 + 16 * j;
+    if (w >= W) break;
+    const float scale = sqrtf((float)C) / fmaxf(sqrtf(ss[j]), 1e-12f);
+    bf16* yp = y + (out_row + w) * C;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = bf16lo(v[j][i][q]) * scale * (q < 2 ? g0[i][2 * q] : g1[i][2 * q - 4]);
+        float b = bf16hi(v[j][i][q]) * scale * (q < 2 ? g0[i][2 * q + 1] : g1[i][2 * q - 3]);
+        if (apply_silu) {
+          a = silu_fast(a);
+          b = silu_fast(b);
+        }
+        o[q] = pack_bf16(a, b);
+      }
+      *reinterpret_cast<u32x4*>(yp + (i * LPA + sub) * 8) = o;
     }
-    *reinterpret_cast<uint32_t*>(yp + c) = pack_bf16(a, b);
   }
 }
 
@@ -347,9 +380,35 @@ extern "C" int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int
 extern "C" int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,
                                 int out_border, int apply_silu, hipStream_t stream) {
   if (!x || !y || !gamma || npix <= 0) return CE_ERR_ARG;
-  if ((C & 31) || C > 512 || H <= 0 || W <= 0) return CE_ERR_SHAPE;
-  hipLaunchKernelGGL(rms_silu_kernel, dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, gamma,
-                     npix, C, H, W, W + 2 * in_border, in_border, W + 2 * out_border, out_border, apply_silu);
+  if ((C & 7) || C > 512 || H <= 0 || W <= 0 || npix % ((long long)H * W)) return CE_ERR_SHAPE;
+  const int chunks = C / 8;
+  int lpa = 16;
+  while (chunks % lpa) --lpa;  // active lanes per pixel: the largest divisor of the chunk count that fits a 16-lane group
+  const int per = chunks / lpa;
+  const long long rows = npix / W;  // frames x image rows
+  if (rows > 0x7fffffffll) return CE_ERR_SHAPE;
+#define CE_RMS(P, G)                                                                                                                \
+  hipLaunchKernelGGL((rms_silu_kernel<P, G>), dim3((unsigned)rows, (unsigned)((W + 16 * G - 1) / (16 * G))), dim3(256), 0, stream,   \
+                     (const bf16*)x, (bf16*)y, gamma, C, lpa, H, W, W + 2 * in_border, in_border, W + 2 * out_border, out_border,   \
+                     apply_silu)
+  switch (per) {
+    case 1: CE_RMS(1, 4); break;
+    case 2: CE_RMS(2, 4); break;
+    case 3: CE_RMS(3, 2); break;
+    case 4: CE_RMS(4, 2); break;
+    default: return CE_ERR_SHAPE;  // (C = 8 * a prime > 16 ...: no VAE width)
+  }
+#undef CE_RMS
+  return (int)hipGetLastError();
+}
+
+/* Zero the one-pixel border of T frames [H+2][W+2][ld] (channels [0, C)): what a producer that writes interiors only leaves to do on a
+ * buffer that was not zero-filled. */
+extern "C" int ce_zero_border_bf16(void* frames, int T, int H, int W, int C, int ld, hipStream_t stream) {
+  if (!frames || T <= 0 || H <= 0 || W <= 0 || (C & 7) || (ld & 7) || ld < C) return CE_ERR_ARG;
+  const int Hp = H + 2, Wp = W + 2;
+  const long long n = (long long)T * (2 * Wp + 2 * (Hp - 2)) * (C / 8);
+  hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16*)frames, T, Hp, Wp, C / 8, ld / 8);
   return (int)hipGetLastError();
 }
 

@@ -507,6 +507,14 @@ def rms_silu(x: torch.Tensor, gamma: torch.Tensor, out: torch.Tensor, T: int, C:
     return out
 
 
+def zero_border(frames: torch.Tensor, T: int, H: int, W: int, C: int):
+    """Zero the one-pixel border of T bordered channels-last frames [T, H+2, W+2, ld] (channels [0, C))."""
+    _dev(frames, torch.bfloat16, "frames")
+    assert frames.is_contiguous() and tuple(frames.shape[:3]) == (T, H + 2, W + 2)
+    _check(lib().ce_zero_border_bf16(_ptr(frames), T, H, W, C, frames.shape[3], _stream()), "ce_zero_border_bf16")
+    return frames
+
+
 def upsample2x(x: torch.Tensor, out: torch.Tensor, T: int, C: int, H: int, W: int):
     _dev(x, torch.bfloat16, "x"), _dev(out, torch.bfloat16, "out")
     _check(lib().ce_upsample2x_bf16(_ptr(x), _ptr(out), T, C, H, W, _stream()), "ce_upsample2x_bf16")

@@ -348,7 +348,8 @@ class ChronoEditPipeline:
         # Defaults of the product pipeline (bit-identical to the eager / uncached loop: tests/test_pipeline_gpu.py): every step of the
         # loop is ONE hipGraph replay (GraphedDenoiser; two graphs when temporal reasoning truncates 8 -> 2 frames), and the
         # step-invariant text / image context projections are computed once per edit (`denoise` clears them at
-        # the start of every edit).  `pipe.use_graph = False` / `pipe.transformer.cache_context = False` switch either off.
+        # the start of every edit).  `pipe.use_graph = False` / `pipe.transformer.cache_context = False` switch either off.  The VAE
+        # follows `use_graph`: from the second edit of a shape on its encode / decode are one graph replay each.
         self.use_graph = True
         self._graph_warm = set()  # (latent shape, guided) pairs whose lazy initialisations have already happened in this process
         if transformer is not None and hasattr(transformer, "cache_context"):
@@ -655,6 +656,8 @@ class ChronoEditPipeline:
             self.image_encoder.cpu()
 
         B = batch_size * num_videos_per_prompt
+        if hasattr(self.vae, "use_graph"):  # the VAE replays captured graphs from the second edit of a shape on (vae.py)
+            self.vae.use_graph = bool(self.use_graph)
         img = self.preprocess_image(image, height, width).to(device=device, dtype=torch.bfloat16)
         latents, condition = self.prepare_latents(img, B, self.vae.config.z_dim, height, width, num_frames, torch.bfloat16, device,
                                                   generator, latents)

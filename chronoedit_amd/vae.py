@@ -38,20 +38,28 @@ class Frames:
     contiguous `stack` [front + T + 1] with `front` frames of room before them (the causal padding / cache frames of the conv that
     reads them) and one zeroed slack frame behind - the operand layout of ce_conv3d_gemm_bf16."""
 
-    def __init__(self, T, H, W, C, device, data=None, front=None):
+    def __init__(self, T, H, W, C, device, data=None, front=None, zero=True):
+        """zero=False: for a producer that writes every interior pixel and zeroes the border itself (ops.zero_border) - a full-resolution
+        chunk is 0.7 GB, and zero-filling every buffer was 9 % of the decode.  The slack frame is zeroed here; the front frames are the
+        consumer's to fill (cache frames or zeros)."""
         self.T, self.H, self.W, self.C = T, H, W, C
         self.stack, self.front = None, 0
+        alloc = torch.zeros if zero else torch.empty
         if front is not None:
-            self.stack = torch.zeros((front + T + 1, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
+            self.stack = alloc((front + T + 1, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
+            if not zero:
+                self.stack[front + T].zero_()
             self.front = front
             data = self.stack[front : front + T]
-        self.data = data if data is not None else torch.zeros((T, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
+        self.data = data if data is not None else alloc((T, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
 
     def frame_list(self):
         return [self.data[t] for t in range(self.T)]
 
     def last(self, k):
-        return self.data[self.T - k :].clone()
+        """The last k frames as a VIEW: a frame cache (wan2pt1.py:200-210) keeps its chunk's buffer alive instead of copying two frames of
+        it - nothing writes into a buffer after the layer that produced it."""
+        return self.data[self.T - k :]
 
 
 class _ConvPack:
@@ -162,13 +170,16 @@ class WanVAEEngine:
                            ss=ss, H_out=H_out, W_out=W_out, in_Wp=in_W + 2, in_off=in_off, out_Wp=W_out, out_border=0,
                            out_cstride=rows.shape[-1])
             return rows
-        if out is None and out_frames is None:
-            out = Frames(T_out, H_out, W_out, out_C or Cout, self.dev)
+        fresh = out is None and out_frames is None
+        if fresh:  # every interior pixel of channels [0, Cout) is written: zero-fill only when the buffer is wider than that
+            out = Frames(T_out, H_out, W_out, out_C or Cout, self.dev, zero=(out_C or Cout) != Cout)
         of = out_frames if out_frames is not None else out.frame_list()
         oC = out.C if out is not None else out_C
         ops.conv_igemm(in_frames, w, b, of, res.frame_list() if res is not None else None, Cin=pk.Cin_p, Cout=Cout, KT=KT, KH=KH, KW=KW,
                        st=st, ss=ss, H_out=H_out, W_out=W_out, in_Wp=in_W + 2, in_off=in_off, out_Wp=W_out + 2, out_border=1,
                        out_cstride=oC)
+        if fresh and out.C == Cout:
+            ops.zero_border(out.data, T_out, H_out, W_out, Cout)
         return out
 
     def _gemm_ok(self, name, C_in) -> bool:
@@ -190,7 +201,7 @@ class WanVAEEngine:
                 x.stack[j].zero_()
             else:
                 x.stack[j].copy_(f)
-        out = Frames(x.T, x.H, x.W, out_C or pk.Cout_p, self.dev)
+        out = Frames(x.T, x.H, x.W, out_C or pk.Cout_p, self.dev, zero=(out_C or pk.Cout_p) != pk.Cout_p)  # (the kernel zeroes the border)
         ops.conv3d_gemm(x.stack, pk.gemm_weight(), pk.b, out.data, res.data if res is not None else None, T_out=x.T, H=x.H, W=x.W,
                         Cin=pk.Cin_p, Cout=pk.Cout_p, KT=KT)
         return out
@@ -221,9 +232,10 @@ class WanVAEEngine:
         return out
 
     def _rms_silu(self, x: Frames, gname, silu=True, border=1, front=None) -> Frames:
-        out = Frames(x.T, x.H, x.W, x.C, self.dev, front=front) if border else None
+        out = Frames(x.T, x.H, x.W, x.C, self.dev, front=front, zero=False) if border else None
         if border:
             ops.rms_silu(x.data, self.gammas[gname], out.data, x.T, x.C, x.H, x.W, 1, 1, silu)
+            ops.zero_border(out.data, x.T, x.H, x.W, x.C)
             return out
         rows = torch.empty((x.T, x.H * x.W, x.C), dtype=torch.bfloat16, device=self.dev)
         ops.rms_silu(x.data, self.gammas[gname], rows, x.T, x.C, x.H, x.W, 1, 0, silu)
@@ -327,8 +339,9 @@ class WanVAEEngine:
                 caches["slots"][i] = keep
                 x = y
         gemm = self._gemm_ok(name + ".resample.1", C)
-        u = Frames(x.T, 2 * x.H, 2 * x.W, C, self.dev, front=0 if gemm else None)
+        u = Frames(x.T, 2 * x.H, 2 * x.W, C, self.dev, front=0 if gemm else None, zero=False)
         ops.upsample2x(x.data, u.data, x.T, C, x.H, x.W)
+        ops.zero_border(u.data, u.T, u.H, u.W, C)
         if gemm:
             return self._conv_gemm(name + ".resample.1", u, [], None)
         return self._conv(name + ".resample.1", u.frame_list(), u.T, u.H, u.W, u.W)
@@ -504,6 +517,11 @@ class AutoencoderKLWan(torch.nn.Module):
         self.temperal_downsample = list(temperal_downsample)
         self._params = params
         self._engine = None
+        # use_graph: from the second call with a given input shape on, encode / decode replay ONE captured hipGraph (several hundred
+        # launches and allocations per call otherwise: at 720p the decode is 49 ms of kernels in 70 ms of wall time).  The first call of
+        # a shape runs eagerly - it also performs every lazy initialisation - so a one-off call pays nothing.
+        self.use_graph = False
+        self._graphs: Dict[tuple, object] = {}
 
     @property
     def dtype(self):
@@ -515,11 +533,33 @@ class AutoencoderKLWan(torch.nn.Module):
             self._engine = WanVAEEngine(self._params, c.base_dim, c.z_dim, tuple(c.dim_mult), c.num_res_blocks, tuple(c.temperal_downsample))
         return self._engine
 
+    def _run(self, kind: str, fn, x: torch.Tensor) -> torch.Tensor:
+        if not self.use_graph or not x.is_cuda:
+            return fn(x)
+        key = (kind, tuple(x.shape), x.dtype)
+        g = self._graphs.get(key)
+        if g is None:  # first call of this shape: eager (and warm)
+            self._graphs[key] = "warm"
+            return fn(x)
+        if isinstance(g, str):
+            if sum(1 for v in self._graphs.values() if not isinstance(v, str)) >= 4:  # every graph keeps its activations' pool alive
+                return fn(x)
+            static_in = x.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = fn(static_in)
+            g = self._graphs[key] = (graph, static_in, static_out)
+        graph, static_in, static_out = g
+        static_in.copy_(x)
+        graph.replay()
+        return static_out.clone()
+
     def encode(self, x: torch.Tensor, return_dict: bool = True):
-        mu = torch.stack([self.engine().encode(x[b]) for b in range(x.shape[0])], 0).to(x.dtype)
+        mu = self._run("encode", lambda t: torch.stack([self.engine().encode(t[b]) for b in range(t.shape[0])], 0), x).to(x.dtype)
         dist = SimpleNamespace(mode=lambda: mu, mean=mu)
         return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
 
     def decode(self, z: torch.Tensor, return_dict: bool = True):
-        v = torch.stack([self.engine().decode(z[b]) for b in range(z.shape[0])], 0).to(z.dtype)
+        v = self._run("decode", lambda t: torch.stack([self.engine().decode(t[b]) for b in range(t.shape[0])], 0), z).to(z.dtype)
         return SimpleNamespace(sample=v) if return_dict else (v,)

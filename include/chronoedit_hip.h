@@ -226,9 +226,14 @@ int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const
                         int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream);
 
 /* y = [silu]( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ) per pixel over C channels; x, y are stacks of npix/(H*W) frames
- * with in_border / out_border zero borders.  Replaces RMS_norm (+ nn.SiLU) (wan2pt1.py:63-75,193-200). */
+ * with in_border / out_border zero borders (the interiors are written, never the border).  C % 8 == 0, C <= 512.
+ * Replaces RMS_norm (+ nn.SiLU) (wan2pt1.py:63-75,193-200). */
 int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,
                      int out_border, int apply_silu, hipStream_t stream);
+
+/* Zero the one-pixel border of T frames [H+2][W+2][ld] (channels [0, C)): for buffers that were not zero-filled and whose producer
+ * writes interiors only (the border is the zero padding of the next convolution). */
+int ce_zero_border_bf16(void* frames, int T, int H, int W, int C, int ld, hipStream_t stream);
 
 /* nearest-exact 2x spatial upsample of T bordered frames [H+2][W+2][C] -> [2H+2][2W+2][C] (wan2pt1.py:78-83,99-104). */
 int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipStream_t stream);

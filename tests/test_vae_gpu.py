@@ -128,3 +128,50 @@ def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
     b_mu, b_rec = rel_l2(mu_b, fx["mu"]), rel_l2(rec_b, fx["rec"])
     print(f"{name}: encode hip {e_mu:.3e} (bf16 eager {b_mu:.3e})  decode hip {e_rec:.3e} (bf16 eager {b_rec:.3e})")
     assert e_mu < 3 * b_mu + 5e-3 and e_rec < 3 * b_rec + 5e-3
+
+
+def test_vae_graph_replay_equals_eager():
+    """AutoencoderKLWan.use_graph: the second call of a shape captures encode / decode into a hipGraph, later calls replay it - on NEW
+    inputs, bit-identical to the eager engine."""
+    from chronoedit_amd.vae import AutoencoderKLWan
+    dev = torch.device("cuda:0")
+    arch = dict(dim=32, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True))
+    vae = AutoencoderKLWan.random_init(dev, seed=3, **arch)
+    g = torch.Generator().manual_seed(1)
+    xs = [(torch.rand(1, 3, 5, 32, 48, generator=g) * 2 - 1).to(torch.bfloat16).to(dev) for _ in range(4)]
+    zs = [torch.randn(1, 16, 2, 4, 6, generator=g).to(torch.bfloat16).to(dev) for _ in range(4)]
+    eager_mu = [vae.encode(x).latent_dist.mode().clone() for x in xs]
+    eager_v = [vae.decode(z, return_dict=False)[0].clone() for z in zs]
+    vae.use_graph = True
+    for i in range(4):  # call 0 eager, call 1 captures and replays, calls 2, 3 replay
+        assert torch.equal(vae.encode(xs[i]).latent_dist.mode(), eager_mu[i]), i
+        assert torch.equal(vae.decode(zs[i], return_dict=False)[0], eager_v[i]), i
+    assert sum(1 for v in vae._graphs.values() if not isinstance(v, str)) == 2
+
+
+@pytest.mark.parametrize("C,T,H,W,silu,border", [(96, 2, 9, 70, True, 1), (192, 1, 5, 33, True, 1), (384, 3, 4, 17, False, 1), (32, 1, 6, 40, True, 1),
+                                                  (128, 2, 3, 100, True, 0), (512, 1, 2, 5, True, 1)])
+def test_rms_silu_kernel_vs_fp32(C, T, H, W, silu, border):
+    """ce_rms_silu_bf16 (channel RMS-norm x gamma [+ SiLU] on bordered channels-last frames, wan2pt1.py:63-75): every lane layout the
+    widths select (12 or 16 active lanes per pixel, 1 - 4 chunks per lane), rows that end inside a workgroup's pixel span, bordered and
+    plain-row outputs; the output border is left alone."""
+    from chronoedit_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + W)
+    x = torch.zeros(T, H + 2, W + 2, C, dtype=torch.bfloat16)
+    x[:, 1:-1, 1:-1] = (torch.randn(T, H, W, C, generator=g) * 3).to(torch.bfloat16)
+    gamma = torch.rand(C, generator=g) + 0.5
+    xf = x[:, 1:-1, 1:-1].float()
+    ref = xf / xf.norm(dim=-1, keepdim=True).clamp_min(1e-12) * C ** 0.5 * gamma
+    if silu:
+        ref = torch.nn.functional.silu(ref)
+    if border:
+        out = torch.full((T, H + 2, W + 2, C), 5.0, dtype=torch.bfloat16, device=dev)
+        ops.rms_silu(x.to(dev), gamma.to(dev), out, T, C, H, W, 1, 1, silu)
+        got = out[:, 1:-1, 1:-1]
+        assert float((out[:, 0] - 5).abs().max()) == 0.0 and float((out[:, :, -1] - 5).abs().max()) == 0.0
+    else:
+        out = torch.empty((T, H * W, C), dtype=torch.bfloat16, device=dev)
+        ops.rms_silu(x.to(dev), gamma.to(dev), out, T, C, H, W, 1, 0, silu)
+        got = out.reshape(T, H, W, C)
+    assert rel_l2(got, ref) < 4e-3, rel_l2(got, ref)

@@ -33,6 +33,17 @@ out = dec()
 torch.cuda.synchronize()
 res["decode_s"] = time.perf_counter() - t0
 print("decode", tuple(out.shape), f"{res['decode_s']:.3f} s", "finite", bool(torch.isfinite(out.float()).all()), flush=True)
+if os.environ.get("CE_VAE_GRAPH", "1") != "0":  # the same calls as replays of captured hipGraphs (AutoencoderKLWan.use_graph)
+    vae.use_graph = True
+    for name, fn in (("encode", lambda: vae.encode(x).latent_dist.mode()), ("decode", dec)):
+        fn(), fn()  # eager + warm, capture + replay
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        res[name + "_graph_s"] = time.perf_counter() - t0
+        print(name, "as a hipGraph replay", f"{res[name + '_graph_s']:.3f} s", flush=True)
+    vae.use_graph = False
 with ops.profile() as prof:
     dec()
 summ = prof.summary()
