@@ -1,10 +1,20 @@
 #!/bin/bash
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_vae_gpu.py -q --no-header -p no:cacheprovider -x > gpurun_out/q_pytest_vae.log 2>&1; grep -v amdgpu.ids gpurun_out/q_pytest_vae.log | tail -15
-timeout 300 python tools/vae_bench.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/q_vae_bench.log; grep -E "encode|decode \(|replay" gpurun_out/q_vae_bench.log
-R=$GRAFT_REPO_ROOT
-cd /tmp
-CE_VAE_GRAPH=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/q_vae_prof -o p -- python $R/tools/vae_bench.py > $R/gpurun_out/q_vae_prof.log 2>&1
-cd $R
-head -14 gpurun_out/q_vae_prof/p_kernel_stats.csv | cut -c1-200
+timeout 1500 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
+grep -v amdgpu.ids gpurun_out/pytest_gpu.log | tail -6
+timeout 900 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench.log
+timeout 600 python bench.py --steps 6 --warmup 2 --graph --no-cpu-baseline --no-vae --no-encoders --no-edit --no-fp8-leg 2>/dev/null | tail -1 > gpurun_out/bench_graph.log
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-vae --no-encoders --no-edit --no-fp8-leg > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1)
+python - <<'PY'
+import json
+for f in ("gpurun_out/bench.log", "gpurun_out/bench_graph.log"):
+    try:
+        d = json.loads(open(f).read())
+        print(f, {k: d[k] for k in ("value", "ms_per_step", "achieved_tflops_per_gpu", "launch", "vae", "sec_per_edit_8_steps_measured", "sec_per_edit_50_steps", "roofline", "roofline_family", "cpu_baseline") if k in d})
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+bash tools/gpu_pmc_traffic.sh gemm384_14400x5120x13824 gemm 14400 5120 13824 2 6 5 > /dev/null 2>&1
+cat gpurun_out/pmc_gemm384_14400x5120x13824.txt | head -40
