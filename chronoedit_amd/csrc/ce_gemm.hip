@@ -261,11 +261,9 @@ extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
 // round (slab write, reduce launch) if it can - times the tile area.  M = 14400 at N = 5120: 1140 tiles of 256 x 256 = 4 rounds + a
 // half round + reduce against 760 tiles of 384 x 256 = 2.97 rounds (measured +3 ... +4 %); N = 13824: 12.02 against 8.02 rounds
 // (256 x 256 wins by 2.6 %); the V^T product (M = 5120 = 13.3 tiles of 384 rows: 5 % of padding) stays on 256 x 256.
-static bool prefer_tile384(int M, int N, int K) {
-  float* ws = nullptr;
-  size_t ws_bytes = 0;
-  int cus = 256;
-  ce_gemm256_workspace(&ws, &ws_bytes, &cus);
+// Exported as a pure function of the shape, the CU count and the split-K workspace size (tests/test_host_cpu.py pins the step's choices).
+extern "C" int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_bytes) {
+  if (M <= 0 || N <= 0 || K < 64 || cus <= 0) return 0;
   const int kt = K / 64;
   auto cost = [&](int bm) -> double {
     const long long nwg = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
@@ -274,17 +272,24 @@ static bool prefer_tile384(int M, int N, int K) {
     double last = 0.0;
     if (tail > 0) {
       int split = 1;
-      if (ws != nullptr)
-        for (int sp = cus / tail < 8 ? cus / tail : 8; sp >= 2; --sp)
-          if (kt % (2 * sp) == 0 && (size_t)tail * sp * bm * 256 * sizeof(float) <= ws_bytes) {
-            split = sp;
-            break;
-          }
+      for (int sp = cus / tail < 8 ? cus / tail : 8; sp >= 2; --sp)
+        if (kt % (2 * sp) == 0 && (long long)tail * sp * bm * 256 * (long long)sizeof(float) <= ws_bytes) {
+          split = sp;
+          break;
+        }
       last = split > 1 ? 1.0 / split + 0.125 : 1.0;
     }
     return ((double)full + last) * bm * 256.0;
   };
-  return cost(384) <= cost(256);
+  return cost(384) <= cost(256) ? 384 : 256;
+}
+
+static bool prefer_tile384(int M, int N, int K) {
+  float* ws = nullptr;
+  size_t ws_bytes = 0;
+  int cus = 256;
+  ce_gemm256_workspace(&ws, &ws_bytes, &cus);
+  return ce_gemm_bf16_tile_rows(M, N, K, cus, ws != nullptr ? (long long)ws_bytes : 0) == 384;
 }
 
 extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,

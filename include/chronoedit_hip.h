@@ -83,6 +83,11 @@ int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, i
  * loop, 3 / 4 its one-wave-per-SIMD main loop (csrc/ce_gemm256w4.hip; A ring of 3 / 2 stages).  Host-side test/bench knob. */
 int ce_set_gemm_variant(int variant);
 
+/* Which macro tile ce_gemm_bf16 runs a LARGE product on when the choice is automatic: 384 (x 256, ce_gemm384.hip) or 256 (x 256,
+ * ce_gemm256w4.hip) rows - the one whose tile count falls better on `cus` compute units (full rounds + the last round, which is cut
+ * along K when the split-K workspace of `ws_bytes` bytes allows it).  A pure function: no device is touched.  0: invalid arguments. */
+int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_bytes);
+
 /* Scratch for the split-K tail of ce_gemm_bf16's 256-tile kernel: the tiles that would run as a partially filled last
  * round of workgroups are cut along K into fp32 slabs (256 KiB each, at most one per CU) and summed by a second
  * launch that applies the epilogue.  ptr is device memory owned by the caller (NULL switches the split off; that is

@@ -167,3 +167,22 @@ def test_conv3d_gemm_address_map_reproduces_the_convolution(KT, T_out, H, W, Cin
     out[Wp + 1 : Wp + 1 + rows] = c
     out = out.reshape(T_out, Hp, Wp, Cout)
     assert torch.allclose(out[:, 1:-1, 1:-1], want, atol=1e-9)
+
+
+def test_macro_tile_choice_of_the_step_shapes():
+    """ce_gemm_bf16_tile_rows: the automatic 384 x 256 / 256 x 256 macro-tile choice is a pure function of the shape, the CU count and
+    the split-K workspace - pinned here for the five large GEMMs of a batched-CFG step at 720p on 256 CUs with the engine's 64 MiB
+    workspace (what the same-box A/B measured as the faster tile for each)."""
+    from chronoedit_amd import hiplib, ops
+    lib = hiplib.load()
+    ws = ops.GEMM_WS_BYTES
+    pick = lambda M, N, K: lib.ce_gemm_bf16_tile_rows(M, N, K, 256, ws)
+    assert pick(14400, 10240, 5120) == 384   # q | k: 1520 tiles = 5.94 rounds (2280 = 8.9)
+    assert pick(5120, 14400, 5120) == 256    # V^T: M = 13.3 tiles of 384 rows would pad 5 %
+    assert pick(14400, 5120, 5120) == 384    # out-projections, q of the cross-attention: 760 tiles = 2.97 rounds (1140 = 4.45)
+    assert pick(14400, 13824, 5120) == 256   # FFN-up: 12.02 rounds against 8.02 x 1.5
+    assert pick(14400, 5120, 13824) == 384   # FFN-down
+    assert pick(0, 5120, 5120) == 0 and pick(256, 256, 32) == 0
+    # without a workspace a partial last round cannot be cut along K: it costs a whole round
+    assert lib.ce_gemm_bf16_tile_rows(14400, 5120, 5120, 256, 0) == 384    # 3 rounds x 1.5 against 5
+    assert lib.ce_gemm_bf16_tile_rows(14400, 13824, 5120, 256, 0) == 256   # 9 rounds x 1.5 against 13
