@@ -78,9 +78,11 @@ int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, i
                      int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride,
                      int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
-/* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default), 0 force the 128x128
- * register-staged kernel, 1 force the 256x256 LDS-DMA kernel wherever the shape allows, 2 the same with the staggered main
- * loop, 3 / 4 its one-wave-per-SIMD main loop (csrc/ce_gemm256w4.hip; A ring of 3 / 2 stages).  Host-side test/bench knob. */
+/* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default: large shapes on the one-wave-per-SIMD
+ * LDS-DMA kernels, macro tile per ce_gemm_bf16_tile_rows), 0 force the 128x128 register-staged kernel; wherever the shape allows the
+ * large-tile kernels: 1 the 8-wave 256x256 main loop (csrc/ce_gemm256.hip), 2 the same staggered, 3 / 4 / 5 the one-wave-per-SIMD
+ * 256x256 main loop (csrc/ce_gemm256w4.hip; A ring of 3 stages / 2 stages / 3 stages and one barrier per K-tile), 6 the 384x256 macro
+ * tile (csrc/ce_gemm384.hip).  Host-side test/bench knob. */
 int ce_set_gemm_variant(int variant);
 
 /* Which macro tile ce_gemm_bf16 runs a LARGE product on when the choice is automatic: 384 (x 256, ce_gemm384.hip) or 256 (x 256,
