@@ -175,3 +175,24 @@ def test_rms_silu_kernel_vs_fp32(C, T, H, W, silu, border):
         ops.rms_silu(x.to(dev), gamma.to(dev), out, T, C, H, W, 1, 0, silu)
         got = out.reshape(T, H, W, C)
     assert rel_l2(got, ref) < 4e-3, rel_l2(got, ref)
+
+
+def test_vae_at_720p_both_conv_routes_agree():
+    """BASELINE configs[1] size (720 x 1280, 5 pixel frames <-> 2 latent frames, production width): the whole encode and decode with the
+    wide convs on the large-tile GEMM (the default) against the same engine with every conv on the implicit-GEMM kernel - the
+    size-independent statement for shapes no CPU oracle finishes (61 M-tiles per frame, 3600-tile launches, Cin = 96 K-run padding,
+    both macro tiles, frame caches as views)."""
+    from chronoedit_amd.vae import AutoencoderKLWan
+    dev = torch.device("cuda:0")
+    vae = AutoencoderKLWan.random_init(dev, seed=11)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(1, 3, 5, 720, 1280, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    z = torch.randn(1, 16, 2, 90, 160, generator=g).to(torch.bfloat16).to(dev)
+    mu_new = vae.encode(x).latent_dist.mode().float()
+    v_new = vae.decode(z, return_dict=False)[0].float()
+    vae.engine().use_gemm_conv = False
+    mu_old = vae.encode(x).latent_dist.mode().float()
+    v_old = vae.decode(z, return_dict=False)[0].float()
+    assert torch.isfinite(mu_new).all() and torch.isfinite(v_new).all()
+    assert rel_l2(mu_new, mu_old) < 1e-2, rel_l2(mu_new, mu_old)   # same products in another summation order, ~60 bf16 roundings deep
+    assert rel_l2(v_new, v_old) < 1e-2, rel_l2(v_new, v_old)
