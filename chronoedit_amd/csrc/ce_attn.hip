@@ -403,11 +403,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       Q += (size_t)bz * Nq * ldq;
       O += (size_t)bz * Nq * ldo;
       seg0.k += (size_t)bz * seg0.len * seg0.ldk;
-      seg0.v += VT ? (size_t)bz * seg0.len : (size_t)bz * seg0.len * seg0.ldv;  // VT: the samples' keys sit side by side in the columns of V^T
+      // VT: the samples' keys sit side by side in the columns of V^T (two-segment form: at the column strides blk.vt_cols / blk.stride)
+      seg0.v += VT ? (size_t)bz * (TWO_SEG ? blk.vt_cols : seg0.len) : (size_t)bz * seg0.len * seg0.ldv;
     }
     if (TWO_SEG) {
       seg1.k += (size_t)bz * seg1.len * seg1.ldk;
-      seg1.v += (size_t)bz * seg1.len * seg1.ldv;
+      seg1.v += VT ? (size_t)bz * blk.stride : (size_t)bz * seg1.len * seg1.ldv;
     }
   }
   const int q0 = qb * QB + wave * QW;
@@ -1047,4 +1048,32 @@ extern "C" int ce_attention_vt_blocked_bf16(const void* Q, const void* K, const 
   if (blk_rows <= 0) return CE_ERR_SHAPE;
   return attention_vt_launch(Q, K, Vt, len, ldk, ldvt, O, Nq, H, head_dim, ldq, ldo, softmax_scale, batch, blk_rows, blk_stride, vt_sample_cols,
                              stream);
+}
+
+
+/* Cross-attention (two key / value segments with a softmax each, outputs added in bf16) with both V operands handed over TRANSPOSED:
+ * V1t [H * 128][ldv1t], V2t [H * 128][ldv2t], sample b's keys at columns [b vt_cols, b vt_cols + len) of its segment (vt_cols a multiple
+ * of 2, >= 64 ceil(len / 64); columns past len finite).  K as in ce_attention_batched_bf16 (samples stacked along the rows).  K and
+ * V^T tiles of both segments go by LDS-DMA. */
+extern "C" int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
+                                         const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq,
+                                         int H, int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
+  if (!Q || !K1 || !V1t || !K2 || !V2t || !O) return CE_ERR_ARG;
+  if (head_dim != HD || Nq <= 0 || H <= 0 || len1 <= 0 || len2 <= 0 || batch <= 0 || batch > 65535) return CE_ERR_SHAPE;
+  const int c1 = (len1 + KVB - 1) / KVB * KVB, c2 = (len2 + KVB - 1) / KVB * KVB;
+  if (vt_cols1 < c1 || vt_cols2 < c2 || ldv1t < (batch - 1) * vt_cols1 + c1 || ldv2t < (batch - 1) * vt_cols2 + c2) return CE_ERR_SHAPE;
+  if ((ldq & 7) || (ldo & 7) || (ldk1 & 7) || (ldk2 & 7) || (ldv1t & 7) || (ldv2t & 7) || (vt_cols1 & 1) || (vt_cols2 & 1)) return CE_ERR_ALIGN;
+  KVSeg s0{(const bf16*)K1, (const bf16*)V1t, len1, ldk1, ldv1t};
+  KVSeg s1{(const bf16*)K2, (const bf16*)V2t, len2, ldk2, ldv2t};
+  const float sl2 = softmax_scale * 1.4426950408889634f;
+  const int nqb = (Nq + 8 * QW - 1) / (8 * QW);
+  static bool done_[CE_MAX_DEVICES] = {};
+  bool& done = done_[ce_device_slot()];
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(true));
+    done = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q, (bf16*)O,
+                     s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, BlkRows{0, vt_cols2, 0u, vt_cols1});  // plain rows; the two column strides
+  return (int)hipGetLastError();
 }

@@ -52,6 +52,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_attention_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     "ce_attention_batched_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_attention_vt_bf16": [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ce_attention_2seg_vt_bf16": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_v_transpose_bf16": [_P, _I, _P, _I, _I, _I, _P],
     "ce_attention_vt_blocked_bf16": [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
     "ce_v_transpose_blocked_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -331,6 +331,33 @@ def attention_vt(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
     return out
 
 
+def attention_2seg_vt(q: torch.Tensor, k1: torch.Tensor, v1t: torch.Tensor, len1: int, k2: torch.Tensor, v2t: torch.Tensor, len2: int,
+                      heads: int, out: Optional[torch.Tensor] = None, scale: Optional[float] = None, batch: int = 1):
+    """Cross-attention over two key / value segments (a softmax each, outputs added in bf16) with V transposed: k1 [batch*len1, H*128],
+    v1t [H*128, batch * c1] with sample b's keys at columns [b*c1, b*c1 + len1), c1 = v1t.shape[1] // batch (even, >= 64*ceil(len1/64),
+    zero beyond len1); the same for segment 2.  Same arithmetic as `attention(..., k2=, v2=)`; K and V^T tiles by LDS-DMA."""
+    for n, t in (("q", q), ("k1", k1), ("v1t", v1t), ("k2", k2), ("v2t", v2t)):
+        _dev(t, torch.bfloat16, n)
+    Nq, Dq, ldq = _rows(q, "q")
+    _, _, ldk1 = _rows(k1, "k1")
+    _, _, ldk2 = _rows(k2, "k2")
+    assert Dq == heads * 128 and v1t.shape[0] == Dq and v2t.shape[0] == Dq and v1t.stride(1) == 1 and v2t.stride(1) == 1
+    assert Nq % batch == 0 and k1.shape[0] == batch * len1 and k2.shape[0] == batch * len2
+    assert v1t.shape[1] % batch == 0 and v2t.shape[1] % batch == 0
+    if out is None:
+        out = torch.empty((Nq, Dq), dtype=torch.bfloat16, device=q.device)
+    _, _, ldo = _rows(out, "out")
+    if scale is None:
+        scale = 128 ** -0.5
+    st = _prof_begin()
+    nq = Nq // batch
+    _check(lib().ce_attention_2seg_vt_bf16(_ptr(q), _ptr(k1), _ptr(v1t), len1, ldk1, v1t.stride(0), v1t.shape[1] // batch, _ptr(k2), _ptr(v2t),
+                                           len2, ldk2, v2t.stride(0), v2t.shape[1] // batch, _ptr(out), nq, heads, 128, ldq, ldo,
+                                           float(scale), batch, _stream()), "ce_attention_2seg_vt_bf16")
+    _prof_end(st, f"attention_{nq}x{len1}+{len2}_h{heads}" + (f"_b{batch}" if batch > 1 else ""), 4.0 * nq * (len1 + len2) * 128 * heads * batch)
+    return out
+
+
 def v_transpose_blocked(v: torch.Tensor, heads: int, batch: int, blk_rows: int, n_keys: int, out: Optional[torch.Tensor] = None):
     """v [W * batch * blk_rows, heads*128] in the all-to-all receive layout ([source rank][sample][local token]) -> V^T
     [heads*128, batch * vt_sample_cols] plain per sample (`attention_vt_blocked`); n_keys = valid tokens per sample."""

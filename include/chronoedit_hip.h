@@ -120,6 +120,14 @@ int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int
 int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int head_dim,
                          int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream);
 
+/* Cross-attention - TWO key / value segments with a softmax each, the two outputs added in bf16 (transformer_chronoedit.py:91-104: text
+ * and image keys) - with both V operands handed over transposed: V1t [H*128][ldv1t], V2t [H*128][ldv2t], sample b's keys at columns
+ * [b*vt_cols, b*vt_cols + len) of its segment's V^T (vt_cols even, >= 64*ceil(len/64); every column read is finite).  K1 / K2 as in
+ * ce_attention_batched_bf16 (samples stacked along the rows).  The K and V^T tiles of both segments reach LDS by LDS-DMA. */
+int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1, const void* K2,
+                              const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq, int H, int head_dim, int ldq,
+                              int ldo, float softmax_scale, int batch, hipStream_t stream);
+
 /* ce_attention_vt_bf16 over the BLOCKED row layout an all-to-all leaves behind when every rank sent [sample][local token] rows
  * (Ulysses sequence parallelism with the guidance pair batched: chronoedit_amd/parallel.py): token g of sample b sits in row
  * (g / blk_rows) blk_stride + b blk_rows + g % blk_rows of Q, K and O (blk_rows = tokens per rank, a multiple of 64; blk_stride =

@@ -373,6 +373,37 @@ def test_attention_two_segments(attn_waves):
     assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("Nq,L1,L2,H,B", [(700, 512, 257, 4, 1), (300, 512, 257, 2, 2), (513, 100, 65, 3, 2), (7200, 512, 257, 8, 2)])
+def test_attention_two_segments_vt_form(Nq, L1, L2, H, B):
+    """ce_attention_2seg_vt_bf16 (cross-attention with both V operands transposed, K and V^T tiles by LDS-DMA) vs fp32 SDPA per segment
+    and vs the register-staged form the engine runs; batches with padded per-sample column strides (257 keys -> 320 columns), key counts
+    that end inside a tile, a remainder query block."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(Nq + L2)
+    D = H * 128
+    q = torch.randn(B * Nq, D, generator=g).to(BF).to(dev)
+    kv1 = torch.randn(B * L1, 2 * D, generator=g).to(BF).to(dev)
+    kv2 = torch.randn(B * L2, 2 * D, generator=g).to(BF).to(dev)
+    kv2[:, D:].add_((torch.arange(B * L2, device=dev) % 5).to(BF)[:, None] * 0.5)  # key-dependent v: a permuted P.V shows up
+
+    def vt_of(v, ln):
+        cols = (ln + 63) // 64 * 64
+        vt = torch.zeros((D, B * cols), dtype=BF, device=dev)
+        for b in range(B):
+            vt[:, b * cols : b * cols + ln] = v[b * ln : (b + 1) * ln].t()
+        return vt
+
+    out = ops.attention_2seg_vt(q, kv1[:, :D], vt_of(kv1[:, D:], L1), L1, kv2[:, :D], vt_of(kv2[:, D:], L2), L2, H, batch=B)
+    old = ops.attention(q, kv1[:, :D], kv1[:, D:], H, k2=kv2[:, :D], v2=kv2[:, D:], batch=B)
+    assert rel_l2(out, old) < 4e-3, rel_l2(out, old)  # same products, another key order inside a tile
+    for b in range(B):
+        qb = q[b * Nq : (b + 1) * Nq]
+        ref = (_sdpa_ref(qb, kv1[b * L1 : (b + 1) * L1, :D], kv1[b * L1 : (b + 1) * L1, D:], H).to(BF).float()
+               + _sdpa_ref(qb, kv2[b * L2 : (b + 1) * L2, :D], kv2[b * L2 : (b + 1) * L2, D:], H).to(BF).float())
+        assert rel_l2(out[b * Nq : (b + 1) * Nq], ref) < 1e-2, (b, rel_l2(out[b * Nq : (b + 1) * Nq], ref))
+
+
 def test_timestep_chain_and_modulation():
     from chronoedit_amd import ops
     from oracle import dit_oracle as O
