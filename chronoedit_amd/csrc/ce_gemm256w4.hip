@@ -524,3 +524,29 @@ extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, c
   return w4_launch(A, W, C, bias, epilogue, nullptr, res, M, N, K, lda, ldw, ldc, ldres, 0, a_seg_k, a_seg_stride, 0, 0, a_seg2_k, a_seg2_stride,
                    2, n_tile / 32, stream);
 }
+
+// The split-K reduce of this file's slab layout for another producer (ce_gemm_fp8w4.hip: the same wave tiles and raster, slabs already
+// scaled): sums the `split` slabs of each of the `tail` tiles, adds the bias, applies the epilogue.
+extern "C" int ce_gemm256w4_reduce_launch(int epilogue, void* C, const float* bias, const float* gate, const void* res, int M, int N, int ldc,
+                                          int ldres, int gate_rows, int tiles_m, int tiles_n, int t_full, int split, const float* ws, int tail,
+                                          hipStream_t stream) {
+  static bool done_[CE_MAX_DEVICES][8] = {};
+  bool* done = done_[ce_device_slot()];
+#define CE_RED(E)                                                                                                            \
+  do {                                                                                                                       \
+    if (!done[E]) {                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)gemm256w4_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * QROW);    \
+      done[E] = true;                                                                                                        \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((gemm256w4_reduce<E>), dim3(4 * tail), dim3(256), 128 * QROW, stream, (bf16*)C, bias, gate, (const bf16*)res, M, N, \
+                       ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, ws);                                          \
+  } while (0)
+  switch (epilogue) {
+    case EPI_BIAS: CE_RED(EPI_BIAS); break;
+    case EPI_BIAS_GELU: CE_RED(EPI_BIAS_GELU); break;
+    case EPI_GATE_RES: CE_RED(EPI_GATE_RES); break;
+    default: return CE_ERR_ARG;
+  }
+#undef CE_RED
+  return (int)hipGetLastError();
+}

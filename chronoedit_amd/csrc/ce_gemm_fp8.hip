@@ -311,6 +311,19 @@ extern "C" int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, in
   return (int)hipGetLastError();
 }
 
+extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias,
+                                    int epilogue, const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc,
+                                    int ldres, int gate_rows, hipStream_t stream);
+
+// main loop of ce_gemm_fp8: 1 = one wave per SIMD (ce_gemm_fp8w4.hip; the default: +2 ... +8 % on the step's shapes,
+// profiles/r03_gemm_fp8_variants_ab.txt), 0 = the 8-wave / 4-phase loop of this file
+static int g_fp8_variant = 1;
+extern "C" int ce_set_gemm_fp8_variant(int v) {
+  const int old = g_fp8_variant;
+  if (v == 0 || v == 1) g_fp8_variant = v;
+  return old;
+}
+
 extern "C" int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias, int epilogue,
                            const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                            int gate_rows, hipStream_t stream) {
@@ -319,6 +332,8 @@ extern "C" int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float*
   if ((lda & 15) || (ldw & 15) || (ldc & 7)) return CE_ERR_ALIGN;
   if ((long long)M * lda >= (1ll << 32) || (long long)N * ldw >= (1ll << 32)) return CE_ERR_SHAPE;  // 32-bit DMA offsets
   if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
+  if (g_fp8_variant == 1 && (epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_GATE_RES))
+    return ce_gemm_fp8w4_launch(Aq, Wq, C, sa, sw, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(512);
   static bool attr_done_[CE_MAX_DEVICES][3] = {};

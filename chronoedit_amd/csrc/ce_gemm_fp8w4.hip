@@ -1,0 +1,297 @@
+// 256x256x128 fp8 (OCP e4m3) GEMM with per-row / per-column scales, ONE WAVE PER SIMD: 4 waves (2 x 2), wave tile 128 x 128 -
+// the register / LDS economy of ce_gemm256w4.hip applied to the contract of ce_gemm_fp8.hip (same arithmetic, same epilogues):
+//     C[m][n] = epilogue( sa[m] * sw[n] * sum_k Aq[m][k] * Wq[n][k] + bias[n] )
+// A 128-byte LDS row is 128 fp8 = ONE k-step of v_mfma_f32_16x16x128_f8f6f4 (the unscaled form: block scales 2^0), so a K-tile is
+// 64 MFMAs per wave on 16 fragments of 32 bytes per lane (8 registers each) - 32 ds_read_b128 per K-tile and wave where the 8-wave
+// kernel reads 48, and one workgroup barrier per K-tile instead of four.
+//
+//  * registers: 64 accumulators = 256 AGPRs (asm MFMAs tied in place, as in ce_gemm256w4.hip); the W fragments of a K-tile
+//    double-buffered (2 x 8 x 8 = 128 VGPRs); the A fragments through a RING of four (32 VGPRs) read three MFMA groups ahead.
+//  * LDS: two stages of [A 32 KiB | W 32 KiB]; rows of 128 B with the source-side chunk swizzle (chunk c of row r in slot
+//    c ^ ((r >> 1) & 7)), filled by buffer_load_dwordx4 ... lds with per-lane row offsets computed once and the K-tile in soffset.
+//  * K-tile t (stage t & 1) = 8 groups; group G = A fragment G against the eight W fragments:
+//        groups 0..4: the ring reads A fragments 3..7 of tile t
+//        vmcnt(0) + lgkmcnt(0) + s_barrier: tile t+1 has landed everywhere, nobody reads stage t & 1 any more (its W fragments were
+//                     taken during tile t-1, its last A fragment in group 4)
+//        groups 5..7: the 16 LDS-DMA pieces of tile t+2 -> stage t & 1; the W fragments of tile t+1 -> the other W set; the ring
+//                     wraps into tile t+1 (A fragments 0..2)
+//    so a piece has five groups (>= 1280 matrix-pipe cycles) plus the wait in front of the barrier to land.
+#include <algorithm>
+
+#include "ce_common.h"
+#include "ce_gemm_epi.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BKB = 128;  // K-tile in bytes (= fp8 elements)
+constexpr int TILE = 256 * BKB;               // one operand K-tile, 32 KiB
+constexpr int STAGE = 2 * TILE;               // [A | W]
+constexpr int CROW = BN * 2 + 16;             // padded epilogue staging row (528 B)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+#define X8_PIN() __builtin_amdgcn_sched_barrier(0)
+#define X8_BAR() __builtin_amdgcn_s_barrier()
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_fp8_w4(
+    const unsigned char* __restrict__ A, const unsigned char* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ sa,
+    const float* __restrict__ sw, const float* __restrict__ bias, const float* __restrict__ gate, const bf16* __restrict__ res, int M,
+    int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int tiles_m, int tiles_n, int t_full, int split,
+    float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // split-K tail (as in ce_gemm256w4.hip): the tiles of a partially filled last round are cut along K into `split` pieces that write
+  // SCALED fp32 slabs (sa[m] sw[n] acc: the sum of the pieces is then the scaled sum) for gemm256w4_reduce, which adds the bias and
+  // applies the epilogue
+  const bool partial = (int)blockIdx.x >= t_full;
+  int wg, kt0 = 0, ktn = K / BKB;
+  if (!partial) {
+    wg = xcd_remap(blockIdx.x, t_full);
+  } else {
+    const int tb = blockIdx.x - t_full;
+    wg = t_full + tb / split;
+    ktn = ktn / split;
+    kt0 = (tb % split) * ktn;
+  }
+  int m0, n0;
+  {
+    constexpr int GROUP = 4;
+    const int group_sz = GROUP * tiles_n, gid = wg / group_sz, first_m = gid * GROUP;
+    const int gm = min(tiles_m - first_m, GROUP);
+    m0 = (first_m + (wg % group_sz) % gm) * BM;
+    n0 = ((wg % group_sz) / gm) * BN;
+  }
+  const int kt_last = ktn - 1;
+
+  // LDS-DMA sources: piece p of this wave = rows 8 (wave + 4 p) .. + 8 of the operand tile, lane l -> row + (l >> 3), slot l & 7
+  uint32_t a_voff[8], w_voff[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = 8 * (wave + 4 * p) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    a_voff[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + chunk * 16;
+    w_voff[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + chunk * 16;
+  }
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xffffffffu, 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xffffffffu, 0x00020000);
+  auto koff = [&](int t) __attribute__((always_inline)) -> int { return (kt0 + min(t, kt_last)) * BKB; };
+  // piece q (0..15) of a tile: 0..7 = A, 8..15 = W
+  auto dma = [&](int q, int stage_bytes, int soff) __attribute__((always_inline)) {
+    if (q < 8)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + stage_bytes + (wave + 4 * q) * 1024), 16, a_voff[q & 7], soff, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + stage_bytes + TILE + (wave + 4 * (q - 8)) * 1024), 16,
+                                               w_voff[q & 7], soff, 0, 0);
+  };
+
+  // fragment = the 32 bytes k = 32 fg + [0, 32) of a row: chunks 2 fg and 2 fg + 1, in slots (2 fg + h) ^ ((row >> 1) & 7) = (2 fg + h) ^ (fr >> 1)
+  int a_rd[2], w_rd[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    a_rd[h] = (wm * 128 + fr) * 128 + (((2 * fg + h) ^ (fr >> 1)) << 4);
+    w_rd[h] = TILE + (wn * 128 + fr) * 128 + (((2 * fg + h) ^ (fr >> 1)) << 4);
+  }
+  auto read_frag = [&](int base0, int base1, int stage_bytes, int f) __attribute__((always_inline)) -> i32x8 {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + base0 + stage_bytes + f * 2048);
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(smem + base1 + stage_bytes + f * 2048);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+
+  f32x4 acc[8][8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: tiles 0 and 1 on their way, tile 0 landed; its W fragments and its first three A fragments read
+  {
+    const int k0 = koff(0), k1 = koff(1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dma(q, 0, k0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dma(q, STAGE, k1);
+  }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  X8_BAR();
+  i32x8 ring[4], bw0[8], bw1[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bw0[g] = read_frag(w_rd[0], w_rd[1], 0, g);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) ring[f] = read_frag(a_rd[0], a_rd[1], 0, f);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  X8_PIN();
+
+  // W fragment first: the accumulator holds C^T, lane (fr, fg) of acc[F][G] owns row F*16 + fr and the columns G*16 + fg*4 + [0,4)
+#define X8_MMA(F, G, BW) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]))
+  // group G of the tile in stage PAR (its W fragments in BW, the next tile's go to BN); fillers between single MFMAs
+#define X8_GROUP(G, PAR, BW, BN_, KNEXT)                                                                                      \
+  {                                                                                                                           \
+    constexpr int fn_ = ((G) + 3) & 7;                     /* the A fragment fetched now ... */                                \
+    constexpr int sn_ = ((G) + 3 >= 8) ? (1 - (PAR)) * STAGE : (PAR) * STAGE; /* ... from this tile or the next */             \
+    if ((G) == 5) {                                                                                                           \
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+      X8_BAR();                                                                                                               \
+      X8_PIN();                                                                                                               \
+    }                                                                                                                         \
+    X8_MMA(G, 0, BW);                                                                                                         \
+    ring[((G) + 3) % 4] = read_frag(a_rd[0], a_rd[1], sn_, fn_);                                                               \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 1, BW);                                                                                                         \
+    if ((G) >= 5) { dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 0, (PAR) * STAGE, KNEXT); }                                       \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 2, BW);                                                                                                         \
+    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 0] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 0); }                                    \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 3, BW);                                                                                                         \
+    if ((G) >= 5) { dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 1, (PAR) * STAGE, KNEXT); dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 2, (PAR) * STAGE, KNEXT); } \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 4, BW);                                                                                                         \
+    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 1] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 1); }                                    \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 5, BW);                                                                                                         \
+    if ((G) >= 5) { dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 3, (PAR) * STAGE, KNEXT); dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 4, (PAR) * STAGE, KNEXT); } \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 6, BW);                                                                                                         \
+    if ((G) == 5 || (G) == 6) { (BN_)[3 * ((G) - 5) + 2] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 2); } \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 7, BW);                                                                                                         \
+    if ((G) == 5) { dma(5, (PAR) * STAGE, KNEXT); }                                                                           \
+    X8_PIN();                                                                                                                 \
+  }
+  // pieces: group 5 -> 0..5 (six), group 6 -> 6..10 (five), group 7 -> 11..15 (five);  W fragments: group 5 -> 0,1,2, group 6 -> 3,4,5, group 7 -> 6,7
+#define X8_TILE(PAR, T, BW, BN_)                                                                                              \
+  {                                                                                                                           \
+    const int knext = koff((T) + 2);                                                                                          \
+    X8_GROUP(0, PAR, BW, BN_, knext) X8_GROUP(1, PAR, BW, BN_, knext) X8_GROUP(2, PAR, BW, BN_, knext) X8_GROUP(3, PAR, BW, BN_, knext) \
+    X8_GROUP(4, PAR, BW, BN_, knext) X8_GROUP(5, PAR, BW, BN_, knext) X8_GROUP(6, PAR, BW, BN_, knext) X8_GROUP(7, PAR, BW, BN_, knext) \
+  }
+  const int npairs = ktn >> 1;
+  for (int it = 0; it < npairs; ++it) {
+    const int t = 2 * it;
+    X8_TILE(0, t, bw0, bw1)
+    X8_TILE(1, t + 1, bw1, bw0)
+  }
+#undef X8_TILE
+#undef X8_GROUP
+#undef X8_MMA
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  X8_BAR();
+
+  // ---- epilogue: scales, bias -> bf16 -> LDS, four passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave),
+  // then the row-contiguous half of ce_gemm_epi.h (activation / gated residual, 16-byte stores)
+  f32x4 swv[8], bvv[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int nc = min(n0 + wn * 128 + g * 16 + fg * 4, N - 4);
+    swv[g] = *reinterpret_cast<const f32x4*>(sw + nc);
+    bvv[g] = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (partial) {  // fp32 slab [wave][f][g][lane], already scaled
+    float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const float sav = sa[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 v = acc[f][g];
+        const f32x4 o = {v[0] * (sav * swv[g][0]), v[1] * (sav * swv[g][1]), v[2] * (sav * swv[g][2]), v[3] * (sav * swv[g][3])};
+        *reinterpret_cast<f32x4*>(slab + (((wave * 64 + f * 8 + g) * 64) + lane) * 4) = o;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    if (p > 0) __syncthreads();
+#pragma unroll
+    for (int ff = 0; ff < 2; ++ff) {
+      const int f = 2 * p + ff;
+      const float sav = sa[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
+      const int rl = wm * 32 + ff * 16 + fr;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const int cl = wn * 128 + g * 16 + fg * 4;
+        const f32x4 v = acc[f][g];
+        const u32x2 pk = {pack_bf16(v[0] * (sav * swv[g][0]) + bvv[g][0], v[1] * (sav * swv[g][1]) + bvv[g][1]),
+                          pack_bf16(v[2] * (sav * swv[g][2]) + bvv[g][2], v[3] * (sav * swv[g][3]) + bvv[g][3])};
+        *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
+      }
+    }
+    __syncthreads();
+    epi_chunks<EPI, 8>(smem, CROW,
+                       [&](int tt, int& rl, int& cc, int& mr) {
+                         const int c = tid + 256 * tt;
+                         rl = c >> 5;
+                         cc = c & 31;
+                         mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
+                       },
+                       m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+  }
+}
+
+}  // namespace
+
+extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+extern "C" int ce_gemm256w4_reduce_launch(int epilogue, void* C, const float* bias, const float* gate, const void* res, int M, int N, int ldc,
+                                          int ldres, int gate_rows, int tiles_m, int tiles_n, int t_full, int split, const float* ws, int tail,
+                                          hipStream_t stream);
+
+extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias,
+                                    int epilogue, const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc,
+                                    int ldres, int gate_rows, hipStream_t stream) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n, kt = K / BKB;
+  float* g_ws = nullptr;
+  size_t g_ws_bytes = 0;
+  int g_cus = 256;
+  ce_gemm256_workspace(&g_ws, &g_ws_bytes, &g_cus);
+  int tail = nwg % g_cus, split = 1;
+  if (tail > 0 && g_ws != nullptr) {
+    for (int sp = std::min(g_cus / tail, 8); sp >= 2; --sp)
+      if (kt % (2 * sp) == 0 && (size_t)tail * sp * BM * BN * sizeof(float) <= g_ws_bytes) {
+        split = sp;
+        break;
+      }
+    // An fp8 round is short (1.7 us per K-tile): cutting the last round only pays when the time it saves clearly exceeds what the
+    // slabs cost (256 KiB written and read back per piece at ~4 TB/s, plus the reduce launch).  Measured: 116 tail tiles of a
+    // K = 5120 product cut in two were 1.5 % SLOWER than run whole; 6 tiles cut in eight, or K = 13824, gain 3 %.
+    if (split > 1) {
+      const double saving_us = (1.0 - 1.0 / split) * kt * 1.7, slabs_us = (double)tail * split * 0.128 + 8.0;
+      if (saving_us < 1.5 * slabs_us) split = 1;
+    }
+  }
+  if (split == 1) tail = 0;
+  const int t_full = nwg - tail;
+  dim3 grid(t_full + tail * split), block(256);
+  const int lds = 2 * STAGE;
+  static bool attr_done_[CE_MAX_DEVICES][3] = {};
+  bool* attr_done = attr_done_[ce_device_slot()];
+#define F8_LAUNCH(E)                                                                                                          \
+  do {                                                                                                                        \
+    if (!attr_done[E]) {                                                                                                      \
+      if (hipFuncSetAttribute((const void*)gemm_fp8_w4<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
+      attr_done[E] = true;                                                                                                    \
+    }                                                                                                                         \
+    hipLaunchKernelGGL((gemm_fp8_w4<E>), grid, block, lds, stream, (const unsigned char*)Aq, (const unsigned char*)Wq, (bf16*)C, sa, sw, \
+                       bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws); \
+  } while (0)
+  switch (epilogue) {
+    case EPI_BIAS: F8_LAUNCH(EPI_BIAS); break;
+    case EPI_BIAS_GELU: F8_LAUNCH(EPI_BIAS_GELU); break;
+    case EPI_GATE_RES: F8_LAUNCH(EPI_GATE_RES); break;
+    default: return CE_ERR_ARG;
+  }
+#undef F8_LAUNCH
+  if (tail) {
+    const int rc = ce_gemm256w4_reduce_launch(epilogue, C, bias, gate, res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws,
+                                              tail, stream);
+    if (rc != CE_OK) return rc;
+  }
+  return (int)hipGetLastError();
+}

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
 HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
 
-SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_gemm256w4.hip", "ce_gemm384.hip", "ce_attn.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip"]
+SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_gemm256w4.hip", "ce_gemm384.hip", "ce_attn.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip", "ce_gemm_fp8w4.hip"]
 
 _c = ctypes
 _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
@@ -43,6 +43,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_ln_affine_fp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "ce_quant_rows_fp8": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ce_gemm_fp8": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_set_gemm_fp8_variant": [_I],
     "ce_gemm_batched_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I] + [ctypes.c_longlong] * 6 + [_P],
     "ce_im2col_patch2d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ce_gather_rows_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -24,6 +24,9 @@ def lib():
     if _lib is None:
         _lib = hiplib.load()
         import os
+        v8 = os.environ.get("CE_GEMM_FP8_VARIANT")  # the same for the fp8 GEMM (ce_set_gemm_fp8_variant)
+        if v8 is not None:
+            _lib.ce_set_gemm_fp8_variant(int(v8))
         v = os.environ.get("CE_GEMM_VARIANT")  # A/B knob for whole-step runs (bench.py under another main loop): see ce_set_gemm_variant
         if v is not None:
             _lib.ce_set_gemm_variant(int(v))
@@ -700,6 +703,11 @@ def ln_affine_fp8(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: float,
     return out, scale
 
 
+def set_gemm_fp8_variant(v: int) -> int:
+    """Main loop of `gemm_fp8`: 0 = 8 waves / 4 phases, 1 = one wave per SIMD (ce_gemm_fp8w4.hip); returns the previous setting."""
+    return lib().ce_set_gemm_fp8_variant(int(v))
+
+
 def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor],
              out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None,
              res: Optional[torch.Tensor] = None, gate_rows: int = 0):
@@ -715,6 +723,7 @@ def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Ten
         out = torch.empty((M, N), dtype=torch.bfloat16, device=aq.device)
     _dev(out, torch.bfloat16, "out")
     _, _, ldc = _rows(out, "out")
+    ensure_gemm_workspace(aq.device)  # the one-wave-per-SIMD loop cuts a partially filled last round of tiles along K (as ce_gemm_bf16)
     ldres = 0
     if epilogue == EPI_GATE_RES:
         if res is None:

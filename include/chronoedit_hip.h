@@ -283,6 +283,11 @@ int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const 
                 const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                 hipStream_t stream);
 
+/* Main loop of ce_gemm_fp8 (returns the previous setting): 0 = 8 waves / 4 phases per K-tile (csrc/ce_gemm_fp8.hip), 1 = one wave per
+ * SIMD (csrc/ce_gemm_fp8w4.hip: 4 waves, 128 x 128 wave tiles, accumulators in AGPRs, one barrier per K-tile).  Same results bit for
+ * bit (same products, same summation order per accumulator).  Host-side test / bench knob. */
+int ce_set_gemm_fp8_variant(int variant);
+
 /* ---- MXFP8 self-attention of the fp8 mode ("fp8 weights+attn", BASELINE.json configs[4]).  Contract (csrc/ce_attn_fp8.hip,
  * oracle/dit_oracle.py::attention_mxfp8): Q, K quantised to OCP MXFP8 - e4m3 elements, one E8M0 scale per 32 head channels - V per
  * 32 keys, products on v_mfma_scale_f32_32x32x64_f8f6f4, P = exp2(S - offset) <= 8 in e4m3 (offset = a row maximum - 3), fp32

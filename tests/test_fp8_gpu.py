@@ -36,9 +36,18 @@ def test_quant_rows_fp8_matches_torch_cast(M, K):
     assert rel_l2(_deq(q, s), x) < 4e-2  # e4m3: 3 mantissa bits
 
 
+@pytest.fixture(params=[0, 1], ids=["w8", "w4"])
+def fp8_variant(request):
+    """Both main loops of ce_gemm_fp8: 8 waves / 4 phases (ce_gemm_fp8.hip) and one wave per SIMD (ce_gemm_fp8w4.hip)."""
+    from chronoedit_amd import ops
+    old = ops.set_gemm_fp8_variant(request.param)
+    yield request.param
+    ops.set_gemm_fp8_variant(old)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 256, "bias"), (300, 520, 512, "bias"), (1000, 1280, 5120, "gelu"),
-                                       (7200, 5120, 13824, "gate"), (14400, 15360, 5120, "bias")])
-def test_gemm_fp8_matches_fp32_on_dequantised_operands(M, N, K, epi):
+                                       (7200, 5120, 13824, "gate"), (14400, 15360, 5120, "bias"), (13068, 5120, 5120, "gate")])
+def test_gemm_fp8_matches_fp32_on_dequantised_operands(M, N, K, epi, fp8_variant):
     from chronoedit_amd import ops
     g = torch.Generator().manual_seed(2)
     a = torch.randn(M, K, generator=g).to(BF).cuda()

@@ -87,6 +87,20 @@ def test_tile384_gemm_keeps_its_384_accumulators_in_place():
         assert not any(op.startswith("v_accvgpr") or op.startswith("scratch") for op in c), (name, c)
 
 
+def test_fp8_one_wave_per_simd_gemm_loop():
+    """ce_gemm_fp8w4.hip: per trip of the K loop (two K-tiles of 128 bytes) 128 MX MFMAs on 8-register fragments, 64 fragment reads (two
+    16-byte halves each), 32 LDS-DMA pieces, ONE barrier per K-tile; accumulators tied in the AGPRs, nothing spilled in the loop."""
+    src = os.path.join(CSRC, "ce_gemm_fp8w4.hip")
+    for r in _pick(_rows("ce_gemm_fp8w4.hip"), "gemm_fp8_w4"):
+        assert r[2] <= 512 and r[3] <= 16, r
+    loops = isa_lint.inner_loops(src, "gemm_fp8_w4")
+    assert len(loops) == 3
+    for name, c in loops:
+        assert c.get("v_mfma_f32_16x16x128_f8f6f4", 0) == 128, (name, c)
+        assert c.get("ds_read_b128", 0) == 64 and c.get("buffer_load_dwordx4", 0) == 32 and c.get("s_barrier", 0) == 2, (name, c)
+        assert not any(op.startswith("v_accvgpr") or op.startswith("scratch") for op in c), (name, c)
+
+
 def test_row_kernels_issue_their_row_loads_back_to_back():
     rows = _rows("ce_rowops.hip")
     (rr,) = _pick(rows, "rmsnorm_rope_kernel", "ILb1E")  # FULL variant (D = 5120)
