@@ -332,7 +332,9 @@ extern "C" int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float*
   if ((lda & 15) || (ldw & 15) || (ldc & 7)) return CE_ERR_ALIGN;
   if ((long long)M * lda >= (1ll << 32) || (long long)N * ldw >= (1ll << 32)) return CE_ERR_SHAPE;  // 32-bit DMA offsets
   if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
-  if (g_fp8_variant == 1 && (epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_GATE_RES))
+  // (the one-wave-per-SIMD loop's gated-residual epilogue holds ONE or TWO samples' gate rows per tile and stores through 32-bit offsets)
+  const bool w4_gate_ok = epilogue != EPI_GATE_RES || ((gate == nullptr || gate_rows == 0 || gate_rows >= BM) && (long long)M * ldc * 2 < (1ll << 32));
+  if (g_fp8_variant == 1 && w4_gate_ok && (epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || epilogue == EPI_GATE_RES))
     return ce_gemm_fp8w4_launch(Aq, Wq, C, sa, sw, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n), block(512);

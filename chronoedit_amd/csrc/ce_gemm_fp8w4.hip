@@ -206,6 +206,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     return;
   }
+  // Gated residual: all of this thread's residual chunks (4 passes x 8 x 16 B) and its gate values are requested HERE, before the first
+  // staging pass, and the stores are predicated by a buffer descriptor's range check (as in ce_gemm256w4.hip: per-pass loads cost four
+  // serial memory round trips per tile).  The launcher sends gate rows shorter than a tile to the 8-wave kernel.
+  constexpr bool prefetch = EPI == EPI_GATE_RES;
+  u32x4 rv[4][8];
+  f32x4 gA0, gA1, gB0, gB1;
+  int g_switch = 0x7fffffff;
+  const int my_n = n0 + (tid & 31) * 8, my_nc = min(my_n, N - 8);
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
+  if (prefetch) {
+    gA0 = gA1 = gB0 = gB1 = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (gate != nullptr) {
+      const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
+      const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
+      const float* ga = gate + (size_t)s0 * N + my_nc;
+      const float* gb = gate + (size_t)s1 * N + my_nc;
+      gA0 = *reinterpret_cast<const f32x4*>(ga);
+      gA1 = *reinterpret_cast<const f32x4*>(ga + 4);
+      gB0 = *reinterpret_cast<const f32x4*>(gb);
+      gB1 = *reinterpret_cast<const f32x4*>(gb + 4);
+      if (s1 != s0) g_switch = s1 * gate_rows;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int rl = (tid + 256 * tt) >> 5;
+        const int m = min(m0 + (rl >> 5) * 128 + p * 32 + (rl & 31), M - 1);
+        rv[p][tt] = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + my_nc);
+      }
+  }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     if (p > 0) __syncthreads();
@@ -224,14 +255,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
     __syncthreads();
-    epi_chunks<EPI, 8>(smem, CROW,
-                       [&](int tt, int& rl, int& cc, int& mr) {
-                         const int c = tid + 256 * tt;
-                         rl = c >> 5;
-                         cc = c & 31;
-                         mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
-                       },
-                       m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+    if (prefetch) {
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int rl = (tid + 256 * tt) >> 5;
+        const int m = m0 + (rl >> 5) * 128 + p * 32 + (rl & 31);
+        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + (tid & 31) * 16);
+        const bool second = m >= g_switch;
+        const f32x4 g0 = second ? gB0 : gA0, g1 = second ? gB1 : gA1;
+        const u32x4 r = rv[p][tt];
+        u32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
+          o[q] = pack_bf16(mul_then_add(bf16lo(y[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(y[q]), gb, bf16hi(r[q])));
+        }
+        const uint32_t coff = (m < M && my_n < N) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)my_n * 2u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
+      }
+    } else {
+      epi_chunks<EPI, 8>(smem, CROW,
+                         [&](int tt, int& rl, int& cc, int& mr) {
+                           const int c = tid + 256 * tt;
+                           rl = c >> 5;
+                           cc = c & 31;
+                           mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
+                         },
+                         m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+    }
   }
 }
 
