@@ -71,16 +71,21 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
     ap.add_argument("--no-edit", action="store_true", help="skip the measured 8-step end-to-end edit")
-    ap.add_argument("--full-edit", action="store_true", help="also MEASURE the 50-step configs[1] edit end to end (~20 s)")
+    ap.add_argument("--full-edit", dest="full_edit", action="store_true", default=True,
+                    help="MEASURE the 50-step configs[1] edit end to end (~17 s; default on one GPU)")
+    ap.add_argument("--no-full-edit", dest="full_edit", action="store_false", help="skip the measured 50-step edit")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the secondary fp8-GEMM-mode timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only", action="store_true",
                     help="no GPU: only the CPU legs (cpu_baseline at N = 7200 and BASELINE configs[0] at N = 512; with /root/reference present also "
                          "the reference's own transformer class) - what profiles/r03_cpu_legs.json holds")
-    ap.add_argument("--reasoning-edit", action="store_true",
-                    help="also MEASURE one temporal-reasoning edit end to end on this GPU (29 pixel frames: 8 latent frames, truncated to 2 after "
-                         "--reasoning-steps steps; two decodes) - minutes at 50 steps")
-    ap.add_argument("--reasoning-steps", type=int, default=10, help="num_temporal_reasoning_steps of --reasoning-edit (50 = never truncates)")
+    ap.add_argument("--reasoning-edit", dest="reasoning_edit", action="store_true", default=True,
+                    help="MEASURE temporal-reasoning edits end to end on this GPU (29 pixel frames: 8 latent frames, truncated to 2 after "
+                         "num_temporal_reasoning_steps steps; two decodes), one per entry of --reasoning-steps (default on one GPU: ~36 s + ~102 s)")
+    ap.add_argument("--no-reasoning-edit", dest="reasoning_edit", action="store_false", help="skip the measured temporal-reasoning edits")
+    ap.add_argument("--reasoning-steps", type=str, default="10,50",
+                    help="num_temporal_reasoning_steps values of the measured reasoning edits, comma separated (50 = the reference's default: "
+                         "never truncates, pipeline_chronoedit.py:700-709)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the single-GPU / replica legs beside the Ulysses line")
     ap.add_argument("--fp8", action="store_true",
@@ -159,7 +164,9 @@ def cpu_baseline(N: int, steps_fwd: int):
     per_step = dt * 40 * steps_fwd
     return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, median of 3 after 1 warm-up = {dt:.2f} s "
-                      f"(runs {', '.join(f'{t:.2f}' for t in times)}); x40 blocks x{steps_fwd} forwards/step"}
+                      f"(runs {', '.join(f'{t:.2f}' for t in times)}); x40 blocks x{steps_fwd} forwards/step.  kind = port (oracle/dit_oracle.py); the "
+                      "reference's own transformer class is timed beside it where /root/reference exists: profiles/r03_cpu_legs.json "
+                      "(18.47 s reference vs 18.07 s port per N = 512 forward on the build container's 8 cores)"}
 
 
 def cpu_config0(with_reference: bool = True, depths=(1, 2, 4)):
@@ -228,7 +235,7 @@ def _pmc_traffic(kernel_label: str):
     """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
     are collected in their own runs, tools/gpu_pmc.sh; they cannot be read live from inside this process).  None when the
     shape of this run has no committed measurement."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -278,7 +285,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
+    dist = ctl = None
     # CE_BENCH_TEST_BACKEND=gloo (tools/gpu_r2_g.sh only): the N > 1 code path of this file on a ONE-GPU box - all ranks share GPU 0
     # and the collectives are host-staged.  The line it prints is marked and is not a measurement of anything.
     test_backend = os.environ.get("CE_BENCH_TEST_BACKEND")
@@ -288,9 +295,15 @@ def main():
         if test_backend:
             local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group(test_backend or "nccl")  # "nccl" == RCCL on ROCm
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("CE_BENCH_PG_TIMEOUT_S", "600")))
+        dist.init_process_group(test_backend or "nccl", timeout=pg_timeout)  # "nccl" == RCCL on ROCm
         if not test_backend and (dist.get_world_size() != world or dist.get_backend() != "nccl"):
             raise RuntimeError(f"RCCL group came up with {dist.get_world_size()} ranks on backend {dist.get_backend()}, expected {world} on nccl")
+        # control plane on its own host-side (gloo) group: the barriers, the MAX over ranks of the host clocks and the "did every rank get
+        # through the sharded leg" vote never ride on RCCL, so a data-path failure still ends in a JSON line (and in the replica fallback)
+        # (its timeout outlasts the data group's: a rank that failed early waits in the vote while its peers run into theirs)
+        ctl = dist.new_group(backend="gloo", timeout=3 * pg_timeout + datetime.timedelta(minutes=5))
         if a.gpus != world:
             raise RuntimeError(f"--gpus {a.gpus} but the launcher started {world} ranks")
     elif a.gpus != 1:
@@ -357,8 +370,15 @@ def main():
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=ctl)
         torch.cuda.synchronize()
+
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=ctl)
+        return float(tt.item())
 
     def timed(step_fn, warm, steps, first=0):
         for i in range(warm):
@@ -368,42 +388,141 @@ def main():
         for i in range(steps):
             step_fn(first + warm + i)
         sync_all()
-        dt_ = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt_], device="cpu" if test_backend else dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_ = float(tt.item())
-        return dt_
+        return max_over_ranks(time.perf_counter() - t0)
 
     total = a.warmup + a.steps + (0 if a.no_profile else 2)
+
+    def all_ranks_ok(ok: bool) -> bool:
+        """Did EVERY rank get here without an exception?  (host-side vote on the control group)"""
+        if world == 1:
+            return ok
+        tt = torch.tensor([0.0 if ok else 1.0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=ctl)
+        return float(tt.item()) == 0.0
+
+    def fall_back_to_replica(err: str):
+        """The sharded leg threw (on this or another rank): say so in ONE JSON line, then run and print the `--parallel replica` line -
+        the driver always gets a parsable last line, and a reader sees why it is not the sharded one."""
+        nonlocal ulysses, mode, wl, N, T
+        if rank == 0:
+            print(json.dumps({"metric": "denoising-steps/sec", "value": None, "n_gpus": world, "error": err,
+                              "config": {"workload": f"ONE configs[3] edit sharded over {world} GPUs (Ulysses over RCCL)"},
+                              "note": "the sharded leg failed; the next line is the --parallel replica measurement of the same run"}), flush=True)
+        model._sp = model._cfgp = None
+        model.invalidate()
+        ulysses, mode = False, "replica"
+        T = a.frames if a.frames is not None else 2
+        wl = Workload(dev, T, h, w, 42 + rank)
+        N = wl.N
+
+    sharded_error = None
     sched = new_sched(total)
-    one_step = make_stepper(wl, sched, graph=a.graph, sequential=a.sequential_cfg)
-    eager_step = one_step if not a.graph else make_stepper(wl, sched, graph=False, sequential=a.sequential_cfg)
+    dt = finite = host_enqueue_ms = rccl = exchange_us = verify = None
+    one_step = eager_step = None
+
+    def headline_leg():
+        nonlocal dt, finite, host_enqueue_ms, rccl, one_step, eager_step, exchange_us, verify
+        one_step = make_stepper(wl, sched, graph=a.graph, sequential=a.sequential_cfg)
+        eager_step = one_step if not a.graph else make_stepper(wl, sched, graph=False, sequential=a.sequential_cfg)
+        if ulysses:
+            model._sp.stats.update(all_to_all_calls=0, all_to_all_bytes_sent_off_rank=0)
+            if os.environ.get("CE_BENCH_INJECT_SHARDED_FAILURE") == str(rank) or os.environ.get("CE_BENCH_INJECT_SHARDED_FAILURE") == "all":
+                raise RuntimeError("injected failure of the sharded leg (CE_BENCH_INJECT_SHARDED_FAILURE; tests/test_bench_multirank_gpu.py)")
+        dt = timed(one_step, a.warmup, a.steps)
+        finite = bool(torch.isfinite(wl.latents).all().item())
+        # how long the host needs to ISSUE one eager step (no wait): the margin by which a launch-per-kernel loop stays GPU-bound
+        # (DESIGN.md section 6: why the sharded loop, which cannot be hipGraph-captured on this stack, loses nothing by running eagerly)
+        if not a.no_profile:
+            sync_all()
+            t0h = time.perf_counter()
+            eager_step(a.warmup + a.steps)
+            host_enqueue_ms = round((time.perf_counter() - t0h) * 1e3, 2)
+            sync_all()
+        if ulysses:
+            st = model._sp.stats
+            pair_batched = not a.cfg_parallel and not a.sequential_cfg and fwd_per_step == 2  # the guidance pair as one B = 2 sharded forward
+            n_fwd = (a.warmup + a.steps) * (1 if (a.cfg_parallel or pair_batched) else fwd_per_step)
+            rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ulysses_group": model._sp.world,
+                    "cfg_parallel_groups": 2 if a.cfg_parallel else 1,
+                    "all_to_all_per_layer_per_forward": st["all_to_all_calls"] / max(1, n_fwd * a.layers),
+                    "bytes_sent_off_rank_per_layer_per_forward": st["all_to_all_bytes_sent_off_rank"] // max(1, n_fwd * a.layers),
+                    "exchange": ("k|v all-to-all overlapped with the q projection; q; attention output (K-segmented operand of the out-projection)"
+                                 if model._sp.world > 1 else "none inside a forward: each GPU runs one guidance pass whole") +
+                                ("; one all_gather of the two predictions per step" if a.cfg_parallel else "")}
+            exchange_us = time_exchanges()
+            rccl["exchange_us_per_layer"] = exchange_us
+            verify = sharded_result()
+
+    def time_exchanges():
+        """The three all-to-all exchanges of ONE layer (k|v, q, attention output), each alone on the engine's own send / receive buffers
+        of this run's shape: median of 5 after one warm call, MAX over ranks; event-timed on the launch stream (RCCL) or, host-staged
+        (test backend), by the host clock.  Outside the timed region."""
+        sp = model._sp
+        if sp is None or sp.world == 1:
+            return None
+        ws = list(model.engine()._ws.values())[-1]
+        W = sp.world
+        legs = {"k|v": (ws.send_kv, ws.recv_kv), "q": (ws.send_q, ws.recv_q), "output": (ws.att_g.view(W, -1, ws.att_g.shape[1]), ws.att_seg)}
+        res = {}
+        for name, (snd, rcv) in legs.items():
+            ts = []
+            for i in range(6):
+                sync_all()
+                if sp._host_staged:
+                    t0 = time.perf_counter()
+                    sp.all_to_all(snd, rcv)
+                    torch.cuda.synchronize()
+                    us = (time.perf_counter() - t0) * 1e6
+                else:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    sp.all_to_all(snd, rcv)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    us = e0.elapsed_time(e1) * 1e3
+                if i:
+                    ts.append(us)
+            us = max_over_ranks(statistics.median(ts))
+            off = snd.numel() * snd.element_size() * (W - 1) // W
+            res[name] = {"us": round(us, 1), "bytes_sent_off_rank": off, "GBps_per_rank": round(off / us / 1e3, 1)}
+        return res
+
+    lat0_verify = None
+
+    def sharded_result():
+        """ONE sharded step from freshly seeded (replicated) inputs; the latents it leaves are compared with the unsharded step on the same
+        inputs further down (rank 0), and - here - between the ranks: every rank must hold the same replicated result."""
+        nonlocal lat0_verify
+        wv = Workload(dev, T, h, w, 4242)
+        lat0_verify = (wv, wv.latents.clone())
+        sv = new_sched(3)
+        make_stepper(wv, sv, sequential=a.sequential_cfg)(0)
+        torch.cuda.synchronize()
+        chk = float(wv.latents.double().abs().sum().item())
+        lo, hi = -max_over_ranks(-chk), max_over_ranks(chk)
+        lat0_verify = lat0_verify + (wv.latents.clone(),)
+        return {"latents_abs_sum_spread_over_ranks": (hi - lo) / max(hi, 1e-30)}
+
     if ulysses:
-        model._sp.stats.update(all_to_all_calls=0, all_to_all_bytes_sent_off_rank=0)
-    dt = timed(one_step, a.warmup, a.steps)
-    finite = bool(torch.isfinite(wl.latents).all().item())
-    # how long the host needs to ISSUE one eager step (no wait): the margin by which a launch-per-kernel loop stays GPU-bound
-    # (why the sharded loop, which cannot be hipGraph-captured on this stack, loses nothing by running eagerly)
-    host_enqueue_ms = None
-    if not a.no_profile:
-        sync_all()
-        t0h = time.perf_counter()
-        eager_step(a.warmup + a.steps)
-        host_enqueue_ms = round((time.perf_counter() - t0h) * 1e3, 2)
-        sync_all()
-    rccl = None
-    if ulysses:
-        st = model._sp.stats
-        pair_batched = not a.cfg_parallel and not a.sequential_cfg and fwd_per_step == 2  # the guidance pair as one B = 2 sharded forward
-        n_fwd = (a.warmup + a.steps) * (1 if (a.cfg_parallel or pair_batched) else fwd_per_step)
-        rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ulysses_group": model._sp.world,
-                "cfg_parallel_groups": 2 if a.cfg_parallel else 1,
-                "all_to_all_per_layer_per_forward": st["all_to_all_calls"] / max(1, n_fwd * a.layers),
-                "bytes_sent_off_rank_per_layer_per_forward": st["all_to_all_bytes_sent_off_rank"] // max(1, n_fwd * a.layers),
-                "exchange": ("k|v all-to-all overlapped with the q projection; q; attention output (K-segmented operand of the out-projection)"
-                             if model._sp.world > 1 else "none inside a forward: each GPU runs one guidance pass whole") +
-                            ("; one all_gather of the two predictions per step" if a.cfg_parallel else "")}
+        try:
+            headline_leg()
+            ok = True
+        except Exception as e:  # noqa: BLE001 - anything: the line must still be printed
+            import traceback
+            sharded_error = f"rank {rank}: {type(e).__name__}: {e} | " + traceback.format_exc(limit=4).replace("\n", " / ")
+            ok = False
+        try:
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            sharded_error = (sharded_error or "") + f" | synchronize: {e!r}"
+            ok = False
+        if not all_ranks_ok(ok):
+            fall_back_to_replica(sharded_error or "another rank failed in the sharded leg (its message is on its stderr)")
+            sharded_error = sharded_error or "a peer rank failed"
+            sched = new_sched(total)
+            headline_leg()
+    else:
+        headline_leg()
 
     # ---- per-kernel HIP-event profile of ONE more step (outside the timed region) -> roofline of the dominant kernel
     roofline = roofline_family = breakdown = None
@@ -461,6 +580,18 @@ def main():
                 torch.cuda.synchronize()
                 ts1.append(time.perf_counter() - t0)
             single_same = round(1.0 / statistics.median(ts1), 4)
+            if verify is not None and lat0_verify is not None:
+                # the SAME step (same seeded inputs, fresh scheduler) unsharded on this GPU: what the sharded answer is checked against.
+                # rel-L2 of the latents the step leaves, and of the update alone (x_new - x_old: the part the forward decides)
+                wv, l0, lat_sh = lat0_verify
+                wv.latents.copy_(l0)
+                make_stepper(wv, new_sched(3), sequential=a.sequential_cfg)(0)
+                torch.cuda.synchronize()
+                ref, got, base = wv.latents.double(), lat_sh.double(), l0.double()
+                verify["sharded_vs_single_rel_l2"] = float((got - ref).norm() / ref.norm())
+                verify["sharded_vs_single_rel_l2_of_update"] = float(((got - base) - (ref - base)).norm() / (ref - base).norm())
+                verify["what"] = ("one guidance step from the same seeded latents: sharded over the ranks vs unsharded on rank 0's GPU; bf16 kernels "
+                                  "on both sides (different summation orders: GEMM M split, attention key-tile order): expect <= 1e-2 on the update")
         wl2 = Workload(dev, 2, h, w, 42 + rank)
         s2 = new_sched(4)
         dt2 = timed(make_stepper(wl2, s2), 1, 2)
@@ -476,7 +607,7 @@ def main():
         per_gpu = fl * a.steps / dt / 1e12 / (world if ulysses else 1)
         out = {
             "metric": "denoising-steps/sec", "value": round(steps_per_s, 4),
-            "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height})" + (
+            "unit": f"denoising-steps/sec (ChronoEdit-14B, {a.width}x{a.height}; steps {a.warmup}..{a.warmup + a.steps - 1} of a {max(50, total)}-step flow-UniPC schedule timed)" + (
                 f"; ONE configs[3] edit (N = {N} tokens) sharded over {world} GPUs - a different workload from the N = 1 line (configs[1], "
                 "N = 7200): read the curve through strong_scaling_speedup_vs_one_gpu" if ulysses else ""),
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
@@ -502,6 +633,9 @@ def main():
             "launch": "hipGraph replay" if a.graph else "eager",
             "host_enqueue_ms_per_step": host_enqueue_ms,
             "rccl": rccl,
+            "sharded_vs_single_rel_l2": None if not verify else verify.get("sharded_vs_single_rel_l2"),
+            "sharded_verification": verify,
+            **({"sharded_error": sharded_error, "fallback": "the sharded leg failed; this line is the --parallel replica measurement"} if sharded_error else {}),
             "single_gpu_same_workload_steps_per_sec": single_same,
             "strong_scaling_speedup_vs_one_gpu": None if not single_same else round(steps_per_s / single_same, 3),
             "replica_mode": replica,
@@ -531,7 +665,10 @@ def main():
                 out["cpu_config0"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        except Exception:  # noqa: BLE001 - a data group that failed may not shut down cleanly; the lines are already printed
+            pass
 
 
 def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w, out):
@@ -664,14 +801,19 @@ def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w,
         s8, ok8 = edit(8, 1.0, 2.0)
         out["edit8"] = {"seconds": s8, "finite": ok8, "includes": "UMT5 (1 prompt) + CLIP + VAE encode + 8 steps x 1 forward + VAE decode; pipeline defaults: "
                                                                   "one hipGraph replay per step (shape seen before: no warm-up step), context projections once per edit"}
-        if a.reasoning_edit:
-            sr, shape_r, okr = reasoning_edit(50, a.reasoning_steps)
-            out["edit_reasoning"] = {"seconds": sr, "finite": okr, "frames": shape_r[2], "num_temporal_reasoning_steps": a.reasoning_steps,
-                                     "includes": f"UMT5 (2 prompts) + CLIP + VAE encode of 29 frames + {a.reasoning_steps} steps x 2 forwards at N = 28800 + "
-                                                 f"{50 - a.reasoning_steps} steps x 2 forwards at N = 7200 + two VAE decodes; hipGraph replay, context projections once per edit"}
         if a.full_edit:
             s50, ok50 = edit(50, 5.0, 5.0)
-            out["edit50"] = {"seconds": s50, "finite": ok50, "includes": "UMT5 (2 prompts) + CLIP + VAE encode + 50 steps x 2 forwards + VAE decode"}
+            out["edit50"] = {"seconds": s50, "finite": ok50, "includes": "UMT5 (2 prompts) + CLIP + VAE encode + 50 steps x 2 forwards + VAE decode; "
+                                                                       "one hipGraph replay per step, context projections once per edit"}
+        if a.reasoning_edit:
+            out["edit_reasoning"] = {}
+            for rs in [int(x) for x in str(a.reasoning_steps).split(",") if x.strip()]:
+                rs = max(0, min(50, rs))
+                sr, shape_r, okr = reasoning_edit(50, rs)
+                out["edit_reasoning"][f"num_temporal_reasoning_steps={rs}" + (" (the reference's default: never truncates)" if rs >= 50 else "")] = {
+                    "seconds": sr, "finite": okr, "frames": shape_r[2], "num_temporal_reasoning_steps": rs,
+                    "includes": f"UMT5 (2 prompts) + CLIP + VAE encode of 29 frames + {rs} steps x 2 forwards at N = 28800 + "
+                                f"{50 - rs} steps x 2 forwards at N = 7200 + two VAE decodes; hipGraph replay, context projections once per edit"}
 
 
 if __name__ == "__main__":

@@ -1053,15 +1053,16 @@ extern "C" int ce_attention_vt_blocked_bf16(const void* Q, const void* K, const 
 
 /* Cross-attention (two key / value segments with a softmax each, outputs added in bf16) with both V operands handed over TRANSPOSED:
  * V1t [H * 128][ldv1t], V2t [H * 128][ldv2t], sample b's keys at columns [b vt_cols, b vt_cols + len) of its segment (vt_cols a multiple
- * of 2, >= 64 ceil(len / 64); columns past len finite).  K as in ce_attention_batched_bf16 (samples stacked along the rows).  K and
- * V^T tiles of both segments go by LDS-DMA. */
+ * of 2, >= len; a row must extend to whole 64-key strips past the LAST sample's first column: ldv*t >= (batch - 1) vt_cols + 64 ceil(len / 64);
+ * columns past a sample's len - the next sample's keys or padding - only ever meet P = 0 and must be finite).  K as in
+ * ce_attention_batched_bf16 (samples stacked along the rows).  K and V^T tiles of both segments go by LDS-DMA. */
 extern "C" int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
                                          const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq,
                                          int H, int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
   if (!Q || !K1 || !V1t || !K2 || !V2t || !O) return CE_ERR_ARG;
   if (head_dim != HD || Nq <= 0 || H <= 0 || len1 <= 0 || len2 <= 0 || batch <= 0 || batch > 65535) return CE_ERR_SHAPE;
   const int c1 = (len1 + KVB - 1) / KVB * KVB, c2 = (len2 + KVB - 1) / KVB * KVB;
-  if (vt_cols1 < c1 || vt_cols2 < c2 || ldv1t < (batch - 1) * vt_cols1 + c1 || ldv2t < (batch - 1) * vt_cols2 + c2) return CE_ERR_SHAPE;
+  if (vt_cols1 < len1 || vt_cols2 < len2 || ldv1t < (batch - 1) * vt_cols1 + c1 || ldv2t < (batch - 1) * vt_cols2 + c2) return CE_ERR_SHAPE;
   if ((ldq & 7) || (ldo & 7) || (ldk1 & 7) || (ldk2 & 7) || (ldv1t & 7) || (ldv2t & 7) || (vt_cols1 & 1) || (vt_cols2 & 1)) return CE_ERR_ALIGN;
   KVSeg s0{(const bf16*)K1, (const bf16*)V1t, len1, ldk1, ldv1t};
   KVSeg s1{(const bf16*)K2, (const bf16*)V2t, len2, ldk2, ldv2t};

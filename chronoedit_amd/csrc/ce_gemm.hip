@@ -253,7 +253,7 @@ extern "C" int ce_set_gemm_variant(int v) {
 // ... and the same for W (w_seg_k, w_seg_stride): weights re-packed K-slab-major ([K/64][N][64]) so that every 16 KiB
 // half-tile of the LDS-DMA stream is one contiguous block (tools/probes/l2_pattern_probe.hip: 21.7 vs 18.3 TB/s for the
 // row-strided form).  Segmented W needs the 256-tile kernel (CE_ERR_SHAPE otherwise).
-extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+extern "C" void ce_gemm256_workspace(hipStream_t stream, float** ws, size_t* bytes, int* cus);
 
 // Which macro tile for a large GEMM: 384 x 256 (ce_gemm384.hip) or 256 x 256 (ce_gemm256w4.hip)?  Their main loops run at the same
 // rate per flop within 1 % (profiles/r03_gemm_variants_ab.txt); what differs is how the tile count falls on the 256 CUs.  Cost model:
@@ -284,11 +284,11 @@ extern "C" int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws
   return cost(384) <= cost(256) ? 384 : 256;
 }
 
-static bool prefer_tile384(int M, int N, int K) {
+static bool prefer_tile384(int M, int N, int K, hipStream_t stream) {
   float* ws = nullptr;
   size_t ws_bytes = 0;
   int cus = 256;
-  ce_gemm256_workspace(&ws, &ws_bytes, &cus);
+  ce_gemm256_workspace(stream, &ws, &ws_bytes, &cus);
   return ce_gemm_bf16_tile_rows(M, N, K, cus, ws != nullptr ? (long long)ws_bytes : 0) == 384;
 }
 
@@ -310,7 +310,7 @@ extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const flo
     if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw)) {
       // the 256-tile kernel has two main loops: one wave per SIMD (ce_gemm256w4.hip; the default: +3...5 % on the step's shapes,
       // profiles/r03_gemm_variants_ab.txt) and the 8-wave / 8-phase loop of ce_gemm256.hip (variants 1, 2)
-      if (g_gemm_variant == 6 || (g_gemm_variant == -1 && prefer_tile384(M, N, K)))  // the 384 x 256 macro tile (ce_gemm384.hip)
+      if (g_gemm_variant == 6 || (g_gemm_variant == -1 && prefer_tile384(M, N, K, stream)))  // the 384 x 256 macro tile (ce_gemm384.hip)
         return ce_gemm384_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
                                  w_seg_k, w_seg_stride, stream);
       if (g_gemm_variant == 1 || g_gemm_variant == 2)

@@ -28,6 +28,8 @@
 //    math and the global stores run on 16-B row-contiguous chunks (same rounding points as ce_gemm.hip).
 #include <algorithm>
 
+#include <mutex>
+
 #include "ce_common.h"
 #include "ce_gemm_epi.h"
 
@@ -448,23 +450,77 @@ extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw) {
 static bool staggered = false;
 extern "C" void ce_gemm256_set_staggered(int on) { staggered = on != 0; }
 
-static float* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-static int g_cus = 256;
-// Scratch for the split-K tail (fp32 slabs); without it every tile runs whole.  Host-side knob, not on the data path.
+// Scratch for the split-K tail (fp32 slabs); without it every tile runs whole.  Host-side registry, not on the data path: one DEFAULT
+// scratch per device (ce_set_gemm_workspace, registered for the current device) and, for callers that run GEMMs on several streams of
+// one device at once, one scratch per (device, stream) (ce_set_gemm_workspace_stream) - a launch uses its stream's own scratch when one
+// is registered and the device default otherwise, so two streams never share slabs unless the caller registered nothing for them.
+namespace {
+struct WsSlot {
+  float* ptr = nullptr;
+  size_t bytes = 0;
+};
+struct WsStream {
+  int dev = -1;
+  hipStream_t stream = nullptr;
+  WsSlot ws;
+};
+constexpr int WS_STREAMS = 32;
+WsSlot g_ws_dev[CE_MAX_DEVICES];
+WsStream g_ws_stream[WS_STREAMS];
+int g_ws_stream_next = 0;
+int g_cus_dev[CE_MAX_DEVICES] = {};
+std::mutex g_ws_mutex;
+int device_cus(int slot) {
+  if (g_cus_dev[slot] == 0) {
+    int dev = 0, cus = 0;
+    g_cus_dev[slot] = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : 256;
+  }
+  return g_cus_dev[slot];
+}
+}  // namespace
+
 extern "C" int ce_set_gemm_workspace(void* ptr, size_t bytes) {
-  g_ws = reinterpret_cast<float*>(ptr);
-  g_ws_bytes = ptr ? bytes : 0;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-    g_cus = cus;
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  const int slot = ce_device_slot();
+  g_ws_dev[slot].ptr = reinterpret_cast<float*>(ptr);
+  g_ws_dev[slot].bytes = ptr ? bytes : 0;
+  (void)device_cus(slot);
   return CE_OK;
 }
 
-extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus) {  // for the other main loop (ce_gemm256w4.hip)
-  *ws = g_ws;
-  *bytes = g_ws_bytes;
-  *cus = g_cus;
+extern "C" int ce_set_gemm_workspace_stream(hipStream_t stream, void* ptr, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  const int slot = ce_device_slot();
+  int at = -1;
+  for (int i = 0; i < WS_STREAMS; ++i)
+    if (g_ws_stream[i].dev == slot && g_ws_stream[i].stream == stream) at = i;
+  if (ptr == nullptr) {  // unregister: the stream falls back to the device default
+    if (at >= 0) g_ws_stream[at] = WsStream{};
+    return CE_OK;
+  }
+  if (at < 0) {
+    for (int i = 0; i < WS_STREAMS && at < 0; ++i)
+      if (g_ws_stream[i].dev < 0) at = i;
+    if (at < 0) at = g_ws_stream_next++ % WS_STREAMS;  // full: the oldest registration makes room (its stream uses the default again)
+  }
+  g_ws_stream[at].dev = slot;
+  g_ws_stream[at].stream = stream;
+  g_ws_stream[at].ws = WsSlot{reinterpret_cast<float*>(ptr), bytes};
+  (void)device_cus(slot);
+  return CE_OK;
+}
+
+// the scratch a launch on `stream` (current device) may use - for every large-tile main loop (this file, ce_gemm256w4.hip, ce_gemm384.hip,
+// ce_gemm_fp8w4.hip) and for the tile choice of ce_gemm.hip
+extern "C" void ce_gemm256_workspace(hipStream_t stream, float** ws, size_t* bytes, int* cus) {
+  std::lock_guard<std::mutex> lock(g_ws_mutex);
+  const int slot = ce_device_slot();
+  WsSlot w = g_ws_dev[slot];
+  for (int i = 0; i < WS_STREAMS; ++i)
+    if (g_ws_stream[i].dev == slot && g_ws_stream[i].stream == stream) w = g_ws_stream[i].ws;
+  *ws = w.ptr;
+  *bytes = w.bytes;
+  *cus = device_cus(slot);
 }
 
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
@@ -489,6 +545,10 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
   if (int rc = seg(a_seg_k, a_seg_stride, a_seg_magic, a_seg_extra)) return rc;
   if (int rc = seg(w_seg_k, w_seg_stride, w_seg_magic, w_seg_extra)) return rc;
   // split-K only for the tail of the last, partially filled round of workgroups
+  float* g_ws = nullptr;
+  size_t g_ws_bytes = 0;
+  int g_cus = 256;
+  ce_gemm256_workspace(stream, &g_ws, &g_ws_bytes, &g_cus);
   int tail = nwg % g_cus, split = 1;
   if (tail > 0 && g_ws != nullptr) {
     for (int s = std::min(g_cus / tail, 8); s >= 2; --s)

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void gemm256w4_reduce(bf16* __restrict__ C, co
 
 }  // namespace
 
-extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+extern "C" void ce_gemm256_workspace(hipStream_t stream, float** ws, size_t* bytes, int* cus);
 
 // nsa: 3 = A ring of three K-tile stages (160 KiB of LDS), 2 = two (128 KiB), 1 = three stages and ONE barrier per K-tile
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
@@ -432,7 +432,7 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
   int g_cus = 256;
-  ce_gemm256_workspace(&g_ws, &g_ws_bytes, &g_cus);
+  ce_gemm256_workspace(stream, &g_ws, &g_ws_bytes, &g_cus);
   int tail = nwg % g_cus, split = 1;
   if (tail > 0 && g_ws != nullptr && !seg2) {
     for (int s = std::min(g_cus / tail, 8); s >= 2; --s)

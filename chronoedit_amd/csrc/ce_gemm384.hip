@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void gemm384_reduce(bf16* __restrict__ C, cons
 
 }  // namespace
 
-extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+extern "C" void ce_gemm256_workspace(hipStream_t stream, float** ws, size_t* bytes, int* cus);
 extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
@@ -378,7 +378,7 @@ extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const fl
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
   int g_cus = 256;
-  ce_gemm256_workspace(&g_ws, &g_ws_bytes, &g_cus);
+  ce_gemm256_workspace(stream, &g_ws, &g_ws_bytes, &g_cus);
   int tail = nwg % g_cus, split = 1;
   if (tail > 0 && g_ws != nullptr) {
     for (int s = std::min(g_cus / tail, 8); s >= 2; --s)

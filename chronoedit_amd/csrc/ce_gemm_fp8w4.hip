@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 }  // namespace
 
-extern "C" void ce_gemm256_workspace(float** ws, size_t* bytes, int* cus);
+extern "C" void ce_gemm256_workspace(hipStream_t stream, float** ws, size_t* bytes, int* cus);
 extern "C" int ce_gemm256w4_reduce_launch(int epilogue, void* C, const float* bias, const float* gate, const void* res, int M, int N, int ldc,
                                           int ldres, int gate_rows, int tiles_m, int tiles_n, int t_full, int split, const float* ws, int tail,
                                           hipStream_t stream);
@@ -301,7 +301,7 @@ extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, con
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
   int g_cus = 256;
-  ce_gemm256_workspace(&g_ws, &g_ws_bytes, &g_cus);
+  ce_gemm256_workspace(stream, &g_ws, &g_ws_bytes, &g_cus);
   int tail = nwg % g_cus, split = 1;
   if (tail > 0 && g_ws != nullptr) {
     for (int sp = std::min(g_cus / tail, 8); sp >= 2; --sp)

@@ -40,6 +40,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_patchify_rows_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_gemm_variant": [_I],
     "ce_set_gemm_workspace": [_P, ctypes.c_size_t],
+    "ce_set_gemm_workspace_stream": [_P, _P, ctypes.c_size_t],
     "ce_ln_affine_fp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "ce_quant_rows_fp8": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ce_gemm_fp8": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -222,19 +222,39 @@ _gemm_split = True
 GEMM_WS_BYTES = 256 * 256 * 256 * 4  # one fp32 256x256 slab per CU
 
 
+GEMM_WS_STREAMS = 8  # streams per device that get a scratch of their own; further ones share the device default
+
+
 def ensure_gemm_workspace(device: torch.device) -> None:
-    """Hand the library its split-K scratch for `device` (allocated once, outside any graph capture)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _gemm_split)
+    """Hand the library its split-K scratch: one default buffer per device (allocated once, outside any graph capture) and, for every
+    further stream GEMMs are launched on, a buffer of that stream's own (ce_set_gemm_workspace_stream) - concurrent streams never share
+    slabs.  A stream that is capturing a graph uses the default (nothing is allocated under capture; captures of one device do not
+    overlap in this package)."""
+    dev = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    key = (dev, _gemm_split, stream)
     if _gemm_ws.get("active") == key:
         return
     if _gemm_split:
-        buf = _gemm_ws.get(key[0])
+        buf = _gemm_ws.get(dev)
+        first = _gemm_ws.get(("first_stream", dev))
         if buf is None:
             buf = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
-            _gemm_ws[key[0]] = buf
-        _check(lib().ce_set_gemm_workspace(buf.data_ptr(), buf.numel()), "ce_set_gemm_workspace")
+            _gemm_ws[dev] = buf
+            _gemm_ws[("first_stream", dev)] = first = stream
+        with torch.cuda.device(dev):
+            _check(lib().ce_set_gemm_workspace(buf.data_ptr(), buf.numel()), "ce_set_gemm_workspace")
+            if stream != first and (dev, stream) not in _gemm_ws and not torch.cuda.is_current_stream_capturing() \
+                    and sum(1 for k in _gemm_ws if isinstance(k, tuple) and len(k) == 2 and k[0] == dev) < GEMM_WS_STREAMS:
+                own = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+                _gemm_ws[(dev, stream)] = own
+                _check(lib().ce_set_gemm_workspace_stream(stream, own.data_ptr(), own.numel()), "ce_set_gemm_workspace_stream")
     else:
-        _check(lib().ce_set_gemm_workspace(None, 0), "ce_set_gemm_workspace")
+        with torch.cuda.device(dev):
+            _check(lib().ce_set_gemm_workspace(None, 0), "ce_set_gemm_workspace")
+            for k in [k for k in _gemm_ws if isinstance(k, tuple) and len(k) == 2 and k[0] == dev]:
+                _check(lib().ce_set_gemm_workspace_stream(k[1], None, 0), "ce_set_gemm_workspace_stream")
+                del _gemm_ws[k]
     _gemm_ws["active"] = key
 
 
@@ -335,10 +355,11 @@ def attention_vt(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
 
 
 def attention_2seg_vt(q: torch.Tensor, k1: torch.Tensor, v1t: torch.Tensor, len1: int, k2: torch.Tensor, v2t: torch.Tensor, len2: int,
-                      heads: int, out: Optional[torch.Tensor] = None, scale: Optional[float] = None, batch: int = 1):
+                      heads: int, out: Optional[torch.Tensor] = None, scale: Optional[float] = None, batch: int = 1,
+                      cols1: Optional[int] = None, cols2: Optional[int] = None):
     """Cross-attention over two key / value segments (a softmax each, outputs added in bf16) with V transposed: k1 [batch*len1, H*128],
-    v1t [H*128, batch * c1] with sample b's keys at columns [b*c1, b*c1 + len1), c1 = v1t.shape[1] // batch (even, >= 64*ceil(len1/64),
-    zero beyond len1); the same for segment 2.  Same arithmetic as `attention(..., k2=, v2=)`; K and V^T tiles by LDS-DMA."""
+    v1t [H*128, >= (batch-1)*c1 + 64*ceil(len1/64)] with sample b's keys at columns [b*c1, b*c1 + len1), c1 = cols1 (default
+    v1t.shape[1] // batch; even, >= len1; every column finite); the same for segment 2.  Same arithmetic as `attention(..., k2=, v2=)`; K and V^T tiles by LDS-DMA."""
     for n, t in (("q", q), ("k1", k1), ("v1t", v1t), ("k2", k2), ("v2t", v2t)):
         _dev(t, torch.bfloat16, n)
     Nq, Dq, ldq = _rows(q, "q")
@@ -346,7 +367,12 @@ def attention_2seg_vt(q: torch.Tensor, k1: torch.Tensor, v1t: torch.Tensor, len1
     _, _, ldk2 = _rows(k2, "k2")
     assert Dq == heads * 128 and v1t.shape[0] == Dq and v2t.shape[0] == Dq and v1t.stride(1) == 1 and v2t.stride(1) == 1
     assert Nq % batch == 0 and k1.shape[0] == batch * len1 and k2.shape[0] == batch * len2
-    assert v1t.shape[1] % batch == 0 and v2t.shape[1] % batch == 0
+    if cols1 is None:  # column stride between samples: explicit, or the row length split evenly
+        assert v1t.shape[1] % batch == 0
+        cols1 = v1t.shape[1] // batch
+    if cols2 is None:
+        assert v2t.shape[1] % batch == 0
+        cols2 = v2t.shape[1] // batch
     if out is None:
         out = torch.empty((Nq, Dq), dtype=torch.bfloat16, device=q.device)
     _, _, ldo = _rows(out, "out")
@@ -354,8 +380,8 @@ def attention_2seg_vt(q: torch.Tensor, k1: torch.Tensor, v1t: torch.Tensor, len1
         scale = 128 ** -0.5
     st = _prof_begin()
     nq = Nq // batch
-    _check(lib().ce_attention_2seg_vt_bf16(_ptr(q), _ptr(k1), _ptr(v1t), len1, ldk1, v1t.stride(0), v1t.shape[1] // batch, _ptr(k2), _ptr(v2t),
-                                           len2, ldk2, v2t.stride(0), v2t.shape[1] // batch, _ptr(out), nq, heads, 128, ldq, ldo,
+    _check(lib().ce_attention_2seg_vt_bf16(_ptr(q), _ptr(k1), _ptr(v1t), len1, ldk1, v1t.stride(0), int(cols1), _ptr(k2), _ptr(v2t),
+                                           len2, ldk2, v2t.stride(0), int(cols2), _ptr(out), nq, heads, 128, ldq, ldo,
                                            float(scale), batch, _stream()), "ce_attention_2seg_vt_bf16")
     _prof_end(st, f"attention_{nq}x{len1}+{len2}_h{heads}" + (f"_b{batch}" if batch > 1 else ""), 4.0 * nq * (len1 + len2) * 128 * heads * batch)
     return out

@@ -113,13 +113,12 @@ class GraphedDenoiser:
             # synchronous collectives, async_op=True and side-stream fork / join alike.  A sharded loop needs two graphs (8 -> 2 frames), so it
             # runs eagerly; DESIGN.md section 6 has the measurement of why that costs nothing at the per-rank kernel times of 4 / 8 GPUs.
             raise NotImplementedError("hipGraph capture of a step with RCCL exchanges is not usable on this torch / RCCL build: the sharded loop runs eagerly")
-        self.cfgp = None
         self.tr, self.sch, self.latents, self.condition = transformer, scheduler, latents, condition
         self.prompt, self.negative, self.image, self.g, self.batch_cfg = prompt_embeds, negative_prompt_embeds, image_embeds, guidance_scale, batch_cfg
         dev = latents.device
         self.cfg_inputs = None
         self.guided = guidance_scale > 1.0 and negative_prompt_embeds is not None
-        if self.guided and self.cfgp is None and batch_cfg:
+        if self.guided and batch_cfg:
             self.cfg_inputs = make_cfg_inputs(prompt_embeds, negative_prompt_embeds, image_embeds)
         self.t_buf = torch.zeros((), dtype=torch.int64, device=dev)
         self.coef_buf = torch.zeros(10, dtype=torch.float32, device=dev)
@@ -165,10 +164,7 @@ class GraphedDenoiser:
         inp = torch.cat([self.latents.to(torch.bfloat16), self.condition], dim=1)
         B = inp.shape[0]
         ts = self.t_buf.expand(B)
-        if self.guided and self.cfgp is not None:  # CFG parallelism: this rank's Ulysses group runs one of the two passes
-            mine = self.tr(inp, ts, self.prompt if self.cfgp.branch == 0 else self.negative, self.image, return_dict=False)[0]
-            c, u = self.cfgp.exchange(mine)
-        elif self.cfg_inputs is not None:
+        if self.cfg_inputs is not None:
             out = self.tr(torch.cat([inp, inp], 0), torch.cat([ts, ts], 0), self.cfg_inputs[0], self.cfg_inputs[1], return_dict=False)[0]
             c, u = out[:B].contiguous(), out[B:].contiguous()
         elif self.guided:
@@ -225,11 +221,15 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
             if graphed is None:
                 if scheduler._step_index is None:
                     scheduler._step_index = i
-                key = (tuple(latents.shape), guidance_scale > 1.0 and negative_prompt_embeds is not None, id(transformer))
+                # engine_generation(): bumped whenever the transformer's engine, its workspaces or a mode that changes the launch sequence
+                # is replaced - a recycled id() or a mode switch that keeps the workspace key must not skip the eager warm-up step
+                def warm_key():
+                    gen = transformer.engine_generation() if hasattr(transformer, "engine_generation") else id(transformer)
+                    return (tuple(latents.shape), guidance_scale > 1.0 and negative_prompt_embeds is not None, gen, id(scheduler))
                 graphed = GraphedDenoiser(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds,
-                                          image_embeds, guidance_scale, warm=graph_warm is not None and key in graph_warm)
+                                          image_embeds, guidance_scale, warm=graph_warm is not None and warm_key() in graph_warm)
                 if graph_warm is not None:
-                    graph_warm.add(key)
+                    graph_warm.add(warm_key())  # (taken AFTER the construction: the first step of a process creates the engine)
             latents = graphed.step(i)
         else:
             latents = denoise_step(transformer, scheduler, latents, condition, t, prompt_embeds, negative_prompt_embeds,
@@ -661,6 +661,8 @@ class ChronoEditPipeline:
         img = self.preprocess_image(image, height, width).to(device=device, dtype=torch.bfloat16)
         latents, condition = self.prepare_latents(img, B, self.vae.config.z_dim, height, width, num_frames, torch.bfloat16, device,
                                                   generator, latents)
+        if offload_model and hasattr(self.vae, "clear_graphs"):
+            self.vae.clear_graphs()  # a captured encode graph pins its activation pool next to the 14B DiT: the low-memory mode drops it
         if prompt_embeds.shape[0] != B or (negative_prompt_embeds is not None and negative_prompt_embeds.shape[0] != B):
             raise ValueError(f"prompt_embeds carry {prompt_embeds.shape[0]} samples, expected batch_size * num_videos_per_prompt = {B}")
         if image_embeds.shape[0] != B:
@@ -707,6 +709,9 @@ class ChronoEditPipeline:
             video = self.postprocess_video(video, output_type=output_type)
         else:
             video = latents
+        if offload_model and hasattr(self.vae, "clear_graphs"):
+            self.vae.clear_graphs()
+            torch.cuda.empty_cache()
         self.maybe_free_model_hooks()
         if not return_dict:
             return (video,)

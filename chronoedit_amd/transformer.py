@@ -134,6 +134,11 @@ class ConditionEmbedderParams(nn.Module):
             self.image_embedder = _ImageEmbedding(image_embed_dim, dim, device=device, dtype=dtype)
 
 
+import itertools
+
+_GENERATION = itertools.count(1)
+
+
 class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
     """MI355X drop-in for the reference class of the same name (transformer_chronoedit.py:298)."""
 
@@ -187,11 +192,13 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.proj_out = nn.Linear(inner, self.config.out_channels * math.prod(patch_size), **kw)
         self.scale_shift_table = nn.Parameter(torch.randn(1, 2, inner, device=device, dtype=torch.float32) / inner**0.5)
         self._engine: Optional["DiTEngine"] = None
+        self._gen = next(_GENERATION)  # engine_generation(): see there
         self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
         self.gemm_dtype = "bf16"    # "fp8": the six large Linears of every block on the OCP-e4m3 MX matrix path
         self.attn_dtype = "bf16"    # "mxfp8": self-attention on the MX-fp8 matrix instruction (csrc/ce_attn_fp8.hip)
         self.v_transposed = True    # bf16 self-attention takes V^T straight from the projection (swapped GEMM) and stages it by LDS-DMA
         self.sp_batch_cfg = True    # sequence-parallel forwards take the guidance pair as one batch of two (blocked-layout kernels)
+        self.cross_vt = True        # cross-attention takes V^T of the text / image context straight from the context projections (LDS-DMA kernel)
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
         self._cfgp = None           # CFG parallelism on top of it (two Ulysses groups), off by default
 
@@ -256,6 +263,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
             raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
         if self._engine is not None:
             self._engine._ws = {}  # workspaces carry the exchange buffers of the group
+            self._engine.ws_generation += 1
         return self
 
     def enable_cfg_parallel(self):
@@ -269,6 +277,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
             raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
         if self._engine is not None:
             self._engine._ws = {}
+            self._engine.ws_generation += 1
         return self
 
     def clear_context_cache(self):
@@ -304,6 +313,16 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         if self._engine is not None:
             self._engine.v_transposed = self.v_transposed
             self._engine._ws = {}
+            self._engine.ws_generation += 1
+        return self
+
+    def enable_cross_vt(self, on: bool = True):
+        """Cross-attention operand form (default on): the V halves of the context projections are produced as V^T (the swapped-role GEMM,
+        all layers in one launch per context stream) and both segments' K / V^T tiles reach the kernel's LDS by LDS-DMA
+        (`ce_attention_2seg_vt_bf16`).  Off = row-major V and the register-staged two-segment kernel; same arithmetic up to the
+        summation order inside a key tile."""
+        self.cross_vt = bool(on)
+        self._engine = None
         return self
 
     def enable_fp8_attention(self, on: bool = True):
@@ -315,6 +334,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         if self._engine is not None:
             self._engine.fp8_attn = on
             self._engine._ws = {}
+            self._engine.ws_generation += 1
         return self
 
     def attention_path(self) -> str:
@@ -335,7 +355,19 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
     def engine(self) -> "DiTEngine":
         if self._engine is None:
             self._engine = DiTEngine(self)
+            self._gen = next(_GENERATION)
         return self._engine
+
+    def engine_generation(self):
+        """A value that changes whenever something a captured step depends on may have been re-created lazily: the engine itself (packed
+        weights), its workspaces, or a mode that alters the launch sequence (sequence / CFG parallelism, operand forms, fp8 switches, the
+        RoPE spelling).  `pipeline.denoise` keys its "this shape has already run eagerly once" set on it, so a capture never records a
+        first-time initialisation.  (Process-unique, unlike id(): a recycled address cannot alias an earlier model.)"""
+        eng = self._engine
+        sp = self._sp
+        return (self._gen, None if eng is None else eng.ws_generation, self.gemm_dtype, self.attn_dtype, self.v_transposed, self.cross_vt,
+                self.sp_batch_cfg, bool(getattr(self, "rope_plain_temporal", False)), self.cache_context,
+                None if sp is None else (sp.world, sp.rank), self._cfgp is not None)
 
     @torch.no_grad()
     def forward(
@@ -463,12 +495,8 @@ class DiTEngine:
             p.w_o1, p.b_o1 = a1.to_out[0].weight.detach().contiguous(), f32(a1.to_out[0].bias)
             p.w_q2, p.b_q2 = a2.to_q.weight.detach().contiguous(), f32(a2.to_q.bias)
             p.nq2, p.nk2 = f32(a2.norm_q.weight), f32(a2.norm_k.weight)
-            p.w_kv_t = self._fuse([a2.to_k, a2.to_v])
-            p.b_kv_t = torch.cat([f32(a2.to_k.bias), f32(a2.to_v.bias)])
             p.has_img = a2.add_k_proj is not None
             if p.has_img:
-                p.w_kv_i = self._fuse([a2.add_k_proj, a2.add_v_proj])
-                p.b_kv_i = torch.cat([f32(a2.add_k_proj.bias), f32(a2.add_v_proj.bias)])
                 p.nk_i = f32(a2.norm_added_k.weight)
             p.w_o2, p.b_o2 = a2.to_out[0].weight.detach().contiguous(), f32(a2.to_out[0].bias)
             if cfg.cross_attn_norm:
@@ -488,19 +516,23 @@ class DiTEngine:
             for p in self.blk:  # per-output-channel e4m3 copies of the six large weights (the bf16 originals stay)
                 for name in ("qkv", "o1", "q2", "o2", "f1", "f2"):
                     setattr(p, "q_" + name, ops.quant_rows_fp8(getattr(p, "w_" + name)))
-        # K13 for ALL layers as one GEMM per context stream: the per-layer [k | v] weights are re-homed, layer after layer, in
-        # one [L*2D, D] buffer (the step-invariant projections of 769 context rows are 40 small GEMMs otherwise: 0.5-1.0 PFLOP/s
-        # at M = 514 / 1024 against 1.35 for one [M, L*2D] product); p.w_kv_* stay views of their layer's rows.
-        self.w_kv_t_all = self._fuse([lin for blk in model.blocks for lin in (blk.attn2.to_k, blk.attn2.to_v)])
-        self.b_kv_t_all = torch.cat([p.b_kv_t for p in self.blk])
-        self.all_img = all(p.has_img for p in self.blk)
+        # K13 for ALL layers as one GEMM per context stream and operand: the per-layer to_k (to_v, add_k_proj, add_v_proj) weights are
+        # re-homed, layer after layer, in one [L*D, D] buffer each (the step-invariant projections of 769 context rows are 160 small
+        # GEMMs otherwise: 0.5-1.0 PFLOP/s at M = 514 / 1024 against 1.35 for one [M, L*D] product).  K and V apart (round 4): the V
+        # half is taken as V^T = W_v . ctx^T - the same GEMM with its operand roles swapped and the bias along rows - which is the
+        # operand the LDS-DMA form of the cross-attention kernel wants, at no extra pass.
+        self.w_k_t_all = self._fuse([blk.attn2.to_k for blk in model.blocks])
+        self.b_k_t_all = torch.cat([f32(blk.attn2.to_k.bias) for blk in model.blocks])
+        self.w_v_t_all = self._fuse([blk.attn2.to_v for blk in model.blocks])
+        self.b_v_t_all = torch.cat([f32(blk.attn2.to_v.bias) for blk in model.blocks])
+        self.all_img = all(p.has_img for p in self.blk)  # (added_kv_proj_dim is one constructor argument: all layers or none)
         if self.all_img:
-            self.w_kv_i_all = self._fuse([lin for blk in model.blocks for lin in (blk.attn2.add_k_proj, blk.attn2.add_v_proj)])
-            self.b_kv_i_all = torch.cat([p.b_kv_i for p in self.blk])
-        for li, p in enumerate(self.blk):
-            p.w_kv_t = self.w_kv_t_all[li * 2 * self.D:(li + 1) * 2 * self.D]
-            if self.all_img:
-                p.w_kv_i = self.w_kv_i_all[li * 2 * self.D:(li + 1) * 2 * self.D]
+            self.w_k_i_all = self._fuse([blk.attn2.add_k_proj for blk in model.blocks])
+            self.b_k_i_all = torch.cat([f32(blk.attn2.add_k_proj.bias) for blk in model.blocks])
+            self.w_v_i_all = self._fuse([blk.attn2.add_v_proj for blk in model.blocks])
+            self.b_v_i_all = torch.cat([f32(blk.attn2.add_v_proj.bias) for blk in model.blocks])
+        self.cross_vt = bool(getattr(model, "cross_vt", True))
+        self._ctx_bufs = {}
         self.tables = torch.stack(tables, 0).contiguous()  # [L, 6, D]
         self.table_out = f32(model.scale_shift_table).reshape(1, 2, self.D)
         self.w_out, self.b_out = _pad_n(model.proj_out.weight.detach().contiguous(), f32(model.proj_out.bias))
@@ -508,6 +540,7 @@ class DiTEngine:
         self.zeros = torch.zeros(self.D, dtype=torch.float32, device=dev)
         self._rope = {}
         self._ws = {}
+        self.ws_generation = 0  # bumped when a workspace is evicted (a shape seen before is then "new" again)
         self._ctx_key = None
         self._ctx = None
         self._ctx_refs = None
@@ -610,6 +643,8 @@ class DiTEngine:
                 ws.att_g, ws.att_seg = e(W * N, Dl), e(W, N, Dl)
             # keep the two most recent shapes resident: a temporal-reasoning edit alternates between its 8-frame and 2-frame shapes, and a
             # hipGraph capture of a shape seen before must find its workspace (nothing may be allocated for the engine under capture)
+            if len(self._ws) > 1:
+                self.ws_generation += 1  # the oldest shape leaves: a warm-set entry for it is stale
             keep = list(self._ws.items())[-1:]
             self._ws = dict(keep + [(N, ws)])
         return ws
@@ -671,29 +706,58 @@ class DiTEngine:
                 hp = torch.zeros((h.shape[0], self.im_w2.shape[1]), dtype=torch.bfloat16, device=self.dev)
                 hp[:, : h.shape[1]] = h
                 h = hp
-            h = ops.gemm(h, self.im_w2, self.im_b2)
+            h_img = ops.gemm(h, self.im_w2, self.im_b2)
             w, b, eps = self.im_n2
-            enc_i = ops.ln_affine(h, w, b, eps)
-        # K13: per-layer cross-attention K/V of the text and image context
-        kv = []
+            enc_i = ops.ln_affine(h_img, w, b, eps)
+        # K13: per-layer cross-attention K/V of the text and image context, all layers per launch: K row-major [B*len, L*D] (layer li
+        # = columns [li D, (li+1) D)), V either row-major the same way or TRANSPOSED [L*D, columns] (layer li = rows [li D, (li+1) D),
+        # sample b's keys at columns [b cols, b cols + len)) for ce_attention_2seg_vt_bf16.  The V^T form needs the N axis of its
+        # swapped-role GEMM (= key rows of all samples) in multiples of 8 with even per-sample strides: Tt % 8 == 0 (512), and the image
+        # context (257 rows) is layer-normed a second time into a copy whose samples are padded to 264 rows (zero rows -> bias-only
+        # columns that meet P = 0).
         eps = self.cfg.eps
         hd = self.cfg.attention_head_dim
-        kv_t_all = ops.gemm(enc_t, self.w_kv_t_all, self.b_kv_t_all)  # [B*Tt, L*2D] = per layer [k | v]
-        kv_i_all = None
+        L = self.L
+        use_vt = self.cross_vt and enc_i is not None and self.all_img and Tt % 8 == 0
+        k_t_all = ops.gemm(enc_t, self.w_k_t_all, self.b_k_t_all)  # [B*Tt, L*D]
+        k_i_all = v_t_all = v_i_all = v1t = v2t = None
+        c1 = c2 = 0
         if enc_i is not None and self.all_img:
-            kv_i_all = ops.gemm(enc_i, self.w_kv_i_all, self.b_kv_i_all)
+            k_i_all = ops.gemm(enc_i, self.w_k_i_all, self.b_k_i_all)
+        if use_vt:
+            c1, c2 = Tt, (Ti + 7) // 8 * 8
+            ld1 = ((B - 1) * c1 + (Tt + 63) // 64 * 64 + 7) // 8 * 8
+            ld2 = ((B - 1) * c2 + (Ti + 63) // 64 * 64 + 7) // 8 * 8
+            bufs = self._ctx_bufs.get((B, Tt, Ti))
+            if bufs is None:  # zero-filled once: the padding rows / columns are never written afterwards.  Engine-owned (not per call):
+                # a captured step that computes the projections (cache_context off) replays into the same addresses
+                z = lambda *sh: torch.zeros(sh, dtype=torch.bfloat16, device=self.dev)
+                bufs = SimpleNamespace(enc_i_pad=z(B * c2, D), v1t=z(L * D, ld1), v2t=z(L * D, ld2))
+                self._ctx_bufs = dict(list(self._ctx_bufs.items())[-1:] + [((B, Tt, Ti), bufs)])  # the guided pair and the single sample
+            v1t, v2t = bufs.v1t, bufs.v2t
+            w, b, eps_i = self.im_n2
+            for bi in range(B):
+                ops.ln_affine(h_img[bi * Ti:(bi + 1) * Ti], w, b, eps_i, out=bufs.enc_i_pad[bi * c2: bi * c2 + Ti])
+            ops.gemm(self.w_v_t_all, enc_t, self.b_v_t_all, out=v1t[:, : B * Tt], epilogue=ops.EPI_BIAS_ROW)
+            ops.gemm(self.w_v_i_all, bufs.enc_i_pad, self.b_v_i_all, out=v2t[:, : B * c2], epilogue=ops.EPI_BIAS_ROW)
+        else:
+            v_t_all = ops.gemm(enc_t, self.w_v_t_all, self.b_v_t_all)
+            if k_i_all is not None:
+                v_i_all = ops.gemm(enc_i, self.w_v_i_all, self.b_v_i_all)
+        kv = []
         for li, p in enumerate(self.blk):
-            kv_t = kv_t_all[:, li * 2 * D:(li + 1) * 2 * D]
-            ops.rmsnorm_rope_(kv_t[:, :D], p.nk2, None, hd, eps)
-            kv_i = None
-            if kv_i_all is not None:
-                kv_i = kv_i_all[:, li * 2 * D:(li + 1) * 2 * D]
-                ops.rmsnorm_rope_(kv_i[:, :D], p.nk_i, None, hd, eps)
-            elif enc_i is not None and p.has_img:
-                kv_i = ops.gemm(enc_i, p.w_kv_i, p.b_kv_i)
-                ops.rmsnorm_rope_(kv_i[:, :D], p.nk_i, None, hd, eps)
-            kv.append((kv_t, kv_i))
-        ctx = SimpleNamespace(kv=kv, Tt=Tt, Ti=Ti)
+            cols = slice(li * D, (li + 1) * D)
+            k_t = k_t_all[:, cols]
+            ops.rmsnorm_rope_(k_t, p.nk2, None, hd, eps)
+            k_i = None
+            if k_i_all is not None:
+                k_i = k_i_all[:, cols]
+                ops.rmsnorm_rope_(k_i, p.nk_i, None, hd, eps)
+            if use_vt:
+                kv.append((k_t, v1t[cols], k_i, v2t[cols]))
+            else:
+                kv.append((k_t, v_t_all[:, cols], k_i, None if v_i_all is None else v_i_all[:, cols]))
+        ctx = SimpleNamespace(kv=kv, Tt=Tt, Ti=Ti, vt=use_vt, c1=c1, c2=c2)
         if key is not None:
             self._ctx_key, self._ctx, self._ctx_refs = key, ctx, keyed
         return ctx
@@ -810,11 +874,13 @@ class DiTEngine:
             else:
                 self._linear(ws, x, p, "q2", ws.q2)
             ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
-            kv_t, kv_i = ctx.kv[li]
-            if kv_i is not None:
-                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, k2=kv_i[:, :D], v2=kv_i[:, D:], batch=B)
+            k_t, v_t, k_i, v_i = ctx.kv[li]
+            if ctx.vt:  # both segments' K and V^T tiles by LDS-DMA (v_t / v_i are V^T row blocks of this layer)
+                ops.attention_2seg_vt(ws.q2, k_t, v_t, Tt, k_i, v_i, Ti, H, out=ws.att, batch=B, cols1=ctx.c1, cols2=ctx.c2)
+            elif k_i is not None:
+                ops.attention(ws.q2, k_t, v_t, H, out=ws.att, k2=k_i, v2=v_i, batch=B)
             else:
-                ops.attention(ws.q2, kv_t[:, :D], kv_t[:, D:], H, out=ws.att, batch=B)
+                ops.attention(ws.q2, k_t, v_t, H, out=ws.att, batch=B)
             self._linear(ws, ws.att, p, "o2", x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
             self._ln_linear(ws, x, mod[li, 0, 4], mod[li, 0, 3], p, "f1", ws.ffn, ab_rows=Nl, ab_stride=6 * D, epilogue=ops.EPI_BIAS_GELU)

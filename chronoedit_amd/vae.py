@@ -113,6 +113,8 @@ class WanVAEEngine:
             elif k.endswith("gamma"):
                 self.gammas[k] = v.float().reshape(-1).contiguous()
         self._zero: Dict[tuple, torch.Tensor] = {}
+        self._attn_vt: Dict[tuple, torch.Tensor] = {}  # mid-block attention scratch per (C, padded h*w): see _attn
+        self._attn_ws: Dict[tuple, tuple] = {}
         self.use_gemm_conv = True  # wide stride-1 3x3(x3) convs on the large-tile GEMM (False: every conv on the implicit-GEMM kernel)
         self._layers()
 
@@ -182,10 +184,12 @@ class WanVAEEngine:
             ops.zero_border(out.data, T_out, H_out, W_out, Cout)
         return out
 
-    def _gemm_ok(self, name, C_in) -> bool:
-        """Does conv `name` run on the large-tile GEMM (ce_conv3d_gemm_bf16)?  Stride-1 3x3(x3), at least 96 channels in and out."""
+    def _gemm_ok(self, name, C_in, st: int = 1, ss: int = 1) -> bool:
+        """Does conv `name` run on the large-tile GEMM (ce_conv3d_gemm_bf16)?  Stride-1 3x3(x3), at least 96 channels in and out.
+        (The strided resample convs share the kernel size: the stride is part of the question.)"""
         pk = self.packs[name]
-        return self.use_gemm_conv and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and C_in >= 96 and pk.Cout_p >= 96
+        return (self.use_gemm_conv and st == 1 and ss == 1 and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and C_in >= 96
+                and pk.Cout_p >= 96)
 
     def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None) -> Frames:
         pk = self.packs[name]
@@ -206,8 +210,9 @@ class WanVAEEngine:
                         Cin=pk.Cin_p, Cout=pk.Cout_p, KT=KT)
         return out
 
-    def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None) -> Frames:
-        """3x3x3 causal conv with the chunk-to-chunk frame cache (wan2pt1.py:200-210): two frames in front of the chunk."""
+    def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None, gemm: Optional[bool] = None) -> Frames:
+        """3x3x3 causal conv with the chunk-to-chunk frame cache (wan2pt1.py:200-210): two frames in front of the chunk.
+        gemm: the routing decision when the caller already took it (the producer sized x's stack by it); None: decide here."""
         i = caches["i"]
         caches["i"] += 1
         prev = caches["slots"].get(i)
@@ -224,7 +229,9 @@ class WanVAEEngine:
             keep = torch.cat([prev[-1:], x.data], 0)
         else:
             keep = x.data.clone()
-        if self._gemm_ok(name, x.C):
+        if gemm is None:
+            gemm = self._gemm_ok(name, x.C)
+        if gemm:
             out = self._conv_gemm(name, x, front, res, out_C)
         else:
             out = self._conv(name, front + x.frame_list(), x.T, x.H, x.W, x.W, res=res, out_C=out_C)
@@ -245,10 +252,12 @@ class WanVAEEngine:
         h = x
         if (name + ".shortcut") in self.packs:
             h = self._conv(name + ".shortcut", x.frame_list(), x.T, x.H, x.W, x.W, in_off=1)
-        y = self._rms_silu(x, name + ".residual.0.gamma", front=2 if self._gemm_ok(name + ".residual.2", x.C) else None)
-        y = self._cached_conv(name + ".residual.2", y, caches)
-        y = self._rms_silu(y, name + ".residual.3.gamma", front=2 if self._gemm_ok(name + ".residual.6", y.C) else None)
-        return self._cached_conv(name + ".residual.6", y, caches, res=h)
+        g2 = self._gemm_ok(name + ".residual.2", x.C)  # one routing decision per layer: it sizes the producer's stack AND picks the conv
+        y = self._rms_silu(x, name + ".residual.0.gamma", front=2 if g2 else None)
+        y = self._cached_conv(name + ".residual.2", y, caches, gemm=g2)
+        g6 = self._gemm_ok(name + ".residual.6", y.C)
+        y = self._rms_silu(y, name + ".residual.3.gamma", front=2 if g6 else None)
+        return self._cached_conv(name + ".residual.6", y, caches, res=h, gemm=g6)
 
     def _attn(self, name, x: Frames) -> Frames:
         """Per-frame single-head attention over h*w (wan2pt1.py:240-259): 1x1 qkv conv -> one flash-style attention kernel
@@ -260,9 +269,12 @@ class WanVAEEngine:
         hwp = (HW + 63) // 64 * 64
         o = torch.empty((x.T, HW, C), dtype=torch.bfloat16, device=self.dev)
         if C in (128, 384):  # the shipped width (384) and the dim-32 test width: one flash-style kernel per frame, nothing [HW, HW]-sized
-            vt = getattr(self, "_attn_vt", None)
-            if vt is None or vt.shape != (C, hwp):
-                vt = self._attn_vt = torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev)  # padding columns stay zero
+            # one V^T scratch PER SHAPE, never released while the engine lives: a hipGraph captured at one resolution keeps the raw
+            # pointer of its scratch, so rebinding a single engine-wide buffer when another resolution comes along would hand the
+            # captured graph freed memory (and its padding columns must stay zero)
+            vt = self._attn_vt.get((C, hwp))
+            if vt is None:
+                vt = self._attn_vt[(C, hwp)] = torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev)  # padding columns stay zero
             for t in range(x.T):
                 vt[:, :HW].copy_(qkv[t, :, 2 * C :].t())
                 ops.attention_1head(qkv[t, :, :C], qkv[t, :, C : 2 * C], vt, C ** -0.5, out=o[t])
@@ -270,11 +282,11 @@ class WanVAEEngine:
             # other widths: query rows in chunks - the fp32 score block is [rows, HW] with rows chosen for <= 256 MiB, and the work
             # buffers live across frames and calls (scores, probabilities, V^T with its padding columns zeroed once)
             rows = min(HW, max(256, (1 << 26) // hwp // 64 * 64))
-            ws = getattr(self, "_attn_ws", None)
-            if ws is None or ws[0] != (rows, hwp, C):
+            ws = self._attn_ws.get((rows, hwp, C))  # keyed by shape and kept, like _attn_vt above
+            if ws is None:
                 ws = ((rows, hwp, C), torch.empty((rows, hwp), dtype=torch.float32, device=self.dev),
                       torch.empty((rows, hwp), dtype=torch.bfloat16, device=self.dev), torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev))
-                self._attn_ws = ws
+                self._attn_ws[(rows, hwp, C)] = ws
             _, s_buf, p_buf, vt = ws
             for t in range(x.T):
                 q, k, v = qkv[t, :, :C], qkv[t, :, C : 2 * C], qkv[t, :, 2 * C :]
@@ -522,6 +534,7 @@ class AutoencoderKLWan(torch.nn.Module):
         # a shape runs eagerly - it also performs every lazy initialisation - so a one-off call pays nothing.
         self.use_graph = False
         self._graphs: Dict[tuple, object] = {}
+        self._graph_pool = None
 
     @property
     def dtype(self):
@@ -533,23 +546,36 @@ class AutoencoderKLWan(torch.nn.Module):
             self._engine = WanVAEEngine(self._params, c.base_dim, c.z_dim, tuple(c.dim_mult), c.num_res_blocks, tuple(c.temperal_downsample))
         return self._engine
 
+    MAX_GRAPHS = 4  # captured shapes kept at once; the least recently used one is dropped for a new shape
+
+    def clear_graphs(self):
+        """Drop every captured encode / decode graph with its static buffers and activation pool (a full-resolution chunk is ~0.7 GB
+        per buffer).  The next call of a shape runs eagerly again, the one after re-captures.  Called by the pipeline's
+        `offload_model`; call it yourself when a serving process is done with a resolution."""
+        self._graphs.clear()
+        self._graph_pool = None
+
     def _run(self, kind: str, fn, x: torch.Tensor) -> torch.Tensor:
         if not self.use_graph or not x.is_cuda:
             return fn(x)
         key = (kind, tuple(x.shape), x.dtype)
-        g = self._graphs.get(key)
+        g = self._graphs.pop(key, None)  # (re-inserted below: dict order = recency)
         if g is None:  # first call of this shape: eager (and warm)
             self._graphs[key] = "warm"
             return fn(x)
         if isinstance(g, str):
-            if sum(1 for v in self._graphs.values() if not isinstance(v, str)) >= 4:  # every graph keeps its activations' pool alive
-                return fn(x)
+            live = [k for k, v in self._graphs.items() if not isinstance(v, str)]
+            while len(live) >= self.MAX_GRAPHS:  # LRU: the oldest captured shape makes room (its pool blocks go back to the shared pool)
+                del self._graphs[live.pop(0)]
             static_in = x.clone()
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            if getattr(self, "_graph_pool", None) is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()  # ONE pool for all VAE graphs: they never run concurrently, so a
+            graph = torch.cuda.CUDAGraph()                          # dropped graph's activations are reused by the next capture
+            with torch.cuda.graph(graph, pool=self._graph_pool):
                 static_out = fn(static_in)
-            g = self._graphs[key] = (graph, static_in, static_out)
+            g = (graph, static_in, static_out)
+        self._graphs[key] = g
         graph, static_in, static_out = g
         static_in.copy_(x)
         graph.replay()

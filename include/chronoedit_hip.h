@@ -93,8 +93,16 @@ int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_bytes);
 /* Scratch for the split-K tail of ce_gemm_bf16's 256-tile kernel: the tiles that would run as a partially filled last
  * round of workgroups are cut along K into fp32 slabs (256 KiB each, at most one per CU) and summed by a second
  * launch that applies the epilogue.  ptr is device memory owned by the caller (NULL switches the split off; that is
- * the default); the library never allocates.  Host-side knob, returns CE_OK. */
+ * the default); the library never allocates.  Registers the DEFAULT scratch of the CURRENT device (one per device: two devices
+ * in one process never share slabs).  Host-side knob, returns CE_OK. */
 int ce_set_gemm_workspace(void* ptr, size_t bytes);
+
+/* The same for ONE stream of the current device: a launch on `stream` uses this scratch instead of the device default, so GEMMs
+ * running concurrently on several streams of a device do not meet in one buffer (the library keeps no other state a launch writes).
+ * ptr == NULL unregisters (the stream falls back to the device default).  At most 32 registrations are kept per process; a 33rd
+ * replaces the oldest.  SURVEY section 8(b): "workspace passed by caller, library stateless" - the registry is caller-owned memory
+ * keyed by the caller's own stream handles.  Returns CE_OK. */
+int ce_set_gemm_workspace_stream(hipStream_t stream, void* ptr, size_t bytes);
 
 /* O = softmax(Q K1^T * scale) V1 [ + softmax(Q K2^T * scale) V2 ], per head, head_dim == 128, bf16.
  * Each segment's result is rounded to bf16 before the add (SDPA output dtype).
@@ -122,7 +130,8 @@ int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, 
 
 /* Cross-attention - TWO key / value segments with a softmax each, the two outputs added in bf16 (transformer_chronoedit.py:91-104: text
  * and image keys) - with both V operands handed over transposed: V1t [H*128][ldv1t], V2t [H*128][ldv2t], sample b's keys at columns
- * [b*vt_cols, b*vt_cols + len) of its segment's V^T (vt_cols even, >= 64*ceil(len/64); every column read is finite).  K1 / K2 as in
+ * [b*vt_cols, b*vt_cols + len) of its segment's V^T (vt_cols even, >= len; ldv*t >= (batch-1)*vt_cols + 64*ceil(len/64); every column
+ * read - a sample's tail strip runs into the next sample's keys or the padding - is finite and meets P = 0).  K1 / K2 as in
  * ce_attention_batched_bf16 (samples stacked along the rows).  The K and V^T tiles of both segments reach LDS by LDS-DMA. */
 int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1, const void* K2,
                               const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq, int H, int head_dim, int ldq,
