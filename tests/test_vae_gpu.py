@@ -103,7 +103,7 @@ def test_single_head_attention_kernel_vs_fp32(N, C):
     assert worst < 1e-2, worst
 
 
-@pytest.mark.parametrize("name", ["small_5f", "small_9f", "full_5f", "full_5f_128x192", "full_29f"])
+@pytest.mark.parametrize("name", ["small_5f", "small_9f", "full_5f", "full_5f_128x192", "full_29f", "full_1f_360x640"])
 def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
     from chronoedit_amd.vae import AutoencoderKLWan
     fx = torch.load(os.path.join(golden_dir, f"vae_{name}.pt"))
@@ -117,6 +117,15 @@ def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
     assert mu.shape == fx["mu"].shape and rec.shape == fx["rec"].shape
     e_mu, e_rec = rel_l2(mu, fx["mu"]), rel_l2(rec, fx["rec"])
     assert e_mu < 5e-2 and e_rec < 5e-2, (e_mu, e_rec)
+    if "bf16_eager_rel_l2" in fx:
+        # 360 x 640 px (3 600 mid-block attention tokens, 14 / 26 / 51 / 225 M-tiles of 256 pixels per conv layer): the 720p-class row
+        # tiling against the REFERENCE's classes.  The error of the reference's own eager precision at this size was measured when the
+        # fixture was made (oracle in bf16 on the host, minutes): the HIP engine must sit within 3 x of it - and inside 3e-2.
+        b = fx["bf16_eager_rel_l2"]
+        print(f"{name}: encode hip {e_mu:.3e} (bf16 eager {b['mu']:.3e})  decode hip {e_rec:.3e} (bf16 eager {b['rec']:.3e})")
+        assert e_mu < 3 * b["mu"] + 5e-3 and e_rec < 3 * b["rec"] + 5e-3, (e_mu, e_rec, b)
+        assert e_mu < 3e-2 and e_rec < 3e-2, (e_mu, e_rec)
+        return
     if name in ("full_5f_128x192", "full_29f"):  # the bf16 CPU oracle at these sizes costs minutes of host time: fp32 golden only
         print(f"{name}: encode hip {e_mu:.3e}  decode hip {e_rec:.3e}")
         return
@@ -147,6 +156,55 @@ def test_vae_graph_replay_equals_eager():
         assert torch.equal(vae.encode(xs[i]).latent_dist.mode(), eager_mu[i]), i
         assert torch.equal(vae.decode(zs[i], return_dict=False)[0], eager_v[i]), i
     assert sum(1 for v in vae._graphs.values() if not isinstance(v, str)) == 2
+
+
+def test_vae_graphs_of_several_resolutions_replay_correctly():
+    """A serving process alternates resolutions (the reference runner derives height / width per input image).  With `use_graph` the
+    sequence A, A, B, B, A, B replays A's graph after B's shapes went through the engine: the mid-block attention scratch (V^T with zero
+    padding columns) is per shape and stays alive, so a captured graph never writes into memory that was handed back (the
+    single engine-wide scratch was rebound by B and A's graph replayed into freed memory).  clear_graphs() drops every graph."""
+    from chronoedit_amd.vae import AutoencoderKLWan
+    dev = torch.device("cuda:0")
+    arch = dict(dim=32, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True))
+    vae = AutoencoderKLWan.random_init(dev, seed=5, **arch)
+    g = torch.Generator().manual_seed(9)
+    shapes = {"A": (5, 32, 48), "B": (5, 96, 64), "C": (1, 128, 96)}  # mid-block attention over 24 / 96 / 192 positions: three scratch shapes
+    mk = lambda k: ((torch.rand(1, 3, *shapes[k], generator=g) * 2 - 1).to(torch.bfloat16).to(dev),
+                    torch.randn(1, 16, (shapes[k][0] - 1) // 4 + 1, shapes[k][1] // 8, shapes[k][2] // 8, generator=g).to(torch.bfloat16).to(dev))
+    seq = ["A", "A", "B", "B", "A", "B", "C", "C", "A", "C", "B"]
+    inputs = [(k,) + mk(k) for k in seq]
+    eager = [(vae.encode(x).latent_dist.mode().clone(), vae.decode(z, return_dict=False)[0].clone()) for _, x, z in inputs]
+    vae.use_graph = True
+    junk = []
+    for i, (k, x, z) in enumerate(inputs):
+        mu = vae.encode(x).latent_dist.mode()
+        v = vae.decode(z, return_dict=False)[0]
+        assert torch.equal(mu, eager[i][0]) and torch.equal(v, eager[i][1]), (i, k)
+        junk.append(torch.full((1 << 20,), float("nan"), dtype=torch.bfloat16, device=dev))  # poison whatever the allocator hands out next
+    assert sum(1 for v in vae._graphs.values() if not isinstance(v, str)) == 6
+    vae.clear_graphs()
+    assert not vae._graphs
+    k, x, z = inputs[0]
+    assert torch.equal(vae.encode(x).latent_dist.mode(), eager[0][0])  # eager again after the clear
+
+
+def test_vae_graph_lru_eviction():
+    from chronoedit_amd.vae import AutoencoderKLWan
+    dev = torch.device("cuda:0")
+    arch = dict(dim=32, z_dim=16, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True))
+    vae = AutoencoderKLWan.random_init(dev, seed=6, **arch)
+    vae.use_graph = True
+    vae.MAX_GRAPHS = 2
+    g = torch.Generator().manual_seed(4)
+    zs = {w: torch.randn(1, 16, 1, 4, w, generator=g).to(torch.bfloat16).to(dev) for w in (4, 5, 6)}
+    ref = {}
+    vae.use_graph = False
+    for w, z in zs.items():
+        ref[w] = vae.decode(z, return_dict=False)[0].clone()
+    vae.use_graph = True
+    for w in (4, 4, 5, 5, 6, 6, 4, 4, 6, 5, 5):  # three shapes through two slots: the least recently used graph leaves, results stay right
+        assert torch.equal(vae.decode(zs[w], return_dict=False)[0], ref[w]), w
+        assert sum(1 for v in vae._graphs.values() if not isinstance(v, str)) <= 2
 
 
 @pytest.mark.parametrize("C,T,H,W,silu,border", [(96, 2, 9, 70, True, 1), (192, 1, 5, 33, True, 1), (384, 3, 4, 17, False, 1), (32, 1, 6, 40, True, 1),

@@ -1,0 +1,108 @@
+"""Parity where WIDTH and DEPTH meet, and at BASELINE.json configs[0].
+
+Every other full-width test runs ONE block; every depth test runs 2 - 4 heads.  Here the 14B width (D = 5120, 40 heads, F = 13 824,
+512 text + 257 image context rows) goes through several residual blocks against the fp32 CPU oracle, at the configs[0] shape
+(256 x 256 px, 5 pixel frames -> latents [1, 16, 2, 32, 32], N = 512 tokens) where the oracle finishes in seconds:
+
+  * L = 8 blocks, one forward: HIP <= 2e-2 from the fp32 oracle and <= 3 x the error of the reference's own eager precision
+    (the oracle run in bf16 on the host) against the same fp32 result;
+  * configs[0] as written, reduced depth (L = 4): the WHOLE edit - production-width Wan VAE encode of the 256 x 256 image, 4 steps at
+    guidance 5 (8 forwards), decode - through oracle/pipeline_oracle.py in fp32 against ChronoEditPipeline on the HIP engine,
+    end of trajectory (latents and video).
+Weights: oracle.make_synthetic_params (seeded; 3.2 B parameters at L = 8: 13 GB in fp32 on the host, 6.5 GB in bf16 on the GPU)."""
+import time
+
+import pytest
+import torch
+
+from oracle import dit_oracle as O
+from oracle import pipeline_oracle as P
+from oracle import vae_oracle as V
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _build(cfg, params):
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    m = ChronoEditTransformer3DModel(
+        num_attention_heads=cfg.num_attention_heads, attention_head_dim=cfg.attention_head_dim, in_channels=cfg.in_channels,
+        out_channels=cfg.out_channels, text_dim=cfg.text_dim, freq_dim=cfg.freq_dim, ffn_dim=cfg.ffn_dim,
+        num_layers=cfg.num_layers, image_dim=cfg.image_dim, added_kv_proj_dim=cfg.added_kv_proj_dim,
+        rope_temporal_skip_len=cfg.rope_temporal_skip_len, device="cuda:0", dtype=BF)
+    m.load_synthetic_({k: v.to("cuda:0") for k, v in params.items()})
+    return m
+
+
+def test_full_width_eight_blocks_at_the_configs0_shape_vs_fp32_oracle():
+    cfg = O.DiTConfig(num_layers=8)
+    p_bf = O.make_synthetic_params(cfg, seed=1234, dtype=BF)
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 32, 32, dtype=BF)
+    model = _build(cfg, p_bf)
+    ts = torch.tensor([637], device="cuda:0")
+    out_hip = model(lat.cuda(), ts, text.cuda(), image.cuda(), return_dict=False)[0].float().cpu()
+    del model
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        eager = O.dit_forward(p_bf, cfg, lat, torch.tensor([637]), text, image).float()  # the reference's run mode: bf16 eager
+    t_bf = time.perf_counter() - t0
+    p32 = {k: v.float() for k, v in p_bf.items()}
+    del p_bf
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([637]), text.float(), image.float())
+    t_32 = time.perf_counter() - t0
+    e_hip, e_eager = rel_l2(out_hip, ref), rel_l2(eager, ref)
+    print(f"D = 5120 x L = 8 at N = 512: HIP vs fp32 oracle {e_hip:.3e} | bf16 eager oracle vs fp32 {e_eager:.3e} ({e_hip / e_eager:.2f} x) "
+          f"| host: fp32 {t_32:.1f} s, bf16 {t_bf:.1f} s")
+    assert torch.isfinite(out_hip).all()
+    assert e_hip < 2e-2, e_hip
+    assert e_hip <= 3 * e_eager, (e_hip, e_eager)
+
+
+def test_configs0_edit_full_width_reduced_depth_vs_fp32_pipeline_oracle():
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    from chronoedit_amd.vae import AutoencoderKLWan
+    dcfg = O.DiTConfig(num_layers=4)
+    vcfg = V.VAEConfig(dim=96, z_dim=16)  # the production VAE width
+    dp = O.make_synthetic_params(dcfg, seed=1234, dtype=BF)
+    vp = V.make_synthetic_params(vcfg)
+    g = torch.Generator().manual_seed(3)
+    H = W = 256
+    F = 5
+    image = (torch.rand(1, 3, H, W, generator=g) * 2 - 1).to(BF)
+    _, text, img_emb = O.make_synthetic_inputs(dcfg, 2, H // 8, W // 8, dtype=BF)
+    negative = torch.randn((1, 512, dcfg.text_dim), generator=torch.Generator().manual_seed(8))
+    negative[:, 20:] = 0
+    negative = negative.to(BF)
+    lat0 = torch.randn(1, 16, 2, H // 8, W // 8, generator=g)
+
+    model = _build(dcfg, dp)
+    vae = AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=vcfg.dim, z_dim=vcfg.z_dim)
+    pipe = ChronoEditPipeline(vae=vae, transformer=model, scheduler=FlowUniPCMultistepScheduler(flow_shift=5.0))
+    args = (image.cuda(), text.cuda(), negative.cuda(), img_emb.cuda())
+    lat = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda(), output_type="latent").float().cpu()
+    vid = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda()).float().cpu()
+    del model, vae, pipe
+    torch.cuda.empty_cache()
+
+    dp32 = {k: v.float() for k, v in dp.items()}
+    del dp
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        lat_ref, vid_ref = P.edit(dp32, dcfg, vp, vcfg, image.float(), text.float(), negative.float(), img_emb.float(), lat0.clone(),
+                                  num_frames=F, steps=4, guidance=5.0, shift=5.0)
+    t_ref = time.perf_counter() - t0
+    e_lat, e_vid = rel_l2(lat, lat_ref), rel_l2(vid, vid_ref)
+    print(f"configs[0] (256x256, 2 latent frames, 4 steps, guidance 5) at D = 5120 x L = 4: final latents {e_lat:.3e}, video {e_vid:.3e} "
+          f"| fp32 CPU oracle edit {t_ref:.1f} s")
+    assert vid.shape == (1, 3, F, H, W) and torch.isfinite(vid).all()
+    assert e_lat < 3e-2, e_lat
+    assert e_vid < 6e-2, e_vid
