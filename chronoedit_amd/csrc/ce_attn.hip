@@ -835,6 +835,399 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 
 
 // ------------------------------------------------------------------------------------------------
+// "w4" (round 4): the V^T / LDS-DMA form with ONE WAVE PER SIMD.  4 waves x 64 query rows (two 32-row sub-blocks A, B per wave), the
+// whole 512-entry register file per wave.  Same LDS images, DMA source swizzles, fragment assignments, products, rounding points and
+// speculative softmax as attn_fwd_sp_kernel<false, true> (every line of arithmetic below has its twin there) - what changes is who
+// shares what:
+//   * a K (V^T) fragment read from LDS feeds TWO MFMAs (sub-block A, then B): 128 KiB of fragment reads per key tile and CU instead
+//     of 256 KiB, and half the ds_read issue slots per MFMA;
+//   * no second wave on the SIMD: the matrix pipe of a SIMD sees one in-order stream - S(t) of both sub-blocks (32 MFMAs carrying the
+//     8 DMA issues of tile t + 1 and the K fragment reads), then P(t-1).V(t-1) of both (32 MFMAs, each pair followed by its share of
+//     softmax(t): 4 v_exp, 4 adds, 2 packed conversions and one V^T fragment read) - <= 5.5 single-issue fillers per MFMA gap, which
+//     one wave per SIMD hides (MI355X guide, cycle-constant table) where two waves per SIMD serialise them;
+//   * 4 waves stage what 8 did: 4 K pieces + 4 V^T pieces of 1 KiB per wave and tile; counted wait vmcnt(4) = K(t) and V(t-1) landed.
+// Registers: O^T 2 x 4 x 16 = 128 accumulators, Q 2 x 8 x 4 = 64, S 64, P 32, offsets 32, fragment rings 40.
+// ------------------------------------------------------------------------------------------------
+// Matrix instructions of the w4 kernel as asm: the operand FILES are part of the design - Q fragments (64 registers) and the O^T
+// accumulators (128) live in the accumulator half of the register file ("a"), S / P / the offsets / the fragment rings in the VGPR
+// half, which is all the VALU can address.  Left to the builtins hipcc allocated 256 + 256 registers, spilled 93 and moved ~130
+// registers between the halves at the top of every tile.  Hazards the compiler does not pad for an asm statement (guide section 5.7):
+//   * D of an asm MFMA -> VALU reader: S is first read (v_exp) behind >= 3 later MFMAs; the rare readers straight behind the S phase
+//     (tail mask, exact offset) and the readers of O (rescale, epilogue) sit behind W4A_SETTLE_* (s_nop 11 = 12 states, 8-pass XDL);
+//   * VALU / v_accvgpr_write -> MFMA operand (2 states): P is written >= 4 units ahead of the MFMA that reads it; a rescaled O passes
+//     W4A_SETTLE_O before the next P.V MFMA.
+#define W4A_S_FIRST(ST, KF, QF, CI) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(ST) : "v"(KF), "a"(QF), "v"(CI))
+#define W4A_S(ST, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ST) : "v"(KF), "a"(QF))
+#define W4A_PV(OA, VF, PP) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(OA) : "v"(VF), "v"(PP))
+#define W4A_SETTLE_S(SB) asm volatile("s_nop 11" : "+v"(st[SB][0]), "+v"(st[SB][1]))
+#define W4A_SETTLE_O(SB) asm volatile("s_nop 11" : "+a"(oacc[SB][0]), "+a"(oacc[SB][1]), "+a"(oacc[SB][2]), "+a"(oacc[SB][3]))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_fwd_w4_kernel(
+    const bf16* __restrict__ Q_, bf16* __restrict__ O_, KVSeg seg0_, int Nq, int H, int ldq, int ldo, int nqb, float scale_log2e, int batch,
+    BlkRows blk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NWAVE = 4, QWW = 64, QB = QWW * NWAVE;  // 256 query rows per workgroup, as in the 8-wave kernel: the work items are the same
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  for (int item = blockIdx.x; item < nqb * H * batch; item += gridDim.x) {
+  const bf16* Q = Q_;
+  bf16* O = O_;
+  KVSeg sg = seg0_;
+  int head, qb, bz;
+  {  // work order: attn_fwd_sp_kernel (full query blocks of an XCD's heads first, the remainder blocks last)
+    const int nqb_full = Nq / QB;
+    if ((H & 7) == 0) {
+      const int xcd = item & 7, local = item >> 3, hx_n = H >> 3;
+      const int full = batch * hx_n * nqb_full;
+      if (local < full) {
+        bz = local / (hx_n * nqb_full);
+        const int r = local % (hx_n * nqb_full);
+        head = xcd + 8 * (r / nqb_full);
+        qb = r % nqb_full;
+      } else {
+        const int l2 = local - full;
+        bz = l2 / hx_n;
+        head = xcd + 8 * (l2 % hx_n);
+        qb = nqb_full;
+      }
+    } else {
+      bz = item / (nqb * H);
+      const int r = item % (nqb * H);
+      head = r / nqb;
+      qb = r % nqb;
+    }
+  }
+  if (blk.rows > 0) {
+    Q += (size_t)bz * blk.rows * ldq;
+    O += (size_t)bz * blk.rows * ldo;
+    sg.k += (size_t)bz * blk.rows * sg.ldk;
+    sg.v += (size_t)bz * blk.vt_cols;
+  } else {
+    Q += (size_t)bz * Nq * ldq;
+    O += (size_t)bz * Nq * ldo;
+    sg.k += (size_t)bz * sg.len * sg.ldk;
+    sg.v += (size_t)bz * sg.len;
+  }
+  const int q0 = qb * QB + wave * QWW;
+  const int hoff = head * HD;
+  const bool active = q0 < Nq;
+  const int q0row = blk.rows > 0 ? (q0 / blk.rows) * blk.stride + q0 % blk.rows : q0;  // (a wave's 64 tokens never straddle a block)
+
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const bf16* qrow = Q + (size_t)(q0 + 32 * sb + l31 < Nq ? q0row + 32 * sb + l31 : 0) * ldq + hoff + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[sb][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+  }
+  // fragment read addresses (see attn_fwd_sp_kernel)
+  const int k_w = l31 & 3;
+  const unsigned char* k_rd = smem + (l31 >> 2) * K_GRP + k_w * 256 + ((hh ^ (k_w & 1)) << 4);
+  const int k_eo[2] = {(k_w >> 1) << 5, ((k_w >> 1) ^ 1) << 5};
+  int vt_off[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const int x = (l31 >> 1) & 7;
+    vt_off[s4] = l31 * 128 + ((2 * (s4 ^ (x >> 1)) + (hh ^ (x & 1))) << 4);
+  }
+  const int ntiles = (sg.len + KVB - 1) / KVB;
+  const int k_rows_span = blk.rows > 0 ? ((sg.len - 1) / blk.rows) * blk.stride + blk.rows : sg.len;
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.k + hoff), 0, (k_rows_span - 1) * sg.ldk * 2 + HD * 2, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.v + (size_t)hoff * sg.ldv), 0, ((HD - 1) * sg.ldv + ntiles * KVB) * 2, 0x00020000);
+  const int k_tile_bytes = KVB * sg.ldk * 2;
+  // K image group g = wave + 4 j (j = 0..3) holds image rows 4 g + (lane >> 4); image row rho holds key rho with bits 2 and 3 swapped
+  const int kd_row = (lane >> 4) + 8 * (wave & 1) + 4 * (wave >> 1);
+  const int kd_voff0 = kd_row * sg.ldk * 2 + (((lane & 15) ^ (lane >> 4)) << 4), kd_step = 16 * sg.ldk * 2;
+  // V^T piece wave + 4 j: rows 8 (wave + 4 j) + (lane >> 3), slot lane & 7 <- chunk slot ^ ((row >> 1) & 7)
+  const int vd_row = 8 * wave + (lane >> 3);
+  const int vd_voff0 = vd_row * sg.ldv * 2 + (((lane & 7) ^ ((vd_row >> 1) & 7)) << 4), vd_step = 32 * sg.ldv * 2;
+  auto dma_v = [&](int t, int buf, int j) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + SP_V0 + buf * PV_TILE + (wave + 4 * j) * 1024), 16, vd_voff0 + j * vd_step,
+                                             t * (KVB * 2), 0, 0);
+  };
+  auto dma_k = [&](int t, int buf, int j) __attribute__((always_inline)) {
+    int soff = t * k_tile_bytes;
+    if (blk.rows > 0) {
+      const int b_ = blk.magic ? (int)__umulhi((uint32_t)t, blk.magic) : t;
+      soff = (b_ * blk.stride + (t - b_ * (blk.rows >> 6)) * KVB) * sg.ldk * 2;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + buf * PK_TILE + (wave + 4 * j) * K_GRP), 16, kd_voff0 + j * kd_step, soff, 0, 0);
+  };
+
+  f32x16 oacc[2][4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[sb][m][r] = 0.f;
+  float l_run[2] = {0.f, 0.f}, alpha_prev[2] = {1.0f, 1.0f}, mc[2] = {0.f, 0.f};
+  f32x16 cinit[2];
+  u32x4 ppk[2][4];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[sb][r] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) ppk[sb][s4] = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // ---- prologue: tile 0 -> K buffer 0 / V buffer 0; V buffer 2 plays "V(-1)" (zeros)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dma_k(0, 0, j);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dma_v(0, 0, j);
+  {
+    const pp_u4 z = {0u, 0u, 0u, 0u};
+    for (int i = tid; i < PV_TILE / 16; i += NWAVE * 64) *reinterpret_cast<pp_u4*>(smem + SP_V0 + 2 * PV_TILE + i * 16) = z;
+  }
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {  // Q scaled once by softmax_scale * log2(e), rounded back to bf16 (see attn_fwd_sp_kernel)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const u32x4 w = __builtin_bit_cast(u32x4, qf[sb][ks]);
+      u32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = pack_bf16(bf16lo(w[i]) * scale_log2e, bf16hi(w[i]) * scale_log2e);
+      qf[sb][ks] = __builtin_bit_cast(bf16x8, o);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[sb][ks]));  // retire the Q loads before the loop; Q lives in the accumulator file
+  }
+  // vector-memory queue of a wave at the top of tile t: K(t) x4, V(t) x4 (issued inside tile t - 1): vmcnt(4) = K(t) and V(t-1) landed
+  int vb_prev = 2, vb_cur = 0;
+  for (int t = 0; !active && t < ntiles; ++t) {  // a wave without query rows only stages, behind the same barriers
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    CE_EPOCH_BARRIER();
+    const int vb_next = 3 - vb_prev - vb_cur;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_k(t + 1, (t + 1) & 1, j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_v(t + 1, vb_next, j);
+    vb_prev = vb_cur;
+    vb_cur = vb_next;
+  }
+  for (int t = 0; active && t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    CE_EPOCH_BARRIER();  // K(t), V(t-1) visible; K(t-1) and V(t-2) no longer read by anyone
+    const int vb_next = 3 - vb_prev - vb_cur;
+    const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
+    const unsigned char* vtb = smem + SP_V0 + vb_prev * PV_TILE;  // V^T image of tile t-1
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 st[2][2];
+    // ---- S^T(t) = K(t).Q^T of both sub-blocks: fragment i (kv fragment f = i & 1, k-step ks = i >> 1) feeds sub-block A then B;
+    // one scheduling region per MFMA pair; the DMAs of tile t + 1 ride behind pairs 0..7
+    {
+      constexpr int RING = 4;
+      bf16x8 kf[RING];
+#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + k_eo[((i) >> 1) & 1] + ((i) & 1) * 8 * K_GRP + ((i) >> 2) * 64))
+#pragma unroll
+      for (int i = 0; i < RING; ++i) kf[i] = CE_LDK(i);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i < 2) {  // untied form: both chains start from the offset registers
+          W4A_S_FIRST(st[0][i & 1], kf[i % RING], qf[0][i >> 1], cinit[0]);
+          W4A_S_FIRST(st[1][i & 1], kf[i % RING], qf[1][i >> 1], cinit[1]);
+        } else {
+          W4A_S(st[0][i & 1], kf[i % RING], qf[0][i >> 1]);
+          W4A_S(st[1][i & 1], kf[i % RING], qf[1][i >> 1]);
+        }
+        if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
+        if (i < 4) dma_k(t + 1, (t + 1) & 1, i);
+        else if (i < 8) dma_v(t + 1, vb_next, i - 4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef CE_LDK
+    }
+    float alpha[2] = {1.0f, 1.0f};
+    float psum[2] = {0.f, 0.f};
+    auto mask_tail = [&](int sb) __attribute__((always_inline)) {
+      if ((t + 1) * KVB > sg.len) {
+        W4A_SETTLE_S(sb);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = t * KVB + 32 * f + 16 * (r >> 3) + 8 * hh + 4 * ((r >> 2) & 1) + (r & 3);  // pi(row), see dma_k
+            if (kv >= sg.len) st[sb][f][r] = NEG_BIG;
+          }
+      }
+    };
+    auto rebase = [&](int sb) __attribute__((always_inline)) {  // exact tile max of both halves of the row: move the offset
+      W4A_SETTLE_S(sb);
+      float mx;
+      {
+        float m0 = fmaxf(st[sb][0][0], st[sb][0][1]), m1 = fmaxf(st[sb][0][8], st[sb][0][9]), m2 = fmaxf(st[sb][1][0], st[sb][1][1]),
+              m3 = fmaxf(st[sb][1][8], st[sb][1][9]);
+#pragma unroll
+        for (int r = 2; r < 8; ++r) {
+          m0 = fmaxf(m0, st[sb][0][r]);
+          m1 = fmaxf(m1, st[sb][0][8 + r]);
+          m2 = fmaxf(m2, st[sb][1][r]);
+          m3 = fmaxf(m3, st[sb][1][8 + r]);
+        }
+        mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      }
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      const float shift = t == 0 ? mx : fmaxf(mx, 0.f);
+      alpha[sb] = __builtin_amdgcn_exp2f(-shift);
+      mc[sb] += shift;
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[sb][f][r] -= shift;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[sb][r] = -mc[sb];
+    };
+    auto pack_pair = [&](int sb, int j) __attribute__((always_inline)) {
+      const f32x2 pr = {st[sb][j >> 3][(2 * j) & 15], st[sb][j >> 3][(2 * j + 1) & 15]};
+      ppk[sb][j >> 2][j & 3] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
+    };
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      mask_tail(sb);
+      if (t == 0) rebase(sb);
+      if (__any(alpha_prev[sb] != 1.0f)) {  // O at the scale of m(t-1) before P(t-1).V(t-1) is added (rare after the first tiles)
+        W4A_SETTLE_O(sb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha_prev[sb];
+        W4A_SETTLE_O(sb);
+      }
+    }
+    // ---- O^T += V^T(t-1).P^T(t-1) of both sub-blocks on the matrix pipe, P(t) on the VALU: unit u = (k-step u >> 2, dv fragment u & 3)
+    // = one V^T fragment, two MFMAs (A, B), and per sub-block the v_exp of elements 2u, 2u+1, two adds into the row sum (one unit
+    // behind) and one packed conversion (four units behind: P(t) replaces P(t-1) in place).  Two scheduling regions per unit.
+    {
+#define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vtb + vt_off[(u) >> 2] + ((u) & 3) * 4096))
+      constexpr int VRING = 6;
+      bf16x8 vf[VRING];
+#pragma unroll
+      for (int u = 0; u < VRING; ++u) vf[u] = CE_LDV(u);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          W4A_PV(oacc[sb][u & 3], vf[u % VRING], ppk[sb][u >> 2]);
+          if (sb == 1 && u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
+#pragma unroll
+          for (int e = 2 * u; e < 2 * u + 2; ++e) st[sb][e >> 4][e & 15] = __builtin_amdgcn_exp2f(st[sb][e >> 4][e & 15]);
+          if (u > 0) {
+            psum[sb] += st[sb][(u - 1) >> 3][(2 * u - 2) & 15];
+            psum[sb] += st[sb][(u - 1) >> 3][(2 * u - 1) & 15];
+          }
+          if (u >= 4) pack_pair(sb, u - 4);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#undef CE_LDV
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        psum[sb] += st[sb][1][14];
+        psum[sb] += st[sb][1][15];
+#pragma unroll
+        for (int j = 12; j < 16; ++j) pack_pair(sb, j);
+      }
+    }
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      if (__builtin_expect(t > 0 && __any(psum[sb] > SP_SPEC_THR), 0)) {
+        // exact_tile: S(t) again (K(t) is untouched until the next barrier), true row max, plain softmax
+        st[sb][0] = zero16;
+        st[sb][1] = zero16;
+        asm volatile("s_nop 1" : "+v"(st[sb][0]), "+v"(st[sb][1]));  // VALU write -> MFMA operand
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb + k_eo[(i >> 1) & 1] + (i & 1) * 8 * K_GRP + (i >> 2) * 64);
+          W4A_S(st[sb][i & 1], kfr, qf[sb][i >> 1]);
+        }
+        W4A_SETTLE_S(sb);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[sb][f][r] -= mc[sb];
+        mask_tail(sb);
+        rebase(sb);
+        psum[sb] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          st[sb][j >> 3][(2 * j) & 15] = __builtin_amdgcn_exp2f(st[sb][j >> 3][(2 * j) & 15]);
+          st[sb][j >> 3][(2 * j + 1) & 15] = __builtin_amdgcn_exp2f(st[sb][j >> 3][(2 * j + 1) & 15]);
+          psum[sb] += st[sb][j >> 3][(2 * j) & 15] + st[sb][j >> 3][(2 * j + 1) & 15];
+          pack_pair(sb, j);
+        }
+      }
+      l_run[sb] = l_run[sb] * alpha[sb] + psum[sb];
+      alpha_prev[sb] = alpha[sb];
+    }
+    vb_prev = vb_cur;
+    vb_cur = vb_next;
+  }
+  // ---- drain: P(ntiles-1).V(ntiles-1); its V buffer (now vb_prev) was issued during the last-but-one tile: land it, for everybody
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (active) {
+    const unsigned char* vtb = smem + SP_V0 + vb_prev * PV_TILE;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+      if (__any(alpha_prev[sb] != 1.0f)) {
+        W4A_SETTLE_O(sb);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha_prev[sb];
+        W4A_SETTLE_O(sb);
+      }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const bf16x8 vfd = *reinterpret_cast<const bf16x8*>(vtb + vt_off[u >> 2] + (u & 3) * 4096);
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) W4A_PV(oacc[sb][u & 3], vfd, ppk[sb][u >> 2]);
+    }
+  }
+  W4A_SETTLE_O(0);
+  W4A_SETTLE_O(1);
+  CE_EPOCH_BARRIER();  // every wave is done with the tile buffers (the O staging overlays them)
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    unsigned char* ost = smem + (size_t)(wave * QWW + 32 * sb + l31) * OST_ROW;
+    const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
+    const float inv = 1.0f / l_tot;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const uint32_t w0 = pack_bf16(oacc[sb][m][4 * a + 0] * inv, oacc[sb][m][4 * a + 1] * inv);
+        const uint32_t w1 = pack_bf16(oacc[sb][m][4 * a + 2] * inv, oacc[sb][m][4 * a + 3] * inv);
+        *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = u32x2{w0, w1};
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // the wave's 64 staged rows as whole 256-B rows, 16 B per lane
+    const int c = lane + 64 * i;
+    const int rl = c >> 4, cc = c & 15;
+    if (q0 + rl < Nq) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QWW + rl) * OST_ROW + cc * 16);
+      *reinterpret_cast<u32x4*>(O + (size_t)(q0row + rl) * ldo + hoff + cc * 8) = v;
+    }
+  }
+  __syncthreads();  // the next item's tile staging overwrites the O staging area
+  }  // item
+}
+
+
+#undef W4A_S_FIRST
+#undef W4A_S
+#undef W4A_PV
+#undef W4A_SETTLE_S
+#undef W4A_SETTLE_O
+
+// ------------------------------------------------------------------------------------------------
 // V [rows = keys of all samples][ldv] (head h at columns 128 h ..) -> V^T [H * 128][ldvt] (row = head channel, column = key; the
 // samples' keys side by side), the operand layout of the VT form of the attention kernel above.  One workgroup per 64-key strip
 // and head: 16-B loads along the channels, 4 x 4 patches transposed in registers, LDS for the change of the fast axis, 16-B stores
@@ -897,7 +1290,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict
 static int g_attn_nwave = 0;
 extern "C" int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
-  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 64) g_attn_nwave = nwave;
+  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 64 || nwave == 128 || nwave == 129) g_attn_nwave = nwave;
   return old;
 }
 
@@ -916,7 +1309,7 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
   KVSeg s0{(const bf16*)K1, (const bf16*)V1, len1, ldk1, ldv1};
   KVSeg s1{(const bf16*)K2, (const bf16*)V2, two ? len2 : 0, ldk2, ldv2};
   const float sl2 = softmax_scale * 1.4426950408889634f;
-  const bool sp = g_attn_nwave == 64 || g_attn_nwave == 0;
+  const bool sp = g_attn_nwave == 64 || g_attn_nwave == 0 || g_attn_nwave >= 128;  // (128 / 129 select a loop body of the V^T form only)
   const int nwave = sp ? 8 : g_attn_nwave;
   const int nqb = (Nq + nwave * QW - 1) / (nwave * QW);
   dim3 grid(nqb * H, batch), block(nwave * 64);
@@ -1031,6 +1424,18 @@ static int attention_vt_launch(const void* Q, const void* K, const void* Vt, int
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
   const int items = nqb * H * batch;
+  if (g_attn_nwave == 128 || g_attn_nwave == 129) {  // one wave per SIMD (attn_fwd_w4_kernel): 128 = one workgroup per item, 129 = #CUs persistent workgroups
+    static bool done4_[CE_MAX_DEVICES] = {};
+    bool& done4 = done4_[ce_device_slot()];
+    if (!done4) {
+      (void)hipFuncSetAttribute((const void*)attn_fwd_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(false));
+      done4 = true;
+    }
+    const int grid4 = (g_attn_nwave == 129 && items > cus) ? (cus & ~7) : items;
+    hipLaunchKernelGGL(attn_fwd_w4_kernel, dim3(grid4), dim3(256), sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O, s0, Nq, H, ldq, ldo, nqb,
+                       sl2, batch, blk);
+    return (int)hipGetLastError();
+  }
   const int grid_vt = items <= 2 * cus ? items : ((2 * cus) & ~7);  // persistent: two workgroups per CU walk the work order (see the kernel); a multiple of 8 keeps heads on their XCD
   hipLaunchKernelGGL((attn_fwd_sp_kernel<false, true>), dim3(grid_vt), dim3(512), sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O,
                      s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, blk);

@@ -1,6 +1,6 @@
 """Wan VAE on the HIP kernels vs (a) the golden vectors from the reference's own classes (fp32) and (b) the oracle run
-in bf16 on the CPU (the reference's eager precision).  Tolerance: rel-L2 <= 5e-2 vs fp32 through ~60 bf16 conv layers and
-<= 3x the bf16 eager oracle's own error."""
+in bf16 on the CPU (the reference's eager precision).  Tolerance: rel-L2 <= 2.5e-2 vs fp32 through ~60 bf16 conv layers (measured
+1.1e-2 ... 1.5e-2) and <= 3x the bf16 eager oracle's own error (measured 0.7 ... 0.8 x)."""
 import os
 
 import pytest
@@ -116,7 +116,10 @@ def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
     rec = vae.decode(z.cuda().to(torch.bfloat16), return_dict=False)[0]
     assert mu.shape == fx["mu"].shape and rec.shape == fx["rec"].shape
     e_mu, e_rec = rel_l2(mu, fx["mu"]), rel_l2(rec, fx["rec"])
-    assert e_mu < 5e-2 and e_rec < 5e-2, (e_mu, e_rec)
+    # 2.5e-2 (round 4; was 5e-2): measured on MI355X 1.06e-2 ... 1.45e-2 over all six fixtures, encode and decode; the reference's own
+    # eager precision (bf16 weights and activations) is 1.4e-2 ... 2.0e-2 from the same fp32 results - the engine keeps fp32
+    # accumulators and RMS statistics through ~60 conv layers and sits below it everywhere
+    assert e_mu < 2.5e-2 and e_rec < 2.5e-2, (e_mu, e_rec)
     if "bf16_eager_rel_l2" in fx:
         # 360 x 640 px (3 600 mid-block attention tokens, 14 / 26 / 51 / 225 M-tiles of 256 pixels per conv layer): the 720p-class row
         # tiling against the REFERENCE's classes.  The error of the reference's own eager precision at this size was measured when the
@@ -124,7 +127,6 @@ def test_vae_encode_decode_vs_reference_golden(golden_dir, name):
         b = fx["bf16_eager_rel_l2"]
         print(f"{name}: encode hip {e_mu:.3e} (bf16 eager {b['mu']:.3e})  decode hip {e_rec:.3e} (bf16 eager {b['rec']:.3e})")
         assert e_mu < 3 * b["mu"] + 5e-3 and e_rec < 3 * b["rec"] + 5e-3, (e_mu, e_rec, b)
-        assert e_mu < 3e-2 and e_rec < 3e-2, (e_mu, e_rec)
         return
     if name in ("full_5f_128x192", "full_29f"):  # the bf16 CPU oracle at these sizes costs minutes of host time: fp32 golden only
         print(f"{name}: encode hip {e_mu:.3e}  decode hip {e_rec:.3e}")
@@ -181,7 +183,7 @@ def test_vae_graphs_of_several_resolutions_replay_correctly():
         v = vae.decode(z, return_dict=False)[0]
         assert torch.equal(mu, eager[i][0]) and torch.equal(v, eager[i][1]), (i, k)
         junk.append(torch.full((1 << 20,), float("nan"), dtype=torch.bfloat16, device=dev))  # poison whatever the allocator hands out next
-    assert sum(1 for v in vae._graphs.values() if not isinstance(v, str)) == 6
+    assert sum(1 for v in vae._graphs.values() if not isinstance(v, str)) == vae.MAX_GRAPHS == 4  # six shapes went through: LRU kept four
     vae.clear_graphs()
     assert not vae._graphs
     k, x, z = inputs[0]

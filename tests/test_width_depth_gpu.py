@@ -62,7 +62,7 @@ def test_full_width_eight_blocks_at_the_configs0_shape_vs_fp32_oracle():
     print(f"D = 5120 x L = 8 at N = 512: HIP vs fp32 oracle {e_hip:.3e} | bf16 eager oracle vs fp32 {e_eager:.3e} ({e_hip / e_eager:.2f} x) "
           f"| host: fp32 {t_32:.1f} s, bf16 {t_bf:.1f} s")
     assert torch.isfinite(out_hip).all()
-    assert e_hip < 2e-2, e_hip
+    assert e_hip < 2e-2, e_hip  # measured 7.9e-3 = 1.00 x the bf16 eager oracle's 7.9e-3
     assert e_hip <= 3 * e_eager, (e_hip, e_eager)
 
 
@@ -104,5 +104,5 @@ def test_configs0_edit_full_width_reduced_depth_vs_fp32_pipeline_oracle():
     print(f"configs[0] (256x256, 2 latent frames, 4 steps, guidance 5) at D = 5120 x L = 4: final latents {e_lat:.3e}, video {e_vid:.3e} "
           f"| fp32 CPU oracle edit {t_ref:.1f} s")
     assert vid.shape == (1, 3, F, H, W) and torch.isfinite(vid).all()
-    assert e_lat < 3e-2, e_lat
-    assert e_vid < 6e-2, e_vid
+    assert e_lat < 3e-2, e_lat   # measured 1.6e-2
+    assert e_vid < 4e-2, e_vid   # measured 2.3e-2
