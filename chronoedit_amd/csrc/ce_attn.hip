@@ -666,14 +666,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       float psum = 0.f;
       auto mask_tail = [&]() {
         if ((t + 1) * KVB > sg.len) {
-          const int base = t * KVB + 4 * hh;
+          // keys of this tile past the segment's end: element (f, r) of the lane holds key t KVB + c(f, r) + (VT ? 8 : 4) hh, masked when
+          // c >= thr.  thr passes through an opaque asm INSIDE the branch: without it hipcc if-converted the whole block - 32 v_cmp +
+          // 31 v_cndmask issued in every tile of every wave (a third of the loop's plain VALU work), for a mask that applies to the
+          // last tile only (round 4; found in the ISA of the one-wave-per-SIMD kernel, where the compares were hoisted and spilled).
+          int thr = sg.len - t * KVB - (VT ? 8 : 4) * hh;
+          asm volatile("" : "+v"(thr));
 #pragma unroll
           for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int kv = VT ? t * KVB + 32 * f + 16 * (r >> 3) + 8 * hh + 4 * ((r >> 2) & 1) + (r & 3)  // pi(row), see dma_k
-                                : base + 32 * f + (r & 3) + 8 * (r >> 2);
-              if (kv >= sg.len) st[f][r] = NEG_BIG;
+              const int c = VT ? 32 * f + 16 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3)  // pi(row), see dma_k
+                               : 32 * f + (r & 3) + 8 * (r >> 2);
+              if (c >= thr) st[f][r] = NEG_BIG;
             }
         }
       };
@@ -859,6 +864,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #define W4A_S_FIRST(ST, KF, QF, CI) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(ST) : "v"(KF), "a"(QF), "v"(CI))
 #define W4A_S(ST, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ST) : "v"(KF), "a"(QF))
 #define W4A_PV(OA, VF, PP) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(OA) : "v"(VF), "v"(PP))
+#define W4A_ADD(ACC, X) asm volatile("v_add_f32 %0, %0, %1" : "+v"(ACC) : "v"(X))
 #define W4A_SETTLE_S(SB) asm volatile("s_nop 11" : "+v"(st[SB][0]), "+v"(st[SB][1]))
 #define W4A_SETTLE_O(SB) asm volatile("s_nop 11" : "+a"(oacc[SB][0]), "+a"(oacc[SB][1]), "+a"(oacc[SB][2]), "+a"(oacc[SB][3]))
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_fwd_w4_kernel(
@@ -1046,12 +1052,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto mask_tail = [&](int sb) __attribute__((always_inline)) {
       if ((t + 1) * KVB > sg.len) {
         W4A_SETTLE_S(sb);
+        int thr = sg.len - t * KVB - 8 * hh;  // (opaque inside the branch: see attn_fwd_sp_kernel - the block must not be if-converted)
+        asm volatile("" : "+v"(thr));
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int kv = t * KVB + 32 * f + 16 * (r >> 3) + 8 * hh + 4 * ((r >> 2) & 1) + (r & 3);  // pi(row), see dma_k
-            if (kv >= sg.len) st[sb][f][r] = NEG_BIG;
+            const int c = 32 * f + 16 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3);  // pi(row), see dma_k
+            if (c >= thr) st[sb][f][r] = NEG_BIG;
           }
       }
     };
@@ -1116,9 +1124,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (sb == 1 && u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
 #pragma unroll
           for (int e = 2 * u; e < 2 * u + 2; ++e) st[sb][e >> 4][e & 15] = __builtin_amdgcn_exp2f(st[sb][e >> 4][e & 15]);
-          if (u > 0) {
-            psum[sb] += st[sb][(u - 1) >> 3][(2 * u - 2) & 15];
-            psum[sb] += st[sb][(u - 1) >> 3][(2 * u - 1) & 15];
+          if (u > 0) {  // (asm: as plain C the two sub-blocks' sums were SLP-packed into one dependent v_pk_add_f32 chain with wait states)
+            W4A_ADD(psum[sb], st[sb][(u - 1) >> 3][(2 * u - 2) & 15]);
+            W4A_ADD(psum[sb], st[sb][(u - 1) >> 3][(2 * u - 1) & 15]);
           }
           if (u >= 4) pack_pair(sb, u - 4);
           __builtin_amdgcn_sched_barrier(0);
@@ -1127,8 +1135,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef CE_LDV
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
-        psum[sb] += st[sb][1][14];
-        psum[sb] += st[sb][1][15];
+        W4A_ADD(psum[sb], st[sb][1][14]);
+        W4A_ADD(psum[sb], st[sb][1][15]);
 #pragma unroll
         for (int j = 12; j < 16; ++j) pack_pair(sb, j);
       }
@@ -1224,6 +1232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef W4A_S_FIRST
 #undef W4A_S
 #undef W4A_PV
+#undef W4A_ADD
 #undef W4A_SETTLE_S
 #undef W4A_SETTLE_O
 

@@ -271,8 +271,8 @@ def set_gemm_variant(v: int) -> int:
 
 
 def set_attention_waves(n: int) -> int:
-    """Attention loop body: 0 auto (= 64), 4 / 8 plain kernel with that many waves, 64 software-pipelined (default); returns
-    the previous value (see include/chronoedit_hip.h)."""
+    """Attention loop body: 0 auto (= 64), 4 / 8 plain kernel with that many waves, 64 software-pipelined (default), 128 / 129 the
+    one-wave-per-SIMD body of the V^T form (one workgroup per item / persistent); returns the previous value (include/chronoedit_hip.h)."""
     return lib().ce_set_attention_waves(int(n))
 
 

@@ -159,8 +159,10 @@ int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, 
 
 /* Loop body behind ce_attention_bf16 / ce_attention_batched_bf16 (returns the previous value; all are tested against the
  * same reference): 0 automatic (= 64); 4 / 8 the plain kernel with 4 / 8 waves per workgroup; 64 software-pipelined, K by
- * LDS-DMA, pre-scaled Q, speculative softmax with an exact fall-back route per tile (default).  Other values are ignored.
- * Host-side tuning knob. */
+ * LDS-DMA, pre-scaled Q, speculative softmax with an exact fall-back route per tile (default); 128 / 129: as 64, but the V^T form
+ * (ce_attention_vt_bf16, ce_attention_vt_blocked_bf16) runs its one-wave-per-SIMD body (4 waves x 64 query rows, Q and O^T in the
+ * accumulator file; bit-identical results) with one workgroup per work item / with one persistent workgroup per CU.  Other values
+ * are ignored.  Host-side tuning knob. */
 int ce_set_attention_waves(int nwave);
 
 /* out[dim] = [cos(t f_i), sin(t f_i)], f_i = 1e4^(-i/(dim/2)), fp32; t is a device int64.

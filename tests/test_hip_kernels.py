@@ -269,10 +269,53 @@ def test_attention_single_segment(Nq, Nkv, H, attn_waves):
     assert (out.float() - ref).abs().max().item() < 3e-2
 
 
+@pytest.fixture(params=[0, 128, 129], ids=["sp-2-waves-per-simd", "w4-1-wave-per-simd", "w4-persistent"])
+def vt_body(request):
+    """Loop body of the V^T form (ce_set_attention_waves): the 8-wave software-pipelined kernel or the one-wave-per-SIMD kernel (round 4)."""
+    from chronoedit_amd import ops
+    old = ops.set_attention_waves(request.param)
+    yield request.param
+    ops.set_attention_waves(old)
+
+
+@pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (7200, 7200, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2), (3000, 200, 40, 2)])
+@pytest.mark.parametrize("slope", [0.0, 0.5, 10.0])
+def test_attention_vt_one_wave_per_simd_body_is_bit_identical_to_the_eight_wave_body(Nq, Nkv, H, B, slope):
+    """attn_fwd_w4_kernel (4 waves x 64 query rows, Q and O^T in the accumulator file, every matrix instruction an asm statement) computes
+    the SAME products in the SAME order with the same rounding points as attn_fwd_sp_kernel<false, true>: outputs are equal bit for bit -
+    on random scores (speculative softmax all the way), with a spike growing 0.5 / 10 octaves per key tile (offset moved on the exact
+    route, in every tile at slope 10), with query blocks whose second sub-block or later waves have no rows, and with key tails."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    D = H * 128
+    q = torch.randn(B * Nq, D, generator=g).to(BF).to(dev)
+    k = torch.randn(B * Nkv, D, generator=g).to(BF).to(dev)
+    v = torch.randn(B * Nkv, D, generator=g).to(BF).to(dev)
+    if slope:
+        for b in range(B):
+            for t in range((Nkv + 63) // 64):
+                k[b * Nkv + min(t * 64 + 5, Nkv - 1)] = q[b * Nq + min(7, Nq - 1)] * (0.5 + slope * t)
+    vt = ops.v_transpose(v, H)
+    outs = {}
+    for body in (0, 128, 129):
+        old = ops.set_attention_waves(body)
+        try:
+            outs[body] = ops.attention_vt(q, k, vt, H, batch=B).clone()
+        finally:
+            ops.set_attention_waves(old)
+    assert torch.isfinite(outs[128].float()).all()
+    assert torch.equal(outs[128], outs[0]), (outs[128].float() - outs[0].float()).abs().max()
+    assert torch.equal(outs[129], outs[0]), (outs[129].float() - outs[0].float()).abs().max()
+    for b in range(B):
+        ref = _sdpa_ref(q[b * Nq:(b + 1) * Nq], k[b * Nkv:(b + 1) * Nkv], v[b * Nkv:(b + 1) * Nkv], H)
+        assert rel_l2(outs[128][b * Nq:(b + 1) * Nq], ref) < 1e-2
+
+
 @pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (512, 104, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2),
                                          (7200, 7200, 8, 2), (1056, 1056, 5, 2), (1090, 1090, 8, 2), (330, 3270, 8, 3),   # these two: sample offsets only 4-byte aligned
                                          (2000, 200, 40, 3), (3000, 64, 24, 2)])  # many work items per persistent workgroup
-def test_attention_vt_matches_sdpa_and_the_register_staged_kernel(Nq, Nkv, H, B):
+def test_attention_vt_matches_sdpa_and_the_register_staged_kernel(Nq, Nkv, H, B, vt_body):
     """ce_attention_vt_bf16 (V handed over transposed by ce_v_transpose_bf16; K rows permuted inside the tile so that a lane's
     keys are contiguous in V^T): vs torch SDPA <= 1e-2, vs the register-staged kernel <= 3e-3 (same products, the row sums and
     the P.V contraction run over the keys of a tile in a different order); the padding columns of V^T are zero."""
@@ -296,7 +339,7 @@ def test_attention_vt_matches_sdpa_and_the_register_staged_kernel(Nq, Nkv, H, B)
 
 
 @pytest.mark.parametrize("N,n,W,H,B", [(300, 128, 3, 2, 2), (128, 64, 2, 8, 1), (1000, 256, 4, 8, 2), (7100, 3584, 2, 8, 2), (500, 64, 8, 5, 3)])
-def test_attention_vt_blocked_layout_equals_plain(N, n, W, H, B):
+def test_attention_vt_blocked_layout_equals_plain(N, n, W, H, B, vt_body):
     """ce_attention_vt_blocked_bf16 + ce_v_transpose_blocked_bf16: q / k / v / out rows in the all-to-all receive layout
     [source rank][sample][local token] (n tokens per rank, W ranks, the last block padded: N valid tokens) == the plain-layout
     kernel on the un-blocked tensors, bit for bit (same kernel, only row addresses differ)."""
@@ -323,7 +366,7 @@ def test_attention_vt_blocked_layout_equals_plain(N, n, W, H, B):
 
 
 @pytest.mark.parametrize("slope", [0.5, 10.0])
-def test_attention_vt_spiked_scores_take_the_exact_route(slope):
+def test_attention_vt_spiked_scores_take_the_exact_route(slope, vt_body):
     from chronoedit_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(5)
