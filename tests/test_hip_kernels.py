@@ -309,7 +309,8 @@ def test_attention_vt_one_wave_per_simd_body_is_bit_identical_to_the_eight_wave_
     assert torch.equal(outs[129], outs[0]), (outs[129].float() - outs[0].float()).abs().max()
     for b in range(B):
         ref = _sdpa_ref(q[b * Nq:(b + 1) * Nq], k[b * Nkv:(b + 1) * Nkv], v[b * Nkv:(b + 1) * Nkv], H)
-        assert rel_l2(outs[128][b * Nq:(b + 1) * Nq], ref) < 1e-2
+        # (spiked rows put nearly all of their weight on one key per tile: 1.08e-2 measured at 7200 keys and slope 10 - for BOTH bodies)
+        assert rel_l2(outs[128][b * Nq:(b + 1) * Nq], ref) < (1e-2 if slope == 0 else 1.5e-2)
 
 
 @pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (512, 104, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2),

@@ -31,6 +31,7 @@ elif kind == "attnvt":
     qkv = torch.randn(B * N, 3 * D, generator=g).to(BF).to(dev)
     vt = ops.v_transpose(qkv[:, 2 * D:], H)
     out = torch.empty(B * N, D, dtype=BF, device=dev)
+    ops.set_attention_waves(int(os.environ.get("CE_ATTN_WAVES", "0")))  # 0: the 8-wave body; 128 / 129: one wave per SIMD
     for _ in range(iters):
         ops.attention_vt(qkv[:, :D], qkv[:, D:2 * D], vt, H, out=out, batch=B)
 elif kind == "attn8":  # MXFP8 self-attention, B samples per launch (producers run once, outside the counted launches' names)
