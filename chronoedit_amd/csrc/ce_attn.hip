@@ -842,16 +842,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 // ------------------------------------------------------------------------------------------------
 // "w4" (round 4): the V^T / LDS-DMA form with ONE WAVE PER SIMD.  4 waves x 64 query rows (two 32-row sub-blocks A, B per wave), the
 // whole 512-entry register file per wave.  Same LDS images, DMA source swizzles, fragment assignments, products, rounding points and
-// speculative softmax as attn_fwd_sp_kernel<false, true> (every line of arithmetic below has its twin there) - what changes is who
-// shares what:
+// speculative softmax as attn_fwd_sp_kernel<false, true> (every line of arithmetic below has its twin there; the outputs are equal bit
+// for bit) - what changes is who shares what, and when:
 //   * a K (V^T) fragment read from LDS feeds TWO MFMAs (sub-block A, then B): 128 KiB of fragment reads per key tile and CU instead
 //     of 256 KiB, and half the ds_read issue slots per MFMA;
-//   * no second wave on the SIMD: the matrix pipe of a SIMD sees one in-order stream - S(t) of both sub-blocks (32 MFMAs carrying the
-//     8 DMA issues of tile t + 1 and the K fragment reads), then P(t-1).V(t-1) of both (32 MFMAs, each pair followed by its share of
-//     softmax(t): 4 v_exp, 4 adds, 2 packed conversions and one V^T fragment read) - <= 5.5 single-issue fillers per MFMA gap, which
-//     one wave per SIMD hides (MI355X guide, cycle-constant table) where two waves per SIMD serialise them;
-//   * 4 waves stage what 8 did: 4 K pieces + 4 V^T pieces of 1 KiB per wave and tile; counted wait vmcnt(4) = K(t) and V(t-1) landed.
-// Registers: O^T 2 x 4 x 16 = 128 accumulators, Q 2 x 8 x 4 = 64, S 64, P 32, offsets 32, fragment rings 40.
+//   * no second wave on the SIMD: the matrix pipe of a SIMD sees one in-order stream - S(t) of both sub-blocks (32 MFMAs), then
+//     P(t-1).V(t-1) of both (32 MFMAs, each followed by its share of softmax(t): 2 v_exp, 2 adds, one packed conversion);
+//   * nothing else covers a wave's stalls, so no phase starts with an LDS round trip and the workgroup barrier does not sit in front
+//     of a phase: the first V^T fragments of P.V are read under the last S units, the first K fragments of the NEXT tile under the
+//     last P.V units, and the tile's one barrier (counted wait: K(t+1) has landed) sits in the MIDDLE of the P.V phase.  The K DMA runs
+//     two tiles ahead through FOUR buffers (a fast wave issues K(t+2) into the buffer of K(t-2) behind barrier t-1, which every wave
+//     reaches after its last read of K(t-2) - the exact route at the end of tile t-2) and the V^T DMA of tile t+1 moves behind the
+//     barrier too (its buffer held V(t-2), read until the end of tile t-1);
+//   * 4 waves stage what 8 did: 4 K pieces + 4 V^T pieces of 1 KiB per wave and tile;
+//   * a wave whose second sub-block has no query rows (the last block of a sequence) runs the NSB = 1 form: half the MFMAs per tile.
+// Registers: O^T 2 x 4 x 16 = 128 accumulators and Q 2 x 8 x 4 = 64 in the accumulator file; S 64, P 32, offsets 32, fragment rings 40.
 // ------------------------------------------------------------------------------------------------
 // Matrix instructions of the w4 kernel as asm: the operand FILES are part of the design - Q fragments (64 registers) and the O^T
 // accumulators (128) live in the accumulator half of the register file ("a"), S / P / the offsets / the fragment rings in the VGPR
@@ -865,8 +870,37 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
 #define W4A_S(ST, KF, QF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ST) : "v"(KF), "a"(QF))
 #define W4A_PV(OA, VF, PP) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(OA) : "v"(VF), "v"(PP))
 #define W4A_ADD(ACC, X) asm volatile("v_add_f32 %0, %0, %1" : "+v"(ACC) : "v"(X))
+#define W4A_CVT(DST, A, B)                                                                  \
+  do {                                                                                      \
+    uint32_t w_;                                                                            \
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w_) : "v"(A), "v"(B));               \
+    (DST) = w_;                                                                             \
+  } while (0)
+#ifndef W4_KDMA_IN_PV
+#define W4_KDMA_IN_PV 1
+#endif
+#ifndef W4_ABLATE
+#define W4_ABLATE 0  // diagnostic builds only (tools/attn_body_ab.py): 1 no tile barrier, 2 no DMA, 4 no softmax fillers, 8 no K reads, 16 no V reads, 32 no S MFMAs, 64 no P.V MFMAs
+#endif
+#ifndef W4_EXP_ASM
+#define W4_EXP_ASM 1
+#endif
+#if W4_EXP_ASM
+#define W4A_EXP(X) asm volatile("v_exp_f32 %0, %0" : "+v"(X))
+#else
+#define W4A_EXP(X) (X) = __builtin_amdgcn_exp2f(X)
+#endif
 #define W4A_SETTLE_S(SB) asm volatile("s_nop 11" : "+v"(st[SB][0]), "+v"(st[SB][1]))
 #define W4A_SETTLE_O(SB) asm volatile("s_nop 11" : "+a"(oacc[SB][0]), "+a"(oacc[SB][1]), "+a"(oacc[SB][2]), "+a"(oacc[SB][3]))
+constexpr int W4_KB = 4;                       // K buffers: the DMA runs TWO tiles ahead (PMC of the one-ahead form: a fifth of the wave cycles parked
+                                               // in front of the barrier - 0.8 us between issue and need is less than a loaded L2 / HBM round trip)
+constexpr int W4_V0 = W4_KB * PK_TILE;         // then three V^T buffers
+constexpr int W4_SMEM = W4_V0 + 3 * PV_TILE;   // 124928 B (also holds the 69632-B O staging)
+template <int N>
+struct w4_int {
+  static constexpr int value = N;
+};
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_fwd_w4_kernel(
     const bf16* __restrict__ Q_, bf16* __restrict__ O_, KVSeg seg0_, int Nq, int H, int ldq, int ldo, int nqb, float scale_log2e, int batch,
     BlkRows blk) {
@@ -917,15 +951,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int q0 = qb * QB + wave * QWW;
   const int hoff = head * HD;
   const bool active = q0 < Nq;
+  const bool two_sub = q0 + 32 < Nq;  // (wave-uniform) the second sub-block has query rows
   const int q0row = blk.rows > 0 ? (q0 / blk.rows) * blk.stride + q0 % blk.rows : q0;  // (a wave's 64 tokens never straddle a block)
 
-  bf16x8 qf[2][8];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    const bf16* qrow = Q + (size_t)(q0 + 32 * sb + l31 < Nq ? q0row + 32 * sb + l31 : 0) * ldq + hoff + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[sb][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
-  }
   // fragment read addresses (see attn_fwd_sp_kernel)
   const int k_w = l31 & 3;
   const unsigned char* k_rd = smem + (l31 >> 2) * K_GRP + k_w * 256 + ((hh ^ (k_w & 1)) << 4);
@@ -948,7 +976,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int vd_row = 8 * wave + (lane >> 3);
   const int vd_voff0 = vd_row * sg.ldv * 2 + (((lane & 7) ^ ((vd_row >> 1) & 7)) << 4), vd_step = 32 * sg.ldv * 2;
   auto dma_v = [&](int t, int buf, int j) __attribute__((always_inline)) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + SP_V0 + buf * PV_TILE + (wave + 4 * j) * 1024), 16, vd_voff0 + j * vd_step,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + W4_V0 + buf * PV_TILE + (wave + 4 * j) * 1024), 16, vd_voff0 + j * vd_step,
                                              t * (KVB * 2), 0, 0);
   };
   auto dma_k = [&](int t, int buf, int j) __attribute__((always_inline)) {
@@ -960,259 +988,332 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + buf * PK_TILE + (wave + 4 * j) * K_GRP), 16, kd_voff0 + j * kd_step, soff, 0, 0);
   };
 
-  f32x16 oacc[2][4];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[sb][m][r] = 0.f;
-  float l_run[2] = {0.f, 0.f}, alpha_prev[2] = {1.0f, 1.0f}, mc[2] = {0.f, 0.f};
-  f32x16 cinit[2];
-  u32x4 ppk[2][4];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cinit[sb][r] = 0.f;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) ppk[sb][s4] = u32x4{0u, 0u, 0u, 0u};
-  }
-
-  // ---- prologue: tile 0 -> K buffer 0 / V buffer 0; V buffer 2 plays "V(-1)" (zeros)
+  // ---- prologue, every wave: tile 0 -> K buffer 0 / V buffer 0; V buffer 2 plays "V(-1)" (zeros: P(-1) = 0 must not meet NaNs)
 #pragma unroll
   for (int j = 0; j < 4; ++j) dma_k(0, 0, j);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) dma_v(0, 0, j);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dma_k(1, 1, j);
   {
     const pp_u4 z = {0u, 0u, 0u, 0u};
-    for (int i = tid; i < PV_TILE / 16; i += NWAVE * 64) *reinterpret_cast<pp_u4*>(smem + SP_V0 + 2 * PV_TILE + i * 16) = z;
+    for (int i = tid; i < PV_TILE / 16; i += NWAVE * 64) *reinterpret_cast<pp_u4*>(smem + W4_V0 + 2 * PV_TILE + i * 16) = z;
   }
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {  // Q scaled once by softmax_scale * log2(e), rounded back to bf16 (see attn_fwd_sp_kernel)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const u32x4 w = __builtin_bit_cast(u32x4, qf[sb][ks]);
-      u32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = pack_bf16(bf16lo(w[i]) * scale_log2e, bf16hi(w[i]) * scale_log2e);
-      qf[sb][ks] = __builtin_bit_cast(bf16x8, o);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[sb][ks]));  // retire the Q loads before the loop; Q lives in the accumulator file
-  }
-  // vector-memory queue of a wave at the top of tile t: K(t) x4, V(t) x4 (issued inside tile t - 1): vmcnt(4) = K(t) and V(t-1) landed
-  int vb_prev = 2, vb_cur = 0;
-  for (int t = 0; !active && t < ntiles; ++t) {  // a wave without query rows only stages, behind the same barriers
+
+  // Tile t of an ACTIVE wave (K buffer of tile t: t & 3; vb_prev / vb_cur = V^T buffers of tiles t - 1 / t):
+  //     S(t): 16 units of NSB MFMAs on the K fragment ring (first four read under the previous P.V tail); units 0..3 issue the K DMA of
+  //           tile t + 2; units 10..15 read the first six V^T(t-1) fragments
+  //     tail mask (last tile) / exact offset (first tile) / O rescale (rare)
+  //     P(t-1).V(t-1): units 0..7 | vmcnt(4), s_barrier: K(t+1), V(t) in LDS, V(t-2) free | units 8..15, carrying the V^T DMA of tile t + 1
+  //           (8..11) and the first four K(t+1) fragment reads (12..15)
+  //     row-sum check of the speculative softmax; exact route (S(t) again from kc) if it fails
+  // A wave without query rows runs the DMA issues and the barriers only.
+  // Vector-memory queue of a wave, oldest first, at the barrier of tile t: K(t+1) x4 (issued in tile t-1), V(t) x4 (tile t-1, behind its
+  // barrier), K(t+2) x4 (tile t): vmcnt(4) = K(t+1) and V(t) have landed, K(t+2) may still fly.
+  if (!active) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     CE_EPOCH_BARRIER();
-    const int vb_next = 3 - vb_prev - vb_cur;
+    int vb_prev = 2, vb_cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_k(t + 1, (t + 1) & 1, j);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int j = 0; j < 4; ++j) dma_k(t + 2, (t + 2) & 3, j);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int vb_next = 3 - vb_prev - vb_cur;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_v(t + 1, vb_next, j);
-    vb_prev = vb_cur;
-    vb_cur = vb_next;
+      for (int j = 0; j < 4; ++j) dma_v(t + 1, vb_next, j);
+      vb_prev = vb_cur;
+      vb_cur = vb_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    CE_EPOCH_BARRIER();
   }
-  for (int t = 0; active && t < ntiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    CE_EPOCH_BARRIER();  // K(t), V(t-1) visible; K(t-1) and V(t-2) no longer read by anyone
-    const int vb_next = 3 - vb_prev - vb_cur;
-    const unsigned char* kb = k_rd + (t & 1) * PK_TILE;
-    const unsigned char* vtb = smem + SP_V0 + vb_prev * PV_TILE;  // V^T image of tile t-1
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 st[2][2];
-    // ---- S^T(t) = K(t).Q^T of both sub-blocks: fragment i (kv fragment f = i & 1, k-step ks = i >> 1) feeds sub-block A then B;
-    // one scheduling region per MFMA pair; the DMAs of tile t + 1 ride behind pairs 0..7
-    {
-      constexpr int RING = 4;
-      bf16x8 kf[RING];
-#define CE_LDK(i) (*reinterpret_cast<const bf16x8*>(kb + k_eo[((i) >> 1) & 1] + ((i) & 1) * 8 * K_GRP + ((i) >> 2) * 64))
+  auto run = [&](auto nsb_c) __attribute__((always_inline)) {
+    constexpr int NSB = decltype(nsb_c)::value;
+    bf16x8 qf[NSB][8];
 #pragma unroll
-      for (int i = 0; i < RING; ++i) kf[i] = CE_LDK(i);
+    for (int sb = 0; sb < NSB; ++sb) {
+      const bf16* qrow = Q + (size_t)(q0 + 32 * sb + l31 < Nq ? q0row + 32 * sb + l31 : 0) * ldq + hoff + 8 * hh;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[sb][ks] = *reinterpret_cast<const bf16x8*>(qrow + 16 * ks);
+    }
+    f32x16 oacc[NSB][4];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[sb][m][r] = 0.f;
+    float l_run[NSB], alpha_prev[NSB], mc[NSB];
+    f32x16 cinit[NSB];
+    u32x4 ppk[NSB][4];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+      l_run[sb] = 0.f;
+      alpha_prev[sb] = 1.0f;
+      mc[sb] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[sb][r] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) ppk[sb][s4] = u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {  // Q scaled once by softmax_scale * log2(e), rounded back to bf16 (see attn_fwd_sp_kernel)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 w = __builtin_bit_cast(u32x4, qf[sb][ks]);
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = pack_bf16(bf16lo(w[i]) * scale_log2e, bf16hi(w[i]) * scale_log2e);
+        qf[sb][ks] = __builtin_bit_cast(bf16x8, o);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(qf[sb][ks]));  // retire the Q loads before the loop; Q lives in the accumulator file
+    }
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (the Q loads above already drained the queue; K(1) may fly in principle)
+    CE_EPOCH_BARRIER();  // K(0), V(0) and the zeros of "V(-1)" are in LDS, for everybody
+
+#define CE_LDK(KB, i) (*reinterpret_cast<const bf16x8*>((KB) + k_eo[((i) >> 1) & 1] + ((i) & 1) * 8 * K_GRP + ((i) >> 2) * 64))
+#define CE_LDV(VB, u) (*reinterpret_cast<const bf16x8*>((VB) + vt_off[(u) >> 2] + ((u) & 3) * 4096))
+    constexpr int RING = 4, VRING = 6;
+    bf16x8 kf[RING], vf[VRING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) kf[i] = CE_LDK(k_rd, i);
+    int vb_prev = 2, vb_cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+      const int vb_next = 3 - vb_prev - vb_cur;
+      const unsigned char* kb = k_rd + (t & 3) * PK_TILE;
+      const unsigned char* kbn = k_rd + ((t + 1) & 3) * PK_TILE;
+      const unsigned char* vtb = smem + W4_V0 + vb_prev * PV_TILE;  // V^T image of tile t-1
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f32x16 st[NSB][2];
+      // ---- S^T(t) = K(t).Q^T: fragment i (kv fragment f = i & 1, k-step ks = i >> 1) feeds every sub-block; one scheduling region each
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        if (i < 2) {  // untied form: both chains start from the offset registers
-          W4A_S_FIRST(st[0][i & 1], kf[i % RING], qf[0][i >> 1], cinit[0]);
-          W4A_S_FIRST(st[1][i & 1], kf[i % RING], qf[1][i >> 1], cinit[1]);
-        } else {
-          W4A_S(st[0][i & 1], kf[i % RING], qf[0][i >> 1]);
-          W4A_S(st[1][i & 1], kf[i % RING], qf[1][i >> 1]);
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) {
+          if (i < 2) W4A_S_FIRST(st[sb][i & 1], kf[i % RING], qf[sb][i >> 1], cinit[sb]);  // untied form: the chain starts from the offset registers
+          else if (!(W4_ABLATE & 32)) W4A_S(st[sb][i & 1], kf[i % RING], qf[sb][i >> 1]);
         }
-        if (i + RING < 16) kf[i % RING] = CE_LDK(i + RING);
-        if (i < 4) dma_k(t + 1, (t + 1) & 1, i);
-        else if (i < 8) dma_v(t + 1, vb_next, i - 4);
+        if (i + RING < 16 && !(W4_ABLATE & 8)) kf[i % RING] = CE_LDK(kb, i + RING);
+#if !W4_KDMA_IN_PV
+        if (i < 4 && !(W4_ABLATE & 2)) dma_k(t + 2, (t + 2) & 3, i);
+#endif
+        if (i >= 16 - VRING && !(W4_ABLATE & 16)) vf[i - (16 - VRING)] = CE_LDV(vtb, i - (16 - VRING));
         __builtin_amdgcn_sched_barrier(0);
       }
-#undef CE_LDK
-    }
-    float alpha[2] = {1.0f, 1.0f};
-    float psum[2] = {0.f, 0.f};
-    auto mask_tail = [&](int sb) __attribute__((always_inline)) {
-      if ((t + 1) * KVB > sg.len) {
+      float alpha[NSB], psum[NSB];
+#pragma unroll
+      for (int sb = 0; sb < NSB; ++sb) {
+        alpha[sb] = 1.0f;
+        psum[sb] = 0.f;
+      }
+      auto mask_tail = [&](int sb) __attribute__((always_inline)) {
+        if ((t + 1) * KVB > sg.len) {
+          W4A_SETTLE_S(sb);
+          int thr = sg.len - t * KVB - 8 * hh;  // (opaque inside the branch: see attn_fwd_sp_kernel - the block must not be if-converted)
+          asm volatile("" : "+v"(thr));
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int c = 32 * f + 16 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3);  // pi(row), see dma_k
+              if (c >= thr) st[sb][f][r] = NEG_BIG;
+            }
+        }
+      };
+      auto rebase = [&](int sb) __attribute__((always_inline)) {  // exact tile max of both halves of the row: move the offset
         W4A_SETTLE_S(sb);
-        int thr = sg.len - t * KVB - 8 * hh;  // (opaque inside the branch: see attn_fwd_sp_kernel - the block must not be if-converted)
-        asm volatile("" : "+v"(thr));
+        float mx;
+        {
+          float m0 = fmaxf(st[sb][0][0], st[sb][0][1]), m1 = fmaxf(st[sb][0][8], st[sb][0][9]), m2 = fmaxf(st[sb][1][0], st[sb][1][1]),
+                m3 = fmaxf(st[sb][1][8], st[sb][1][9]);
+#pragma unroll
+          for (int r = 2; r < 8; ++r) {
+            m0 = fmaxf(m0, st[sb][0][r]);
+            m1 = fmaxf(m1, st[sb][0][8 + r]);
+            m2 = fmaxf(m2, st[sb][1][r]);
+            m3 = fmaxf(m3, st[sb][1][8 + r]);
+          }
+          mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        }
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        const float shift = t == 0 ? mx : fmaxf(mx, 0.f);
+        alpha[sb] = __builtin_amdgcn_exp2f(-shift);
+        mc[sb] += shift;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = 32 * f + 16 * (r >> 3) + 4 * ((r >> 2) & 1) + (r & 3);  // pi(row), see dma_k
-            if (c >= thr) st[sb][f][r] = NEG_BIG;
-          }
-      }
-    };
-    auto rebase = [&](int sb) __attribute__((always_inline)) {  // exact tile max of both halves of the row: move the offset
-      W4A_SETTLE_S(sb);
-      float mx;
-      {
-        float m0 = fmaxf(st[sb][0][0], st[sb][0][1]), m1 = fmaxf(st[sb][0][8], st[sb][0][9]), m2 = fmaxf(st[sb][1][0], st[sb][1][1]),
-              m3 = fmaxf(st[sb][1][8], st[sb][1][9]);
+          for (int r = 0; r < 16; ++r) st[sb][f][r] -= shift;
 #pragma unroll
-        for (int r = 2; r < 8; ++r) {
-          m0 = fmaxf(m0, st[sb][0][r]);
-          m1 = fmaxf(m1, st[sb][0][8 + r]);
-          m2 = fmaxf(m2, st[sb][1][r]);
-          m3 = fmaxf(m3, st[sb][1][8 + r]);
+        for (int r = 0; r < 16; ++r) cinit[sb][r] = -mc[sb];
+      };
+      auto pack_pair = [&](int sb, int j) __attribute__((always_inline)) {
+        const f32x2 pr = {st[sb][j >> 3][(2 * j) & 15], st[sb][j >> 3][(2 * j + 1) & 15]};
+        ppk[sb][j >> 2][j & 3] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
+      };
+#pragma unroll
+      for (int sb = 0; sb < NSB; ++sb) {
+        mask_tail(sb);
+        if (t == 0) rebase(sb);
+        if (__any(alpha_prev[sb] != 1.0f)) {  // O at the scale of m(t-1) before P(t-1).V(t-1) is added (rare after the first tiles)
+          W4A_SETTLE_O(sb);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha_prev[sb];
+          W4A_SETTLE_O(sb);
         }
-        mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
       }
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      const float shift = t == 0 ? mx : fmaxf(mx, 0.f);
-      alpha[sb] = __builtin_amdgcn_exp2f(-shift);
-      mc[sb] += shift;
-#pragma unroll
-      for (int f = 0; f < 2; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[sb][f][r] -= shift;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cinit[sb][r] = -mc[sb];
-    };
-    auto pack_pair = [&](int sb, int j) __attribute__((always_inline)) {
-      const f32x2 pr = {st[sb][j >> 3][(2 * j) & 15], st[sb][j >> 3][(2 * j + 1) & 15]};
-      ppk[sb][j >> 2][j & 3] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));
-    };
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      mask_tail(sb);
-      if (t == 0) rebase(sb);
-      if (__any(alpha_prev[sb] != 1.0f)) {  // O at the scale of m(t-1) before P(t-1).V(t-1) is added (rare after the first tiles)
-        W4A_SETTLE_O(sb);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha_prev[sb];
-        W4A_SETTLE_O(sb);
-      }
-    }
-    // ---- O^T += V^T(t-1).P^T(t-1) of both sub-blocks on the matrix pipe, P(t) on the VALU: unit u = (k-step u >> 2, dv fragment u & 3)
-    // = one V^T fragment, two MFMAs (A, B), and per sub-block the v_exp of elements 2u, 2u+1, two adds into the row sum (one unit
-    // behind) and one packed conversion (four units behind: P(t) replaces P(t-1) in place).  Two scheduling regions per unit.
-    {
-#define CE_LDV(u) (*reinterpret_cast<const bf16x8*>(vtb + vt_off[(u) >> 2] + ((u) & 3) * 4096))
-      constexpr int VRING = 6;
-      bf16x8 vf[VRING];
-#pragma unroll
-      for (int u = 0; u < VRING; ++u) vf[u] = CE_LDV(u);
+      // ---- O^T += V^T(t-1).P^T(t-1) on the matrix pipe, P(t) on the VALU: unit u = (k-step u >> 2, dv fragment u & 3) = one V^T fragment,
+      // one MFMA per sub-block, and per sub-block the v_exp of elements 2u, 2u+1, two adds into the row sum (one unit behind) and one
+      // packed conversion (four units behind: P(t) replaces P(t-1) in place).  One scheduling region per MFMA.
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
+        if (u == 8) {  // K(t+1) and V(t) have landed (this wave's pieces; everybody's behind the barrier); all reads of V(t-2), K(t-1) are over
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          if (!(W4_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
-          W4A_PV(oacc[sb][u & 3], vf[u % VRING], ppk[sb][u >> 2]);
-          if (sb == 1 && u + VRING < 16) vf[u % VRING] = CE_LDV(u + VRING);
-#pragma unroll
-          for (int e = 2 * u; e < 2 * u + 2; ++e) st[sb][e >> 4][e & 15] = __builtin_amdgcn_exp2f(st[sb][e >> 4][e & 15]);
-          if (u > 0) {  // (asm: as plain C the two sub-blocks' sums were SLP-packed into one dependent v_pk_add_f32 chain with wait states)
-            W4A_ADD(psum[sb], st[sb][(u - 1) >> 3][(2 * u - 2) & 15]);
-            W4A_ADD(psum[sb], st[sb][(u - 1) >> 3][(2 * u - 1) & 15]);
+        for (int sb = 0; sb < NSB; ++sb) {
+          if (!(W4_ABLATE & 64)) W4A_PV(oacc[sb][u & 3], vf[u % VRING], ppk[sb][u >> 2]);
+          if (sb == NSB - 1) {
+            if (u + VRING < 16 && !(W4_ABLATE & 16)) vf[u % VRING] = CE_LDV(vtb, u + VRING);
+#if W4_KDMA_IN_PV
+            // the K DMA of tile t + 2 rides in the P.V phase too: an LDS-DMA piece costs its wave 100-185 cycles of issue among the ds_reads
+            // of the S phase and 25-60 in VALU-only gaps (MI355X guide, cycle-constant table) - with one wave per SIMD nobody covers that
+            if (u < 4 && !(W4_ABLATE & 2)) dma_k(t + 2, (t + 2) & 3, u);
+#endif
+            if (u >= 8 && u < 12 && !(W4_ABLATE & 2)) dma_v(t + 1, vb_next, u - 8);
+            if (u >= 12 && !(W4_ABLATE & 8)) kf[u - 12] = CE_LDK(kbn, u - 12);
           }
-          if (u >= 4) pack_pair(sb, u - 4);
+          // hand-placed: add (previous unit's first element), exp, add, exp, pack - adds as asm (as plain C the two sub-blocks' sums were
+          // SLP-packed into one dependent v_pk_add_f32 chain), exps as asm so that they sit BETWEEN the two dependent adds (hipcc pads a
+          // wait state between two back-to-back asm statements on one register)
+          // (the conversion as asm too: as a builtin hipcc SANK the second sub-block's sixteen conversions out of this block, behind the
+          // last MFMA of the tile - nothing consumes P(t) before the next tile)
+#define W4_F_ADD0 if (u > 0) W4A_ADD(psum[sb], st[sb][(u - 1) >> 3][(2 * u - 2) & 15])
+#define W4_F_ADD1 if (u > 0) W4A_ADD(psum[sb], st[sb][(u - 1) >> 3][(2 * u - 1) & 15])
+#define W4_F_CVT if (u >= 4) W4A_CVT(ppk[sb][(u - 4) >> 2][(u - 4) & 3], st[sb][(u - 4) >> 3][(2 * (u - 4)) & 15], st[sb][(u - 4) >> 3][(2 * (u - 4) + 1) & 15])
+#define W4_F_EXP0 W4A_EXP(st[sb][(2 * u) >> 4][(2 * u) & 15])
+#define W4_F_EXP1 W4A_EXP(st[sb][(2 * u + 1) >> 4][(2 * u + 1) & 15])
+#ifndef W4_ORDER
+#define W4_ORDER 0
+#endif
+#if W4_ABLATE & 4
+#elif W4_ORDER == 0
+          W4_F_ADD0; W4_F_CVT; W4_F_EXP0; W4_F_ADD1; W4_F_EXP1;
+#elif W4_ORDER == 1
+          W4_F_ADD0; W4_F_EXP0; W4_F_CVT; W4_F_ADD1; W4_F_EXP1;
+#elif W4_ORDER == 2
+          W4_F_CVT; W4_F_ADD0; W4_F_EXP0; W4_F_EXP1; W4_F_ADD1;
+#elif W4_ORDER == 3
+          W4_F_EXP0; W4_F_EXP1; W4_F_ADD0; W4_F_CVT; W4_F_ADD1;
+#elif W4_ORDER == 4
+          W4_F_EXP0; W4_F_ADD0; W4_F_EXP1; W4_F_CVT; W4_F_ADD1;
+#elif W4_ORDER == 5
+          W4_F_ADD0; W4_F_EXP0; W4_F_EXP1; W4_F_CVT; W4_F_ADD1;
+#endif
+#undef W4_F_ADD0
+#undef W4_F_ADD1
+#undef W4_F_CVT
+#undef W4_F_EXP0
+#undef W4_F_EXP1
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-#undef CE_LDV
 #pragma unroll
-      for (int sb = 0; sb < 2; ++sb) {
+      for (int sb = 0; sb < NSB; ++sb) {
         W4A_ADD(psum[sb], st[sb][1][14]);
         W4A_ADD(psum[sb], st[sb][1][15]);
 #pragma unroll
         for (int j = 12; j < 16; ++j) pack_pair(sb, j);
       }
-    }
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      if (__builtin_expect(t > 0 && __any(psum[sb] > SP_SPEC_THR), 0)) {
-        // exact_tile: S(t) again (K(t) is untouched until the next barrier), true row max, plain softmax
-        st[sb][0] = zero16;
-        st[sb][1] = zero16;
-        asm volatile("s_nop 1" : "+v"(st[sb][0]), "+v"(st[sb][1]));  // VALU write -> MFMA operand
+      for (int sb = 0; sb < NSB; ++sb) {
+        if (__builtin_expect(W4_ABLATE == 0 && t > 0 && __any(psum[sb] > SP_SPEC_THR), 0)) {
+          // exact_tile: S(t) again (K(t) stays in its buffer until barrier t + 1), true row max, plain softmax
+          st[sb][0] = zero16;
+          st[sb][1] = zero16;
+          asm volatile("s_nop 1" : "+v"(st[sb][0]), "+v"(st[sb][1]));  // VALU write -> MFMA operand
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb + k_eo[(i >> 1) & 1] + (i & 1) * 8 * K_GRP + (i >> 2) * 64);
-          W4A_S(st[sb][i & 1], kfr, qf[sb][i >> 1]);
+          for (int i = 0; i < 16; ++i) {
+            const bf16x8 kfr = CE_LDK(kb, i);
+            W4A_S(st[sb][i & 1], kfr, qf[sb][i >> 1]);
+          }
+          W4A_SETTLE_S(sb);
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[sb][f][r] -= mc[sb];
+          mask_tail(sb);
+          rebase(sb);
+          psum[sb] = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            st[sb][j >> 3][(2 * j) & 15] = __builtin_amdgcn_exp2f(st[sb][j >> 3][(2 * j) & 15]);
+            st[sb][j >> 3][(2 * j + 1) & 15] = __builtin_amdgcn_exp2f(st[sb][j >> 3][(2 * j + 1) & 15]);
+            psum[sb] += st[sb][j >> 3][(2 * j) & 15] + st[sb][j >> 3][(2 * j + 1) & 15];
+            pack_pair(sb, j);
+          }
         }
-        W4A_SETTLE_S(sb);
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) st[sb][f][r] -= mc[sb];
-        mask_tail(sb);
-        rebase(sb);
-        psum[sb] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          st[sb][j >> 3][(2 * j) & 15] = __builtin_amdgcn_exp2f(st[sb][j >> 3][(2 * j) & 15]);
-          st[sb][j >> 3][(2 * j + 1) & 15] = __builtin_amdgcn_exp2f(st[sb][j >> 3][(2 * j + 1) & 15]);
-          psum[sb] += st[sb][j >> 3][(2 * j) & 15] + st[sb][j >> 3][(2 * j + 1) & 15];
-          pack_pair(sb, j);
-        }
+        l_run[sb] = l_run[sb] * alpha[sb] + psum[sb];
+        alpha_prev[sb] = alpha[sb];
       }
-      l_run[sb] = l_run[sb] * alpha[sb] + psum[sb];
-      alpha_prev[sb] = alpha[sb];
+      vb_prev = vb_cur;
+      vb_cur = vb_next;
     }
-    vb_prev = vb_cur;
-    vb_cur = vb_next;
-  }
-  // ---- drain: P(ntiles-1).V(ntiles-1); its V buffer (now vb_prev) was issued during the last-but-one tile: land it, for everybody
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+    // ---- drain: P(ntiles-1).V(ntiles-1) (its V buffer, now vb_prev, became visible at the last barrier); the surplus prefetches of
+    // the last tile must retire before the O staging overlays the tile buffers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+      const unsigned char* vtb = smem + W4_V0 + vb_prev * PV_TILE;
+#pragma unroll
+      for (int sb = 0; sb < NSB; ++sb)
+        if (__any(alpha_prev[sb] != 1.0f)) {
+          W4A_SETTLE_O(sb);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha_prev[sb];
+          W4A_SETTLE_O(sb);
+        }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const bf16x8 vfd = CE_LDV(vtb, u);
+#pragma unroll
+        for (int sb = 0; sb < NSB; ++sb) W4A_PV(oacc[sb][u & 3], vfd, ppk[sb][u >> 2]);
+      }
+    }
+#undef CE_LDK
+#undef CE_LDV
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) W4A_SETTLE_O(sb);
+    CE_EPOCH_BARRIER();  // every wave is done with the tile buffers (the O staging overlays them)
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+      unsigned char* ost = smem + (size_t)(wave * QWW + 32 * sb + l31) * OST_ROW;
+      const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
+      const float inv = 1.0f / l_tot;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const uint32_t w0 = pack_bf16(oacc[sb][m][4 * a + 0] * inv, oacc[sb][m][4 * a + 1] * inv);
+          const uint32_t w1 = pack_bf16(oacc[sb][m][4 * a + 2] * inv, oacc[sb][m][4 * a + 3] * inv);
+          *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = u32x2{w0, w1};
+        }
+    }
+  };
   if (active) {
-    const unsigned char* vtb = smem + SP_V0 + vb_prev * PV_TILE;
-#pragma unroll
-    for (int sb = 0; sb < 2; ++sb)
-      if (__any(alpha_prev[sb] != 1.0f)) {
-        W4A_SETTLE_O(sb);
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[sb][m][r] *= alpha_prev[sb];
-        W4A_SETTLE_O(sb);
-      }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const bf16x8 vfd = *reinterpret_cast<const bf16x8*>(vtb + vt_off[u >> 2] + (u & 3) * 4096);
-#pragma unroll
-      for (int sb = 0; sb < 2; ++sb) W4A_PV(oacc[sb][u & 3], vfd, ppk[sb][u >> 2]);
-    }
-  }
-  W4A_SETTLE_O(0);
-  W4A_SETTLE_O(1);
-  CE_EPOCH_BARRIER();  // every wave is done with the tile buffers (the O staging overlays them)
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    unsigned char* ost = smem + (size_t)(wave * QWW + 32 * sb + l31) * OST_ROW;
-    const float l_tot = l_run[sb] + __shfl_xor(l_run[sb], 32, 64);
-    const float inv = 1.0f / l_tot;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const uint32_t w0 = pack_bf16(oacc[sb][m][4 * a + 0] * inv, oacc[sb][m][4 * a + 1] * inv);
-        const uint32_t w1 = pack_bf16(oacc[sb][m][4 * a + 2] * inv, oacc[sb][m][4 * a + 3] * inv);
-        *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = u32x2{w0, w1};
-      }
+    if (two_sub) run(w4_int<2>{});
+    else run(w4_int<1>{});
   }
   __syncthreads();
 #pragma unroll
@@ -1227,12 +1328,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();  // the next item's tile staging overwrites the O staging area
   }  // item
 }
-
-
 #undef W4A_S_FIRST
 #undef W4A_S
 #undef W4A_PV
 #undef W4A_ADD
+#undef W4A_CVT
+#undef W4A_EXP
 #undef W4A_SETTLE_S
 #undef W4A_SETTLE_O
 
@@ -1437,11 +1538,11 @@ static int attention_vt_launch(const void* Q, const void* K, const void* Vt, int
     static bool done4_[CE_MAX_DEVICES] = {};
     bool& done4 = done4_[ce_device_slot()];
     if (!done4) {
-      (void)hipFuncSetAttribute((const void*)attn_fwd_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(false));
+      (void)hipFuncSetAttribute((const void*)attn_fwd_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM);
       done4 = true;
     }
     const int grid4 = (g_attn_nwave == 129 && items > cus) ? (cus & ~7) : items;
-    hipLaunchKernelGGL(attn_fwd_w4_kernel, dim3(grid4), dim3(256), sp_smem_bytes(false), stream, (const bf16*)Q, (bf16*)O, s0, Nq, H, ldq, ldo, nqb,
+    hipLaunchKernelGGL(attn_fwd_w4_kernel, dim3(grid4), dim3(256), W4_SMEM, stream, (const bf16*)Q, (bf16*)O, s0, Nq, H, ldq, ldo, nqb,
                        sl2, batch, blk);
     return (int)hipGetLastError();
   }

@@ -225,7 +225,9 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
                 # is replaced - a recycled id() or a mode switch that keeps the workspace key must not skip the eager warm-up step
                 def warm_key():
                     gen = transformer.engine_generation() if hasattr(transformer, "engine_generation") else id(transformer)
-                    return (tuple(latents.shape), guidance_scale > 1.0 and negative_prompt_embeds is not None, gen, id(scheduler))
+                    # (the scheduler object is not part of the key: everything a step reads from it is created eagerly by GraphedDenoiser
+                    # before the capture - _ensure_state, the staged timestep / coefficient row - so a fresh scheduler per edit stays warm)
+                    return (tuple(latents.shape), guidance_scale > 1.0 and negative_prompt_embeds is not None, gen)
                 graphed = GraphedDenoiser(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds,
                                           image_embeds, guidance_scale, warm=graph_warm is not None and warm_key() in graph_warm)
                 if graph_warm is not None:
