@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--no-transposed-v", action="store_true",
                     help="(A/B) fused q|k|v GEMM + register-staged attention kernel instead of V^T from the swapped GEMM + LDS-DMA staging")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph-captured step instead of launching eagerly")
+    ap.add_argument("--owned-comm", action="store_true",
+                    help="sharded mode: run the exchanges on the RCCL communicator owned by libchronoedit_hip (ce_comm_*; parallel.OwnedComm) instead "
+                         "of torch.distributed's - the form under which --graph can capture the sharded step")
     ap.add_argument("--no-vae", action="store_true", help="skip the VAE encode/decode timing used for the sec/edit figure")
     ap.add_argument("--no-encoders", action="store_true", help="skip the UMT5 / CLIP timing used for the sec/edit figure")
     ap.add_argument("--no-edit", action="store_true", help="skip the measured 8-step end-to-end edit")
@@ -347,7 +350,7 @@ def main():
         if a.cfg_parallel:
             model.enable_cfg_parallel()
         else:
-            model.enable_sequence_parallel()
+            model.enable_sequence_parallel(owned_comm=a.owned_comm)
     wl = Workload(dev, T, h, w, 42 + (0 if ulysses else rank))  # Ulysses: replicated inputs
     N = wl.N
     fwd_per_step = 2 if a.guidance > 1.0 else 1
@@ -443,6 +446,8 @@ def main():
             pair_batched = not a.cfg_parallel and not a.sequential_cfg and fwd_per_step == 2  # the guidance pair as one B = 2 sharded forward
             n_fwd = (a.warmup + a.steps) * (1 if (a.cfg_parallel or pair_batched) else fwd_per_step)
             rccl = {"backend": dist.get_backend(), "world": dist.get_world_size(), "ulysses_group": model._sp.world,
+                    "communicator": "library-owned (ce_comm_*: grouped ncclSend / ncclRecv on the step's streams)" if getattr(model._sp, "comm", None) is not None
+                                    else "torch.distributed process group",
                     "cfg_parallel_groups": 2 if a.cfg_parallel else 1,
                     "all_to_all_per_layer_per_forward": st["all_to_all_calls"] / max(1, n_fwd * a.layers),
                     "bytes_sent_off_rank_per_layer_per_forward": st["all_to_all_bytes_sent_off_rank"] // max(1, n_fwd * a.layers),

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
 HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
 
-SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_gemm256w4.hip", "ce_gemm384.hip", "ce_attn.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip", "ce_gemm_fp8w4.hip"]
+SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_gemm256w4.hip", "ce_gemm384.hip", "ce_attn.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip", "ce_gemm_fp8w4.hip", "ce_comm.hip"]
 
 _c = ctypes
 _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float
@@ -41,6 +41,12 @@ SIGNATURES: Dict[str, List] = {
     "ce_set_gemm_variant": [_I],
     "ce_set_gemm_workspace": [_P, ctypes.c_size_t],
     "ce_set_gemm_workspace_stream": [_P, _P, ctypes.c_size_t],
+    "ce_comm_load": [ctypes.c_char_p],
+    "ce_comm_unique_id": [_P],
+    "ce_comm_init": [ctypes.POINTER(ctypes.c_void_p), _P, _I, _I],
+    "ce_comm_destroy": [_P],
+    "ce_comm_all_to_all": [_P, _P, _P, ctypes.c_size_t, _P],
+    "ce_comm_all_gather": [_P, _P, _P, ctypes.c_size_t, _P],
     "ce_ln_affine_fp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "ce_quant_rows_fp8": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ce_gemm_fp8": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -92,7 +98,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, *srcs, "-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, *srcs, "-ldl", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

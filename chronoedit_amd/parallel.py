@@ -45,14 +45,90 @@ class _Done:
         return True
 
 
+class _StreamJoin:
+    """work.wait() of an exchange issued on the communicator's side stream: orders the CURRENT stream behind it (an event wait - legal
+    under hipGraph capture, where it becomes the join edge of the fork the exchange was issued on)."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+        return True
+
+
+class OwnedComm:
+    """A RCCL communicator owned by libchronoedit_hip (csrc/ce_comm.hip, `ce_comm_*`) next to torch.distributed's own: the exchanges are
+    plain C-ABI calls on a stream - no `Work` objects, no process-group watchdog polling them - so a sharded denoising step can be captured
+    into a hipGraph (with torch's "nccl" backend the second capture kills the process: profiles/r03_rccl_graph_probe.txt).  SURVEY.md
+    section 8b: "one ncclComm_t per process passed in".  The unique id travels over the existing process group (any backend); RCCL itself
+    is the librccl.so torch ships, dlopen()ed by the library (one copy per process)."""
+
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None):
+        import ctypes
+        import os
+
+        from . import hiplib
+        self.lib = hiplib.load()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if not os.path.exists(path):
+            path = "librccl.so"  # the system copy (dlopen search path)
+        if self.lib.ce_comm_load(path.encode()) != 0:
+            raise RuntimeError(f"ce_comm_load({path}) failed")
+        ident = [None]
+        if self.rank == 0:
+            buf = (ctypes.c_ubyte * 128)()
+            if self.lib.ce_comm_unique_id(buf) != 0:
+                raise RuntimeError("ce_comm_unique_id failed")
+            ident = [bytes(buf)]
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(ident, src=src, group=group)
+        handle = ctypes.c_void_p()
+        idb = (ctypes.c_ubyte * 128).from_buffer_copy(ident[0])
+        with torch.cuda.device(self.device):
+            if self.lib.ce_comm_init(ctypes.byref(handle), idb, self.rank, self.world) != 0:
+                raise RuntimeError("ce_comm_init (ncclCommInitRank) failed")
+        self.handle = handle
+        self.side = torch.cuda.Stream(device=self.device)  # the stream asynchronous exchanges run on (created outside any capture)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed with code {rc} (RCCL's message is on stderr)")
+
+    def all_to_all(self, send: torch.Tensor, recv: torch.Tensor, async_op: bool):
+        nbytes = send.numel() * send.element_size() // self.world
+        if not async_op:
+            self._check(self.lib.ce_comm_all_to_all(self.handle, send.data_ptr(), recv.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
+                        "ce_comm_all_to_all")
+            return _Done()
+        self.side.wait_stream(torch.cuda.current_stream())  # fork: the exchange starts when the producer kernels of `send` are done
+        self._check(self.lib.ce_comm_all_to_all(self.handle, send.data_ptr(), recv.data_ptr(), nbytes, self.side.cuda_stream), "ce_comm_all_to_all")
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return _StreamJoin(ev)
+
+    def all_gather(self, x_local: torch.Tensor, out: torch.Tensor):
+        self._check(self.lib.ce_comm_all_gather(self.handle, x_local.data_ptr(), out.data_ptr(), x_local.numel() * x_local.element_size(),
+                                                torch.cuda.current_stream().cuda_stream), "ce_comm_all_gather")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ce_comm_destroy(self.handle)
+            self.handle = None
+
+
 class Ulysses:
     @property
     def sharded(self) -> bool:
         return self.world > 1 or self.force
 
-    def __init__(self, group: Optional[dist.ProcessGroup] = None, force: bool = False):
+    def __init__(self, group: Optional[dist.ProcessGroup] = None, force: bool = False, owned_comm: bool = False):
         """force: take the sharded code path even in a group of ONE rank (every exchange then runs as a real collective of the
-        backend on a single rank) - how the RCCL call sequence is exercised on a one-GPU box (tests/test_ulysses.py)."""
+        backend on a single rank) - how the RCCL call sequence is exercised on a one-GPU box (tests/test_ulysses.py).
+        owned_comm: run the exchanges on a RCCL communicator owned by libchronoedit_hip (`OwnedComm`) instead of torch.distributed's -
+        what makes the sharded step capturable into a hipGraph (`capturable`)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed must be initialised before enabling Ulysses sequence parallelism")
         self.group = group
@@ -62,6 +138,12 @@ class Ulysses:
         self.backend = dist.get_backend(group)
         self._host_staged = self.backend == "gloo"
         self.stats = {"all_to_all_calls": 0, "all_to_all_bytes_sent_off_rank": 0, "all_gather_calls": 0}
+        self.comm = OwnedComm(group) if owned_comm else None
+
+    @property
+    def capturable(self) -> bool:
+        """Can a step with this group's exchanges be captured into a hipGraph?  Only on the library-owned communicator."""
+        return self.comm is not None
 
     # -- token sharding ----------------------------------------------------------------
     def shard(self, n_tokens: int, align: int = 1) -> Tuple[int, int, int]:
@@ -96,6 +178,8 @@ class Ulysses:
         if self.world == 1 and not self.force:
             recv.copy_(send)
             return recv, _Done()
+        if self.comm is not None and send.is_cuda:
+            return recv, self.comm.all_to_all(send, recv, async_op)
         if self._host_staged and send.is_cuda:
             sc = send.cpu()
             rc = torch.empty_like(sc)
@@ -111,6 +195,10 @@ class Ulysses:
         if self.world == 1 and not self.force:
             return x_local
         x_local = x_local.contiguous()
+        if self.comm is not None and x_local.is_cuda:
+            out = torch.empty((self.world * x_local.shape[0],) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+            self.comm.all_gather(x_local, out)
+            return out
         if self._host_staged and x_local.is_cuda:
             xc = x_local.cpu()
             out = torch.empty((self.world * xc.shape[0],) + tuple(xc.shape[1:]), dtype=xc.dtype)

@@ -51,6 +51,17 @@ def _token_sharded(transformer) -> bool:
     return sp is not None and sp.sharded
 
 
+def _capturable(transformer) -> bool:
+    """Can a step of this transformer be captured into a hipGraph?  Unsharded: yes.  Token-sharded: only when the exchanges run on the
+    library-owned RCCL communicator (`enable_sequence_parallel(owned_comm=True)`, parallel.OwnedComm); CFG parallelism (its pairwise
+    exchange is a torch.distributed collective) runs eagerly."""
+    if getattr(transformer, "_cfgp", None) is not None:
+        return False
+    if not _token_sharded(transformer):
+        return True
+    return bool(getattr(transformer._sp, "capturable", False))
+
+
 def _sharded_batchable(transformer) -> bool:
     """Can a token-sharded (Ulysses) forward take the guidance pair as ONE batch of two?  Yes on the V^T attention path (the
     blocked-layout kernels, chronoedit_amd/parallel.py) - with bf16 or fp8 GEMMs; the sharded self-attention itself is always the
@@ -105,14 +116,16 @@ class GraphedDenoiser:
         edit; only the step-invariant context projections are computed eagerly in front of the capture so that the graph holds the
         cache HIT (`cache_context`), not the projections."""
         assert latents.dtype == torch.float32 and latents.is_contiguous()
-        if _token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None:
+        if not _capturable(transformer):
             # Measured on this stack (ROCm 7.0 / RCCL 2.26 / torch 2.10: tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt): ONE
             # collective of torch.distributed's "nccl" backend can be captured and replayed, but the process-group watchdog thread keeps
             # polling the event of every Work created under capture - the next capture (or any later poll) kills the process
             # (hipErrorStreamCaptureUnsupported in "global" capture mode, a segmentation fault in "thread_local" / "relaxed"), with
             # synchronous collectives, async_op=True and side-stream fork / join alike.  A sharded loop needs two graphs (8 -> 2 frames), so it
-            # runs eagerly; DESIGN.md section 6 has the measurement of why that costs nothing at the per-rank kernel times of 4 / 8 GPUs.
-            raise NotImplementedError("hipGraph capture of a step with RCCL exchanges is not usable on this torch / RCCL build: the sharded loop runs eagerly")
+            # runs eagerly on torch's communicator; DESIGN.md section 6 has the measurement of why that costs nothing at the per-rank kernel
+            # times of 4 / 8 GPUs.  The way to capture it: the library-owned communicator (`enable_sequence_parallel(owned_comm=True)`).
+            raise NotImplementedError("hipGraph capture of a step with torch.distributed exchanges is not usable on this torch / RCCL build: "
+                                      "enable_sequence_parallel(owned_comm=True) or run the sharded loop eagerly")
         self.tr, self.sch, self.latents, self.condition = transformer, scheduler, latents, condition
         self.prompt, self.negative, self.image, self.g, self.batch_cfg = prompt_embeds, negative_prompt_embeds, image_embeds, guidance_scale, batch_cfg
         dev = latents.device
@@ -202,8 +215,8 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
     if hasattr(transformer, "clear_context_cache"):
         transformer.clear_context_cache()  # a new edit: nothing of the previous edit's conditioning may be reused
     graphed = None
-    if use_graph and (_token_sharded(transformer) or getattr(transformer, "_cfgp", None) is not None):
-        use_graph = False  # a step with RCCL exchanges runs eagerly (GraphedDenoiser says why); the pipeline default stays use_graph=True
+    if use_graph and not _capturable(transformer):
+        use_graph = False  # a step with torch.distributed exchanges runs eagerly (GraphedDenoiser says why); the pipeline default stays use_graph=True
     for i, t in enumerate(scheduler.timesteps):
         if interrupted is not None and interrupted():
             continue
@@ -229,7 +242,7 @@ def denoise(transformer, scheduler, latents, condition, prompt_embeds, negative_
                     # before the capture - _ensure_state, the staged timestep / coefficient row - so a fresh scheduler per edit stays warm)
                     return (tuple(latents.shape), guidance_scale > 1.0 and negative_prompt_embeds is not None, gen)
                 graphed = GraphedDenoiser(transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds,
-                                          image_embeds, guidance_scale, warm=graph_warm is not None and warm_key() in graph_warm)
+                                          image_embeds, guidance_scale, batch_cfg=not sharded, warm=graph_warm is not None and warm_key() in graph_warm)
                 if graph_warm is not None:
                     graph_warm.add(warm_key())  # (taken AFTER the construction: the first step of a process creates the engine)
             latents = graphed.step(i)

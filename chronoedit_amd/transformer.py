@@ -254,11 +254,12 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.invalidate()
         return self
 
-    def enable_sequence_parallel(self, group=None, force: bool = False):
+    def enable_sequence_parallel(self, group=None, force: bool = False, owned_comm: bool = False):
         """Shard the token axis over the ranks of `group` (Ulysses: three all-to-all per self-attention).  Every rank
-        must call forward with the same (replicated) inputs and receives the full output.  force: see parallel.Ulysses."""
+        must call forward with the same (replicated) inputs and receives the full output.  force, owned_comm: see parallel.Ulysses
+        (owned_comm = the exchanges on a RCCL communicator owned by libchronoedit_hip: the sharded step becomes hipGraph-capturable)."""
         from .parallel import Ulysses
-        self._sp = Ulysses(group, force=force)
+        self._sp = Ulysses(group, force=force, owned_comm=owned_comm)
         if self.config.num_attention_heads % self._sp.world:
             raise ValueError(f"{self.config.num_attention_heads} heads do not divide over {self._sp.world} ranks")
         if self._engine is not None:

@@ -358,6 +358,24 @@ int ce_rmsnorm_bf16(const void* x, void* y, const void* w, int M, int D, int ldx
 int ce_softmax_t5_bf16(const float* scores, void* probs, int batch, int heads, int Lq, int Lk, int ld, int ldp,
                        const int* bucket_lut, const float* table, const int* valid_len, hipStream_t stream);
 
+/* ---- a RCCL communicator owned by the library (csrc/ce_comm.hip): the exchanges of the sequence-parallel forward as C-ABI calls on the
+ * caller's stream.  Replaces the torch.distributed collectives of the reference's sequence-parallel path (xfuser's Ulysses all-to-all behind
+ * chronoedit_diffsynth/wan_video_new_chronoedit.py:330-355, the final all_gather :1495-1498) where the caller needs a step with
+ * exchanges under hipGraph capture: these calls create no Work objects and nothing polls them.  RCCL is not linked - ce_comm_load()
+ * dlopen()s the librccl.so the process already uses (the one torch ships).  All return CE_OK or CE_ERR_ARG (the RCCL error text goes to
+ * stderr). */
+int ce_comm_load(const char* librccl_path);
+/* 128 bytes: ncclGetUniqueId, called by ONE rank; the caller distributes the bytes to the other ranks (any transport). */
+int ce_comm_unique_id(void* id128);
+/* ncclCommInitRank on the CURRENT device - collective over the `world` ranks that share id128; *comm_out is the handle of the other calls. */
+int ce_comm_init(void** comm_out, const void* id128, int rank, int world);
+int ce_comm_destroy(void* comm);
+/* send / recv: `world` chunks of bytes_per_peer bytes, chunk p to / from rank p (all_to_all_single with equal splits), as one grouped
+ * batch of ncclSend / ncclRecv on `stream`.  Buffers must stay valid until the stream has passed the call. */
+int ce_comm_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream);
+/* recv = every rank's bytes_per_rank-byte block, in rank order (ncclAllGather on `stream`). */
+int ce_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -464,6 +464,55 @@ def _rccl_eager_default_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _owned_comm_graph_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from chronoedit_amd.pipeline import GraphedDenoiser, denoise
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    m, cfg, O = _tiny_model()
+    g = torch.Generator().manual_seed(11)
+    lat0 = torch.randn(1, 16, 8, 8, 12, generator=g).cuda()
+    cond = torch.randn(1, 20, 8, 8, 12, generator=g).cuda().to(BF)
+    pr, ng = torch.randn(1, 40, 128, generator=g).cuda().to(BF), torch.randn(1, 40, 128, generator=g).cuda().to(BF)
+    img = torch.randn(1, 257, 64, generator=g).cuda().to(BF)
+    kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)
+    ref = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=False, **kw).clone()  # un-sharded, eager
+    m.enable_sequence_parallel(force=True, owned_comm=True)  # every exchange a ce_comm_* call on the library's own RCCL communicator
+    eager = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=False, **kw).clone()
+    calls_eager = m._sp.stats["all_to_all_calls"]
+    # two captures in one process (8 latent frames, then 2 after the truncation) and 2 + 2 replays - the sequence that kills the process
+    # with torch.distributed's communicator (profiles/r03_rccl_graph_probe.txt)
+    graphed = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=True, **kw).clone()
+    again = denoise(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0.clone(), cond, pr, ng, img, 4, 5.0, use_graph=True, **kw).clone()  # a second edit: new captures
+    torch.cuda.synchronize()
+    accepted = True
+    try:
+        GraphedDenoiser(m, FlowUniPCMultistepScheduler(flow_shift=5.0), lat0[:, :, :2].clone().contiguous(), cond[:, :, :2].contiguous(), pr, ng, img, 5.0)
+    except NotImplementedError:
+        accepted = False
+    torch.cuda.synchronize()
+    q.put((rank, accepted, bool(torch.equal(graphed, eager)), bool(torch.equal(again, eager)), float((eager - ref).norm() / ref.norm()),
+           calls_eager, bool(torch.isfinite(graphed).all())))
+    m._sp.comm.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_loop_is_captured_on_the_library_owned_communicator():
+    """north_star: the temporal-reasoning loops hipGraph-captured AND sharded.  With `enable_sequence_parallel(owned_comm=True)` the
+    exchanges are ce_comm_* calls (csrc/ce_comm.hip: grouped ncclSend / ncclRecv of the librccl.so torch ships, on the capturing stream,
+    the k|v exchange forked onto the communicator's side stream and joined by an event) - no Work objects, no watchdog.  One rank over
+    RCCL, the most a one-GPU box allows: the sharded 4-step temporal-reasoning loop as TWO captured graphs (8 -> 2 latent frames),
+    replayed, equals the eager sharded loop bit for bit, twice in one process; GraphedDenoiser accepts the sharded step."""
+    (rank, accepted, same, same_again, err, calls, finite), = _spawn(_owned_comm_graph_worker, 1, timeout=300)
+    assert accepted and finite, (accepted, finite)
+    assert same and same_again, (same, same_again)
+    assert err < 5e-3, err   # sharded vs un-sharded (different GEMM M splits)
+    assert calls == 4 * 2 * 3  # eager loop: 4 steps x ONE batched pass x 2 layers x 3 exchanges
+
+
 @pytest.mark.gpu
 def test_sharded_loop_runs_eagerly_under_the_graph_default():
     """`use_graph=True` is the pipeline default; a step that holds RCCL exchanges cannot be captured on this torch / RCCL build
