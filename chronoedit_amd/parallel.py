@@ -99,7 +99,11 @@ class OwnedComm:
 
     def all_to_all(self, send: torch.Tensor, recv: torch.Tensor, async_op: bool):
         nbytes = send.numel() * send.element_size() // self.world
-        if not async_op:
+        # Under hipGraph capture every exchange goes on the CAPTURING stream: a grouped ncclSend / ncclRecv issued on a stream that joined
+        # the capture through an event (fork / join) takes the process down inside RCCL 2.26 (tools/owned_comm_probe.py, stage 7), while
+        # any number of captures and replays with the exchanges on the capturing stream itself work.  The k|v-exchange / q-projection
+        # overlap is an eager-mode nicety (it hides ~5 % of a layer at 8 GPUs: DESIGN.md section 6).
+        if not async_op or torch.cuda.is_current_stream_capturing():
             self._check(self.lib.ce_comm_all_to_all(self.handle, send.data_ptr(), recv.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
                         "ce_comm_all_to_all")
             return _Done()
@@ -114,9 +118,9 @@ class OwnedComm:
                                                 torch.cuda.current_stream().cuda_stream), "ce_comm_all_gather")
 
     def close(self):
-        if getattr(self, "handle", None):
-            self.lib.ce_comm_destroy(self.handle)
-            self.handle = None
+        """Forget the communicator.  ncclCommDestroy is NOT called: on this stack (RCCL 2.26.6 beside torch's own process group) it blocks
+        for good on a one-rank communicator (tools/owned_comm_probe.py); the handle lives until the process exits, like torch's own."""
+        self.handle = None
 
 
 class Ulysses:
