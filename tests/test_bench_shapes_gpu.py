@@ -81,6 +81,53 @@ def test_attention_at_28800_keys_blocked_layout_at_the_8_gpu_rank_shape():
             assert e < 1e-2, (b, rows, e)
 
 
+def test_attention_at_the_literal_121_frame_stress_shape():
+    """BASELINE.json's "121-frame reasoning mode" read literally (optional stress shape - NOT reference
+    behaviour): 121 pixel frames -> 31 latent frames at 720p = 111 600 tokens, 1 744 key tiles of online softmax per query row.  Two
+    heads, every 12th 2 400-row slab against fp32 softmax on the device; the V^T operand's 32-bit DMA offsets (111 600 keys x 256 B rows)
+    and the work order at 436 query blocks per head."""
+    from chronoedit_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(47)
+    N, H = 111600, 2
+    D = H * 128
+    qkv = torch.randn(N, 3 * D, generator=g).to(BF).to(dev)
+    qkv[:, 2 * D:].add_((torch.arange(N, device=dev) % 7).to(BF)[:, None] * 0.25)
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    out = ops.attention_vt(q, k, ops.v_transpose(v, H), H)
+    assert torch.isfinite(out.float()).all()
+    worst = 0.0
+    for r0 in list(range(0, N - 2400, 12 * 2400)) + [N - 2400]:  # (scores in fp32: 2400 x 111600 x 2 heads = 2.1 GB per slab)
+        rows = slice(r0, r0 + 2400)
+        worst = max(worst, rel_l2(out[rows], _sdpa_rows(q, k, v, H, rows)))
+    print(f"attention 111600 x 111600 (31 latent frames at 720p): worst sampled slab rel-L2 vs fp32 {worst:.3e}")
+    assert worst < 1e-2
+
+
+def test_full_width_block_at_the_121_frame_stress_shape():
+    """One block of the 14B width at [1, 36, 31, 90, 160] with rope_temporal_skip_len = 31 (the constructor parameter the stress reading
+    needs: transformer_chronoedit.py:205-209 asserts num_frames in {2, skip_len}): N = 111 600 token rows through every kernel of the
+    step - 436-tile GEMM M axes, 1 744 key tiles per attention row, ~10 GB of workspaces.  No CPU oracle finishes this size (attention
+    couples all frames, so no crop is comparable): the statement here is finite + deterministic, the temporal RoPE table at 31 plain
+    positions against the fp64 oracle table, and the per-kernel parity at this key count by the attention test above and the GEMM tests."""
+    cfg = O.DiTConfig(num_layers=1, rope_temporal_skip_len=31)
+    p_bf = O.make_synthetic_params(cfg, seed=7, dtype=BF)
+    lat, text, image = O.make_synthetic_inputs(cfg, 31, 90, 160, dtype=BF)
+    model = _build(cfg, p_bf)
+    ts = torch.tensor([800], device="cuda:0")
+    args = (lat.cuda(), ts, text.cuda(), image.cuda())
+    out = model(*args, return_dict=False)[0]
+    again = model(*args, return_dict=False)[0]
+    assert out.shape == (1, 16, 31, 90, 160) and torch.isfinite(out.float()).all()
+    assert torch.equal(out, again)
+    # the temporal RoPE table at 31 frames against the fp64 oracle table
+    from chronoedit_amd.transformer import rope_cos_sin
+    cs = rope_cos_sin(128, cfg.rope_max_seq_len, 31, 31, 45, 80)
+    ref = O.rope_table(cfg, 31, 90, 160)  # complex128 [1, 1, N, 64]
+    ang = torch.view_as_real(ref.reshape(-1, 64))
+    assert torch.allclose(cs[..., 0].double(), ang[..., 0], atol=1e-6) and torch.allclose(cs[..., 1].double(), ang[..., 1], atol=1e-6)
+
+
 def _build(cfg, params):
     from chronoedit_amd.transformer import ChronoEditTransformer3DModel
     m = ChronoEditTransformer3DModel(
