@@ -95,6 +95,8 @@ def parse():
                     help="BASELINE.json configs[4] arithmetic: the six large Linears of every block in fp8 e4m3 (MX matrix instruction); "
                          "reported with dtype fp8, never the headline bf16 number")
     ap.add_argument("--fp8-gemms-only", action="store_true", help="with --fp8: keep the self-attention in bf16 (round-1 fp8 mode)")
+    ap.add_argument("--fp8-row-scales", action="store_true",
+                    help="with --fp8: the round-1..3 GEMM contract (one fp32 scale per token row / output channel) instead of OCP-MX block scales")
     ap.add_argument("--attn-kernel", type=int, default=0,
                     help="(tuning) self-attention kernel knob of ce_set_attention_waves: 0 auto, 8 plain, 64 sw-pipelined")
     return ap.parse_args()
@@ -329,7 +331,7 @@ def main():
     if a.no_transposed_v:
         model.enable_transposed_v(False)
     if a.fp8:
-        model.enable_fp8_gemms()
+        model.enable_fp8_gemms(mx=not a.fp8_row_scales)
         if not a.fp8_gemms_only:
             model.enable_fp8_attention()
     mode = a.parallel
@@ -618,8 +620,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "strong" if ulysses else "weak", "vs_baseline": None,
             # from the path actually taken (transformer.attention_path()): under sequence parallelism the self-attention is the bf16 kernel
-            "dtype": ("fp8 e4m3 GEMMs (fp32 accumulate), bf16 attention / norms / residual" if model.attention_path() == "bf16" else
-                      "fp8: e4m3 GEMMs + MXFP8 self-attention on the MX matrix instruction (fp32 accumulate); bf16 cross-attention / norms / residual")
+            "dtype": (("fp8 e4m3 GEMMs (" + ("per-row scales" if a.fp8_row_scales else "OCP-MX block scales, applied in the matrix pipe") + "; fp32 accumulate), bf16 attention / norms / residual"
+                       if model.attention_path() == "bf16" else
+                       "fp8: e4m3 GEMMs (" + ("per-row scales" if a.fp8_row_scales else "OCP-MX block scales") + ") + MXFP8 self-attention on the MX matrix instruction "
+                       "(fp32 accumulate); bf16 cross-attention / norms / residual"))
                      if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": f"ChronoEdit-14B DiT ({a.layers} blocks), {a.width}x{a.height}, {T} latent frames (N={N} tokens), "
                                    f"guidance {a.guidance} ({fwd_per_step} forwards/step) + CFG + flow-UniPC update; "

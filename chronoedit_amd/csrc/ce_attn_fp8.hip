@@ -33,13 +33,7 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 constexpr int HD = 128, QW = 32, KVB = 64;
 constexpr int ROW_MAXC = 10;
 
-// E8M0 scale byte and its inverse (as a float) for a block with the given amax: scale = 2^(floor(log2 amax) - 8)
-__device__ __forceinline__ int mx_scale_byte(float amax) {
-  const int ef = (int)(__float_as_uint(amax) >> 23);  // biased exponent (amax >= 0)
-  return max(ef - 8, 1);
-}
-__device__ __forceinline__ float mx_inv_scale(int byte) { return __uint_as_float((uint32_t)(254 - byte) << 23); }
-__device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
+// (mx_scale_byte / mx_inv_scale / clamp448: ce_common.h)
 
 // ------------------------------------------------------------------------------------------------
 // RMSNorm(across heads) [+ RoPE] -> MXFP8 (same rounding points as rmsnorm_rope_kernel up to the bf16 value, then quantised)

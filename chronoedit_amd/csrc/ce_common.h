@@ -89,3 +89,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + local;
 }
+
+// ---- OCP MXFP8 helpers (e4m3 elements, one E8M0 scale per 32 elements): shared by the attention producers (ce_attn_fp8.hip) and the
+// GEMM operand quantisers (ce_gemm_fp8.hip, ce_rowops.hip).  E8M0 scale byte and its inverse (as a float) for a block with the given
+// amax: scale = 2^(floor(log2 amax) - 8) (byte 1 = 2^-126 for an all-zero block); elements are clamped to +-448 before the conversion
+// (v_cvt_pk_fp8_f32 does not saturate: above 464 it returns NaN, tools/probes/fp8_cvt_probe.hip).
+__device__ __forceinline__ int mx_scale_byte(float amax) {
+  const int ef = (int)(__float_as_uint(amax) >> 23);  // biased exponent (amax >= 0)
+  return max(ef - 8, 1);
+}
+__device__ __forceinline__ float mx_inv_scale(int byte) { return __uint_as_float((uint32_t)(254 - byte) << 23); }
+__device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fmed3f(x, -448.0f, 448.0f); }
+// Byte offset of the scale of elements [32 blk, 32 blk + 32) of row `row` in the TILED scale layout of the MX GEMM operands
+// ([ceil(rows / 128)][K / 128][4][16][8]; ce_gemm_fp8w4.hip reads 8 consecutive bytes - the 8 row fragments of a wave tile - per lane)
+__device__ __forceinline__ size_t mx_gemm_scale_offset(int row, int blk, int ktiles) {
+  return ((size_t)(row >> 7) * ktiles + (blk >> 2)) * 512 + (blk & 3) * 128 + (row & 15) * 8 + ((row >> 4) & 7);
+}

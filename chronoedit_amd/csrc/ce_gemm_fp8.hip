@@ -296,7 +296,61 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restr
   }
 }
 
+// MX form: one wave per row, every 32 consecutive elements (= 4 lanes x 8) get their own E8M0 scale: no row-wide amax, one pass.
+// Scales go to the TILED layout the MX GEMM reads (mx_gemm_scale_offset, ce_common.h).
+__global__ __launch_bounds__(256) void quant_rows_mxfp8_kernel(const bf16* __restrict__ x, unsigned char* __restrict__ q,
+                                                               unsigned char* __restrict__ sc, int M, int K, int ldx, int ldq) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = K >> 3, ktiles = K >> 7;
+  const bf16* xr = x + (size_t)row * ldx;
+  unsigned char* qr = q + (size_t)row * ldq;
+  for (int c0 = 0; c0 < nch; c0 += 256) {  // four chunks per lane in flight
+    u32x4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + lane + 64 * i;
+      raw[i] = c < nch ? *reinterpret_cast<const u32x4*>(xr + c * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + lane + 64 * i;
+      float amax = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(raw[i][j])), fabsf(bf16hi(raw[i][j]))));
+      amax = fmaxf(amax, __shfl_xor(amax, 1, 64));  // a block = chunks 4a .. 4a+3 = lanes 4a' .. 4a'+3 (K % 32 == 0: whole blocks only)
+      amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+      if (c < nch) {
+        const int byte = mx_scale_byte(amax);
+        const float inv = mx_inv_scale(byte);
+        const u32x4 v = raw[i];
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[0]) * inv), clamp448(bf16hi(v[0]) * inv), w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[1]) * inv), clamp448(bf16hi(v[1]) * inv), w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[2]) * inv), clamp448(bf16hi(v[2]) * inv), w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[3]) * inv), clamp448(bf16hi(v[3]) * inv), w1, true);
+        const u32x2 o = {(uint32_t)w0, (uint32_t)w1};
+        *reinterpret_cast<u32x2*>(qr + c * 8) = o;
+        if ((lane & 3) == 0) sc[mx_gemm_scale_offset(row, c >> 2, ktiles)] = (unsigned char)byte;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+/* x bf16 [M][ldx] -> q e4m3 bytes [M][ldq] + E8M0 block scales (one per 32 consecutive elements of a row, scale = 2^(floor(log2 amax) - 8),
+ * elements RNE(x / scale) clamped to +-448: the OCP MX contract of oracle.dit_oracle.mx_quant) in the tiled layout of ce_gemm_mxfp8:
+ * scale8 holds ceil(M / 128) * (K / 128) * 512 bytes.  K % 128 == 0. */
+extern "C" int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream) {
+  if (!x || !q || !scale8) return CE_ERR_ARG;
+  if (M <= 0 || K <= 0 || (K & 127)) return CE_ERR_SHAPE;
+  if ((ldx & 7) || (ldq & 7)) return CE_ERR_ALIGN;
+  hipLaunchKernelGGL(quant_rows_mxfp8_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (unsigned char*)q, (unsigned char*)scale8, M, K,
+                     ldx, ldq);
+  return (int)hipGetLastError();
+}
 
 extern "C" int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, int K, int ldx, int ldq, hipStream_t stream) {
   if (!x || !q || !scale) return CE_ERR_ARG;

@@ -16,6 +16,20 @@
 //        groups 5..7: the 16 LDS-DMA pieces of tile t+2 -> stage t & 1; the W fragments of tile t+1 -> the other W set; the ring
 //                     wraps into tile t+1 (A fragments 0..2)
 //    so a piece has five groups (>= 1280 matrix-pipe cycles) plus the wait in front of the barrier to land.
+//
+// MX form (round 4; template flag MX, entry ce_gemm_mxfp8): both operands carry OCP-MX block scales - one E8M0 byte per 32 consecutive K
+// elements of a row - and the SCALED form of the same instruction applies them inside the matrix pipe:
+//     C[m][n] = epilogue( sum_blocks 2^(ea[m][blk] + ew[n][blk]) * sum_{k in blk} Aq[m][k] * Wq[n][k] + bias[n] )
+// Operand geometry of v_mfma_scale_f32_16x16x128_f8f6f4 (tools/probes/mx16_probe.hip, profiles/r04_mx16_probe.txt): lane (r, g) feeds
+// row r with 32 bytes - bytes 0-15 are k = 16 g .. 16 g + 15 and bytes 16-31 are k = 64 + 16 g .. of the 128-deep step (so MX block
+// beta = k / 32 is bytes 0-15 of lanes g = 2 beta, 2 beta + 1 for beta < 2 and bytes 16-31 of lanes g = 2 (beta - 2), + 1 otherwise) -
+// and the scale byte of block beta is taken from lane (r, beta), byte op_sel + 2 op_sel_hi of its scale register.  So a lane fetches
+// the 16-byte chunks g and 4 + g of its row's 128 bytes (the unscaled form reads 2 g and 2 g + 1: any packing common to both operands
+// gives the same product) and passes the scale of block g.  Scales live in memory in the order this loop reads them,
+// [row / 128][K / 128][g = 4][row % 16][(row / 16) % 8] bytes: the eight row fragments of a wave tile are 8 consecutive bytes, so ONE
+// 8-byte load per lane, operand and K-tile (512 contiguous bytes per wave) brings all its scales, and op_sel picks fragment F & 3 out of
+// register F >> 2 - 0.8 % of the operand bytes, fetched one K-tile ahead into 8 registers.  (A first form - [row][4][K / 128], one dword
+// per fragment covering four K-tiles - needed 32 registers and spilled.)
 #include <algorithm>
 
 #include "ce_common.h"
@@ -34,12 +48,39 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #define X8_PIN() __builtin_amdgcn_sched_barrier(0)
 #define X8_BAR() __builtin_amdgcn_s_barrier()
 
-template <int EPI>
+// acc (C^T fragment, accumulator file) += W fragment x A fragment; the W fragment's scale is byte SW of sw_, the A fragment's byte SA of sa_
+// (byte index = op_sel + 2 op_sel_hi; first operand slot = W)
+#define CE_MX_ASM(OS, OH) \
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:" OS " op_sel_hi:" OH : "+a"(acc) : "v"(w), "v"(a), "v"(sw_), "v"(sa_))
+template <int SW, int SA>
+__device__ __forceinline__ void mma_mx(f32x4& acc, const i32x8& w, const i32x8& a, uint32_t sw_, uint32_t sa_) {
+  constexpr int lo = (SW & 1) | ((SA & 1) << 1), hi = (SW >> 1) | ((SA >> 1) << 1);
+  if constexpr (lo == 0 && hi == 0) CE_MX_ASM("[0,0,0]", "[0,0,0]");
+  else if constexpr (lo == 1 && hi == 0) CE_MX_ASM("[1,0,0]", "[0,0,0]");
+  else if constexpr (lo == 2 && hi == 0) CE_MX_ASM("[0,1,0]", "[0,0,0]");
+  else if constexpr (lo == 3 && hi == 0) CE_MX_ASM("[1,1,0]", "[0,0,0]");
+  else if constexpr (lo == 0 && hi == 1) CE_MX_ASM("[0,0,0]", "[1,0,0]");
+  else if constexpr (lo == 1 && hi == 1) CE_MX_ASM("[1,0,0]", "[1,0,0]");
+  else if constexpr (lo == 2 && hi == 1) CE_MX_ASM("[0,1,0]", "[1,0,0]");
+  else if constexpr (lo == 3 && hi == 1) CE_MX_ASM("[1,1,0]", "[1,0,0]");
+  else if constexpr (lo == 0 && hi == 2) CE_MX_ASM("[0,0,0]", "[0,1,0]");
+  else if constexpr (lo == 1 && hi == 2) CE_MX_ASM("[1,0,0]", "[0,1,0]");
+  else if constexpr (lo == 2 && hi == 2) CE_MX_ASM("[0,1,0]", "[0,1,0]");
+  else if constexpr (lo == 3 && hi == 2) CE_MX_ASM("[1,1,0]", "[0,1,0]");
+  else if constexpr (lo == 0 && hi == 3) CE_MX_ASM("[0,0,0]", "[1,1,0]");
+  else if constexpr (lo == 1 && hi == 3) CE_MX_ASM("[1,0,0]", "[1,1,0]");
+  else if constexpr (lo == 2 && hi == 3) CE_MX_ASM("[0,1,0]", "[1,1,0]");
+  else CE_MX_ASM("[1,1,0]", "[1,1,0]");
+}
+#undef CE_MX_ASM
+
+template <int EPI, bool MX = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_fp8_w4(
     const unsigned char* __restrict__ A, const unsigned char* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ sa,
     const float* __restrict__ sw, const float* __restrict__ bias, const float* __restrict__ gate, const bf16* __restrict__ res, int M,
     int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int tiles_m, int tiles_n, int t_full, int split,
     float* __restrict__ ws) {
+  // (MX: sa / sw point at the E8M0 scale bytes [rows][4][K / 128])
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,8 +135,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   int a_rd[2], w_rd[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    a_rd[h] = (wm * 128 + fr) * 128 + (((2 * fg + h) ^ (fr >> 1)) << 4);
-    w_rd[h] = TILE + (wn * 128 + fr) * 128 + (((2 * fg + h) ^ (fr >> 1)) << 4);
+    const int chunk = MX ? fg + 4 * h : 2 * fg + h;  // (MX: the hardware's block geometry, see the header)
+    a_rd[h] = (wm * 128 + fr) * 128 + ((chunk ^ (fr >> 1)) << 4);
+    w_rd[h] = TILE + (wn * 128 + fr) * 128 + ((chunk ^ (fr >> 1)) << 4);
   }
   auto read_frag = [&](int base0, int base1, int stage_bytes, int f) __attribute__((always_inline)) -> i32x8 {
     const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + base0 + stage_bytes + f * 2048);
@@ -109,6 +151,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int g = 0; g < 8; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // MX: this lane's scale bytes of its 8 A and 8 W fragments for ONE K-tile = 8 + 8 bytes (see the header); two sets by tile parity
+  u32x2 sAq[2], sWq[2];
+  const int ktiles = K / BKB;
+  const unsigned char* sa_base = nullptr;
+  const unsigned char* sw_base = nullptr;
+  if (MX) {
+    const int rba = min(m0 / 128 + wm, (M - 1) / 128), rbw = min(n0 / 128 + wn, (N - 1) / 128);  // (row blocks past the end: scales of rows never stored)
+    sa_base = reinterpret_cast<const unsigned char*>(sa) + (size_t)rba * ktiles * 512 + fg * 128 + fr * 8;
+    sw_base = reinterpret_cast<const unsigned char*>(sw) + (size_t)rbw * ktiles * 512 + fg * 128 + fr * 8;
+  }
+  auto load_scales = [&](int t, int par) __attribute__((always_inline)) {
+    const int ta = kt0 + min(t, kt_last);  // (surplus prefetch: re-read the last tile)
+    // asm loads (hipcc does not count them): they are issued at the top of a K-tile, in FRONT of that tile's LDS-DMA pieces, so the
+    // tile's own "vmcnt(0)" in group 5 retires them - and the W4 / X8 waits stay exactly as counted.  As compiler-visible loads hipcc
+    // waited for them at the top of the next tile with vmcnt(2): every DMA piece in flight had to land five groups early.
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sAq[par]) : "v"(sa_base + (size_t)ta * 512));
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sWq[par]) : "v"(sw_base + (size_t)ta * 512));
+  };
+  if (MX) load_scales(0, 0);
+
   // prologue: tiles 0 and 1 on their way, tile 0 landed; its W fragments and its first three A fragments read
   {
     const int k0 = koff(0), k1 = koff(1);
@@ -118,6 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int q = 0; q < 16; ++q) dma(q, STAGE, k1);
   }
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if (MX) asm volatile("" : "+v"(sAq[0]), "+v"(sWq[0]));  // (requested in front of the 32 pieces above)
   X8_BAR();
   i32x8 ring[4], bw0[8], bw1[8];
 #pragma unroll
@@ -128,14 +191,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   X8_PIN();
 
   // W fragment first: the accumulator holds C^T, lane (fr, fg) of acc[F][G] owns row F*16 + fr and the columns G*16 + fg*4 + [0,4)
-#define X8_MMA(F, G, BW) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]))
+#define X8_MMA(F, G, BW)                                                                                                          \
+  do {                                                                                                                            \
+    if (MX) mma_mx<(G) & 3, (F) & 3>(acc[F][G], (BW)[G], ring[(F) % 4], sWq[SEL_][(G) >> 2], sAq[SEL_][(F) >> 2]);                  \
+    else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]));          \
+  } while (0)
   // group G of the tile in stage PAR (its W fragments in BW, the next tile's go to BN); fillers between single MFMAs
-#define X8_GROUP(G, PAR, BW, BN_, KNEXT)                                                                                      \
+#define X8_GROUP(G, PAR, BW, BN_, KNEXT, SEL)                                                                                 \
   {                                                                                                                           \
+    constexpr int SEL_ = (SEL);                            /* scale register set = tile parity (MX) */                        \
     constexpr int fn_ = ((G) + 3) & 7;                     /* the A fragment fetched now ... */                                \
     constexpr int sn_ = ((G) + 3 >= 8) ? (1 - (PAR)) * STAGE : (PAR) * STAGE; /* ... from this tile or the next */             \
     if ((G) == 5) {                                                                                                           \
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+      if (MX) asm volatile("" : "+v"(sAq[1 - SEL_]), "+v"(sWq[1 - SEL_])); /* the next tile's scales have landed too */         \
       X8_BAR();                                                                                                               \
       X8_PIN();                                                                                                               \
     }                                                                                                                         \
@@ -165,17 +234,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     X8_PIN();                                                                                                                 \
   }
   // pieces: group 5 -> 0..5 (six), group 6 -> 6..10 (five), group 7 -> 11..15 (five);  W fragments: group 5 -> 0,1,2, group 6 -> 3,4,5, group 7 -> 6,7
-#define X8_TILE(PAR, T, BW, BN_)                                                                                              \
+#define X8_TILE(PAR, T, BW, BN_, SEL)                                                                                         \
   {                                                                                                                           \
     const int knext = koff((T) + 2);                                                                                          \
-    X8_GROUP(0, PAR, BW, BN_, knext) X8_GROUP(1, PAR, BW, BN_, knext) X8_GROUP(2, PAR, BW, BN_, knext) X8_GROUP(3, PAR, BW, BN_, knext) \
-    X8_GROUP(4, PAR, BW, BN_, knext) X8_GROUP(5, PAR, BW, BN_, knext) X8_GROUP(6, PAR, BW, BN_, knext) X8_GROUP(7, PAR, BW, BN_, knext) \
+    X8_GROUP(0, PAR, BW, BN_, knext, SEL) X8_GROUP(1, PAR, BW, BN_, knext, SEL) X8_GROUP(2, PAR, BW, BN_, knext, SEL)          \
+    X8_GROUP(3, PAR, BW, BN_, knext, SEL) X8_GROUP(4, PAR, BW, BN_, knext, SEL) X8_GROUP(5, PAR, BW, BN_, knext, SEL)          \
+    X8_GROUP(6, PAR, BW, BN_, knext, SEL) X8_GROUP(7, PAR, BW, BN_, knext, SEL)                                                \
   }
-  const int npairs = ktn >> 1;
-  for (int it = 0; it < npairs; ++it) {
-    const int t = 2 * it;
-    X8_TILE(0, t, bw0, bw1)
-    X8_TILE(1, t + 1, bw1, bw0)
+  {
+    const int npairs = ktn >> 1;
+    for (int it = 0; it < npairs; ++it) {
+      const int t = 2 * it;
+      if (MX) load_scales(t + 1, 1);  // (one K-tile ahead: ~1.7 us of matrix work between the request and the first MFMA that reads it)
+      X8_TILE(0, t, bw0, bw1, 0)
+      if (MX) load_scales(t + 2, 0);
+      X8_TILE(1, t + 1, bw1, bw0, 1)
+    }
   }
 #undef X8_TILE
 #undef X8_GROUP
@@ -189,14 +263,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int nc = min(n0 + wn * 128 + g * 16 + fg * 4, N - 4);
-    swv[g] = *reinterpret_cast<const f32x4*>(sw + nc);
+    swv[g] = MX ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(sw + nc);  // (MX: the matrix pipe applied the scales)
     bvv[g] = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + nc) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   if (partial) {  // fp32 slab [wave][f][g][lane], already scaled
     float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
-      const float sav = sa[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
+      const float sav = MX ? 1.0f : sa[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const f32x4 v = acc[f][g];
@@ -243,7 +317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int ff = 0; ff < 2; ++ff) {
       const int f = 2 * p + ff;
-      const float sav = sa[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
+      const float sav = MX ? 1.0f : sa[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
       const int rl = wm * 32 + ff * 16 + fr;
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
@@ -293,9 +367,9 @@ extern "C" int ce_gemm256w4_reduce_launch(int epilogue, void* C, const float* bi
                                           int ldres, int gate_rows, int tiles_m, int tiles_n, int t_full, int split, const float* ws, int tail,
                                           hipStream_t stream);
 
-extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias,
-                                    int epilogue, const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc,
-                                    int ldres, int gate_rows, hipStream_t stream) {
+static int fp8w4_launch(bool mx, const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias,
+                        int epilogue, const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc,
+                        int ldres, int gate_rows, hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n, kt = K / BKB;
   float* g_ws = nullptr;
@@ -327,10 +401,15 @@ extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, con
   do {                                                                                                                        \
     if (!attr_done[E]) {                                                                                                      \
       if (hipFuncSetAttribute((const void*)gemm_fp8_w4<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
+      if (hipFuncSetAttribute((const void*)gemm_fp8_w4<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
       attr_done[E] = true;                                                                                                    \
     }                                                                                                                         \
-    hipLaunchKernelGGL((gemm_fp8_w4<E>), grid, block, lds, stream, (const unsigned char*)Aq, (const unsigned char*)Wq, (bf16*)C, sa, sw, \
-                       bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws); \
+    if (mx)                                                                                                                   \
+      hipLaunchKernelGGL((gemm_fp8_w4<E, true>), grid, block, lds, stream, (const unsigned char*)Aq, (const unsigned char*)Wq, (bf16*)C, sa, sw, \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws); \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((gemm_fp8_w4<E>), grid, block, lds, stream, (const unsigned char*)Aq, (const unsigned char*)Wq, (bf16*)C, sa, sw, \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws); \
   } while (0)
   switch (epilogue) {
     case EPI_BIAS: F8_LAUNCH(EPI_BIAS); break;
@@ -345,4 +424,28 @@ extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, con
     if (rc != CE_OK) return rc;
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias,
+                                    int epilogue, const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc,
+                                    int ldres, int gate_rows, hipStream_t stream) {
+  return fp8w4_launch(false, Aq, Wq, C, sa, sw, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, stream);
+}
+
+/* The MX form (header of this file): Aq [M][lda], Wq [N][ldw] e4m3 bytes; sa8 / sw8 E8M0 bytes in the tiled order
+ * [ceil(rows / 128)][K / 128][4][16][8] (byte of row r, elements [128 t + 32 g, + 32): ((r / 128 * K/128 + t) * 4 + g) * 128 + (r % 16) * 8 +
+ * (r / 16) % 8 = exponent + 127), as ce_quant_rows_mxfp8 / ce_ln_affine_mxfp8 write them. */
+extern "C" int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void* sa8, const void* sw8, const float* bias, int epilogue,
+                             const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                             hipStream_t stream) {
+  if (!Aq || !Wq || !C || !sa8 || !sw8) return CE_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % (2 * BKB)) || (N & 7)) return CE_ERR_SHAPE;
+  if ((lda & 15) || (ldw & 15) || (ldc & 7)) return CE_ERR_ALIGN;
+  if ((long long)M * lda >= (1ll << 32) || (long long)N * ldw >= (1ll << 32)) return CE_ERR_SHAPE;  // 32-bit DMA offsets
+  if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
+  if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_GATE_RES) return CE_ERR_ARG;
+  // (the gated-residual epilogue of this loop holds ONE or TWO samples' gate rows per tile and stores through 32-bit offsets)
+  if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32))) return CE_ERR_SHAPE;
+  return fp8w4_launch(true, Aq, Wq, C, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, epilogue, gate, res, M, N, K,
+                      lda, ldw, ldc, ldres, gate_rows, stream);
 }

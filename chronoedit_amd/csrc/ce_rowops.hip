@@ -23,7 +23,9 @@
 // R rows per wave: the (a, b) rows are fp32 - 40 KB of L2 reads per activation row against 10 KB read + 10 KB written of HBM traffic,
 // which made the L2, not HBM, the limit of the one-row-per-wave form (4.2 TB/s).  A wave that owns R consecutive rows of one
 // sample reads each (a, b) chunk once for all of them.  The launcher picks R so that a wave's rows never straddle two samples.
-template <bool FP8, bool FULL, int R>
+// FP8 == 2: the MX form - every 32 consecutive elements of the row get their own E8M0 scale (ce_quant_rows_mxfp8's contract applied to
+// the bf16 row this kernel would have written); no row-wide amax, so the quantisation runs in the same sweep as the affine.
+template <int FP8, bool FULL, int R>
 __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
                                                         const float* __restrict__ a, const float* __restrict__ b,
                                                         int M, int D, int ldx, int ldy, float eps, int ab_rows, int ab_stride,
@@ -91,14 +93,41 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__
           const float bb0 = j < 2 ? b0[2 * j] : b1[2 * j - 4], bb1 = j < 2 ? b0[2 * j + 1] : b1[2 * j - 3];
           const float n0 = (bf16lo(raw[k][i][j]) - mean[k]) * rstd[k], n1 = (bf16hi(raw[k][i][j]) - mean[k]) * rstd[k];
           o[j] = pack_bf16(n0 * aa0 + bb0, n1 * aa1 + bb1);
-          if (FP8) amax[k] = fmaxf(amax[k], fmaxf(fabsf(bf16lo(o[j])), fabsf(bf16hi(o[j]))));
+          if (FP8 == 1) amax[k] = fmaxf(amax[k], fmaxf(fabsf(bf16lo(o[j])), fabsf(bf16hi(o[j]))));
         }
-        if (FP8) raw[k][i] = o;
-        else if (row0 + k < M) *reinterpret_cast<u32x4*>(y + (size_t)(row0 + k) * ldy + c * 8) = o;
+        if (FP8 == 1) raw[k][i] = o;
+        else if (FP8 == 0 && row0 + k < M) *reinterpret_cast<u32x4*>(y + (size_t)(row0 + k) * ldy + c * 8) = o;
+        if (FP8 == 2) raw[k][i] = o;  // (quantised below, outside the chunk guard: the block amax is a cross-lane exchange)
+      }
+    }
+    if (FP8 == 2) {
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const bool on = (FULL || c < nch) && row0 + k < M;
+        const u32x4 v = raw[k][i];
+        float am = 0.f;
+        if (FULL || c < nch) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) am = fmaxf(am, fmaxf(fabsf(bf16lo(v[j])), fabsf(bf16hi(v[j]))));
+        }
+        am = fmaxf(am, __shfl_xor(am, 1, 64));  // a block = 4 consecutive chunks = 4 consecutive lanes
+        am = fmaxf(am, __shfl_xor(am, 2, 64));
+        if (on) {
+          const int byte = mx_scale_byte(am);
+          const float inv = mx_inv_scale(byte);
+          int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[0]) * inv), clamp448(bf16hi(v[0]) * inv), w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[1]) * inv), clamp448(bf16hi(v[1]) * inv), w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[2]) * inv), clamp448(bf16hi(v[2]) * inv), w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[3]) * inv), clamp448(bf16hi(v[3]) * inv), w1, true);
+          const u32x2 ov = {(uint32_t)w0, (uint32_t)w1};
+          *reinterpret_cast<u32x2*>(q8 + (size_t)(row0 + k) * ldq + c * 8) = ov;
+          if ((lane & 3) == 0) reinterpret_cast<unsigned char*>(qscale)[mx_gemm_scale_offset(row0 + k, c >> 2, D >> 7)] = (unsigned char)byte;
+        }
       }
     }
   }
-  if (FP8) {
+  if (FP8 == 1) {
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       const float am = wave_max(amax[k]);
@@ -397,13 +426,13 @@ extern "C" int ce_ln_affine_bf16(const void* x, void* y, const float* a, const f
   // rows per wave (see the kernel): the full-width form shares each (a, b) chunk between CE_LN_ROWS rows of one sample
   const bool multi = D == 64 * 8 * ROW_MAXC && (ab_rows <= 0 || ab_rows % CE_LN_ROWS == 0);
   if (multi)
-    hipLaunchKernelGGL((ln_affine_kernel<false, true, CE_LN_ROWS>), dim3((M + 4 * CE_LN_ROWS - 1) / (4 * CE_LN_ROWS)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((ln_affine_kernel<0, true, CE_LN_ROWS>), dim3((M + 4 * CE_LN_ROWS - 1) / (4 * CE_LN_ROWS)), dim3(256), 0, stream,
                        (const bf16*)x, (bf16*)y, a, b, M, D, ldx, ldy, eps, ab_rows, ab_stride, nullptr, nullptr, 0);
   else if (D == 64 * 8 * ROW_MAXC)
-    hipLaunchKernelGGL((ln_affine_kernel<false, true, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
+    hipLaunchKernelGGL((ln_affine_kernel<0, true, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
                        D, ldx, ldy, eps, ab_rows, ab_stride, nullptr, nullptr, 0);
   else
-    hipLaunchKernelGGL((ln_affine_kernel<false, false, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
+    hipLaunchKernelGGL((ln_affine_kernel<0, false, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, a, b, M,
                        D, ldx, ldy, eps, ab_rows, ab_stride, nullptr, nullptr, 0);
   return (int)hipGetLastError();
 }
@@ -414,11 +443,26 @@ extern "C" int ce_ln_affine_fp8(const void* x, void* q, float* scale, const floa
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
   // (one row per wave here: with two the fp8 form needs 360 registers - the quantised rows stay live for the amax)
   if (D == 64 * 8 * ROW_MAXC)
-    hipLaunchKernelGGL((ln_affine_kernel<true, true, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
+    hipLaunchKernelGGL((ln_affine_kernel<1, true, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
                        ldx, 0, eps, ab_rows, ab_stride, (unsigned char*)q, scale, ldq);
   else
-    hipLaunchKernelGGL((ln_affine_kernel<true, false, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
+    hipLaunchKernelGGL((ln_affine_kernel<1, false, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D,
                        ldx, 0, eps, ab_rows, ab_stride, (unsigned char*)q, scale, ldq);
+  return (int)hipGetLastError();
+}
+
+/* ce_ln_affine_bf16 followed by ce_quant_rows_mxfp8 in one pass (q: e4m3 bytes, scale8: E8M0 block scales in the tiled layout of
+ * ce_gemm_mxfp8, ceil(M / 128) * (D / 128) * 512 bytes).  D % 128 == 0. */
+extern "C" int ce_ln_affine_mxfp8(const void* x, void* q, void* scale8, const float* a, const float* b, int M, int D, int ldx, int ldq, float eps,
+                                  int ab_rows, int ab_stride, hipStream_t stream) {
+  if (!x || !q || !scale8 || !a || !b) return CE_ERR_ARG;
+  if (M <= 0 || D <= 0 || (D & 127) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
+  if (D == 64 * 8 * ROW_MAXC)
+    hipLaunchKernelGGL((ln_affine_kernel<2, true, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D, ldx, 0, eps,
+                       ab_rows, ab_stride, (unsigned char*)q, (float*)scale8, ldq);
+  else
+    hipLaunchKernelGGL((ln_affine_kernel<2, false, 1>), dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, nullptr, a, b, M, D, ldx, 0, eps,
+                       ab_rows, ab_stride, (unsigned char*)q, (float*)scale8, ldq);
   return (int)hipGetLastError();
 }
 

@@ -729,6 +729,82 @@ def ln_affine_fp8(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: float,
     return out, scale
 
 
+def mx_scale_bytes(rows: int, K: int) -> int:
+    """Size of the tiled E8M0 scale buffer of a [rows, K] MX operand ([ceil(rows/128)][K/128][4][16][8] bytes)."""
+    return (rows + 127) // 128 * (K // 128) * 512
+
+
+def mx_scales_to_rows(scale8: torch.Tensor, rows: int, K: int) -> torch.Tensor:
+    """The tiled scale buffer as a plain [rows, K/32] uint8 matrix (E8M0 bytes; for tests and tools - not on the hot path)."""
+    rb, kt = (rows + 127) // 128, K // 128
+    t = scale8[: rb * kt * 512].view(rb, kt, 4, 16, 8)          # [rb][kt][g][fr][F]
+    return t.permute(0, 4, 3, 1, 2).reshape(rb * 128, kt * 4)[:rows]  # row = rb*128 + F*16 + fr, block = kt*4 + g
+
+
+def quant_rows_mxfp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """x [M,K] bf16 -> (q [M,K] uint8 holding e4m3, scale8 uint8: one E8M0 byte per 32 consecutive elements of a row, tiled layout of
+    `gemm_mxfp8`): the OCP MX contract of oracle.dit_oracle.mx_quant.  K % 128 == 0."""
+    _dev(x, torch.bfloat16, "x")
+    M, K, ldx = _rows(x, "x")
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty((mx_scale_bytes(M, K),), dtype=torch.uint8, device=x.device)
+    _dev(out, torch.uint8, "out"), _dev(scale, torch.uint8, "scale")
+    assert scale.is_contiguous() and scale.numel() >= mx_scale_bytes(M, K)
+    _, _, ldq = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_quant_rows_mxfp8(_ptr(x), _ptr(out), _ptr(scale), M, K, ldx, ldq, _stream()), "ce_quant_rows_mxfp8")
+    _prof_end(st, f"quant_mxfp8_{M}x{K}", 3.0 * M * K)
+    return out, scale
+
+
+def ln_affine_mxfp8(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: float, out: torch.Tensor, scale: torch.Tensor,
+                    ab_rows: int = 0, ab_stride: int = 0):
+    """ln_affine + quant_rows_mxfp8 in one pass: out (uint8 e4m3) and the tiled E8M0 scales of LN(x) * a + b rounded to bf16."""
+    _dev(x, torch.bfloat16, "x"), _dev(a, torch.float32, "a"), _dev(b, torch.float32, "b")
+    _dev(out, torch.uint8, "out"), _dev(scale, torch.uint8, "scale")
+    M, D, ldx = _rows(x, "x")
+    assert scale.is_contiguous() and scale.numel() >= mx_scale_bytes(M, D)
+    _, _, ldq = _rows(out, "out")
+    st = _prof_begin()
+    _check(lib().ce_ln_affine_mxfp8(_ptr(x), _ptr(out), _ptr(scale), _ptr(a), _ptr(b), M, D, ldx, ldq, float(eps), int(ab_rows),
+                                    int(ab_stride), _stream()), "ce_ln_affine_mxfp8")
+    _prof_end(st, f"ln_affine_mxfp8_{M}x{D}", 3.0 * M * D)
+    return out, scale
+
+
+def gemm_mxfp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor],
+               out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None,
+               res: Optional[torch.Tensor] = None, gate_rows: int = 0):
+    """out[M,N] (bf16) = epilogue(MX-scaled aq @ wq^T + bias); aq [M,K], wq [N,K] uint8 (e4m3) with their tiled E8M0 scale buffers."""
+    _dev(aq, torch.uint8, "aq"), _dev(wq, torch.uint8, "wq"), _dev(sa, torch.uint8, "sa"), _dev(sw, torch.uint8, "sw")
+    M, K, lda = _rows(aq, "aq")
+    N, K2, ldw = _rows(wq, "wq")
+    if K != K2 or sa.numel() < mx_scale_bytes(M, K) or sw.numel() < mx_scale_bytes(N, K):
+        raise ValueError("gemm_mxfp8: operand / scale shapes do not match")
+    if bias is not None:
+        _dev(bias, torch.float32, "bias")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=aq.device)
+    _dev(out, torch.bfloat16, "out")
+    _, _, ldc = _rows(out, "out")
+    ensure_gemm_workspace(aq.device)
+    ldres = 0
+    if epilogue == EPI_GATE_RES:
+        if res is None:
+            raise ValueError("EPI_GATE_RES needs res")
+        _dev(res, torch.bfloat16, "res")
+        _, _, ldres = _rows(res, "res")
+        if gate is not None:
+            _dev(gate, torch.float32, "gate")
+    st = _prof_begin()
+    _check(lib().ce_gemm_mxfp8(_ptr(aq), _ptr(wq), _ptr(out), _ptr(sa), _ptr(sw), _ptr(bias), epilogue, _ptr(gate), _ptr(res), M, N, K, lda, ldw,
+                               ldc, ldres, int(gate_rows), _stream()), "ce_gemm_mxfp8")
+    _prof_end(st, f"gemm_mxfp8_{M}x{N}x{K}_epi{epilogue}", 2.0 * M * N * K)
+    return out
+
+
 def set_gemm_fp8_variant(v: int) -> int:
     """Main loop of `gemm_fp8`: 0 = 8 waves / 4 phases, 1 = one wave per SIMD (ce_gemm_fp8w4.hip); returns the previous setting."""
     return lib().ce_set_gemm_fp8_variant(int(v))

@@ -296,12 +296,14 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         """Call after changing parameters in place (LoRA fuse, load_state_dict): re-packs on next forward."""
         self._engine = None
 
-    def enable_fp8_gemms(self, on: bool = True):
+    def enable_fp8_gemms(self, on: bool = True, mx: bool = True):
         """BASELINE.json configs[4]: run the six large Linears of every block (fused q|k|v, the two output projections, the
-        cross-attention query, FFN up / down) in fp8 - weights quantised once per output channel to OCP e4m3, activations per
-        token row on the fly, fp32 accumulation on the MX matrix instruction (`ce_gemm_fp8`).  Attention, norms, the residual
-        stream, the conditioning projections and the head stay bf16 / fp32 as before.  The bf16 parameters are kept."""
-        self.gemm_dtype = "fp8" if on else "bf16"
+        cross-attention query, FFN up / down) in fp8 e4m3 with fp32 accumulation on the MX matrix instruction.
+        mx=True (default since round 4): OCP MXFP8 operands - one E8M0 scale per 32 consecutive input channels of every activation row and
+        of every weight row, applied inside the matrix pipe (`ce_gemm_mxfp8`; quantisers `ce_quant_rows_mxfp8` / `ce_ln_affine_mxfp8`);
+        mx=False: one fp32 scale per token row / per output channel (`ce_gemm_fp8`, the round-1..3 contract).  Weights are quantised once;
+        attention, norms, the residual stream, the conditioning projections and the head stay bf16 / fp32.  The bf16 parameters are kept."""
+        self.gemm_dtype = ("mxfp8" if mx else "fp8") if on else "bf16"
         self._engine = None
         return self
 
@@ -509,14 +511,15 @@ class DiTEngine:
             tables.append(f32(blk.scale_shift_table).reshape(6, self.D))
             self.blk.append(p)
         self.fp8_attn = model.attn_dtype == "mxfp8"
-        self.fp8 = model.gemm_dtype == "fp8"
+        self.fp8 = model.gemm_dtype in ("fp8", "mxfp8")
+        self.mx = model.gemm_dtype == "mxfp8"  # MX block scales on both GEMM operands (ce_gemm_mxfp8)
         self.v_transposed = bool(getattr(model, "v_transposed", True))
         if self.fp8:
             if self.D % 256 or self.F % 256:
                 raise NotImplementedError("fp8 GEMMs need inner and ffn dims that are multiples of 256")
             for p in self.blk:  # per-output-channel e4m3 copies of the six large weights (the bf16 originals stay)
                 for name in ("qkv", "o1", "q2", "o2", "f1", "f2"):
-                    setattr(p, "q_" + name, ops.quant_rows_fp8(getattr(p, "w_" + name)))
+                    setattr(p, "q_" + name, (ops.quant_rows_mxfp8 if self.mx else ops.quant_rows_fp8)(getattr(p, "w_" + name)))
         # K13 for ALL layers as one GEMM per context stream and operand: the per-layer to_k (to_v, add_k_proj, add_v_proj) weights are
         # re-homed, layer after layer, in one [L*D, D] buffer each (the step-invariant projections of 769 context rows are 160 small
         # GEMMs otherwise: 0.5-1.0 PFLOP/s at M = 514 / 1024 against 1.35 for one [M, L*D] product).  K and V apart (round 4): the V
@@ -564,8 +567,11 @@ class DiTEngine:
             ops.ln_affine(x, a_row, b_row, eps, out=ws.h, ab_rows=ab_rows, ab_stride=ab_stride)
             return ops.gemm(ws.h, getattr(p, "w_" + name), getattr(p, "b_" + name), out=out, **kw)
         aq = ws.a8[:, : x.shape[1]]
-        ops.ln_affine_fp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=ab_rows, ab_stride=ab_stride)
         wq, sw = getattr(p, "q_" + name)
+        if self.mx:
+            ops.ln_affine_mxfp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=ab_rows, ab_stride=ab_stride)
+            return ops.gemm_mxfp8(aq, ws.s8, wq, sw, getattr(p, "b_" + name), out=out, **kw)
+        ops.ln_affine_fp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=ab_rows, ab_stride=ab_stride)
         return ops.gemm_fp8(aq, ws.s8, wq, sw, getattr(p, "b_" + name), out=out, **kw)
 
     def _linear(self, ws, a: torch.Tensor, p, name: str, out: torch.Tensor, **kw):
@@ -575,8 +581,11 @@ class DiTEngine:
             return ops.gemm(a, w, b, out=out, **kw)
         K = a.shape[1]
         aq = ws.a8[:, :K]
-        ops.quant_rows_fp8(a, out=aq, scale=ws.s8)
         wq, sw = getattr(p, "q_" + name)
+        if self.mx:
+            ops.quant_rows_mxfp8(a, out=aq, scale=ws.s8)
+            return ops.gemm_mxfp8(aq, ws.s8, wq, sw, b, out=out, **kw)
+        ops.quant_rows_fp8(a, out=aq, scale=ws.s8)
         return ops.gemm_fp8(aq, ws.s8, wq, sw, b, out=out, **kw)
 
     def _self_attention_ulysses(self, ws, sp, x, a_row, b_row, p, cs, N: int, Nl: int, B: int = 1):
@@ -592,9 +601,14 @@ class DiTEngine:
             lin = lambda lo, hi, out: ops.gemm(ws.h, p.w_qkv[lo:hi], p.b_qkv[lo:hi], out=out)
         else:
             aq = ws.a8[:, :D]
-            ops.ln_affine_fp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=Nl, ab_stride=6 * D)
             wq, sw = p.q_qkv
-            lin = lambda lo, hi, out: ops.gemm_fp8(aq, ws.s8, wq[lo:hi], sw[lo:hi], p.b_qkv[lo:hi], out=out)
+            if self.mx:  # (row slices of the fused weight at multiples of D = whole 128-row scale blocks: 512 (D / 128) bytes per block)
+                ops.ln_affine_mxfp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=Nl, ab_stride=6 * D)
+                sblk = (D // 128) * 512
+                lin = lambda lo, hi, out: ops.gemm_mxfp8(aq, ws.s8, wq[lo:hi], sw[lo // 128 * sblk: hi // 128 * sblk], p.b_qkv[lo:hi], out=out)
+            else:
+                ops.ln_affine_fp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=Nl, ab_stride=6 * D)
+                lin = lambda lo, hi, out: ops.gemm_fp8(aq, ws.s8, wq[lo:hi], sw[lo:hi], p.b_qkv[lo:hi], out=out)
         lin(D, 3 * D, ws.qkv[:, D:])
         ops.rope_scatter(ws.qkv, (D, 2 * D), (p.nk1, None), D, W, cs, hd, eps, out=ws.send_kv)
         _, wait_kv = sp.all_to_all(ws.send_kv, ws.recv_kv, async_op=True)
@@ -629,9 +643,10 @@ class DiTEngine:
             e = lambda *s: torch.empty(s, dtype=torch.bfloat16, device=dev)
             ws = SimpleNamespace(x=e(N, D), h=e(N, D), qkv=e(N, 3 * D), att=e(N, D), q2=e(N, D), ffn=e(N, F),
                                  cols=e(N, self.kpatch), head=e(N, self.w_out.shape[0]))
-            if self.fp8:  # activation rows as fp8 + one scale per row
+            if self.fp8:  # activation rows as fp8 + one scale per row (MX: one E8M0 byte per 32 elements, tiled: ops.mx_scale_bytes)
                 ws.a8 = torch.empty((N, max(D, F)), dtype=torch.uint8, device=dev)
-                ws.s8 = torch.empty((N,), dtype=torch.float32, device=dev)
+                ws.s8 = (torch.empty((ops.mx_scale_bytes(N, max(D, F)),), dtype=torch.uint8, device=dev) if self.mx else
+                         torch.empty((N,), dtype=torch.float32, device=dev))
             if self.fp8_attn:  # MXFP8 q / k (+ E8M0 scale bytes); the V^T tiles depend on the batch split and are sized in forward
                 u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
                 ws.q8, ws.k8, ws.sq, ws.sk = u8(N, D), u8(N, D), u8(N, D // 32), u8(N, D // 32)

@@ -294,6 +294,26 @@ int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const 
                 const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                 hipStream_t stream);
 
+/* ---- the MX form of the fp8 GEMMs (round 4; BASELINE.json configs[4] "fp8 weights"): OCP MXFP8 operands - e4m3 elements with one E8M0
+ * scale per 32 consecutive K elements of a row, scale = 2^(floor(log2 amax) - 8), elements RNE(x / scale) clamped to +-448 - and the block
+ * scales applied INSIDE the matrix pipe by v_mfma_scale_f32_16x16x128_f8f6f4.  Scale bytes are stored in the order the GEMM reads them:
+ * [ceil(rows / 128)][K / 128][4][16][8], i.e. the scale of elements [128 t + 32 g, + 32) of row r at byte
+ * ((r / 128 * (K / 128) + t) * 4 + g) * 128 + (r % 16) * 8 + (r / 16) % 8; a scale buffer holds ceil(rows / 128) * (K / 128) * 512 bytes.
+ * The reference has no fp8 path: the contract is oracle.dit_oracle.mx_quant / linear_mxfp8. ---- */
+
+/* x bf16 [M][ldx] -> q e4m3 bytes [M][ldq] + scale8 (above).  K % 128 == 0.  Activations (per token row) and, at load time, weights. */
+int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream);
+
+/* ce_ln_affine_bf16 followed by ce_quant_rows_mxfp8 in one pass (the quantisation of the bf16 row ce_ln_affine_bf16 would have written). */
+int ce_ln_affine_mxfp8(const void* x, void* q, void* scale8, const float* a, const float* b, int M, int D, int ldx, int ldq, float eps,
+                       int ab_rows, int ab_stride, hipStream_t stream);
+
+/* C = epilogue(sum_blocks 2^(ea + ew) (Aq Wq^T)_block + bias[n]); Aq [M][lda], Wq [N][ldw] e4m3 bytes with their scale buffers sa8 / sw8,
+ * C bf16; K % 256 == 0, N % 8 == 0.  Epilogues 0 (bias), 1 (bias + tanh GELU), 2 (gated residual; gate rows per sample >= 256 or one gate)
+ * as ce_gemm_bf16; the one-wave-per-SIMD main loop of csrc/ce_gemm_fp8w4.hip, split-K tail through the ce_set_gemm_workspace scratch. */
+int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void* sa8, const void* sw8, const float* bias, int epilogue, const float* gate,
+                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, hipStream_t stream);
+
 /* Main loop of ce_gemm_fp8 (returns the previous setting): 0 = 8 waves / 4 phases per K-tile (csrc/ce_gemm_fp8.hip), 1 = one wave per
  * SIMD (csrc/ce_gemm_fp8w4.hip: 4 waves, 128 x 128 wave tiles, accumulators in AGPRs, one barrier per K-tile).  Same results bit for
  * bit (same products, same summation order per accumulator).  Host-side test / bench knob. */

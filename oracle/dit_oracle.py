@@ -249,6 +249,20 @@ def linear_fp8(x, p, name):
     return F.linear(fake_quant_rows_fp8(x), fake_quant_rows_fp8(p[name + ".weight"]), p[name + ".bias"])
 
 
+def linear_mxfp8(x, p, name):
+    """A Linear under the MX form of the fp8 contract (round 4: include/chronoedit_hip.h ce_gemm_mxfp8): activations and weights as OCP
+    MXFP8 - e4m3 elements, one E8M0 scale per 32 consecutive INPUT channels of a row (mx_quant below) - exact products, block scales
+    applied to the partial sums, bias added afterwards.  (The reference has no fp8 path: this is the definition.)"""
+    return F.linear(mx_quant(x, -1).to(x.dtype), mx_quant(p[name + ".weight"], -1).to(x.dtype), p[name + ".bias"])
+
+
+def _fp8_linear(fp8):
+    """fp8 = False: plain Linear; True / "row": per-row scales (linear_fp8); "mx": MX block scales (linear_mxfp8)."""
+    if not fp8:
+        return linear
+    return linear_mxfp8 if fp8 == "mx" else linear_fp8
+
+
 def mx_quant(x: torch.Tensor, dim: int = -1, block_index: Optional[torch.Tensor] = None) -> torch.Tensor:
     """OCP MXFP8 (e4m3 elements, one E8M0 scale per 32 elements along `dim`), returned de-quantised in fp32: the contract of
     chronoedit_amd/csrc/ce_attn_fp8.hip.  scale = 2^(floor(log2 amax) - 8) (2^-126 for an all-zero block), elements =
@@ -256,6 +270,14 @@ def mx_quant(x: torch.Tensor, dim: int = -1, block_index: Optional[torch.Tensor]
     32-element blocks are not the contiguous ones (the V operand: see attention_mxfp8)."""
     xf = x.float().movedim(dim, -1)
     n = xf.shape[-1]
+    if block_index is None and n % 32 == 0:  # contiguous whole blocks: the same arithmetic without the scatter (weights of 70 M elements)
+        xb = xf.reshape(xf.shape[:-1] + (n // 32, 32))
+        amax = xb.abs().amax(-1, keepdim=True)
+        e = torch.floor(torch.log2(torch.clamp(amax, min=2.0 ** -118))) - 8.0
+        e = torch.where(amax > 0, torch.clamp(e, min=-126.0), torch.full_like(e, -126.0))
+        scale = torch.exp2(e)
+        q = torch.clamp(xb / scale, -448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
+        return q.reshape(xf.shape).movedim(-1, dim)
     if block_index is None:
         block_index = torch.arange(n) // 32
     nb = int(block_index.max()) + 1
@@ -321,8 +343,8 @@ def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=No
     fp8_attn: the SELF-attention product under the MXFP8 contract (attention_mxfp8); cross-attention stays SDPA."""
     self_attn = encoder is None
     H = cfg.num_attention_heads
-    lin_q = linear_fp8 if fp8 else linear
-    lin_kv = linear_fp8 if (fp8 and encoder is None) else linear
+    lin_q = _fp8_linear(fp8)
+    lin_kv = _fp8_linear(fp8) if encoder is None else linear
     enc_img = None
     has_added = (pre + ".add_k_proj.weight") in p
     if has_added and encoder is not None:
@@ -364,7 +386,7 @@ def feed_forward(p, pre, x, approximate: str, fp8=False):
     """diffusers FeedForward: net.0 = GELU(proj + gelu), net.1 = Dropout(0), net.2 = Linear.
     "gelu-approximate" -> tanh (block FFN, transformer_chronoedit.py:262);
     "gelu" -> erf (image MLP, :116).  Sibling: wan_video_dit_chronoedit.py:224-225,251-257."""
-    lin = linear_fp8 if fp8 else linear
+    lin = _fp8_linear(fp8)
     h = F.gelu(lin(x, p, pre + ".net.0.proj"), approximate=approximate)
     return lin(h, p, pre + ".net.2")
 
@@ -422,11 +444,12 @@ def dit_forward(
     encoder_hidden_states: torch.Tensor,
     encoder_hidden_states_image: Optional[torch.Tensor] = None,
     taps: Optional[dict] = None,
-    fp8: bool = False,
+    fp8=False,
     fp8_attn: bool = False,
 ) -> torch.Tensor:
-    """ChronoEditTransformer3DModel.forward (transformer_chronoedit.py:397-476).  fp8=True restates chronoedit_amd's fp8 GEMM mode
-    (the six large Linears of every block under linear_fp8; everything else unchanged); fp8_attn=True its MXFP8 self-attention."""
+    """ChronoEditTransformer3DModel.forward (transformer_chronoedit.py:397-476).  fp8 restates chronoedit_amd's fp8 GEMM modes (the six
+    large Linears of every block under linear_fp8 - fp8=True / "row": per-row scales - or linear_mxfp8 - fp8="mx": MX block scales; everything
+    else unchanged); fp8_attn=True its MXFP8 self-attention."""
     B, C, T, Hh, Ww = hidden_states.shape
     pt, ph, pw = cfg.patch_size
     ppf, pph, ppw = T // pt, Hh // ph, Ww // pw

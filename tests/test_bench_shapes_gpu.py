@@ -154,17 +154,21 @@ def test_full_width_block_bf16_and_fp8_modes_vs_fp32_oracle(h, w, tag):
     ts = torch.tensor([800], device="cuda:0")
     args = (lat.cuda(), ts, text.cuda(), image.cuda())
     out_bf16 = model(*args, return_dict=False)[0].float().cpu()
-    model.enable_fp8_gemms().enable_fp8_attention()
+    model.enable_fp8_gemms().enable_fp8_attention()           # the fp8 mode of bench.py --fp8: MX block scales on the GEMM operands (round 4)
     out_fp8 = model(*args, return_dict=False)[0].float().cpu()
+    model.enable_fp8_gemms(mx=False)                          # the round-1..3 contract: one scale per 5120- / 13824-long row
+    out_row = model(*args, return_dict=False)[0].float().cpu()
     del model
     p32 = {k: v.float() for k, v in p_bf.items()}
     with torch.no_grad():
         ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([800]), text.float(), image.float())
-    e_bf16, e_fp8 = rel_l2(out_bf16, ref), rel_l2(out_fp8, ref)
-    print(f"full-width block, {tag}: bf16 path vs fp32 {e_bf16:.3e} | fp8 mode vs fp32 {e_fp8:.3e} ({e_fp8 / e_bf16:.2f} x)")
-    assert torch.isfinite(out_bf16).all() and torch.isfinite(out_fp8).all()
+    e_bf16, e_fp8, e_row = rel_l2(out_bf16, ref), rel_l2(out_fp8, ref), rel_l2(out_row, ref)
+    print(f"full-width block, {tag}: bf16 path vs fp32 {e_bf16:.3e} | fp8 mode (MX block scales) vs fp32 {e_fp8:.3e} ({e_fp8 / e_bf16:.2f} x) | "
+          f"per-row scales {e_row:.3e} ({e_row / e_bf16:.2f} x)")
+    assert torch.isfinite(out_bf16).all() and torch.isfinite(out_fp8).all() and torch.isfinite(out_row).all()
     assert e_bf16 < 1e-2
-    assert e_fp8 <= 10 * e_bf16 and e_fp8 < 5e-2, (e_fp8, e_bf16)
+    assert e_row <= 10 * e_bf16 and e_row < 5e-2, (e_row, e_bf16)
+    assert e_fp8 <= e_row * 1.02 and e_fp8 <= 8 * e_bf16, (e_fp8, e_row, e_bf16)  # (bound tightened once measured: see DESIGN.md section 9)
 
 
 def test_fp8_mode_error_growth_over_forty_blocks():

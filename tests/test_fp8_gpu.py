@@ -84,9 +84,11 @@ def test_gemm_fp8_rejects_bad_shapes():
         ops.gemm_fp8(aq, s, wq, torch.ones(16, device="cuda"), None)  # K % 256 != 0
 
 
-def test_dit_forward_fp8_mode_vs_fp8_contract_oracle():
-    """enable_fp8_gemms(): the HIP forward against the fp32 oracle that restates the same fp8 contract (fake-quantised operands of
-    the six large Linears per block), and - reported - against the un-quantised fp32 oracle (the price of fp8 itself)."""
+@pytest.mark.parametrize("mx", [False, True], ids=["row-scales", "mx-block-scales"])
+def test_dit_forward_fp8_mode_vs_fp8_contract_oracle(mx):
+    """enable_fp8_gemms(mx=...): the HIP forward against the fp32 oracle that restates the same fp8 contract (fake-quantised operands of
+    the six large Linears per block; per-row scales or OCP-MX block scales), and - reported - against the un-quantised fp32 oracle
+    (the price of fp8 itself)."""
     from chronoedit_amd.transformer import ChronoEditTransformer3DModel
     from oracle import dit_oracle as O
     cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=4, text_dim=128, image_dim=64, added_kv_proj_dim=256)
@@ -98,16 +100,16 @@ def test_dit_forward_fp8_mode_vs_fp8_contract_oracle():
     ts = torch.tensor([400], device="cuda:0")
     args = (lat.cuda(), ts, text.cuda(), image.cuda())
     out16 = m(*args, return_dict=False)[0].clone()
-    m.enable_fp8_gemms()
+    m.enable_fp8_gemms(mx=mx)
     out8 = m(*args, return_dict=False)[0].clone()
     m.enable_fp8_gemms(False)
     assert torch.equal(m(*args, return_dict=False)[0], out16)  # switching back restores the bf16 path bit for bit
     p32 = {k: v.float() for k, v in p_bf.items()}
     with torch.no_grad():
         ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([400]), text.float(), image.float())
-        ref8 = O.dit_forward(p32, cfg, lat.float(), torch.tensor([400]), text.float(), image.float(), fp8=True)
+        ref8 = O.dit_forward(p32, cfg, lat.float(), torch.tensor([400]), text.float(), image.float(), fp8="mx" if mx else True)
     e_contract, e_price, e_bf16 = rel_l2(out8, ref8), rel_l2(ref8, ref), rel_l2(out16, ref)
-    print(f"fp8 mode: hip-vs-fp8-contract-oracle {e_contract:.3e}; fp8 contract vs exact fp32 {e_price:.3e}; bf16 path vs fp32 {e_bf16:.3e}")
+    print(f"fp8 mode ({'MX block' if mx else 'per-row'} scales): hip-vs-fp8-contract-oracle {e_contract:.3e}; fp8 contract vs exact fp32 {e_price:.3e}; bf16 path vs fp32 {e_bf16:.3e}")
     assert e_contract <= 2.5e-2      # bf16-level agreement with the contract (rounding boundaries of fp8 add a little)
     assert rel_l2(out8, ref) <= 0.12  # the whole fp8 forward stays close to the exact one
     assert rel_l2(out8, out16) > 1e-3
@@ -131,7 +133,8 @@ def test_ln_affine_fp8_equals_two_launch_form():
         assert torch.equal(s, s_ref) and torch.equal(q, q_ref)
 
 
-def test_edit_end_to_end_fp8_mode_vs_fp8_contract_oracle():
+@pytest.mark.parametrize("mx", [False, True], ids=["row-scales", "mx-block-scales"])
+def test_edit_end_to_end_fp8_mode_vs_fp8_contract_oracle(mx):
     """A whole 4-step CFG edit (prepare_latents -> loop -> decode) with the transformer in fp8 GEMM mode, against the oracle edit
     whose DiT follows the same fp8 contract; and how far that is from the exact-arithmetic edit (reported)."""
     from chronoedit_amd.pipeline import ChronoEditPipeline
@@ -154,12 +157,12 @@ def test_edit_end_to_end_fp8_mode_vs_fp8_contract_oracle():
     dp32 = {k: v.float() for k, v in dp.items()}
     cpu_args = (image.to(BF).float(), prompt.to(BF).float(), negative.to(BF).float(), img_emb.to(BF).float())
     with torch.no_grad():
-        lat8, vid8 = P.edit(dp32, dcfg, vp, vcfg, *cpu_args, lat0.clone(), num_frames=F, steps=4, fp8=True)
+        lat8, vid8 = P.edit(dp32, dcfg, vp, vcfg, *cpu_args, lat0.clone(), num_frames=F, steps=4, fp8="mx" if mx else True)
         lat_x, _ = P.edit(dp32, dcfg, vp, vcfg, *cpu_args, lat0.clone(), num_frames=F, steps=4, decode=False)
     m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
                                      added_kv_proj_dim=256, device="cuda:0")
     m.load_synthetic_({k: v.cuda() for k, v in dp.items()})
-    m.enable_fp8_gemms()
+    m.enable_fp8_gemms(mx=mx)
     pipe = ChronoEditPipeline(vae=AutoencoderKLWan({k: v.cuda() for k, v in vp.items()}, dim=32, z_dim=16), transformer=m,
                               scheduler=FlowUniPCMultistepScheduler(flow_shift=5.0))
     args = (image.cuda().to(BF), prompt.cuda().to(BF), negative.cuda().to(BF), img_emb.cuda().to(BF))
@@ -269,7 +272,8 @@ def test_mxfp8_attention_kernel_vs_contract(N, H, B, spread):
     assert torch.isfinite(out).all() and e_k < 1.5e-2 and e_k0 < 1.5e-2
 
 
-def test_dit_forward_with_mxfp8_attention_vs_contract_oracle():
+@pytest.mark.parametrize("mx", [False, True], ids=["row-scales", "mx-block-scales"])
+def test_dit_forward_with_mxfp8_attention_vs_contract_oracle(mx):
     """fp8 GEMMs + MXFP8 self-attention (bench.py --fp8) through the whole DiT: vs the oracle restating both contracts (<= 2.5e-2), and
     the mode's distance from exact fp32 bounded against the bf16 path's as SURVEY section 8c prescribes (<= 10 x the bf16 error)."""
     from chronoedit_amd.transformer import ChronoEditTransformer3DModel
@@ -283,7 +287,7 @@ def test_dit_forward_with_mxfp8_attention_vs_contract_oracle():
     ts = torch.tensor([500], device="cuda:0")
     args = (lat.cuda(), ts, text.cuda(), image.cuda())
     out_bf16 = m(*args).sample.float().cpu()
-    m.enable_fp8_gemms().enable_fp8_attention()
+    m.enable_fp8_gemms(mx=mx).enable_fp8_attention()
     out_fp8 = m(*args).sample.float().cpu()
     m.enable_fp8_gemms(False)
     out_attn_only = m(*args).sample.float().cpu()
@@ -291,7 +295,7 @@ def test_dit_forward_with_mxfp8_attention_vs_contract_oracle():
     with torch.no_grad():
         a32 = (lat.float(), torch.tensor([500]), text.float(), image.float())
         exact = O.dit_forward(pf, cfg, *a32)
-        contract = O.dit_forward(pf, cfg, *a32, fp8=True, fp8_attn=True)
+        contract = O.dit_forward(pf, cfg, *a32, fp8="mx" if mx else True, fp8_attn=True)
     e_bf16, e_fp8, e_attn = rel_l2(out_bf16, exact), rel_l2(out_fp8, exact), rel_l2(out_attn_only, exact)
     e_contract = rel_l2(out_fp8, contract)
     print(f"DiT 4 blocks: bf16 path vs exact {e_bf16:.3e} | fp8 GEMMs + MXFP8 attention vs exact {e_fp8:.3e} (attention only: {e_attn:.3e}) | "

@@ -94,11 +94,15 @@ def test_fp8_one_wave_per_simd_gemm_loop():
     for r in _pick(_rows("ce_gemm_fp8w4.hip"), "gemm_fp8_w4"):
         assert r[2] <= 512 and r[3] <= 16, r
     loops = isa_lint.inner_loops(src, "gemm_fp8_w4")
-    assert len(loops) == 3
+    assert len(loops) == 6  # three epilogues x {per-row scales: the plain instruction, MX: the block-scaled one}
     for name, c in loops:
-        assert c.get("v_mfma_f32_16x16x128_f8f6f4", 0) == 128, (name, c)
+        mfma = c.get("v_mfma_f32_16x16x128_f8f6f4", 0) + c.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0)
+        assert mfma == 128 and (c.get("v_mfma_f32_16x16x128_f8f6f4", 0) == 0 or c.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0) == 0), (name, c)
         assert c.get("ds_read_b128", 0) == 64 and c.get("buffer_load_dwordx4", 0) == 32 and c.get("s_barrier", 0) == 2, (name, c)
         assert not any(op.startswith("v_accvgpr") or op.startswith("scratch") for op in c), (name, c)
+        if c.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0):  # MX: the block scales of a K-tile = two 8-byte loads per lane, nothing else
+            assert c.get("global_load_dwordx2", 0) == 4 and c.get("v_mov_b32_e32", 0) <= 2, (name, c)
+            assert not any("vmcnt" in op for op in c if op.startswith("s_waitcnt") and op not in ("s_waitcnt",)), (name, c)
 
 
 def test_row_kernels_issue_their_row_loads_back_to_back():
