@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void quant_rows_mxfp8_kernel(const bf16* __res
       amax = fmaxf(amax, __shfl_xor(amax, 1, 64));  // a block = chunks 4a .. 4a+3 = lanes 4a' .. 4a'+3 (K % 32 == 0: whole blocks only)
       amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
       if (c < nch) {
-        const int byte = mx_scale_byte(amax);
+        const int byte = mx_scale_byte_nosat(amax);
         const float inv = mx_inv_scale(byte);
         const u32x4 v = raw[i];
         int w0 = 0, w1 = 0;

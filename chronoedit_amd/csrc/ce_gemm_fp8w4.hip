@@ -45,6 +45,7 @@ constexpr int CROW = BN * 2 + 16;             // padded epilogue staging row (52
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+#define EPI_BIAS_GELU_Q 7  // (this file only) bias + tanh GELU, then MX-quantised: the next GEMM's A operand instead of a bf16 matrix
 #define X8_PIN() __builtin_amdgcn_sched_barrier(0)
 #define X8_BAR() __builtin_amdgcn_s_barrier()
 
@@ -74,13 +75,13 @@ __device__ __forceinline__ void mma_mx(f32x4& acc, const i32x8& w, const i32x8& 
 }
 #undef CE_MX_ASM
 
-template <int EPI, bool MX = false>
+template <int EPI, bool MX = false, bool GP = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_fp8_w4(
     const unsigned char* __restrict__ A, const unsigned char* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ sa,
     const float* __restrict__ sw, const float* __restrict__ bias, const float* __restrict__ gate, const bf16* __restrict__ res, int M,
     int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int tiles_m, int tiles_n, int t_full, int split,
-    float* __restrict__ ws) {
-  // (MX: sa / sw point at the E8M0 scale bytes [rows][4][K / 128])
+    float* __restrict__ ws, unsigned char* __restrict__ qs_out) {
+  // (MX: sa / sw point at the tiled E8M0 scale bytes.  EPI_BIAS_GELU_Q: C is the e4m3 output [M][ldc BYTES], qs_out its tiled scales)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,7 +284,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // Gated residual: all of this thread's residual chunks (4 passes x 8 x 16 B) and its gate values are requested HERE, before the first
   // staging pass, and the stores are predicated by a buffer descriptor's range check (as in ce_gemm256w4.hip: per-pass loads cost four
   // serial memory round trips per tile).  The launcher sends gate rows shorter than a tile to the 8-wave kernel.
-  constexpr bool prefetch = EPI == EPI_GATE_RES;
+  // (GP = false - gate rows shorter than a tile, or a C beyond 32-bit byte offsets: the per-pass path of ce_gemm_epi.h)
+  constexpr bool prefetch = EPI == EPI_GATE_RES && GP;
   u32x4 rv[4][8];
   f32x4 gA0, gA1, gB0, gB1;
   int g_switch = 0x7fffffff;
@@ -347,8 +349,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const uint32_t coff = (m < M && my_n < N) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)my_n * 2u : 0xffffffffu;
         __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
       }
+    } else if (EPI == EPI_BIAS_GELU_Q) {
+      // GELU on the staged bf16 rows, then ce_quant_rows_mxfp8's contract on the bf16 result: chunk cc (8 columns) of a staged row sits with
+      // its block mates cc ^ 1, cc ^ 2, cc ^ 3 in adjacent lanes (c = tid + 256 tt: cc = tid & 31), so the block amax is two lane exchanges
+      unsigned char* q_out = reinterpret_cast<unsigned char*>(C);
+#pragma unroll
+      for (int tt = 0; tt < 8; ++tt) {
+        const int c = tid + 256 * tt;
+        const int rl = c >> 5, cc = c & 31;
+        const int m = m0 + (rl >> 5) * 128 + p * 32 + (rl & 31), n = n0 + cc * 8;
+        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + cc * 16);
+        u32x4 o;
+        float am = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = pack_bf16(gelu_tanh(bf16lo(y[q])), gelu_tanh(bf16hi(y[q])));
+          am = fmaxf(am, fmaxf(fabsf(bf16lo(o[q])), fabsf(bf16hi(o[q]))));
+        }
+        am = fmaxf(am, __shfl_xor(am, 1, 64));
+        am = fmaxf(am, __shfl_xor(am, 2, 64));
+        const int byte = mx_scale_byte_nosat(am);
+        const float inv = mx_inv_scale(byte);
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[0]) * inv), clamp448(bf16hi(o[0]) * inv), w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[1]) * inv), clamp448(bf16hi(o[1]) * inv), w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[2]) * inv), clamp448(bf16hi(o[2]) * inv), w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[3]) * inv), clamp448(bf16hi(o[3]) * inv), w1, true);
+        if (m < M && n < N) {
+          *reinterpret_cast<u32x2*>(q_out + (size_t)m * ldc + n) = u32x2{(uint32_t)w0, (uint32_t)w1};
+          if ((cc & 3) == 0) qs_out[mx_gemm_scale_offset(m, n >> 5, N >> 7)] = (unsigned char)byte;
+        }
+      }
     } else {
-      epi_chunks<EPI, 8>(smem, CROW,
+      epi_chunks<EPI == EPI_BIAS_GELU_Q ? EPI_BIAS : EPI, 8>(smem, CROW,
                          [&](int tt, int& rl, int& cc, int& mr) {
                            const int c = tid + 256 * tt;
                            rl = c >> 5;
@@ -372,6 +405,8 @@ static int fp8w4_launch(bool mx, const void* Aq, const void* Wq, void* C, const 
                         int ldres, int gate_rows, hipStream_t stream) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n, kt = K / BKB;
+  // (the prefetched gated-residual epilogue holds ONE or TWO samples' gate rows per tile and stores through 32-bit offsets)
+  const bool gate_prefetch = epilogue != EPI_GATE_RES || ((gate == nullptr || gate_rows <= 0 || gate_rows >= BM) && (long long)M * ldc * 2 < (1ll << 32));
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
   int g_cus = 256;
@@ -402,14 +437,18 @@ static int fp8w4_launch(bool mx, const void* Aq, const void* Wq, void* C, const 
     if (!attr_done[E]) {                                                                                                      \
       if (hipFuncSetAttribute((const void*)gemm_fp8_w4<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
       if (hipFuncSetAttribute((const void*)gemm_fp8_w4<E, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
+      if (hipFuncSetAttribute((const void*)gemm_fp8_w4<E, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
       attr_done[E] = true;                                                                                                    \
     }                                                                                                                         \
-    if (mx)                                                                                                                   \
+    if (mx && !gate_prefetch)                                                                                                 \
+      hipLaunchKernelGGL((gemm_fp8_w4<E, true, false>), grid, block, lds, stream, (const unsigned char*)Aq, (const unsigned char*)Wq, (bf16*)C, sa, sw, \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws, nullptr); \
+    else if (mx)                                                                                                              \
       hipLaunchKernelGGL((gemm_fp8_w4<E, true>), grid, block, lds, stream, (const unsigned char*)Aq, (const unsigned char*)Wq, (bf16*)C, sa, sw, \
-                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws); \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws, nullptr); \
     else                                                                                                                      \
       hipLaunchKernelGGL((gemm_fp8_w4<E>), grid, block, lds, stream, (const unsigned char*)Aq, (const unsigned char*)Wq, (bf16*)C, sa, sw, \
-                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws); \
+                         bias, gate, (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full, split, g_ws, nullptr); \
   } while (0)
   switch (epilogue) {
     case EPI_BIAS: F8_LAUNCH(EPI_BIAS); break;
@@ -444,8 +483,27 @@ extern "C" int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void
   if ((long long)M * lda >= (1ll << 32) || (long long)N * ldw >= (1ll << 32)) return CE_ERR_SHAPE;  // 32-bit DMA offsets
   if (epilogue == EPI_GATE_RES && (!res || (ldres & 7))) return CE_ERR_ARG;
   if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_GATE_RES) return CE_ERR_ARG;
-  // (the gated-residual epilogue of this loop holds ONE or TWO samples' gate rows per tile and stores through 32-bit offsets)
-  if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32))) return CE_ERR_SHAPE;
   return fp8w4_launch(true, Aq, Wq, C, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, epilogue, gate, res, M, N, K,
                       lda, ldw, ldc, ldres, gate_rows, stream);
+}
+
+/* bias + tanh GELU with the MX quantisation of the result fused into the epilogue (include/chronoedit_hip.h).  No split-K tail: the
+ * slab reduce writes bf16. */
+extern "C" int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* sa8, const void* sw8, const float* bias, void* q_out, void* qs_out,
+                                        int M, int N, int K, int lda, int ldw, int ldq, hipStream_t stream) {
+  if (!Aq || !Wq || !sa8 || !sw8 || !q_out || !qs_out) return CE_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % (2 * BKB)) || (N & 127)) return CE_ERR_SHAPE;
+  if ((lda & 15) || (ldw & 15) || (ldq & 7)) return CE_ERR_ALIGN;
+  if ((long long)M * lda >= (1ll << 32) || (long long)N * ldw >= (1ll << 32)) return CE_ERR_SHAPE;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  static bool done_[CE_MAX_DEVICES] = {};
+  bool& done = done_[ce_device_slot()];
+  if (!done) {
+    if (hipFuncSetAttribute((const void*)gemm_fp8_w4<EPI_BIAS_GELU_Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return CE_ERR_ARG;
+    done = true;
+  }
+  hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true>), dim3(tiles_m * tiles_n), dim3(256), 2 * STAGE, stream, (const unsigned char*)Aq,
+                     (const unsigned char*)Wq, (bf16*)q_out, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, nullptr,
+                     nullptr, M, N, K, lda, ldw, ldq, 0, 0, tiles_m, tiles_n, tiles_m * tiles_n, 1, nullptr, (unsigned char*)qs_out);
+  return (int)hipGetLastError();
 }

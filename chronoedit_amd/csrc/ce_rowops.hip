@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const bf16* __restrict__
         am = fmaxf(am, __shfl_xor(am, 1, 64));  // a block = 4 consecutive chunks = 4 consecutive lanes
         am = fmaxf(am, __shfl_xor(am, 2, 64));
         if (on) {
-          const int byte = mx_scale_byte(am);
+          const int byte = mx_scale_byte_nosat(am);
           const float inv = mx_inv_scale(byte);
           int w0 = 0, w1 = 0;
           w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[0]) * inv), clamp448(bf16hi(v[0]) * inv), w0, false);

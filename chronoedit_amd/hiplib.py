@@ -54,6 +54,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_quant_rows_mxfp8": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ce_ln_affine_mxfp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "ce_gemm_mxfp8": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_gemm_mxfp8_gelu_quant": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ce_gemm_batched_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I] + [ctypes.c_longlong] * 6 + [_P],
     "ce_im2col_patch2d_bf16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ce_gather_rows_bf16": [_P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -805,6 +805,26 @@ def gemm_mxfp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.T
     return out
 
 
+def gemm_mxfp8_gelu_quant(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor],
+                          out: torch.Tensor, scale: torch.Tensor):
+    """quant_rows_mxfp8(gelu_tanh(aq @ wq^T + bias) rounded to bf16) with the quantisation fused into the GEMM epilogue: `out` (uint8 e4m3
+    [M, N]) and `scale` (tiled E8M0 bytes of an [M, N] operand) are the next GEMM's A operand; no bf16 matrix is written.  N % 128 == 0."""
+    _dev(aq, torch.uint8, "aq"), _dev(wq, torch.uint8, "wq"), _dev(sa, torch.uint8, "sa"), _dev(sw, torch.uint8, "sw")
+    _dev(out, torch.uint8, "out"), _dev(scale, torch.uint8, "scale")
+    M, K, lda = _rows(aq, "aq")
+    N, K2, ldw = _rows(wq, "wq")
+    Mo, No, ldq = _rows(out, "out")
+    if K != K2 or (Mo, No) != (M, N) or sa.numel() < mx_scale_bytes(M, K) or sw.numel() < mx_scale_bytes(N, K) or scale.numel() < mx_scale_bytes(M, N):
+        raise ValueError("gemm_mxfp8_gelu_quant: operand / scale shapes do not match")
+    if bias is not None:
+        _dev(bias, torch.float32, "bias")
+    st = _prof_begin()
+    _check(lib().ce_gemm_mxfp8_gelu_quant(_ptr(aq), _ptr(wq), _ptr(sa), _ptr(sw), _ptr(bias), _ptr(out), _ptr(scale), M, N, K, lda, ldw, ldq,
+                                          _stream()), "ce_gemm_mxfp8_gelu_quant")
+    _prof_end(st, f"gemm_mxfp8_{M}x{N}x{K}_gelu_quant", 2.0 * M * N * K)
+    return out, scale
+
+
 def set_gemm_fp8_variant(v: int) -> int:
     """Main loop of `gemm_fp8`: 0 = 8 waves / 4 phases, 1 = one wave per SIMD (ce_gemm_fp8w4.hip); returns the previous setting."""
     return lib().ce_set_gemm_fp8_variant(int(v))

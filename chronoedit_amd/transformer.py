@@ -198,6 +198,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.attn_dtype = "bf16"    # "mxfp8": self-attention on the MX-fp8 matrix instruction (csrc/ce_attn_fp8.hip)
         self.v_transposed = True    # bf16 self-attention takes V^T straight from the projection (swapped GEMM) and stages it by LDS-DMA
         self.sp_batch_cfg = True    # sequence-parallel forwards take the guidance pair as one batch of two (blocked-layout kernels)
+        self.fp8_fuse_quant = True  # MX fp8 mode: the FFN-up epilogue emits the FFN-down operand quantised (no bf16 hidden matrix, no quant pass)
         self.cross_vt = True        # cross-attention takes V^T of the text / image context straight from the context projections (LDS-DMA kernel)
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
         self._cfgp = None           # CFG parallelism on top of it (two Ulysses groups), off by default
@@ -513,6 +514,7 @@ class DiTEngine:
         self.fp8_attn = model.attn_dtype == "mxfp8"
         self.fp8 = model.gemm_dtype in ("fp8", "mxfp8")
         self.mx = model.gemm_dtype == "mxfp8"  # MX block scales on both GEMM operands (ce_gemm_mxfp8)
+        self.fuse_quant = bool(getattr(model, "fp8_fuse_quant", True)) and self.F % 128 == 0  # MX: quantisation fused into the FFN-up epilogue
         self.v_transposed = bool(getattr(model, "v_transposed", True))
         if self.fp8:
             if self.D % 256 or self.F % 256:
@@ -647,6 +649,9 @@ class DiTEngine:
                 ws.a8 = torch.empty((N, max(D, F)), dtype=torch.uint8, device=dev)
                 ws.s8 = (torch.empty((ops.mx_scale_bytes(N, max(D, F)),), dtype=torch.uint8, device=dev) if self.mx else
                          torch.empty((N,), dtype=torch.float32, device=dev))
+                if self.mx and self.fuse_quant and F % 128 == 0:  # the FFN hidden activation as the up-projection's epilogue writes it
+                    ws.a8b = torch.empty((N, F), dtype=torch.uint8, device=dev)
+                    ws.s8b = torch.empty((ops.mx_scale_bytes(N, F),), dtype=torch.uint8, device=dev)
             if self.fp8_attn:  # MXFP8 q / k (+ E8M0 scale bytes); the V^T tiles depend on the batch split and are sized in forward
                 u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
                 ws.q8, ws.k8, ws.sq, ws.sk = u8(N, D), u8(N, D), u8(N, D // 32), u8(N, D // 32)
@@ -899,9 +904,18 @@ class DiTEngine:
                 ops.attention(ws.q2, k_t, v_t, H, out=ws.att, batch=B)
             self._linear(ws, ws.att, p, "o2", x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
-            self._ln_linear(ws, x, mod[li, 0, 4], mod[li, 0, 3], p, "f1", ws.ffn, ab_rows=Nl, ab_stride=6 * D, epilogue=ops.EPI_BIAS_GELU)
-            self._linear(ws, ws.ffn, p, "f2", x, epilogue=ops.EPI_GATE_RES, gate=gate_ffn[li] if B > 1 else mods[0][li, 5],
-                         res=x, gate_rows=grow)
+            if self.mx and self.fuse_quant:
+                # MX: the up-projection's bias + GELU epilogue emits the down-projection's fp8 operand and its block scales directly (a
+                # block = 32 consecutive output columns: no row-wide reduction) - no bf16 [N, F] matrix, no quantisation pass
+                aq = ws.a8[:, :D]
+                ops.ln_affine_mxfp8(x, mod[li, 0, 4], mod[li, 0, 3], eps, out=aq, scale=ws.s8, ab_rows=Nl, ab_stride=6 * D)
+                ops.gemm_mxfp8_gelu_quant(aq, ws.s8, *p.q_f1, p.b_f1, out=ws.a8b, scale=ws.s8b)
+                ops.gemm_mxfp8(ws.a8b, ws.s8b, *p.q_f2, p.b_f2, out=x, epilogue=ops.EPI_GATE_RES,
+                               gate=gate_ffn[li] if B > 1 else mods[0][li, 5], res=x, gate_rows=grow)
+            else:
+                self._ln_linear(ws, x, mod[li, 0, 4], mod[li, 0, 3], p, "f1", ws.ffn, ab_rows=Nl, ab_stride=6 * D, epilogue=ops.EPI_BIAS_GELU)
+                self._linear(ws, ws.ffn, p, "f2", x, epilogue=ops.EPI_GATE_RES, gate=gate_ffn[li] if B > 1 else mods[0][li, 5],
+                             res=x, gate_rows=grow)
 
         # K18
         ops.ln_affine(x, mod_out[0, 0, 1], mod_out[0, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=2 * D)

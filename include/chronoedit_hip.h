@@ -295,8 +295,9 @@ int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const 
                 hipStream_t stream);
 
 /* ---- the MX form of the fp8 GEMMs (round 4; BASELINE.json configs[4] "fp8 weights"): OCP MXFP8 operands - e4m3 elements with one E8M0
- * scale per 32 consecutive K elements of a row, scale = 2^(floor(log2 amax) - 8), elements RNE(x / scale) clamped to +-448 - and the block
- * scales applied INSIDE the matrix pipe by v_mfma_scale_f32_16x16x128_f8f6f4.  Scale bytes are stored in the order the GEMM reads them:
+ * scale per 32 consecutive K elements of a row, scale = the smallest power of two with amax / scale <= 448 (2^-126 for an all-zero block:
+ * the non-saturating choice - with the OCP floor rule 2^(floor(log2 amax) - 8) an eighth of the blocks have their largest elements clipped),
+ * elements RNE(x / scale) - and the block scales applied INSIDE the matrix pipe by v_mfma_scale_f32_16x16x128_f8f6f4.  Scale bytes are stored in the order the GEMM reads them:
  * [ceil(rows / 128)][K / 128][4][16][8], i.e. the scale of elements [128 t + 32 g, + 32) of row r at byte
  * ((r / 128 * (K / 128) + t) * 4 + g) * 128 + (r % 16) * 8 + (r / 16) % 8; a scale buffer holds ceil(rows / 128) * (K / 128) * 512 bytes.
  * The reference has no fp8 path: the contract is oracle.dit_oracle.mx_quant / linear_mxfp8. ---- */
@@ -313,6 +314,13 @@ int ce_ln_affine_mxfp8(const void* x, void* q, void* scale8, const float* a, con
  * as ce_gemm_bf16; the one-wave-per-SIMD main loop of csrc/ce_gemm_fp8w4.hip, split-K tail through the ce_set_gemm_workspace scratch. */
 int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void* sa8, const void* sw8, const float* bias, int epilogue, const float* gate,
                   const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, hipStream_t stream);
+
+/* The FFN-up form: q_out / qs_out = ce_quant_rows_mxfp8( bf16( gelu_tanh( bf16( Aq Wq^T + bias ) ) ) ) - the bias + GELU epilogue emits the
+ * NEXT GEMM's MX operand directly (bit-identical to ce_gemm_mxfp8 with epilogue 1 followed by ce_quant_rows_mxfp8; the bf16 matrix is
+ * never written: an MX block is 32 consecutive output columns = four adjacent 16-byte chunks of the staged row, so its scale needs no
+ * row-wide reduction).  q_out e4m3 bytes [M][ldq], qs_out the tiled scales of an [M][N] operand.  N % 128 == 0, K % 256 == 0. */
+int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* sa8, const void* sw8, const float* bias, void* q_out, void* qs_out,
+                             int M, int N, int K, int lda, int ldw, int ldq, hipStream_t stream);
 
 /* Main loop of ce_gemm_fp8 (returns the previous setting): 0 = 8 waves / 4 phases per K-tile (csrc/ce_gemm_fp8.hip), 1 = one wave per
  * SIMD (csrc/ce_gemm_fp8w4.hip: 4 waves, 128 x 128 wave tiles, accumulators in AGPRs, one barrier per K-tile).  Same results bit for

@@ -251,9 +251,9 @@ def linear_fp8(x, p, name):
 
 def linear_mxfp8(x, p, name):
     """A Linear under the MX form of the fp8 contract (round 4: include/chronoedit_hip.h ce_gemm_mxfp8): activations and weights as OCP
-    MXFP8 - e4m3 elements, one E8M0 scale per 32 consecutive INPUT channels of a row (mx_quant below) - exact products, block scales
-    applied to the partial sums, bias added afterwards.  (The reference has no fp8 path: this is the definition.)"""
-    return F.linear(mx_quant(x, -1).to(x.dtype), mx_quant(p[name + ".weight"], -1).to(x.dtype), p[name + ".bias"])
+    MXFP8 - e4m3 elements, one E8M0 scale per 32 consecutive INPUT channels of a row (mx_quant below, non-saturating scale choice: the
+    smallest power of two with amax / scale <= 448) - exact products, block scales applied to the partial sums, bias added afterwards.  (The reference has no fp8 path: this is the definition.)"""
+    return F.linear(mx_quant(x, -1, saturating=False).to(x.dtype), mx_quant(p[name + ".weight"], -1, saturating=False).to(x.dtype), p[name + ".bias"])
 
 
 def _fp8_linear(fp8):
@@ -263,10 +263,11 @@ def _fp8_linear(fp8):
     return linear_mxfp8 if fp8 == "mx" else linear_fp8
 
 
-def mx_quant(x: torch.Tensor, dim: int = -1, block_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+def mx_quant(x: torch.Tensor, dim: int = -1, block_index: Optional[torch.Tensor] = None, saturating: bool = True) -> torch.Tensor:
     """OCP MXFP8 (e4m3 elements, one E8M0 scale per 32 elements along `dim`), returned de-quantised in fp32: the contract of
     chronoedit_amd/csrc/ce_attn_fp8.hip.  scale = 2^(floor(log2 amax) - 8) (2^-126 for an all-zero block), elements =
-    RNE(x / scale) clamped to +-448.  block_index (optional, [size of dim] long): block id of every element along `dim` when the
+    RNE(x / scale) clamped to +-448 (saturating=True: the OCP floor rule, what the attention operands use; saturating=False: one step up
+    when amax / scale would exceed 448, what the GEMM operands use).  block_index (optional, [size of dim] long): block id of every element along `dim` when the
     32-element blocks are not the contiguous ones (the V operand: see attention_mxfp8)."""
     xf = x.float().movedim(dim, -1)
     n = xf.shape[-1]
@@ -274,6 +275,8 @@ def mx_quant(x: torch.Tensor, dim: int = -1, block_index: Optional[torch.Tensor]
         xb = xf.reshape(xf.shape[:-1] + (n // 32, 32))
         amax = xb.abs().amax(-1, keepdim=True)
         e = torch.floor(torch.log2(torch.clamp(amax, min=2.0 ** -118))) - 8.0
+        if not saturating:  # the smallest power of two with amax / scale <= 448 (the GEMM operands: ce_common.h mx_scale_byte_nosat)
+            e = e + (amax > 448.0 * torch.exp2(e)).float()
         e = torch.where(amax > 0, torch.clamp(e, min=-126.0), torch.full_like(e, -126.0))
         scale = torch.exp2(e)
         q = torch.clamp(xb / scale, -448.0, 448.0).to(torch.float8_e4m3fn).float() * scale
