@@ -393,6 +393,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// Split-K tail of the FFN-up form: sums the `split` fp32 slabs of one quadrant (= one producer wave's 128 x 128 accumulators, layout
+// [wave][f][g][lane] as the partial tiles above write them) of a tail tile, adds the bias, applies GELU and the MX quantisation of
+// EPI_BIAS_GELU_Q.  grid = 4 x the number of tail tiles, 256 threads: thread (w, lane) takes accumulator rows f = 2w, 2w+1 of the quadrant.
+__global__ __launch_bounds__(256) void gemm_fp8w4_reduce_gelu_q(unsigned char* __restrict__ q_out, unsigned char* __restrict__ qs_out,
+                                                                const float* __restrict__ bias, int M, int N, int ldq, int tiles_m, int tiles_n,
+                                                                int t_full, int split, const float* __restrict__ ws) {
+  constexpr int QROW = 128 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[128 * QROW];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;  // q = producer wave = (wm, wn)
+  int m0, n0;
+  {
+    constexpr int GROUP = 4;  // the raster of gemm_fp8_w4
+    const int wg = t_full + tile;
+    const int group_sz = GROUP * tiles_n, gid = wg / group_sz, first_m = gid * GROUP;
+    const int gm = min(tiles_m - first_m, GROUP);
+    m0 = (first_m + (wg % group_sz) % gm) * BM + (q >> 1) * 128;
+    n0 = ((wg % group_sz) / gm) * BN + (q & 1) * 128;
+  }
+  const float* slab = ws + (size_t)tile * split * (BM * BN);
+#pragma unroll
+  for (int ff = 0; ff < 2; ++ff) {
+    const int f = 2 * w + ff;
+    const int rl = f * 16 + fr;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int cl = g * 16 + fg * 4;
+      const f32x4 bv = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + min(n0 + cl, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int e = (((q * 64 + f * 8 + g) * 64) + lane) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
+      for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
+      const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
+      *reinterpret_cast<u32x2*>(smem + rl * QROW + cl * 2) = pk;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tt = 0; tt < 8; ++tt) {
+    const int c = tid + 256 * tt;
+    const int rl = c >> 4, cc = c & 15;
+    const int m = m0 + rl, n = n0 + cc * 8;
+    const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * QROW + cc * 16);
+    u32x4 o;
+    float am = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o[k] = pack_bf16(gelu_tanh(bf16lo(y[k])), gelu_tanh(bf16hi(y[k])));
+      am = fmaxf(am, fmaxf(fabsf(bf16lo(o[k])), fabsf(bf16hi(o[k]))));
+    }
+    am = fmaxf(am, __shfl_xor(am, 1, 64));
+    am = fmaxf(am, __shfl_xor(am, 2, 64));
+    const int byte = mx_scale_byte_nosat(am);
+    const float inv = mx_inv_scale(byte);
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[0]) * inv), clamp448(bf16hi(o[0]) * inv), w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[1]) * inv), clamp448(bf16hi(o[1]) * inv), w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[2]) * inv), clamp448(bf16hi(o[2]) * inv), w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[3]) * inv), clamp448(bf16hi(o[3]) * inv), w1, true);
+    if (m < M && n < N) {
+      *reinterpret_cast<u32x2*>(q_out + (size_t)m * ldq + n) = u32x2{(uint32_t)w0, (uint32_t)w1};
+      if ((cc & 3) == 0) qs_out[mx_gemm_scale_offset(m, n >> 5, N >> 7)] = (unsigned char)byte;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" void ce_gemm256_workspace(hipStream_t stream, float** ws, size_t* bytes, int* cus);
@@ -487,8 +553,8 @@ extern "C" int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void
                       lda, ldw, ldc, ldres, gate_rows, stream);
 }
 
-/* bias + tanh GELU with the MX quantisation of the result fused into the epilogue (include/chronoedit_hip.h).  No split-K tail: the
- * slab reduce writes bf16. */
+/* bias + tanh GELU with the MX quantisation of the result fused into the epilogue (include/chronoedit_hip.h); the split-K tail of a
+ * partially filled last round goes through gemm_fp8w4_reduce_gelu_q. */
 extern "C" int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* sa8, const void* sw8, const float* bias, void* q_out, void* qs_out,
                                         int M, int N, int K, int lda, int ldw, int ldq, hipStream_t stream) {
   if (!Aq || !Wq || !sa8 || !sw8 || !q_out || !qs_out) return CE_ERR_ARG;
@@ -496,14 +562,36 @@ extern "C" int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const vo
   if ((lda & 15) || (ldw & 15) || (ldq & 7)) return CE_ERR_ALIGN;
   if ((long long)M * lda >= (1ll << 32) || (long long)N * ldw >= (1ll << 32)) return CE_ERR_SHAPE;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n, kt = K / BKB;
+  float* g_ws = nullptr;
+  size_t g_ws_bytes = 0;
+  int g_cus = 256;
+  ce_gemm256_workspace(stream, &g_ws, &g_ws_bytes, &g_cus);
+  int tail = nwg % g_cus, split = 1;
+  if (tail > 0 && g_ws != nullptr) {  // (the heuristics of fp8w4_launch)
+    for (int sp = std::min(g_cus / tail, 8); sp >= 2; --sp)
+      if (kt % (2 * sp) == 0 && (size_t)tail * sp * BM * BN * sizeof(float) <= g_ws_bytes) {
+        split = sp;
+        break;
+      }
+    if (split > 1) {
+      const double saving_us = (1.0 - 1.0 / split) * kt * 1.7, slabs_us = (double)tail * split * 0.128 + 8.0;
+      if (saving_us < 1.5 * slabs_us) split = 1;
+    }
+  }
+  if (split == 1) tail = 0;
+  const int t_full = nwg - tail;
   static bool done_[CE_MAX_DEVICES] = {};
   bool& done = done_[ce_device_slot()];
   if (!done) {
     if (hipFuncSetAttribute((const void*)gemm_fp8_w4<EPI_BIAS_GELU_Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return CE_ERR_ARG;
     done = true;
   }
-  hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true>), dim3(tiles_m * tiles_n), dim3(256), 2 * STAGE, stream, (const unsigned char*)Aq,
+  hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true>), dim3(t_full + tail * split), dim3(256), 2 * STAGE, stream, (const unsigned char*)Aq,
                      (const unsigned char*)Wq, (bf16*)q_out, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, nullptr,
-                     nullptr, M, N, K, lda, ldw, ldq, 0, 0, tiles_m, tiles_n, tiles_m * tiles_n, 1, nullptr, (unsigned char*)qs_out);
+                     nullptr, M, N, K, lda, ldw, ldq, 0, 0, tiles_m, tiles_n, t_full, split, g_ws, (unsigned char*)qs_out);
+  if (tail)
+    hipLaunchKernelGGL(gemm_fp8w4_reduce_gelu_q, dim3(4 * tail), dim3(256), 0, stream, (unsigned char*)q_out, (unsigned char*)qs_out, bias, M, N, ldq,
+                       tiles_m, tiles_n, t_full, split, g_ws);
   return (int)hipGetLastError();
 }
