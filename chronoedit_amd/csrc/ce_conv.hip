@@ -314,6 +314,136 @@ extern "C" int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames,
   return (int)hipGetLastError();
 }
 
+// ---- the decoder's head conv: 3 x 3 x 3, stride 1, 96 -> 3 channels at full resolution (wan2pt1.py:401-403, Decoder3d.head) -------
+// As an implicit GEMM it has N = 3 (padded to 8, computed as a 32-wide tile): 2.7 ms at 720p for ~1 GB of input.  Here the three
+// kernel ROWS ride in the matrix instruction's idle output rows instead: A = weights with row n = (kh, co) = 3 x 4 of the 16,
+// B = 16 consecutive pixels of ONE input row rho, K = 32 input channels.  P[rho][(kh, co)][pixel] summed over (kt, kw, channel
+// chunk) is then every contribution input row rho makes to the three output rows rho - kh at once, and out[h] = P[h][kh = 0] +
+// P[h + 1][kh = 1] + P[h + 2][kh = 2] is three lanes' registers (row n of D lives in lane group n >> 2): two cross-lane moves per
+// value at the very end.  A wave owns 8 output rows x 16 columns = 10 input rows: 27 x 10 MFMAs (a third of the per-tap count), the
+// B fragments straight from global memory - 16-byte loads, a pixel row's 18 x 192 B strip is touched by nine loads in one burst and
+// comes out of the L1 - with the 27 weight fragments of the workgroup in LDS (27 KiB) and the nine of the current kt in registers.
+// Workgroup: 4 waves = 8 rows x 64 columns (162 registers: three workgroups per CU).
+namespace {
+constexpr int HEAD_ROWS = 8, HEAD_COLS = 64;
+
+__global__ __launch_bounds__(256) void conv_head_kernel(ConvParams p, int H_tiles, int W_tiles) {
+  __shared__ __attribute__((aligned(16))) unsigned char wsm[27 * 1024];
+  __shared__ const bf16* s_in[MAX_FRAMES];
+  __shared__ bf16* s_out[MAX_FRAMES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int CIN = 96, CCH = 3;
+  const int taps = p.KT * 9;
+  if (tid < MAX_FRAMES) {
+    s_in[tid] = p.in_frames[tid];
+    s_out[tid] = p.out_frames[tid];
+  }
+  // weight fragments, lane-linear: fragment (kt, kw, c), lane (n = (kh, co), g) <- W[co][(kt, kh, kw)][32 c + 8 g ...]
+  for (int i = tid; i < p.KT * 9 * 64; i += 256) {
+    const int f = i >> 6, l = i & 63, n = l & 15, g = l >> 4;
+    const int kt = f / 9, kw = (f % 9) / CCH, c = f % CCH, kh = n >> 2, co = n & 3;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (kh < 3 && co < p.Cout) v = *reinterpret_cast<const u32x4*>(p.weight + ((size_t)co * taps + (kt * 3 + kh) * 3 + kw) * CIN + c * 32 + g * 8);
+    *reinterpret_cast<u32x4*>(wsm + (size_t)i * 16) = v;
+  }
+  __syncthreads();
+
+  const int wb = blockIdx.x % W_tiles, hb = (blockIdx.x / W_tiles) % H_tiles, t = blockIdx.x / (W_tiles * H_tiles);
+  const int h0 = hb * HEAD_ROWS, w0 = wb * HEAD_COLS + wave * 16;
+  if (w0 >= p.W_out) return;
+  const int Hp = p.H_out + 2;
+  const int wcol = min(w0 + fr, p.W_out - 1);  // (clamped columns are computed and not stored)
+  int roff[HEAD_ROWS + 2];
+#pragma unroll
+  for (int r = 0; r < HEAD_ROWS + 2; ++r) roff[r] = (min(h0 + r, Hp - 1) * p.in_Wp + wcol) * CIN + fg * 8;
+
+  f32x4 acc[HEAD_ROWS + 2];
+#pragma unroll
+  for (int r = 0; r < HEAD_ROWS + 2; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t frame_bytes = (uint32_t)Hp * (uint32_t)p.in_Wp * CIN * 2u;
+  for (int kt = 0; kt < p.KT; ++kt) {
+    // the frame as a buffer resource (uniform base, 32-bit byte offsets): buffer loads count on vmcnt alone - a pointer read back from
+    // LDS is a generic one to hipcc, and flat loads made it wait for every single fragment
+    const uint64_t fp = reinterpret_cast<uint64_t>(s_in[t + kt]);
+    const uint64_t fpu = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)fp);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(fpu), 0, frame_bytes, 0x00020000);
+    bf16x8 wf[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wf[q] = *reinterpret_cast<const bf16x8*>(wsm + ((size_t)(kt * 9 + q) * 64 + lane) * 16);
+    u32x4 bq[2][9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) bq[0][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, roff[0] * 2, ((q / CCH) * CIN + (q % CCH) * 32) * 2, 0);
+#pragma unroll
+    for (int r = 0; r < HEAD_ROWS + 2; ++r) {
+      if (r + 1 < HEAD_ROWS + 2) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+          bq[(r + 1) & 1][q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, roff[r + 1] * 2, ((q / CCH) * CIN + (q % CCH) * 32) * 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // row r+1's nine loads are in flight BEFORE row r's MFMAs (hipcc otherwise walks q outermost)
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q], __builtin_bit_cast(bf16x8, bq[r & 1][q]), acc[r], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // out[h0 + j] = P[j][kh 0] + P[j + 1][kh 1] + P[j + 2][kh 2]: lane group fg holds kernel row kh = fg of every P
+  f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < p.Cout) bias[i] = p.bias[i];
+  }
+  bf16* __restrict__ out = s_out[t];
+#pragma unroll
+  for (int j = 0; j < HEAD_ROWS; ++j) {
+    f32x4 v = acc[j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += __shfl_down(acc[j + 1][i], 16) + __shfl_down(acc[j + 2][i], 32) + bias[i];
+    const int h = h0 + j, w = w0 + fr;
+    if (fg == 0 && h < p.H_out && w < p.W_out) {
+      const size_t o = ((size_t)(h + p.out_border) * p.out_Wp + (w + p.out_border)) * p.out_cstride + p.out_coff;
+      if (p.out_cstride - p.out_coff >= 8)
+        *reinterpret_cast<u32x4*>(out + o) = u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), 0u, 0u};
+      else
+        *reinterpret_cast<u32x2*>(out + o) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    }
+  }
+}
+}  // namespace
+
+// 3 x 3 x 3 (KT = 3) or 1 x 3 x 3 (KT = 1) stride-1 conv of 96 input channels onto Cout <= 4 channels (weight [>= Cout][KT*9][96]).
+// Frames, addressing and result as ce_conv_igemm_bf16 with st = ss = 1, in_off = 0 and no residual; channels Cout .. 3 (and .. 7 when the
+// pixel stride leaves room for them) are written as zeros.
+extern "C" int ce_conv3d_head_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias,
+                                   void* const* out_frames, int n_out_frames, int Cin, int Cout, int KT, int H_out, int W_out, int in_Wp,
+                                   int out_Wp, int out_border, int out_cstride, int out_coff, hipStream_t stream) {
+  if (!in_frames || !weight || !out_frames) return CE_ERR_ARG;
+  if (n_in_frames <= 0 || n_in_frames > MAX_FRAMES || n_out_frames <= 0 || n_out_frames > MAX_FRAMES) return CE_ERR_SHAPE;
+  if (Cin != 96 || Cout < 1 || Cout > 4 || (KT != 1 && KT != 3) || (out_cstride & 3) || (out_coff & 3) || out_cstride - out_coff < 4 ||
+      n_out_frames - 1 + KT > n_in_frames || in_Wp < W_out + 2 || H_out < 1 || W_out < 1)
+    return CE_ERR_SHAPE;
+  ConvParams p;
+  for (int i = 0; i < MAX_FRAMES; ++i) {
+    p.in_frames[i] = (const bf16*)in_frames[i < n_in_frames ? i : n_in_frames - 1];
+    p.out_frames[i] = (bf16*)out_frames[i < n_out_frames ? i : n_out_frames - 1];
+    p.res_frames[i] = nullptr;
+  }
+  p.weight = (const bf16*)weight;
+  p.bias = bias;
+  p.n_out_frames = n_out_frames;
+  p.Cin = Cin; p.Cout = Cout; p.KT = KT; p.KH = 3; p.KW = 3; p.st = 1; p.ss = 1;
+  p.H_out = H_out; p.W_out = W_out; p.in_Wp = in_Wp; p.in_off_h = 0; p.in_off_w = 0;
+  p.out_Wp = out_Wp; p.out_border = out_border; p.out_cstride = out_cstride; p.out_coff = out_coff;
+  p.has_res = 0;
+  const int H_tiles = (H_out + HEAD_ROWS - 1) / HEAD_ROWS, W_tiles = (W_out + HEAD_COLS - 1) / HEAD_COLS;
+  hipLaunchKernelGGL(conv_head_kernel, dim3(n_out_frames * H_tiles * W_tiles), dim3(256), 0, stream, p, H_tiles, W_tiles);
+  return (int)hipGetLastError();
+}
+
 // ---- 3 x 3 (x 3) stride-1 convolutions of >= 128 output channels on the 256 x 256 x 64 LDS-DMA GEMM (ce_gemm256w4.hip) -------------
 // On bordered channels-last frames a stride-1 3 x 3 x 3 convolution IS a GEMM whose A rows are linear in memory: count output
 // positions on the PADDED grid, p = (t Hp + hp) Wp + wp, and tap (kt, kh, kw) of output position p reads input position

@@ -75,6 +75,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_patchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ce_unpatchify_bf16": [_P, _P, _I, _I, _I, _I, _I, _P],
     "ce_conv_igemm_bf16": [_P, _I, _P, _P, _P, _I, _P] + [_I] * 16 + [_P],
+    "ce_conv3d_head_bf16": [_P, _I, _P, _P, _P, _I] + [_I] * 10 + [_P],
     "ce_gemm_bf16_tile_rows": [_I, _I, _I, _I, _c.c_longlong],
     "ce_zero_border_bf16": [_P, _I, _I, _I, _I, _I, _P],
     "ce_conv3d_gemm_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

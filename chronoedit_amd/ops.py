@@ -555,6 +555,20 @@ def conv_igemm(in_frames, weight: torch.Tensor, bias: Optional[torch.Tensor], ou
               2.0 * len(out_frames) * H_out * W_out * Cout * Cin * KT * KH * KW)
 
 
+def conv3d_head(in_frames, weight: torch.Tensor, bias: Optional[torch.Tensor], out_frames, *, Cin: int, Cout: int, KT: int, H_out: int,
+                W_out: int, in_Wp: int, out_Wp: int, out_border: int, out_cstride: int, out_coff: int = 0):
+    """Stride-1 3x3(x3) conv of 96 channels onto <= 4 (the VAE decoder's head conv) - ce_conv3d_head_bf16, see include/chronoedit_hip.h."""
+    for t in list(in_frames) + list(out_frames):
+        _dev(t, torch.bfloat16, "frame")
+    _dev(weight, torch.bfloat16, "weight")
+    assert weight.is_contiguous() and weight.numel() >= Cout * KT * 9 * Cin
+    ia, oa = _ptr_array(in_frames), _ptr_array(out_frames)
+    st_ev = _prof_begin()
+    _check(lib().ce_conv3d_head_bf16(ia, len(in_frames), _ptr(weight), _ptr(bias), oa, len(out_frames), Cin, Cout, KT, H_out, W_out, in_Wp,
+                                     out_Wp, out_border, out_cstride, out_coff, _stream()), "ce_conv3d_head_bf16")
+    _prof_end(st_ev, f"conv_head_{KT}x3x3_{Cin}->{Cout}_{len(out_frames)}x{H_out}x{W_out}", 2.0 * len(out_frames) * H_out * W_out * Cout * Cin * KT * 9)
+
+
 def rms_silu(x: torch.Tensor, gamma: torch.Tensor, out: torch.Tensor, T: int, C: int, H: int, W: int, in_border: int,
              out_border: int, silu: bool = True):
     _dev(x, torch.bfloat16, "x"), _dev(out, torch.bfloat16, "out"), _dev(gamma, torch.float32, "gamma")

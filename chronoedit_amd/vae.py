@@ -116,6 +116,7 @@ class WanVAEEngine:
         self._attn_vt: Dict[tuple, torch.Tensor] = {}  # mid-block attention scratch per (C, padded h*w): see _attn
         self._attn_ws: Dict[tuple, tuple] = {}
         self.use_gemm_conv = True  # wide stride-1 3x3(x3) convs on the large-tile GEMM (False: every conv on the implicit-GEMM kernel)
+        self.use_head_conv = True  # the decoder's 96 -> 3 head conv on its own bandwidth kernel (False: implicit GEMM with N = 8)
         self._layers()
 
     # -- architecture (wan2pt1.py:283-305, 384-415) ------------------------------------------------
@@ -177,9 +178,15 @@ class WanVAEEngine:
             out = Frames(T_out, H_out, W_out, out_C or Cout, self.dev, zero=(out_C or Cout) != Cout)
         of = out_frames if out_frames is not None else out.frame_list()
         oC = out.C if out is not None else out_C
-        ops.conv_igemm(in_frames, w, b, of, res.frame_list() if res is not None else None, Cin=pk.Cin_p, Cout=Cout, KT=KT, KH=KH, KW=KW,
-                       st=st, ss=ss, H_out=H_out, W_out=W_out, in_Wp=in_W + 2, in_off=in_off, out_Wp=W_out + 2, out_border=1,
-                       out_cstride=oC)
+        if (self.use_head_conv and pk.Cout <= 4 and pk.Cin_p == 96 and (KH, KW) == (3, 3) and KT in (1, 3) and st == 1 and ss == 1
+                and in_off == 0 and res is None and cout_slice is None):
+            # the decoder's 96 -> 3 head conv: three channels do not fill an implicit-GEMM tile (ce_conv3d_head_bf16)
+            ops.conv3d_head(in_frames, w, b, of, Cin=96, Cout=pk.Cout, KT=KT, H_out=H_out, W_out=W_out, in_Wp=in_W + 2, out_Wp=W_out + 2,
+                            out_border=1, out_cstride=oC)
+        else:
+            ops.conv_igemm(in_frames, w, b, of, res.frame_list() if res is not None else None, Cin=pk.Cin_p, Cout=Cout, KT=KT, KH=KH, KW=KW,
+                           st=st, ss=ss, H_out=H_out, W_out=W_out, in_Wp=in_W + 2, in_off=in_off, out_Wp=W_out + 2, out_border=1,
+                           out_cstride=oC)
         if fresh and out.C == Cout:
             ops.zero_border(out.data, T_out, H_out, W_out, Cout)
         return out

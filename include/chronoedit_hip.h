@@ -236,6 +236,15 @@ int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames, const void
                        int KH, int KW, int st, int ss, int H_out, int W_out, int in_Wp, int in_off_h, int in_off_w, int out_Wp,
                        int out_border, int out_cstride, int out_coff, hipStream_t stream);
 
+/* The decoder's head conv (Decoder3d.head, wan2pt1.py:401-403: CausalConv3d(96, 3, 3, padding=1)) as a bandwidth kernel: stride-1
+ * 3 x 3 x 3 (KT = 3) or 1 x 3 x 3 (KT = 1) of Cin = 96 onto Cout <= 4 channels.  Same frames, addressing and result as
+ * ce_conv_igemm_bf16 with st = ss = 1, in_off = 0 and no residual (weight [>= Cout][KT*9][96] bf16, bias fp32 [>= Cout] or NULL);
+ * channels Cout..3 of an output pixel - and 4..7 when out_cstride - out_coff >= 8 - are written as zeros.  The three kernel rows ride
+ * in the matrix instruction's output rows, so one pass over ten input rows yields eight output rows. */
+int ce_conv3d_head_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias, void* const* out_frames,
+                        int n_out_frames, int Cin, int Cout, int KT, int H_out, int W_out, int in_Wp, int out_Wp, int out_border,
+                        int out_cstride, int out_coff, hipStream_t stream);
+
 /* The stride-1 3 x 3 (KT = 1) / 3 x 3 x 3 (KT = 3) convolutions of wide layers on the 256 x 256 x 64 LDS-DMA GEMM (same result as
  * ce_conv_igemm_bf16 with st = ss = 1, in_off = 0, out_border = 1): on bordered frames of one contiguous stack the A rows of the
  * implicit GEMM are linear in memory and the taps are constant offsets, so the product runs on the large-tile kernel and the border

@@ -81,6 +81,40 @@ def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, 
     assert rel_l2(out.data, old.data) < 3e-3, rel_l2(out.data, old.data)  # same products, another summation order, one bf16 rounding
 
 
+@pytest.mark.parametrize("KT,Cout,T,H,W", [(3, 3, 4, 40, 128), (3, 3, 1, 13, 70), (1, 3, 2, 8, 64), (3, 4, 2, 17, 129), (3, 1, 1, 3, 5)])
+def test_head_conv_kernel_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cout, T, H, W):
+    """ce_conv3d_head_bf16 (the decoder's 96 -> 3 head conv with the three kernel rows in the matrix instruction's output rows) vs fp32
+    conv3d and vs ce_conv_igemm_bf16 on the same frames: whole and ragged 8 x 64 tiles, one to four output channels, KT 1 and 3; the
+    pad channels of a pixel come back zero and the border stays untouched."""
+    from chronoedit_amd import ops
+    from chronoedit_amd.vae import Frames, _ConvPack
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(KT * 100 + Cout * 10 + T)
+    Cin, n_in = 96, T + KT - 1
+    x = torch.randn(Cin, n_in, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn((Cout, Cin, KT, 3, 3), generator=g) / (9 * KT * Cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(x.float()[None], (1, 1, 1, 1, 0, 0)), w.float(), b)[0]  # [Cout, T, H, W]
+    f = Frames(n_in, H, W, Cin, dev)
+    f.data[:, 1:-1, 1:-1] = x.permute(1, 2, 3, 0).to(dev)
+    pk = _ConvPack(w.to(dev), b.to(dev))
+    out = Frames(T, H, W, 8, dev, zero=False)
+    out.data.fill_(7.0)
+    ops.conv3d_head(f.frame_list(), pk.w, pk.b, out.frame_list(), Cin=Cin, Cout=Cout, KT=KT, H_out=H, W_out=W, in_Wp=W + 2, out_Wp=W + 2,
+                    out_border=1, out_cstride=8)
+    old = Frames(T, H, W, 8, dev)
+    ops.conv_igemm(f.frame_list(), pk.w, pk.b, old.frame_list(), None, Cin=Cin, Cout=8, KT=KT, KH=3, KW=3, st=1, ss=1, H_out=H, W_out=W,
+                   in_Wp=W + 2, in_off=0, out_Wp=W + 2, out_border=1, out_cstride=8)
+    got = out.data[:, 1:-1, 1:-1, :Cout].permute(3, 0, 1, 2)
+    e, e_old = rel_l2(got, ref), rel_l2(old.data[:, 1:-1, 1:-1, :Cout].permute(3, 0, 1, 2), ref)
+    assert e < 6e-3 and e <= 1.5 * e_old + 1e-4, (e, e_old)
+    assert float(out.data[:, 1:-1, 1:-1, Cout:].abs().max()) == 0.0  # pad channels
+    assert float((out.data[:, 0] - 7.0).abs().max()) == 0.0 and float((out.data[:, :, -1] - 7.0).abs().max()) == 0.0  # border untouched
+    with pytest.raises(ops.HipKernelError):
+        ops.conv3d_head(f.frame_list(), pk.w, pk.b, out.frame_list(), Cin=64, Cout=Cout, KT=KT, H_out=H, W_out=W, in_Wp=W + 2, out_Wp=W + 2,
+                        out_border=1, out_cstride=8)
+
+
 @pytest.mark.parametrize("N,C", [(384, 384), (1000, 384), (100, 128), (3600, 384), (14400, 384)])
 def test_single_head_attention_kernel_vs_fp32(N, C):
     """ce_attention_1head_bf16 (the VAE mid-block attention as one flash-style kernel, head dim 384 / 128) vs fp32 softmax(q k^T) v;
