@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_head_kernel(ConvParams p, int H_tile
     // the frame as a buffer resource (uniform base, 32-bit byte offsets): buffer loads count on vmcnt alone - a pointer read back from
     // LDS is a generic one to hipcc, and flat loads made it wait for every single fragment
     const uint64_t fp = reinterpret_cast<uint64_t>(s_in[t + kt]);
-    const uint64_t fpu = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(fp >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)fp);
+    const uint64_t fpu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fp >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fp);
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(fpu), 0, frame_bytes, 0x00020000);
     bf16x8 wf[9];
 #pragma unroll

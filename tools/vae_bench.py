@@ -14,6 +14,8 @@ H, W, T = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (720, 1280, 
 vae = AutoencoderKLWan.random_init(torch.device("cuda:0"), seed=4321)
 if os.environ.get("CE_VAE_GEMM_CONV") == "0":  # A/B: every conv on the implicit-GEMM kernel (the wide 3x3(x3) ones not on the large-tile GEMM)
     vae.engine().use_gemm_conv = False
+if os.environ.get("CE_VAE_HEAD_CONV") == "0":  # A/B: the decoder's 96 -> 3 head conv on the implicit-GEMM kernel
+    vae.engine().use_head_conv = False
 x = (torch.rand(1, 3, T, H, W, device="cuda") * 2 - 1).to(torch.bfloat16)
 res = {}
 for name, fn in (("encode", lambda: vae.encode(x).latent_dist.mode()),):
@@ -53,5 +55,5 @@ res["decode_profiled_ms"] = tot
 res["decode_top"] = {k: {"n": d["n"], "ms": round(d["total_ms"], 2), "tflops": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e12, 1)} for k, d in top}
 print(json.dumps(res, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/vae_bench.json", "w"), indent=1)
+json.dump(res, open(os.environ.get("CE_VAE_BENCH_OUT", "gpurun_out/vae_bench.json"), "w"), indent=1)
 print("max mem GB", torch.cuda.max_memory_allocated() / 1e9)
