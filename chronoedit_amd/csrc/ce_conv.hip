@@ -579,40 +579,66 @@ __global__ __launch_bounds__(256) void attn_1head_kernel(const bf16* __restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = smem + 64 * KROW;
+  unsigned char* sQ = sV + C * VROW;  // the workgroup's 64 query rows (fragments are re-read per tile: 48 registers the staging needs)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int q0 = blockIdx.x * 64 + wave * 16;
-  bf16x8 qf[KS];
-  {
-    const bf16* qrow = Q + (size_t)min(q0 + fr, Nq - 1) * ldq + 8 * fg;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks);
+  for (int c = tid; c < 64 * (C / 8); c += 256) {
+    const int r = c / (C / 8), cc = c - r * (C / 8);
+    *reinterpret_cast<u32x4*>(sQ + r * KROW + cc * 16) = *reinterpret_cast<const u32x4*>(Q + (size_t)min(blockIdx.x * 64 + r, Nq - 1) * ldq + cc * 8);
   }
   f32x4 o[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -3.0e38f, l_run = 0.f;
   const int ntiles = (Nk + 63) / 64;
+  // Tiles are register-staged ONE AHEAD: the global loads of tile t + 1 are issued before tile t's products and written to LDS after
+  // them (a lone wave per SIMD owns 512 registers: 2 x C / 32 staging vectors are free), so the only exposed memory round trip is the
+  // first tile's.  (Round 3 loaded each tile between two barriers with nothing in flight: 2.25 ms per 14 400-position frame.)
+  // Chunk -> thread maps that keep ONE per-thread offset per operand (everything else is a wave-uniform or immediate term; with 24
+  // per-chunk 64-bit pointers hipcc parked 190 values in the accumulator file and moved 550 of them per tile):
+  //   K tile:   rows (tid >> 4) + 16 j, 16-byte chunks (tid & 15) + 16 m   (j < 4, m < C / 128)
+  //   V^T tile: rows (tid >> 3) + 32 j, chunk tid & 7                       (j < C / 32)
+  // as buffer loads: rows past Nk read as zero (their scores are masked below; V^T columns past Nk are zero by contract).
+  constexpr int NKM = C / 128, NVJ = C / 32;
+  u32x4 stK[4][NKM], stV[NVJ];
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (uint32_t)(Nk - 1) * (uint32_t)(ldk * 2) + C * 2u, 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, (uint32_t)(C - 1) * (uint32_t)(ldvt * 2) + (uint32_t)ntiles * 128u, 0x00020000);
+  const int k_voff = (tid >> 4) * ldk * 2 + (tid & 15) * 16, v_voff = (tid >> 3) * ldvt * 2 + (tid & 7) * 16;
+  unsigned char* const k_dst = sK + (tid >> 4) * KROW + (tid & 15) * 16;
+  unsigned char* const v_dst = sV + (tid >> 3) * VROW + (tid & 7) * 16;
+  auto gload = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < NKM; ++m) stK[j][m] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff + m * 256, (t * 64 + j * 16) * ldk * 2, 0);
+#pragma unroll
+    for (int j = 0; j < NVJ; ++j) stV[j] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_voff, j * 32 * ldvt * 2 + t * 128, 0);
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int m = 0; m < NKM; ++m) *reinterpret_cast<u32x4*>(k_dst + j * 16 * KROW + m * 256) = stK[j][m];
+#pragma unroll
+    for (int j = 0; j < NVJ; ++j) *reinterpret_cast<u32x4*>(v_dst + j * 32 * VROW) = stV[j];
+  };
+  gload(0);
+  lstore();
   for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();
-    constexpr int KCH = 64 * (C / 8);  // 16-byte chunks of the K tile
-    for (int c = tid; c < KCH; c += 256) {
-      const int r = c / (C / 8), cc = c - r * (C / 8);
-      *reinterpret_cast<u32x4*>(sK + r * KROW + cc * 16) = *reinterpret_cast<const u32x4*>(K + (size_t)min(t * 64 + r, Nk - 1) * ldk + cc * 8);
-    }
-    for (int c = tid; c < C * 8; c += 256) {
-      const int r = c >> 3, cc = c & 7;
-      *reinterpret_cast<u32x4*>(sV + r * VROW + cc * 16) = *reinterpret_cast<const u32x4*>(Vt + (size_t)r * ldvt + t * 64 + cc * 8);
-    }
-    __syncthreads();
+    __syncthreads();  // tile t is in LDS
+    gload(min(t + 1, ntiles - 1));  // (the last iteration re-loads the last tile: harmless, and the loop stays branch-free)
+    __builtin_amdgcn_sched_barrier(0);  // (in flight across the whole tile: hipcc must not sink them towards the LDS stores)
     f32x4 s[4];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < 4; ++kb) s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (wave * 16 + fr) * KROW + (32 * ks + 8 * fg) * 2);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 16 + fr) * KROW + (32 * ks + 8 * fg) * 2);
-        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s[kb], 0, 0, 0);
       }
     }
     // online softmax in the exp2 domain; keys past Nk are masked (their K rows were clamped copies)
@@ -639,8 +665,10 @@ __global__ __launch_bounds__(256) void attn_1head_kernel(const bf16* __restrict_
         psum += s[kb][j];
       }
     l_run = l_run * alpha + psum;
+    if (__any(alpha != 1.0f)) {  // the running maxima settle after a few tiles: most tiles rescale nothing
 #pragma unroll
-    for (int d = 0; d < DB; ++d) o[d] *= alpha;
+      for (int d = 0; d < DB; ++d) o[d] *= alpha;
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       u32x4 pw = {pack_bf16(s[2 * h][0], s[2 * h][1]), pack_bf16(s[2 * h][2], s[2 * h][3]), pack_bf16(s[2 * h + 1][0], s[2 * h + 1][1]),
@@ -654,6 +682,9 @@ __global__ __launch_bounds__(256) void attn_1head_kernel(const bf16* __restrict_
         o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[d], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // every wave is done with tile t
+    lstore();
   }
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
@@ -681,7 +712,7 @@ extern "C" int ce_attention_1head_bf16(const void* Q, const void* K, const void*
   const dim3 grid((Nq + 63) / 64), block(256);
   static bool done_[CE_MAX_DEVICES] = {};
   bool& done = done_[ce_device_slot()];
-  const int smem384 = 64 * (384 * 2 + 16) + 384 * 144, smem128 = 64 * (128 * 2 + 16) + 128 * 144;
+  const int smem384 = 128 * (384 * 2 + 16) + 384 * 144, smem128 = 128 * (128 * 2 + 16) + 128 * 144;  // K tile + Q rows + V^T tile
   if (!done) {
     (void)hipFuncSetAttribute((const void*)attn_1head_kernel<384>, hipFuncAttributeMaxDynamicSharedMemorySize, smem384);
     (void)hipFuncSetAttribute((const void*)attn_1head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem128);
