@@ -94,7 +94,9 @@ def test_fp8_one_wave_per_simd_gemm_loop():
     for r in _pick(_rows("ce_gemm_fp8w4.hip"), "gemm_fp8_w4"):
         assert r[2] <= 512 and r[3] <= 16, r
     loops = isa_lint.inner_loops(src, "gemm_fp8_w4")
-    assert len(loops) == 6  # three epilogues x {per-row scales: the plain instruction, MX: the block-scaled one}
+    # template arguments <EPI, MX, GP>: three epilogues x {per-row scales: the plain instruction | MX: the block-scaled one, with the gated
+    # residual's prefetching epilogue (GP) or the generic per-pass one} + the fused bias + GELU + MX-quantising epilogue (EPI 7) of FFN-up
+    assert len(loops) == 10
     for name, c in loops:
         mfma = c.get("v_mfma_f32_16x16x128_f8f6f4", 0) + c.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0)
         assert mfma == 128 and (c.get("v_mfma_f32_16x16x128_f8f6f4", 0) == 0 or c.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0) == 0), (name, c)
@@ -109,10 +111,10 @@ def test_row_kernels_issue_their_row_loads_back_to_back():
     rows = _rows("ce_rowops.hip")
     (rr,) = _pick(rows, "rmsnorm_rope_kernel", "ILb1E")  # FULL variant (D = 5120)
     assert rr[5] == 0 and rr[3] == 0 and rr[2] <= 168, rr  # three waves per SIMD
-    for r in _pick(rows, "ln_affine_kernel", "ELb1ELi1E"):  # FULL variants, one row per wave (fp8 output; bf16 fallback)
+    for r in _pick(rows, "ln_affine_kernel", "ELb1ELi1E"):  # FULL variants, one row per wave (fp8 per-row and MX outputs; bf16 fallback)
         assert r[3] == 0 and r[2] <= 168, r
         assert r[5] <= 20, r  # the (a, b) table reads of the third pass (L2 hits); the ten row loads are not among them
-    (two,) = _pick(rows, "ln_affine_kernel", "ILb0ELb1ELi2E")  # bf16, two rows per wave sharing the (a, b) chunks
+    (two,) = _pick(rows, "ln_affine_kernel", "ILi0ELb1ELi2E")  # bf16 (FP8 = 0), two rows per wave sharing the (a, b) chunks
     assert two[3] == 0 and two[2] <= 256 and two[5] == 0, two
 
 

@@ -53,6 +53,12 @@ tot = sum(d["total_ms"] for d in summ.values())
 top = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]
 res["decode_profiled_ms"] = tot
 res["decode_top"] = {k: {"n": d["n"], "ms": round(d["total_ms"], 2), "tflops": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e12, 1)} for k, d in top}
+with ops.profile() as prof:
+    vae.encode(x).latent_dist.mode()
+summ = prof.summary()
+res["encode_profiled_ms"] = sum(d["total_ms"] for d in summ.values())
+top = sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]
+res["encode_top"] = {k: {"n": d["n"], "ms": round(d["total_ms"], 2), "tflops": round(d["work"] / (d["avg_ms"] * 1e-3) / 1e12, 1)} for k, d in top}
 print(json.dumps(res, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open(os.environ.get("CE_VAE_BENCH_OUT", "gpurun_out/vae_bench.json"), "w"), indent=1)
