@@ -95,6 +95,8 @@ def parse():
                     help="BASELINE.json configs[4] arithmetic: the six large Linears of every block in fp8 e4m3 (MX matrix instruction); "
                          "reported with dtype fp8, never the headline bf16 number")
     ap.add_argument("--fp8-gemms-only", action="store_true", help="with --fp8: keep the self-attention in bf16 (round-1 fp8 mode)")
+    ap.add_argument("--fp8-no-attn-quant-fusion", action="store_true",
+                    help="with --fp8 (MX): A/B switch - the attention kernels write bf16 and a separate pass quantises the out-projections' operands")
     ap.add_argument("--fp8-row-scales", action="store_true",
                     help="with --fp8: the round-1..3 GEMM contract (one fp32 scale per token row / output channel) instead of OCP-MX block scales")
     ap.add_argument("--attn-kernel", type=int, default=0,
@@ -331,6 +333,7 @@ def main():
     if a.no_transposed_v:
         model.enable_transposed_v(False)
     if a.fp8:
+        model.fp8_fuse_attn_quant = not a.fp8_no_attn_quant_fusion
         model.enable_fp8_gemms(mx=not a.fp8_row_scales)
         if not a.fp8_gemms_only:
             model.enable_fp8_attention()

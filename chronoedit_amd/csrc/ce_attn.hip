@@ -66,6 +66,10 @@ struct BlkRows {
   int stride;      // rows between the starts of consecutive blocks
   uint32_t magic;  // ceil(2^32 / (rows / 64)): tile index -> block by multiply-high (0: rows == 64, block = tile)
   int vt_cols;     // column stride between samples in V^T
+  // two-segment V^T form only (ce_attention_2seg_vt_quant_bf16): the output as the out-projection's MX fp8 operand instead of bf16 rows
+  unsigned char* q8;  // e4m3 [batch Nq][ld8]
+  unsigned char* s8;  // E8M0 block scales, tiled layout of ce_gemm_mxfp8
+  int ld8;
 };
 
 template <bool TWO_SEG, int NWAVE>
@@ -348,7 +352,7 @@ constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow t
 constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
 constexpr int sp_smem_bytes(bool two_seg) { return two_seg ? SP_TILE_BYTES + 8 * QW * OST_ROW : SP_TILE_BYTES; }
 
-template <bool TWO_SEG, bool VT = false>
+template <bool TWO_SEG, bool VT = false, bool QOUT = false>  // QOUT: the output as an MX fp8 operand (two-segment V^T form only)
 __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restrict__ Q_, bf16* __restrict__ O_, KVSeg seg0_,
                                                               KVSeg seg1_, int Nq, int H, int ldq, int ldo, int nqb,
                                                               float scale_log2e, int batch, BlkRows blk) {
@@ -824,6 +828,47 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       }
   }
 
+  if (TWO_SEG && VT && QOUT) {
+    // MX fp8 output (fp8 mode's cross-attention feeding ce_gemm_mxfp8): the bf16 rows just staged, quantised as ce_quant_rows_mxfp8 would -
+    // a 32-channel block m of a query row is this lane's 16 values and the 16 of lane ^ 32.  The e4m3 bytes of block m overwrite bytes
+    // [32 m, 32 m + 32) of the row's staging area: only bf16 slots of blocks <= m, which this lane pair has read by then.
+    const int ktiles = (H * HD) >> 7;
+    const int grow = bz * Nq + q0 + l31;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      uint32_t pk[8];
+      float amax = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const u32x2 pv = *reinterpret_cast<const u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2);
+        pk[2 * a] = pv[0];
+        pk[2 * a + 1] = pv[1];
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16lo(pv[0])), fabsf(bf16hi(pv[0]))), fmaxf(fabsf(bf16lo(pv[1])), fabsf(bf16hi(pv[1])))));
+      }
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const int byte = mx_scale_byte_nosat(amax);
+      const float is = mx_inv_scale(byte);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(pk[2 * a]) * is), clamp448(bf16hi(pk[2 * a]) * is), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(pk[2 * a + 1]) * is), clamp448(bf16hi(pk[2 * a + 1]) * is), w, true);
+        *reinterpret_cast<uint32_t*>(ost + 32 * m + 8 * a + 4 * hh) = (uint32_t)w;
+      }
+      if (hh == 0 && q0 + l31 < Nq) blk.s8[mx_gemm_scale_offset(grow, head * 4 + m, ktiles)] = (unsigned char)byte;
+    }
+    __syncthreads();
+    unsigned char* O8 = blk.q8 + (size_t)bz * Nq * blk.ld8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      const int rl = c >> 3, cc = c & 7;
+      if (q0 + rl < Nq) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(smem + SP_TILE_BYTES + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+        *reinterpret_cast<u32x4*>(O8 + (size_t)(q0 + rl) * blk.ld8 + hoff + cc * 16) = v;
+      }
+    }
+  } else {
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -833,6 +878,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (TWO_SEG ? SP_TILE_BYTES : 0) + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
       *reinterpret_cast<u32x4*>(O + (size_t)(q0row + rl) * ldo + hoff + cc * 8) = v;
     }
+  }
   }
   __syncthreads();  // the next item's tile staging overwrites the O staging area
   }  // item
@@ -1571,10 +1617,11 @@ extern "C" int ce_attention_vt_blocked_bf16(const void* Q, const void* K, const 
  * of 2, >= len; a row must extend to whole 64-key strips past the LAST sample's first column: ldv*t >= (batch - 1) vt_cols + 64 ceil(len / 64);
  * columns past a sample's len - the next sample's keys or padding - only ever meet P = 0 and must be finite).  K as in
  * ce_attention_batched_bf16 (samples stacked along the rows).  K and V^T tiles of both segments go by LDS-DMA. */
-extern "C" int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
-                                         const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq,
-                                         int H, int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
-  if (!Q || !K1 || !V1t || !K2 || !V2t || !O) return CE_ERR_ARG;
+static int attention_2seg_vt_launch(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
+                                    const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq,
+                                    int H, int head_dim, int ldq, int ldo, float softmax_scale, int batch, void* O8, void* S8, int ldo8,
+                                    hipStream_t stream) {
+  if (!Q || !K1 || !V1t || !K2 || !V2t || (!O && !O8)) return CE_ERR_ARG;
   if (head_dim != HD || Nq <= 0 || H <= 0 || len1 <= 0 || len2 <= 0 || batch <= 0 || batch > 65535) return CE_ERR_SHAPE;
   const int c1 = (len1 + KVB - 1) / KVB * KVB, c2 = (len2 + KVB - 1) / KVB * KVB;
   if (vt_cols1 < len1 || vt_cols2 < len2 || ldv1t < (batch - 1) * vt_cols1 + c1 || ldv2t < (batch - 1) * vt_cols2 + c2) return CE_ERR_SHAPE;
@@ -1587,9 +1634,35 @@ extern "C" int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const vo
   bool& done = done_[ce_device_slot()];
   if (!done) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(true));
+    (void)hipFuncSetAttribute((const void*)attn_fwd_sp_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sp_smem_bytes(true));
     done = true;
   }
-  hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q, (bf16*)O,
-                     s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, BlkRows{0, vt_cols2, 0u, vt_cols1});  // plain rows; the two column strides
+  const BlkRows blk{0, vt_cols2, 0u, vt_cols1, (unsigned char*)O8, (unsigned char*)S8, ldo8};  // plain rows; the two column strides
+  if (O8)
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q,
+                       (bf16*)O, s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, blk);
+  else
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q, (bf16*)O,
+                       s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, blk);
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
+                                         const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq,
+                                         int H, int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
+  if (!O) return CE_ERR_ARG;
+  return attention_2seg_vt_launch(Q, K1, V1t, len1, ldk1, ldv1t, vt_cols1, K2, V2t, len2, ldk2, ldv2t, vt_cols2, O, Nq, H, head_dim, ldq, ldo,
+                                  softmax_scale, batch, nullptr, nullptr, 0, stream);
+}
+
+/* The same attention with the output written as the MX fp8 operand of the out-projection that follows it in the fp8 mode: o8 e4m3
+ * [batch Nq][ldo8] + E8M0 scales per 32 channels in the tiled layout of ce_gemm_mxfp8 (rows = batch Nq, K = H head_dim) - bit-identical to
+ * ce_attention_2seg_vt_bf16 followed by ce_quant_rows_mxfp8. */
+extern "C" int ce_attention_2seg_vt_quant_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
+                                               const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* o8,
+                                               void* scale8, int Nq, int H, int head_dim, int ldq, int ldo8, float softmax_scale, int batch,
+                                               hipStream_t stream) {
+  if (!o8 || !scale8 || (ldo8 & 15) || ((H * head_dim) & 127)) return CE_ERR_ARG;
+  return attention_2seg_vt_launch(Q, K1, V1t, len1, ldk1, ldv1t, vt_cols1, K2, V2t, len2, ldk2, ldv2t, vt_cols2, nullptr, Nq, H, head_dim, ldq,
+                                  8, softmax_scale, batch, o8, scale8, ldo8, stream);
 }

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
                                                                   const unsigned char* __restrict__ K8_, const unsigned char* __restrict__ SK_,
                                                                   const unsigned char* __restrict__ V8T_, const unsigned char* __restrict__ SV_,
                                                                   bf16* __restrict__ O_, int Nq, int Nkv, int npad, int H, int ldq8,
-                                                                  int ldk8, int ldo, int nqb, int batch) {
+                                                                  int ldk8, int ldo, int nqb, int batch, unsigned char* __restrict__ O8_,
+                                                                  unsigned char* __restrict__ S8_, int ldo8) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D32 = (H * HD) >> 5;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -737,21 +738,60 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
 
   const float inv = 1.0f / l_run;  // the matrix pipe summed over all 64 k-slots: every lane holds its row's full sum
   unsigned char* ost = smem + (size_t)(wave * QW + l31) * OST_ROW;
+  if (O8_ != nullptr) {
+    // The out-projection's MX operand straight from the accumulators (ce_attention_mxfp8_quant): the bf16 value the plain form stores,
+    // quantised as ce_quant_rows_mxfp8 would - a 32-channel block m of a query row is this lane's 16 values and the 16 of lane ^ 32.
+    const int ktiles = (H * HD) >> 7;
+    const int grow = bz * Nq + q0 + l31;
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+      uint32_t pk[8];
+      float amax = 0.f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const u32x2 val = {pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv), pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv)};
-      *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
+      for (int a = 0; a < 4; ++a) {
+        pk[2 * a] = pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv);
+        pk[2 * a + 1] = pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16lo(pk[2 * a])), fabsf(bf16hi(pk[2 * a]))), fmaxf(fabsf(bf16lo(pk[2 * a + 1])), fabsf(bf16hi(pk[2 * a + 1])))));
+      }
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      const int byte = mx_scale_byte_nosat(amax);
+      const float is = mx_inv_scale(byte);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(pk[2 * a]) * is), clamp448(bf16hi(pk[2 * a]) * is), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(pk[2 * a + 1]) * is), clamp448(bf16hi(pk[2 * a + 1]) * is), w, true);
+        *reinterpret_cast<uint32_t*>(ost + 32 * m + 8 * a + 4 * hh) = (uint32_t)w;
+      }
+      if (hh == 0 && q0 + l31 < Nq) S8_[mx_gemm_scale_offset(grow, head * 4 + m, ktiles)] = (unsigned char)byte;
     }
-  __syncthreads();
+    __syncthreads();
+    unsigned char* O8 = O8_ + (size_t)bz * Nq * ldo8;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + 64 * i;
-    const int rl = c >> 4, cc = c & 15;
-    const int q = min(q0 + rl, Nq - 1);  // clamped address, predicated store: no per-chunk branch around the LDS read
-    const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
-    if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      const int rl = c >> 3, cc = c & 7;
+      const int q = min(q0 + rl, Nq - 1);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O8 + (size_t)q * ldo8 + hoff + cc * 16) = v;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const u32x2 val = {pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv), pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv)};
+        *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
+      }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + 64 * i;
+      const int rl = c >> 4, cc = c & 15;
+      const int q = min(q0 + rl, Nq - 1);  // clamped address, predicated store: no per-chunk branch around the LDS read
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      if (q0 + rl < Nq) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = v;
+    }
   }
   __syncthreads();
   }  // item
@@ -793,11 +833,12 @@ extern "C" int ce_set_attention_mxfp8_variant(int v) {
   return old;
 }
 
-extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
-                                  int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, hipStream_t stream) {
-  if (!q8 || !sq || !k8 || !sk || !v8t || !sv || !O) return CE_ERR_ARG;
+static int attention_mxfp8_launch(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
+                                  int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, void* O8, void* S8,
+                                  int ldo8, hipStream_t stream) {
+  if (!q8 || !sq || !k8 || !sk || !v8t || !sv || (!O && !O8) || (O8 && !S8)) return CE_ERR_ARG;
   if (head_dim != HD || Nq <= 0 || Nkv <= 0 || H <= 0 || batch <= 0 || (npad & 63) || npad < Nkv || npad - Nkv >= KVB) return CE_ERR_SHAPE;
-  if ((ldq8 & 15) || (ldk8 & 15) || (ldo & 7)) return CE_ERR_ALIGN;
+  if ((ldq8 & 15) || (ldk8 & 15) || (O && (ldo & 7)) || (O8 && (ldo8 & 15))) return CE_ERR_ALIGN;
   const int nqb = (Nq + QW * 8 - 1) / (QW * 8);
   static bool attr_[CE_MAX_DEVICES] = {};
   bool& attr = attr_[ce_device_slot()];
@@ -806,13 +847,30 @@ extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8
     (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_SP);
     attr = true;
   }
-  if (g_mxfp8_variant == 0)
+  if (g_mxfp8_variant == 0 && !O8)
     hipLaunchKernelGGL(attn_fwd_mxfp8_kernel, dim3(H * nqb, batch), dim3(512), SMEM, stream, (const unsigned char*)q8, (const unsigned char*)sq,
                        (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t, (const unsigned char*)sv, (bf16*)O, Nq, Nkv,
                        npad, H, ldq8, ldk8, ldo, nqb);
   else
     hipLaunchKernelGGL(attn_fwd_mxfp8_sp_kernel, dim3(g_mxfp8_persist > 0 && H * nqb * batch > g_mxfp8_persist ? g_mxfp8_persist : H * nqb * batch), dim3(512), SMEM_SP, stream, (const unsigned char*)q8,
                        (const unsigned char*)sq, (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t,
-                       (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb, batch);
+                       (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb, batch, (unsigned char*)O8, (unsigned char*)S8,
+                       ldo8);
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
+                                  int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, hipStream_t stream) {
+  if (!O) return CE_ERR_ARG;
+  return attention_mxfp8_launch(q8, sq, k8, sk, v8t, sv, O, Nq, Nkv, npad, H, head_dim, ldq8, ldk8, ldo, batch, nullptr, nullptr, 0, stream);
+}
+
+// The same attention with its output written as the out-projection's MX operand: o8 e4m3 [batch Nq][ldo8] + E8M0 block scales in the
+// tiled layout of ce_gemm_mxfp8 (rows = batch Nq, K = H head_dim) - bit-identical to ce_attention_mxfp8 followed by ce_quant_rows_mxfp8
+// (the software-pipelined kernel whatever ce_set_attention_mxfp8_variant says).
+extern "C" int ce_attention_mxfp8_quant(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv,
+                                        void* o8, void* scale8, int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo8,
+                                        int batch, hipStream_t stream) {
+  if (!o8 || !scale8) return CE_ERR_ARG;
+  return attention_mxfp8_launch(q8, sq, k8, sk, v8t, sv, nullptr, Nq, Nkv, npad, H, head_dim, ldq8, ldk8, 0, batch, o8, scale8, ldo8, stream);
 }

@@ -34,6 +34,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_rmsnorm_rope_mxfp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _F, _P],
     "ce_v_mxfp8_transpose": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
     "ce_attention_mxfp8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_attention_mxfp8_quant": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_attention_mxfp8_variant": [_I],
     "ce_set_attention_mxfp8_persistent": [_I],
     "ce_rope_scatter_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _I, _P],
@@ -65,6 +66,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_attention_batched_bf16": [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_attention_vt_bf16": [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_attention_2seg_vt_bf16": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "ce_attention_2seg_vt_quant_bf16": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "ce_v_transpose_bf16": [_P, _I, _P, _I, _I, _I, _P],
     "ce_attention_vt_blocked_bf16": [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _I, _I, _P],
     "ce_v_transpose_blocked_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],

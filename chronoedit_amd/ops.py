@@ -356,7 +356,8 @@ def attention_vt(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int,
 
 def attention_2seg_vt(q: torch.Tensor, k1: torch.Tensor, v1t: torch.Tensor, len1: int, k2: torch.Tensor, v2t: torch.Tensor, len2: int,
                       heads: int, out: Optional[torch.Tensor] = None, scale: Optional[float] = None, batch: int = 1,
-                      cols1: Optional[int] = None, cols2: Optional[int] = None):
+                      cols1: Optional[int] = None, cols2: Optional[int] = None, out8: Optional[torch.Tensor] = None,
+                      scale8: Optional[torch.Tensor] = None):
     """Cross-attention over two key / value segments (a softmax each, outputs added in bf16) with V transposed: k1 [batch*len1, H*128],
     v1t [H*128, >= (batch-1)*c1 + 64*ceil(len1/64)] with sample b's keys at columns [b*c1, b*c1 + len1), c1 = cols1 (default
     v1t.shape[1] // batch; even, >= len1; every column finite); the same for segment 2.  Same arithmetic as `attention(..., k2=, v2=)`; K and V^T tiles by LDS-DMA."""
@@ -373,13 +374,24 @@ def attention_2seg_vt(q: torch.Tensor, k1: torch.Tensor, v1t: torch.Tensor, len1
     if cols2 is None:
         assert v2t.shape[1] % batch == 0
         cols2 = v2t.shape[1] // batch
+    if scale is None:
+        scale = 128 ** -0.5
+    nq = Nq // batch
+    if out8 is not None:  # the result as the MX fp8 operand of the out-projection (e4m3 rows + tiled E8M0 block scales): no bf16 output
+        _dev(out8, torch.uint8, "out8"), _dev(scale8, torch.uint8, "scale8")
+        _, D8, ld8 = _rows(out8, "out8")
+        assert out8.shape[0] == Nq and D8 == Dq and scale8.is_contiguous() and scale8.numel() >= mx_scale_bytes(Nq, Dq)
+        st = _prof_begin()
+        _check(lib().ce_attention_2seg_vt_quant_bf16(_ptr(q), _ptr(k1), _ptr(v1t), len1, ldk1, v1t.stride(0), int(cols1), _ptr(k2), _ptr(v2t),
+                                                     len2, ldk2, v2t.stride(0), int(cols2), _ptr(out8), _ptr(scale8), nq, heads, 128, ldq, ld8,
+                                                     float(scale), batch, _stream()), "ce_attention_2seg_vt_quant_bf16")
+        _prof_end(st, f"attention_{nq}x{len1}+{len2}_h{heads}" + (f"_b{batch}" if batch > 1 else "") + "_mxq",
+                  4.0 * nq * (len1 + len2) * 128 * heads * batch)
+        return out8
     if out is None:
         out = torch.empty((Nq, Dq), dtype=torch.bfloat16, device=q.device)
     _, _, ldo = _rows(out, "out")
-    if scale is None:
-        scale = 128 ** -0.5
     st = _prof_begin()
-    nq = Nq // batch
     _check(lib().ce_attention_2seg_vt_bf16(_ptr(q), _ptr(k1), _ptr(v1t), len1, ldk1, v1t.stride(0), int(cols1), _ptr(k2), _ptr(v2t),
                                            len2, ldk2, v2t.stride(0), int(cols2), _ptr(out), nq, heads, 128, ldq, ldo,
                                            float(scale), batch, _stream()), "ce_attention_2seg_vt_bf16")
@@ -935,9 +947,11 @@ def set_attention_mxfp8_variant(v: int) -> int:
 
 
 def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: torch.Tensor, v8t: torch.Tensor, sv: torch.Tensor,
-                    heads: int, out: Optional[torch.Tensor] = None, batch: int = 1):
+                    heads: int, out: Optional[torch.Tensor] = None, batch: int = 1, out8: Optional[torch.Tensor] = None,
+                    scale8: Optional[torch.Tensor] = None):
     """Self-attention on the MX-fp8 matrix instruction from the operands the two producers above write (q with post_scale =
-    MXFP8_Q_SCALE); out [batch*Nq, heads*128] bf16."""
+    MXFP8_Q_SCALE); out [batch*Nq, heads*128] bf16 - or, with out8 / scale8, the same values as the MX fp8 operand of the out-projection
+    (e4m3 rows + tiled E8M0 block scales, bit-identical to quant_rows_mxfp8 of the bf16 output)."""
     for n, t in (("q8", q8), ("sq", sq), ("k8", k8), ("sk", sk), ("v8t", v8t), ("sv", sv)):
         _dev(t, torch.uint8, n)
     Mq, D, ldq = _rows(q8, "q8")
@@ -947,6 +961,15 @@ def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: to
     npad = v8t.shape[-1]
     assert sq.is_contiguous() and sk.is_contiguous() and v8t.is_contiguous() and sv.is_contiguous()
     assert sq.shape == (Mq, D // 32) and sk.shape == (Mk, D // 32) and v8t.shape == (batch, heads, 128, npad) and sv.shape == (batch, heads, npad // 64, 128, 2)
+    if out8 is not None:
+        _dev(out8, torch.uint8, "out8"), _dev(scale8, torch.uint8, "scale8")
+        _, D8, ld8 = _rows(out8, "out8")
+        assert out8.shape[0] == Mq and D8 == D and scale8.is_contiguous() and scale8.numel() >= mx_scale_bytes(Mq, D)
+        st = _prof_begin()
+        _check(lib().ce_attention_mxfp8_quant(_ptr(q8), _ptr(sq), _ptr(k8), _ptr(sk), _ptr(v8t), _ptr(sv), _ptr(out8), _ptr(scale8), nq, nkv, npad,
+                                              heads, 128, ldq, ldk, ld8, batch, _stream()), "ce_attention_mxfp8_quant")
+        _prof_end(st, f"attention_mxfp8_{nq}x{nkv}_h{heads}" + (f"_b{batch}" if batch > 1 else "") + "_mxq", 4.0 * nq * nkv * 128 * heads * batch)
+        return out8
     if out is None:
         out = torch.empty((Mq, D), dtype=torch.bfloat16, device=q8.device)
     _dev(out, torch.bfloat16, "out")

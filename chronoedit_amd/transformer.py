@@ -199,6 +199,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self.v_transposed = True    # bf16 self-attention takes V^T straight from the projection (swapped GEMM) and stages it by LDS-DMA
         self.sp_batch_cfg = True    # sequence-parallel forwards take the guidance pair as one batch of two (blocked-layout kernels)
         self.fp8_fuse_quant = True  # MX fp8 mode: the FFN-up epilogue emits the FFN-down operand quantised (no bf16 hidden matrix, no quant pass)
+        self.fp8_fuse_attn_quant = True  # ... and both attention kernels emit the out-projections' operands (A/B switch; needs fp8_fuse_quant)
         self.cross_vt = True        # cross-attention takes V^T of the text / image context straight from the context projections (LDS-DMA kernel)
         self._sp = None             # Ulysses sequence parallelism (chronoedit_amd.parallel), off by default
         self._cfgp = None           # CFG parallelism on top of it (two Ulysses groups), off by default
@@ -515,6 +516,7 @@ class DiTEngine:
         self.fp8 = model.gemm_dtype in ("fp8", "mxfp8")
         self.mx = model.gemm_dtype == "mxfp8"  # MX block scales on both GEMM operands (ce_gemm_mxfp8)
         self.fuse_quant = bool(getattr(model, "fp8_fuse_quant", True)) and self.F % 128 == 0  # MX: quantisation fused into the FFN-up epilogue
+        self.fuse_attn_quant = self.fuse_quant and bool(getattr(model, "fp8_fuse_attn_quant", True))
         self.v_transposed = bool(getattr(model, "v_transposed", True))
         if self.fp8:
             if self.D % 256 or self.F % 256:
@@ -576,8 +578,9 @@ class DiTEngine:
         ops.ln_affine_fp8(x, a_row, b_row, eps, out=aq, scale=ws.s8, ab_rows=ab_rows, ab_stride=ab_stride)
         return ops.gemm_fp8(aq, ws.s8, wq, sw, getattr(p, "b_" + name), out=out, **kw)
 
-    def _linear(self, ws, a: torch.Tensor, p, name: str, out: torch.Tensor, **kw):
-        """One of the six large projections of a block: bf16 GEMM, or (fp8 mode) row-quantise the activations and run the MX GEMM."""
+    def _linear(self, ws, a: torch.Tensor, p, name: str, out: torch.Tensor, quantised: bool = False, **kw):
+        """One of the six large projections of a block: bf16 GEMM, or (fp8 mode) row-quantise the activations and run the MX GEMM.
+        quantised: the producer already wrote the MX operand into ws.a8 / ws.s8 (an attention kernel's fused output)."""
         w, b = getattr(p, "w_" + name), getattr(p, "b_" + name)
         if not self.fp8:
             return ops.gemm(a, w, b, out=out, **kw)
@@ -585,7 +588,8 @@ class DiTEngine:
         aq = ws.a8[:, :K]
         wq, sw = getattr(p, "q_" + name)
         if self.mx:
-            ops.quant_rows_mxfp8(a, out=aq, scale=ws.s8)
+            if not quantised:
+                ops.quant_rows_mxfp8(a, out=aq, scale=ws.s8)
             return ops.gemm_mxfp8(aq, ws.s8, wq, sw, b, out=out, **kw)
         ops.quant_rows_fp8(a, out=aq, scale=ws.s8)
         return ops.gemm_fp8(aq, ws.s8, wq, sw, b, out=out, **kw)
@@ -858,7 +862,9 @@ class DiTEngine:
         grow = Nl if B > 1 else 0
 
         x = ws.x
+        fuse_o = self.mx and self.fuse_attn_quant and D % 128 == 0  # MX: both attention kernels emit the out-projections' fp8 operands themselves
         for li, p in enumerate(self.blk):
+            q_o1 = False
             # 1. self-attention
             if sp is None and self.fp8_attn:  # MXFP8: the norm / RoPE pass and a V^T pass write the quantised operands
                 self._ln_linear(ws, x, mod[li, 0, 1], mod[li, 0, 0], p, "qkv", ws.qkv, ab_rows=Nl, ab_stride=6 * D)
@@ -867,7 +873,11 @@ class DiTEngine:
                 if ws.v8t is None or ws.v8t.shape[0] != B:
                     ws.v8t = ws.sv = None
                 ws.v8t, ws.sv = ops.v_mxfp8_transpose(ws.qkv[:, 2 * D :], Nl, B, H, out=ws.v8t, scale=ws.sv)
-                ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, out=ws.att, batch=B)
+                if fuse_o:  # the out-projection's MX operand straight from the attention epilogue (no bf16 output, no quantisation pass)
+                    ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, batch=B, out8=ws.a8[:, :D], scale8=ws.s8)
+                    q_o1 = True
+                else:
+                    ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, out=ws.att, batch=B)
                 att = ws.att
             elif sp is None and self.v_transposed and not self.fp8 and (B * Nl) % 8 == 0 and (B == 1 or Nl % 2 == 0):
                 # q | k as one GEMM, V^T = W_v.h^T as the same GEMM with the operand roles swapped (bias along rows): the attention
@@ -887,7 +897,7 @@ class DiTEngine:
                 att = ws.att
             else:
                 att = self._self_attention_ulysses(ws, sp, x, mod[li, 0, 1], mod[li, 0, 0], p, cs, N, Nl, B)
-            self._linear(ws, att, p, "o1", x, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
+            self._linear(ws, att, p, "o1", x, quantised=q_o1, epilogue=ops.EPI_GATE_RES, gate=gate_msa[li] if B > 1 else mods[0][li, 2],
                          res=x, gate_rows=grow)
             # 2. cross-attention (text + image segments)
             if p.n2w is not None:
@@ -896,13 +906,15 @@ class DiTEngine:
                 self._linear(ws, x, p, "q2", ws.q2)
             ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
             k_t, v_t, k_i, v_i = ctx.kv[li]
-            if ctx.vt:  # both segments' K and V^T tiles by LDS-DMA (v_t / v_i are V^T row blocks of this layer)
+            if ctx.vt and fuse_o:
+                ops.attention_2seg_vt(ws.q2, k_t, v_t, Tt, k_i, v_i, Ti, H, batch=B, cols1=ctx.c1, cols2=ctx.c2, out8=ws.a8[:, :D], scale8=ws.s8)
+            elif ctx.vt:  # both segments' K and V^T tiles by LDS-DMA (v_t / v_i are V^T row blocks of this layer)
                 ops.attention_2seg_vt(ws.q2, k_t, v_t, Tt, k_i, v_i, Ti, H, out=ws.att, batch=B, cols1=ctx.c1, cols2=ctx.c2)
             elif k_i is not None:
                 ops.attention(ws.q2, k_t, v_t, H, out=ws.att, k2=k_i, v2=v_i, batch=B)
             else:
                 ops.attention(ws.q2, k_t, v_t, H, out=ws.att, batch=B)
-            self._linear(ws, ws.att, p, "o2", x, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
+            self._linear(ws, ws.att, p, "o2", x, quantised=bool(ctx.vt and fuse_o), epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
             if self.mx and self.fuse_quant:
                 # MX: the up-projection's bias + GELU epilogue emits the down-projection's fp8 operand and its block scales directly (a

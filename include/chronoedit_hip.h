@@ -137,6 +137,14 @@ int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, in
                               const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq, int H, int head_dim, int ldq,
                               int ldo, float softmax_scale, int batch, hipStream_t stream);
 
+/* ce_attention_2seg_vt_bf16 with its output written as the MX fp8 operand of the out-projection that follows it in the fp8 mode
+ * (transformer_chronoedit.py:106 `attn.to_out[0]`; no counterpart in the reference): o8 e4m3 [batch Nq][ldo8] (ldo8 % 16 == 0) + one
+ * E8M0 scale per 32 channels in the tiled layout of ce_gemm_mxfp8 (rows = batch Nq, K = H head_dim, K % 128 == 0) - bit-identical to
+ * ce_attention_2seg_vt_bf16 followed by ce_quant_rows_mxfp8 (a 32-channel block of a query row is two lanes' accumulator registers). */
+int ce_attention_2seg_vt_quant_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1, const void* K2,
+                                    const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* o8, void* scale8, int Nq, int H,
+                                    int head_dim, int ldq, int ldo8, float softmax_scale, int batch, hipStream_t stream);
+
 /* ce_attention_vt_bf16 over the BLOCKED row layout an all-to-all leaves behind when every rank sent [sample][local token] rows
  * (Ulysses sequence parallelism with the guidance pair batched: chronoedit_amd/parallel.py): token g of sample b sits in row
  * (g / blk_rows) blk_stride + b blk_rows + g % blk_rows of Q, K and O (blk_rows = tokens per rank, a multiple of 64; blk_stride =
@@ -358,6 +366,12 @@ int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv, int n_toke
  * [rows][H * 4]); head_dim == 128. */
 int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O, int Nq,
                        int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, hipStream_t stream);
+
+/* ce_attention_mxfp8 with its output written as the out-projection's MX fp8 operand (o8 / scale8 as in ce_attention_2seg_vt_quant_bf16):
+ * bit-identical to ce_attention_mxfp8 followed by ce_quant_rows_mxfp8; always the software-pipelined body. */
+int ce_attention_mxfp8_quant(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* o8,
+                             void* scale8, int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo8, int batch,
+                             hipStream_t stream);
 
 /* Loop body of ce_attention_mxfp8 (returns the previous value): 0 plain (exact running maximum every tile), 1 software-pipelined
  * with a speculative integer offset, row sums on the matrix pipe and an exact repair route per tile (default).  Other values are

@@ -127,6 +127,73 @@ def test_gemm_mxfp8_gelu_quant_equals_gemm_then_quant(M, N, K):
     assert torch.equal(ops.mx_scales_to_rows(s, M, N), ops.mx_scales_to_rows(s_ref, M, N))
 
 
+@pytest.mark.parametrize("N,H,B", [(200, 2, 1), (333, 4, 2), (560, 8, 2), (1024, 2, 1)])
+def test_mxfp8_attention_quantised_output_equals_attention_then_quant(N, H, B):
+    """ce_attention_mxfp8_quant (the self-attention of the fp8 mode writing the out-projection's MX operand from its accumulators) ==
+    ce_attention_mxfp8 followed by ce_quant_rows_mxfp8, bit for bit: element bytes and tiled scale bytes; remainder query blocks, several
+    samples (the scale rows of sample b start at b Nq), the XCD-aware work order (H % 8 == 0)."""
+    from chronoedit_amd import ops
+    D = H * 128
+    g = torch.Generator().manual_seed(N + H)
+    qkv = torch.randn(B * N, 3 * D, generator=g).to(BF).cuda()
+    one = torch.ones(D).cuda()
+    q8, sq = ops.rmsnorm_rope_mxfp8(qkv[:, :D], one, None, 128, 1e-6, post_scale=ops.MXFP8_Q_SCALE)
+    k8, sk = ops.rmsnorm_rope_mxfp8(qkv[:, D:2 * D], one, None, 128, 1e-6)
+    v8t, sv = ops.v_mxfp8_transpose(qkv[:, 2 * D:], N, B, H)
+    o = ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, batch=B)
+    q_ref, s_ref = ops.quant_rows_mxfp8(o)
+    q = torch.zeros((B * N, D), dtype=torch.uint8, device="cuda")
+    s = torch.zeros((ops.mx_scale_bytes(B * N, D),), dtype=torch.uint8, device="cuda")
+    ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, batch=B, out8=q, scale8=s)
+    assert torch.equal(q, q_ref), (q.view(torch.float8_e4m3fn).float() - q_ref.view(torch.float8_e4m3fn).float()).abs().max()
+    assert torch.equal(ops.mx_scales_to_rows(s, B * N, D), ops.mx_scales_to_rows(s_ref, B * N, D))
+
+
+@pytest.mark.parametrize("Nq,H,B,Tt,Ti", [(200, 2, 1, 64, 33), (520, 4, 2, 512, 257), (1000, 8, 2, 128, 257)])
+def test_cross_attention_quantised_output_equals_attention_then_quant(Nq, H, B, Tt, Ti):
+    """ce_attention_2seg_vt_quant_bf16 (the cross-attention of the fp8 mode writing the out-projection's MX operand) ==
+    ce_attention_2seg_vt_bf16 followed by ce_quant_rows_mxfp8, bit for bit."""
+    from chronoedit_amd import ops
+    D = H * 128
+    g = torch.Generator().manual_seed(Nq + Ti)
+    c1, c2 = (Tt + 7) // 8 * 8, (Ti + 7) // 8 * 8
+    q = torch.randn(B * Nq, D, generator=g).to(BF).cuda()
+    k1 = torch.randn(B * Tt, D, generator=g).to(BF).cuda()
+    k2 = torch.randn(B * Ti, D, generator=g).to(BF).cuda()
+    v1t = torch.zeros(D, (B - 1) * c1 + (Tt + 63) // 64 * 64, dtype=BF, device="cuda")
+    v2t = torch.zeros(D, (B - 1) * c2 + (Ti + 63) // 64 * 64, dtype=BF, device="cuda")
+    for b in range(B):
+        v1t[:, b * c1: b * c1 + Tt] = torch.randn(D, Tt, generator=g).to(BF).cuda()
+        v2t[:, b * c2: b * c2 + Ti] = torch.randn(D, Ti, generator=g).to(BF).cuda()
+    o = ops.attention_2seg_vt(q, k1, v1t, Tt, k2, v2t, Ti, H, batch=B, cols1=c1, cols2=c2)
+    q_ref, s_ref = ops.quant_rows_mxfp8(o)
+    q8 = torch.zeros((B * Nq, D), dtype=torch.uint8, device="cuda")
+    s8 = torch.zeros((ops.mx_scale_bytes(B * Nq, D),), dtype=torch.uint8, device="cuda")
+    ops.attention_2seg_vt(q, k1, v1t, Tt, k2, v2t, Ti, H, batch=B, cols1=c1, cols2=c2, out8=q8, scale8=s8)
+    assert torch.equal(q8, q_ref), (q8.view(torch.float8_e4m3fn).float() - q_ref.view(torch.float8_e4m3fn).float()).abs().max()
+    assert torch.equal(ops.mx_scales_to_rows(s8, B * Nq, D), ops.mx_scales_to_rows(s_ref, B * Nq, D))
+
+
+def test_dit_forward_mx_mode_fused_quantisers_equal_the_unfused_form():
+    """fp8 mode with MX block scales: the forward with every fused quantiser (LN, FFN-up epilogue, both attention epilogues) is
+    bit-identical to the forward that quantises in separate passes (`fp8_fuse_quant = False`)."""
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from oracle import dit_oracle as O
+    cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    p = O.make_synthetic_params(cfg, dtype=BF)
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 16, 24, dtype=BF, text_len=40, real_text=8)
+    outs = []
+    for fuse in (True, False):
+        m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
+                                         added_kv_proj_dim=256, device="cuda:0")
+        m.load_synthetic_({k: v.cuda() for k, v in p.items()})
+        m.fp8_fuse_quant = fuse
+        m.enable_fp8_gemms(mx=True).enable_fp8_attention()
+        outs.append(m(lat.cuda(), torch.tensor([500], device="cuda:0"), text.cuda(), image.cuda()).sample.float().cpu())
+        del m
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max()
+
+
 def test_gemm_mxfp8_rejects_bad_shapes():
     from chronoedit_amd import ops
     aq = torch.zeros(8, 128, dtype=torch.uint8, device="cuda")
