@@ -67,6 +67,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
 
+#ifdef G384_STAGGER_CYC  // diagnostic builds only: the first round's workgroups start in four phases G384_STAGGER_CYC shader cycles apart, so
+  // that the rounds of a launch stop finishing (and storing their C tiles) on all CUs at the same moment
+  if (blockIdx.x < 256) {
+    const long long t0 = __builtin_readcyclecounter();
+    const long long wait = (long long)((blockIdx.x >> 3) & 3) * G384_STAGGER_CYC;
+    while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   const bool partial = (int)blockIdx.x >= t_full;
   int wg, kt0 = 0, ktn = K / BK;
   if (!partial) {
@@ -219,6 +227,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     return;
   }
 
+#ifdef G384_ABLATE_EPILOGUE  // diagnostic builds only (tools/gemm_ab.py): what the tile costs without its epilogue (results are not written)
+  if (M > 0) return;
+#endif
   // ---- epilogue: six passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave = tile rows wm*192 + p*32 + [0,32))
   f32x4 bcol[8];
 #pragma unroll

@@ -29,7 +29,7 @@ def main():
         lib.ce_set_gemm_workspace(ws.data_ptr(), ws.numel())
     g = torch.Generator().manual_seed(0)
     st = torch.cuda.current_stream().cuda_stream
-    for (M, N, K, epi) in [(14400, 15360, 5120, 0), (14400, 13824, 5120, 1), (14400, 5120, 13824, 2), (14400, 5120, 5120, 2),
+    for (M, N, K, epi) in [(14400, 15360, 5120, 0), (14400, 13824, 5120, 1), (14400, 5120, 13824, 2), (14400, 5120, 5120, 2), (14400, 5120, 5120, 0), (5120, 14400, 5120, 6),
                            (7200, 5120, 5120, 0)]:
         a = torch.randn(M, K, generator=g).to(BF).to(dev)
         w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
