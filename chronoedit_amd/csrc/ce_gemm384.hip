@@ -230,6 +230,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef G384_ABLATE_EPILOGUE  // diagnostic builds only (tools/gemm_ab.py): what the tile costs without its epilogue (results are not written)
   if (M > 0) return;
 #endif
+#ifdef G384_DIRECT_EPILOGUE
+  // ---- epilogue straight from the accumulators (round 4 A/B build, tools/gemm_ab.py; bit-identical to the LDS-staged form below and
+  // level with it - profiles/r04_gemm384_epilogue_ablation_and_stagger.txt: the epilogue's time is its memory traffic, not its instructions).
+  // A lane holds 4 consecutive columns of one row per fragment: cols 4 fg .. of fragment g.  One v_permlane16_swap per packed dword
+  // between the fragments of a pair (g, g + 1) - lane rows 1 / 3 of the first operand change places with rows 0 / 2 of the second -
+  // leaves every lane with 8 CONSECUTIVE columns of its row: fg 0 / 2 the lower / upper half of fragment g, fg 1 / 3 of g + 1, i.e.
+  // column 32 gp + 16 (fg & 1) + 8 (fg >> 1) of the wave's 128.  A wave instruction then stores 16 rows x 64 contiguous bytes; no LDS
+  // round trip, no barrier, half the instructions of the staged form, and the same arithmetic on the same bf16-rounded values.
+  // (The erf GELU of the CLIP tower keeps the staged form: its libm call spills beside 384 live accumulators.)
+  if constexpr (EPI != EPI_BIAS_GELU_ERF) {
+    f32x4 bcol[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const int n = n0 + wn * 128 + g * 16 + fg * 4;
+      bcol[g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int ccol = wn * 128 + (fg & 1) * 16 + (fg >> 1) * 8;  // + 32 gp: this lane's 8 columns of pair gp inside the tile
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
+    const auto r_rsrc = EPI == EPI_GATE_RES ? __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, (uint32_t)(M - 1) * (uint32_t)(ldres * 2) + (uint32_t)N * 2u, 0x00020000)
+                                            : c_rsrc;
+    int g_switch = 0x7fffffff;  // first global row that takes the second sample's gate
+    float* gtab = reinterpret_cast<float*>(smem);  // gate values of the tile's 256 columns: [first sample | second sample] (LDS is free now)
+    if (EPI == EPI_GATE_RES) {
+      const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
+      const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
+      const int nc = min(n0 + tid, N - 1);
+      gtab[tid] = gate != nullptr ? gate[(size_t)s0 * N + nc] : 1.0f;
+      gtab[256 + tid] = gate != nullptr ? gate[(size_t)s1 * N + nc] : 1.0f;
+      if (s1 != s0) g_switch = s1 * gate_rows;
+      __syncthreads();
+    }
+    u32x4 rv[2][4];
+    auto res_load = [&](int f, u32x4* dst) __attribute__((always_inline)) {
+      const int m = m0 + wm * 192 + f * 16 + fr;
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) {
+        const int n = n0 + ccol + gp * 32;
+        const uint32_t off = (m < M && n < N) ? (uint32_t)m * (uint32_t)(ldres * 2) + (uint32_t)n * 2u : 0xffffffffu;
+        dst[gp] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
+      }
+    };
+    if (EPI == EPI_GATE_RES) res_load(0, rv[0]);
+#pragma unroll
+    for (int f = 0; f < 12; ++f) {
+      if (EPI == EPI_GATE_RES && f + 1 < 12) res_load(f + 1, rv[(f + 1) & 1]);  // one row fragment ahead
+      const int m = m0 + wm * 192 + f * 16 + fr;
+      float brow = 0.f;
+      if (EPI == EPI_BIAS_ROW) brow = bias[min(m, M - 1)];
+      const float* gsel = gtab + (m >= g_switch ? 256 : 0) + ccol;
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) {
+        f32x4 b0 = bcol[2 * gp], b1 = bcol[2 * gp + 1];
+        if (EPI == EPI_BIAS_ROW) b0 = b1 = f32x4{brow, brow, brow, brow};
+        const f32x4 v0 = acc[f][2 * gp], v1 = acc[f][2 * gp + 1];
+        uint32_t a0 = pack_bf16(v0[0] + b0[0], v0[1] + b0[1]), a1 = pack_bf16(v0[2] + b0[2], v0[3] + b0[3]);
+        uint32_t c0 = pack_bf16(v1[0] + b1[0], v1[1] + b1[1]), c1 = pack_bf16(v1[2] + b1[2], v1[3] + b1[3]);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, c1, false, false);
+        u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // this lane's 8 consecutive columns of row m
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_tanh(bf16lo(o[q])), gelu_tanh(bf16hi(o[q])));
+        } else if (EPI == EPI_GATE_RES) {
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gsel + gp * 32), g1 = *reinterpret_cast<const f32x4*>(gsel + gp * 32 + 4);
+          const u32x4 r = rv[f & 1][gp];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
+            // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
+            o[q] = pack_bf16(mul_then_add(bf16lo(o[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(o[q]), gb, bf16hi(r[q])));
+          }
+        }
+        const int n = n0 + ccol + gp * 32;
+        const uint32_t coff = (m < M && n < N) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)n * 2u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
+      }
+    }
+    return;
+  }
+#endif
   // ---- epilogue: six passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave = tile rows wm*192 + p*32 + [0,32))
   f32x4 bcol[8];
 #pragma unroll
