@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (s1 != s0) g_switch = s1 * gate_rows;
       __syncthreads();
     }
-    u32x4 rv[2][4];
+#ifndef G384_RES_AHEAD
+#define G384_RES_AHEAD 1
+#endif
+    constexpr int RA = G384_RES_AHEAD;  // row fragments of residual in flight ahead of the one being finished
+    u32x4 rv[RA + 1][4];
     auto res_load = [&](int f, u32x4* dst) __attribute__((always_inline)) {
       const int m = m0 + wm * 192 + f * 16 + fr;
 #pragma unroll
@@ -271,10 +275,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         dst[gp] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
       }
     };
-    if (EPI == EPI_GATE_RES) res_load(0, rv[0]);
+    if (EPI == EPI_GATE_RES) {
+#pragma unroll
+      for (int f = 0; f < RA; ++f) res_load(f, rv[f % (RA + 1)]);
+    }
 #pragma unroll
     for (int f = 0; f < 12; ++f) {
-      if (EPI == EPI_GATE_RES && f + 1 < 12) res_load(f + 1, rv[(f + 1) & 1]);  // one row fragment ahead
+      if (EPI == EPI_GATE_RES && f + RA < 12) res_load(f + RA, rv[(f + RA) % (RA + 1)]);
       const int m = m0 + wm * 192 + f * 16 + fr;
       float brow = 0.f;
       if (EPI == EPI_BIAS_ROW) brow = bias[min(m, M - 1)];
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_tanh(bf16lo(o[q])), gelu_tanh(bf16hi(o[q])));
         } else if (EPI == EPI_GATE_RES) {
           const f32x4 g0 = *reinterpret_cast<const f32x4*>(gsel + gp * 32), g1 = *reinterpret_cast<const f32x4*>(gsel + gp * 32 + 4);
-          const u32x4 r = rv[f & 1][gp];
+          const u32x4 r = rv[f % (RA + 1)][gp];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
