@@ -365,7 +365,7 @@ def main():
         if graph:
             sched_._step_index = 0
             gd = GraphedDenoiser(model, sched_, wl_.latents, wl_.condition, wl_.prompt, wl_.negative, wl_.image, a.guidance,
-                                 batch_cfg=not sequential)
+                                 batch_cfg=not sequential, keep_warmup_step=False)  # every timed step() is a replay
             return lambda i: gd.step(i)
         return lambda i: denoise_step(model, sched_, wl_.latents, wl_.condition, sched_.timesteps[i], wl_.prompt, wl_.negative,
                                       wl_.image, a.guidance, batch_cfg=not sequential, cfg_inputs=cfg_inputs)

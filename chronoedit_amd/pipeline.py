@@ -110,11 +110,14 @@ class GraphedDenoiser:
     A new graph is needed when the latent shape changes (temporal-reasoning truncation 8 -> 2 frames)."""
 
     def __init__(self, transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
-                 guidance_scale: float, batch_cfg: bool = True, warm: bool = False):
+                 guidance_scale: float, batch_cfg: bool = True, warm: bool = False, keep_warmup_step: bool = True):
         """warm: this process has already run a step of exactly this shape / guidance form through `transformer` (packed weights,
-        workspaces, kernel attributes exist), so the un-captured warm-up step is skipped - it costs a whole step, 12 % of an 8-step
-        edit; only the step-invariant context projections are computed eagerly in front of the capture so that the graph holds the
-        cache HIT (`cache_context`), not the projections."""
+        workspaces, kernel attributes exist), so no un-captured step is needed in front of the capture; only the step-invariant context
+        projections are computed eagerly so that the graph holds the cache HIT (`cache_context`), not the projections.
+        Not warm: the un-captured step that triggers the lazy initialisations IS the trajectory's current step (it runs eagerly on the
+        live state, `step()` then skips the replay for that index) - a discarded warm-up cost a whole step per new shape: 2 s of a
+        temporal-reasoning edit at 28 800 tokens, 12 % of an 8-step edit.  keep_warmup_step=False: run it on saved state and put the
+        state back (a caller that wants every `step()` to be a replay: bench.py)."""
         assert latents.dtype == torch.float32 and latents.is_contiguous()
         if not _capturable(transformer):
             # Measured on this stack (ROCm 7.0 / RCCL 2.26 / torch 2.10: tools/rccl_graph_probe.py, profiles/r03_rccl_graph_probe.txt): ONE
@@ -136,38 +139,39 @@ class GraphedDenoiser:
         self.t_buf = torch.zeros((), dtype=torch.int64, device=dev)
         self.coef_buf = torch.zeros(10, dtype=torch.float32, device=dev)
         scheduler._ensure_state(latents)
-        # warm-up (lazy initialisations: packed weights, workspaces, function attributes) on saved state, then capture
         if scheduler.last_sample is None:
             scheduler.last_sample = torch.zeros_like(latents)
-        saved = (latents.clone(), [m.clone() for m in scheduler.model_outputs], scheduler.last_sample.clone(), scheduler._step_index)
-        self._stage(scheduler._step_index or 0)
+        idx0 = scheduler._step_index
+        self._stage(idx0 or 0)
         eng = getattr(transformer, "_engine", None)
         n_samples = latents.shape[0] * (2 if self.cfg_inputs is not None else 1)
         warm = bool(warm and eng is not None and hasattr(eng, "is_warm") and eng.is_warm(n_samples, *latents.shape[2:]))
+        self._done_index = None  # the step that already ran eagerly (below); step() does not replay it
         if not warm:
+            # lazy initialisations (packed weights, workspaces, function attributes) must not happen under capture: run the CURRENT step
+            # eagerly, for real, on a side stream as torch asks of anything that precedes a capture
+            saved = None if keep_warmup_step else (latents.clone(), [m.clone() for m in scheduler.model_outputs], scheduler.last_sample.clone())
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._body()
             torch.cuda.current_stream().wait_stream(side)
-            self._restore(saved)
+            if keep_warmup_step:
+                self._done_index = idx0 or 0
+            else:
+                self.latents.copy_(saved[0])
+                for m, sv in zip(scheduler.model_outputs, saved[1]):
+                    m.copy_(sv)
+                scheduler.last_sample.copy_(saved[2])
         elif getattr(transformer, "cache_context", False) and hasattr(transformer, "prime_context"):
             if self.cfg_inputs is not None:
                 transformer.prime_context(self.cfg_inputs[0], self.cfg_inputs[1])
             elif not self.guided:
                 transformer.prime_context(prompt_embeds, image_embeds)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph):  # (a capture executes nothing: the device state stays what the eager step left)
             self._body()
-        self._restore(saved)
-
-    def _restore(self, saved):
-        lat, mos, last, idx = saved
-        self.latents.copy_(lat)
-        for m, s in zip(self.sch.model_outputs, mos):
-            m.copy_(s)
-        self.sch.last_sample.copy_(last)
-        self.sch._step_index = idx
+        scheduler._step_index = idx0  # step_cfg counts on the host, also while being captured
 
     def _stage(self, i):
         self.t_buf.copy_(self.sch.timesteps[i])
@@ -188,6 +192,11 @@ class GraphedDenoiser:
         self.sch.step_cfg(c, u, self.g, self.latents, coef=self.coef_buf)
 
     def step(self, i: int) -> torch.Tensor:
+        if self._done_index is not None and i == self._done_index:  # this step ran eagerly in front of the capture
+            self._done_index = None
+            self.sch._step_index = i + 1
+            return self.latents
+        self._done_index = None
         self._stage(i)
         self.graph.replay()
         self.sch._step_index = i + 1
