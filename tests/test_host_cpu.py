@@ -186,3 +186,21 @@ def test_macro_tile_choice_of_the_step_shapes():
     # without a workspace a partial last round cannot be cut along K: it costs a whole round
     assert lib.ce_gemm_bf16_tile_rows(14400, 5120, 5120, 256, 0) == 384    # 3 rounds x 1.5 against 5
     assert lib.ce_gemm_bf16_tile_rows(14400, 13824, 5120, 256, 0) == 256   # 9 rounds x 1.5 against 13
+
+
+def test_mx_scale_layout_helpers_agree_with_the_kernels_offset_formula():
+    """The tiled E8M0 scale layout of the MX fp8 GEMM operands ([rows / 128][K / 128][4 blocks][16 rows][8 row groups], ce_common.h
+    `mx_gemm_scale_offset`): `ops.mx_scale_bytes` sizes it and `ops.mx_scales_to_rows` undoes it - replayed here against the device
+    formula ((row >> 7) ktiles + (blk >> 2)) 512 + (blk & 3) 128 + (row & 15) 8 + ((row >> 4) & 7), incl. a ragged last row tile."""
+    from chronoedit_amd import ops
+    for rows, K in ((128, 128), (300, 512), (1003, 5120), (17, 256)):
+        ktiles = K // 128
+        buf = torch.zeros(ops.mx_scale_bytes(rows, K), dtype=torch.uint8)
+        assert buf.numel() == (rows + 127) // 128 * ktiles * 512
+        want = torch.randint(1, 255, (rows, K // 32), dtype=torch.uint8, generator=torch.Generator().manual_seed(rows))
+        r = torch.arange(rows)[:, None]
+        b = torch.arange(K // 32)[None, :]
+        off = ((r >> 7) * ktiles + (b >> 2)) * 512 + (b & 3) * 128 + (r & 15) * 8 + ((r >> 4) & 7)
+        assert int(off.max()) < buf.numel() and off.unique().numel() == off.numel()  # a bijection onto distinct bytes
+        buf[off.reshape(-1)] = want.reshape(-1)
+        assert torch.equal(ops.mx_scales_to_rows(buf, rows, K), want)
