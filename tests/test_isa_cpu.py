@@ -133,3 +133,33 @@ def test_mxfp8_attention_kernels_have_no_spills_and_their_matrix_work_per_tile()
     assert sp[5] <= 1, sp    # no tile load is waited for where it is issued (LDS-DMA three iterations ahead); one per-item prologue load is
     # 4 S + 4 P.V + 1 row-sum MFMA in the steady-state body, the peeled first tile (4 + 1), the repair route (4) and the drain (4 + 1 ...)
     assert 20 <= sp[4] <= 28, sp
+
+
+def test_vae_head_conv_and_mid_block_attention_kernels_keep_their_shape():
+    """ce_conv.hip, round 4.  conv_head_kernel: 90 MFMAs per kt (10 input rows x 9 fragments) in three workgroups' worth of registers, its
+    input fragments by BUFFER loads issued a row ahead (a frame pointer read back from LDS made hipcc emit flat loads with a full wait
+    behind every one: 10 x slower) - no flat load, no load waited for where it is issued beyond the weight staging.  attn_1head_kernel:
+    no scratch, the staging registers do not push O into spill copies (the accumulators live in the AGPRs as the MFMAs' own operand:
+    per tile only the conditional rescale block moves them)."""
+    import subprocess
+    import tempfile
+    rows = _rows("ce_conv.hip")
+    (head,) = _pick(rows, "conv_head_kernel")
+    assert head[3] == 0 and head[2] <= 168 and head[4] == 90 and head[5] <= 1, head
+    for r in _pick(rows, "attn_1head_kernel"):
+        assert r[3] == 0, r
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, "ce_conv.hip"),
+                        "-o", asm], check=True, stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+
+    def body(sub):
+        m = re.search(r"^(\S*" + sub + r"\S*):\s*; @\1$", text, flags=re.M)
+        return text[m.end():text.index(".Lfunc_end", m.end())]
+
+    hb = body("conv_head_kernel")
+    assert "flat_load" not in hb and hb.count("buffer_load_dwordx4") >= 90, (hb.count("flat_load"), hb.count("buffer_load_dwordx4"))
+    ab = body("attn_1head_kernelILi384E")
+    assert "flat_load" not in ab and ab.count("buffer_load_dwordx4") == 48  # 2 x 24 staging loads (prologue tile + the in-loop prefetch)
+    assert ab.count("v_accvgpr") <= 560, ab.count("v_accvgpr")  # (init, one conditional rescale block, the final normalisation)
