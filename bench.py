@@ -37,7 +37,11 @@ import statistics
 import sys
 import time
 
-import torch
+# dmabuf IPC is the only kind this host driver supports: without it RCCL's hipIpcGetMemHandle fails at N > 1 (already exported on the GPU
+# boxes; a default here keeps a bare `torchrun bench.py` working - it must be set before the HIP runtime comes up)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
