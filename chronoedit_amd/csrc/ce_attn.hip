@@ -1638,11 +1638,21 @@ static int attention_2seg_vt_launch(const void* Q, const void* K1, const void* V
     done = true;
   }
   const BlkRows blk{0, vt_cols2, 0u, vt_cols1, (unsigned char*)O8, (unsigned char*)S8, ldo8};  // plain rows; the two column strides
+  // persistent like the single-segment V^T launch: two workgroups per CU walk the work order (an item is 13 key tiles here: -3 % against
+  // one workgroup per item, profiles/r04_cross_attention_persistent_ab.txt; 3 and 4 per CU are level with 2)
+  static int cus2_[CE_MAX_DEVICES] = {};
+  int& cus = cus2_[ce_device_slot()];
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const int items = nqb * H * batch;
+  const int grid = items <= 2 * cus ? items : ((2 * cus) & ~7);
   if (O8)
-    hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q,
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true, true>), dim3(grid), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q,
                        (bf16*)O, s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, blk);
   else
-    hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true>), dim3(nqb * H * batch), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q, (bf16*)O,
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<true, true>), dim3(grid), dim3(512), sp_smem_bytes(true), stream, (const bf16*)Q, (bf16*)O,
                        s0, s1, Nq, H, ldq, ldo, nqb, sl2, batch, blk);
   return (int)hipGetLastError();
 }
