@@ -204,3 +204,42 @@ def test_mx_scale_layout_helpers_agree_with_the_kernels_offset_formula():
         assert int(off.max()) < buf.numel() and off.unique().numel() == off.numel()  # a bijection onto distinct bytes
         buf[off.reshape(-1)] = want.reshape(-1)
         assert torch.equal(ops.mx_scales_to_rows(buf, rows, K), want)
+
+
+@pytest.mark.parametrize("KT,T,H,W,Cout", [(3, 2, 11, 21, 3), (1, 1, 8, 16, 4)])
+def test_head_conv_row_packing_reproduces_the_convolution(KT, T, H, W, Cout):
+    """The arithmetic of conv_head_kernel (csrc/ce_conv.hip) replayed on the CPU: the three kernel ROWS ride in the matrix instruction's
+    output rows - A row n = (kh, co), B = 16 consecutive pixels of ONE padded input row rho - so P[rho][(kh, co)][pixel], summed over
+    (kt, kw, 32-channel chunk), holds what input row rho contributes to the output rows rho - kh, and out[h] = P[h][0] + P[h+1][1] +
+    P[h+2][2].  A wave owns 8 output rows x 16 columns = 10 input rows; ragged tiles clamp their loads and skip their stores."""
+    g = torch.Generator().manual_seed(KT + W)
+    Cin = 96
+    x = torch.randn(Cin, T + KT - 1, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, KT, 3, 3, generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.conv3d(torch.nn.functional.pad(x[None], (1, 1, 1, 1, 0, 0)), w)[0]  # [Cout, T, H, W]
+    xp = torch.zeros(T + KT - 1, H + 2, W + 2, Cin, dtype=torch.float64)  # bordered channels-last frames
+    xp[:, 1:-1, 1:-1] = x.permute(1, 2, 3, 0)
+    A = torch.zeros(KT, 3, 3, 16, 32, dtype=torch.float64)  # weight fragments [kt][kw][chunk][n = (kh, co)][k]
+    for kh in range(3):
+        for co in range(Cout):
+            A[:, :, :, kh * 4 + co] = w[co].permute(1, 3, 2, 0)[:, :, kh].reshape(KT, 3, 3, 32)  # [kt][kw][Cin -> (chunk, k)] of row kh
+    out = torch.zeros(Cout, T, H, W, dtype=torch.float64)
+    for t in range(T):
+        for h0 in range(0, H, 8):
+            for w0 in range(0, W, 16):
+                cols = torch.clamp(torch.arange(w0, w0 + 16), max=W - 1)
+                P = torch.zeros(10, 16, 16, dtype=torch.float64)  # [rho][n][pixel]
+                for kt in range(KT):
+                    for rho in range(10):
+                        row = min(h0 + rho, H + 1)
+                        for kw in range(3):
+                            for c in range(3):
+                                B = xp[t + kt, row, cols + kw, 32 * c: 32 * c + 32]  # [pixel][k]
+                                P[rho] += A[kt, kw, c] @ B.t()
+                for j in range(8):
+                    if h0 + j >= H:
+                        continue
+                    o = P[j, 0:4] + P[j + 1, 4:8] + P[j + 2, 8:12]  # lane groups 0 / 1 / 2 hold kernel rows 0 / 1 / 2
+                    ok = torch.arange(w0, w0 + 16) < W
+                    out[:, t, h0 + j, w0: w0 + int(ok.sum())] = o[:Cout, : int(ok.sum())]
+    assert torch.allclose(out, ref, rtol=1e-10, atol=1e-10), float((out - ref).abs().max())
