@@ -82,6 +82,7 @@ def parse():
                     help="MEASURE the 50-step configs[1] edit end to end (~17 s; default on one GPU)")
     ap.add_argument("--no-full-edit", dest="full_edit", action="store_false", help="skip the measured 50-step edit")
     ap.add_argument("--no-fp8-leg", action="store_true", help="skip the secondary fp8-GEMM-mode timing")
+    ap.add_argument("--no-fp8-config4", action="store_true", help="skip the BASELINE configs[4] leg (1584x1056, fp8, 3 steps) of the one-GPU line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-only", action="store_true",
                     help="no GPU: only the CPU legs (cpu_baseline at N = 7200 and BASELINE configs[0] at N = 512; with /root/reference present also "
@@ -146,19 +147,40 @@ def _host_cores() -> int:
     return max(1, n)
 
 
-def _median_time(fn, runs=3, warm=1):
+def _median_time(fn, runs=3, warm=1, budget_s=None):
+    """Median wall time of `runs` calls after `warm` untimed ones.  With `budget_s`: a bounded sample - when the warm-up call alone took more
+    than a third of the budget it IS the sample (one cold run; the caller's text says so), and the timed runs stop once the budget is spent."""
     ts = []
+    t_begin = time.perf_counter()
     for i in range(warm + runs):
         t0 = time.perf_counter()
         fn()
+        dt = time.perf_counter() - t0
         if i >= warm:
-            ts.append(time.perf_counter() - t0)
+            ts.append(dt)
+        elif budget_s is not None and dt > budget_s / 3:
+            return dt, [dt]
+        if budget_s is not None and ts and time.perf_counter() - t_begin > budget_s:
+            break
     return statistics.median(ts), ts
 
 
-def cpu_baseline(N: int, steps_fwd: int):
-    """Oracle ("port") on the host cores: one full-width transformer block at N tokens, fp32; one warm-up run, then the
-    median of three."""
+def _reference_transformer():
+    """The reference's own transformer_chronoedit.py as built by oracle/build_ref.py into oracle/_ref/transformer_ref.bin (a marshalled
+    code object: /root/reference does not exist on the GPU box, the build output does).  None when it was not built."""
+    try:
+        from oracle import build_ref
+        return build_ref.load_transformer()
+    except Exception:  # noqa: BLE001 - a baseline leg must never take the bench line down
+        return None
+
+
+def cpu_baseline(N: int, steps_fwd: int, budget_s: float = 45.0, grid=None):
+    """The reference's OWN `ChronoEditTransformerBlock` (chronoedit_diffusers/transformer_chronoedit.py:215-295, executed from
+    oracle/_ref/transformer_ref.bin over oracle/refshim's diffusers leaves: "kind": "reference") on this host's cores: one full-width block at
+    N tokens, fp32 eager; one warm-up run, then the median of three; x40 blocks x forwards/step.  The CPU oracle
+    ("port", oracle/dit_oracle.py) is timed on the same tensors right after it and reported beside it; it alone is the baseline when the
+    reference build output is absent (kind "port")."""
     from oracle import dit_oracle as O
     cores = _host_cores()
     torch.set_num_threads(cores)
@@ -168,16 +190,46 @@ def cpu_baseline(N: int, steps_fwd: int):
     x = torch.randn(1, N, cfg.inner_dim, generator=g)
     enc = torch.randn(1, 769, cfg.inner_dim, generator=g)
     temb6 = torch.randn(1, 6, cfg.inner_dim, generator=g) * 0.1
-    T, hp, wp = 2, 45, N // 90
-    rot = O.rope_table(cfg, T, 2 * hp, 2 * wp) if T * hp * wp == N else None
+    T, hp, wp = grid if grid is not None else (2, 45, N // 90)  # (latent frames, patch rows, patch columns): 720p edit shape by default
+    shaped = T * hp * wp == N
+    rot = O.rope_table(cfg, T, 2 * hp, 2 * wp) if shaped else None
+    t_start = time.perf_counter()
+    ref = None
+    mod = _reference_transformer()
     with torch.no_grad():
-        dt, times = _median_time(lambda: O.block_forward(p, 0, cfg, x, enc, temb6, rot))
-    per_step = dt * 40 * steps_fwd
-    return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
-            "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, median of 3 after 1 warm-up = {dt:.2f} s "
-                      f"(runs {', '.join(f'{t:.2f}' for t in times)}); x40 blocks x{steps_fwd} forwards/step.  kind = port (oracle/dit_oracle.py); the "
-                      "reference's own transformer class is timed beside it where /root/reference exists: profiles/r03_cpu_legs.json "
-                      "(18.47 s reference vs 18.07 s port per N = 512 forward on the build container's 8 cores)"}
+        if mod is not None and shaped:
+            blk = mod.ChronoEditTransformerBlock(cfg.inner_dim, cfg.ffn_dim, cfg.num_attention_heads, cfg.qk_norm, cfg.cross_attn_norm, cfg.eps,
+                                                 cfg.added_kv_proj_dim).eval()
+            sd = {k[len("blocks.0."):]: v for k, v in p.items()}
+            blk.load_state_dict(sd, strict=True, assign=True)
+            rope = mod.ChronoEditRotaryPosEmbed(cfg.attention_head_dim, tuple(cfg.patch_size), cfg.rope_max_seq_len,
+                                                temporal_skip_len=cfg.rope_temporal_skip_len)
+            rot_ref = rope(torch.empty(1, 1, T, 2 * hp, 2 * wp))
+            dt_r, times_r = _median_time(lambda: blk(x, enc, temb6, rot_ref), budget_s=budget_s)
+            ref = (dt_r, times_r, None)
+            del blk
+        # the port beside it: the full median-of-three when it is the only baseline, one timed run after a warm-up when the reference
+        # class was timed (and less if the host is slow: the whole leg stays inside `budget_s`)
+        runs = 3 if ref is None else (1 if time.perf_counter() - t_start > budget_s / 2 else 2)
+        dt_p, times_p = _median_time(lambda: O.block_forward(p, 0, cfg, x, enc, temb6, rot), runs=runs, budget_s=budget_s)
+    port = {"seconds_per_block": round(dt_p, 3), "runs": [round(t, 2) for t in times_p], "steps_per_sec": 1.0 / (dt_p * 40 * steps_fwd),
+            "what": "oracle/dit_oracle.block_forward (the CPU restatement the parity tests check against), same tensors, same threads"}
+    if ref is None:
+        per_step = dt_p * 40 * steps_fwd
+        return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
+                "sample": f"1 of 40 DiT blocks, N={N}, fp32 torch-CPU oracle, median of {len(times_p)} after 1 warm-up = {dt_p:.2f} s "
+                          f"(runs {', '.join(f'{t:.2f}' for t in times_p)}); x40 blocks x{steps_fwd} forwards/step.  kind = port (oracle/dit_oracle.py): "
+                          "oracle/_ref/transformer_ref.bin (the reference's own class, built by __graft_entry__.build() where /root/reference exists) "
+                          "was not found on this box", "port": port}
+    dt_r, times_r, _ = ref
+    per_step = dt_r * 40 * steps_fwd
+    return {"value": 1.0 / per_step, "unit": "denoising-steps/sec", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "reference",
+            "sample": f"1 of 40 DiT blocks, N={N}, fp32 eager: the reference's own ChronoEditTransformerBlock.forward (chronoedit_diffusers/"
+                      f"transformer_chronoedit.py:215-295 compiled into oracle/_ref/transformer_ref.bin; diffusers leaf modules from oracle/refshim) "
+                      f"with its own ChronoEditRotaryPosEmbed table, torch-CPU on {cores} threads, " +
+                      (f"median of {len(times_r)} after 1 warm-up" if len(times_r) > 1 else f"ONE run (bounded sample: a single call already exceeds a third of the {budget_s:.0f} s budget)") +
+                      f" = {dt_r:.2f} s (runs {', '.join(f'{t:.2f}' for t in times_r)}); x40 blocks x{steps_fwd} forwards/step",
+            "port": port, "reference_over_port_time": round(dt_r / dt_p, 3)}
 
 
 def cpu_config0(with_reference: bool = True, depths=(1, 2, 4)):
@@ -221,18 +273,19 @@ def cpu_config0(with_reference: bool = True, depths=(1, 2, 4)):
             t_port.append(dt)
             Ls_port.append(L)
         legs["port"] = (Ls_port, t_port)
-        ref_py = "/root/reference/chronoedit_diffusers/transformer_chronoedit.py"
-        if with_reference and os.path.exists(ref_py):
-            sys.path.insert(0, os.path.join(ROOT, "oracle", "refshim"))
-            from oracle import gen_golden as G
-            mod = G.load_reference_module()
+        mod = _reference_transformer() if with_reference else None
+        if mod is not None:
+            from oracle import gen_golden as G  # (build_reference_model only: constructs the reference class and loads the synthetic state dict)
             t_ref = []
             for L in Ls_port:
+                if t_ref and time.perf_counter() - t_start > 2 * budget_s:
+                    break
                 m = G.build_reference_model(mod, O.DiTConfig(num_layers=L), sub(L))
                 dt, _ = _median_time(lambda: m(lat, ts, text, image, return_dict=False), runs=2, warm=0 if t_ref else 1)
                 t_ref.append(dt)
                 del m
-            legs["reference"] = (Ls_port, t_ref)
+            if len(t_ref) >= 2:
+                legs["reference"] = (Ls_port[:len(t_ref)], t_ref)
     for kind, (Ls, tl) in legs.items():
         a0, b = fit([float(l) for l in Ls], tl)
         fwd40 = a0 + 40 * b
@@ -287,6 +340,30 @@ class Workload:
         self.image = torch.randn((1, 257, 1280), generator=g, device=dev).to(torch.bfloat16)
 
 
+def _self_launch(n: int):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): re-execute this very command line under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` - the form the driver
+    uses for N > 1 - so the same verb works at every N.  Replaces the process (exit code and stdout are the launcher's).  A box with fewer
+    than N GPUs gets ONE parsable error line and exit code 2 instead of N ranks dying in set_device."""
+    if os.environ.get("CE_BENCH_SELF_LAUNCHED"):
+        raise RuntimeError("bench.py re-launched itself but still sees no WORLD_SIZE: torch.distributed.run did not set the rank environment")
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("CE_BENCH_TEST_BACKEND"):
+        print(json.dumps({"metric": "denoising-steps/sec", "value": None, "n_gpus": n,
+                          "error": f"--gpus {n} but this box exposes {have} GPU(s)"}), flush=True)
+        sys.exit(2)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CE_BENCH_SELF_LAUNCHED="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     a = parse()
     if a.cpu_only:
@@ -318,7 +395,7 @@ def main():
         if a.gpus != world:
             raise RuntimeError(f"--gpus {a.gpus} but the launcher started {world} ranks")
     elif a.gpus != 1:
-        raise RuntimeError(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` (one rank per GPU)")
+        _self_launch(a.gpus)  # bare `python bench.py --gpus N`: becomes the torch.distributed.run launch the driver uses (never returns)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -525,6 +602,8 @@ def main():
             import traceback
             sharded_error = f"rank {rank}: {type(e).__name__}: {e} | " + traceback.format_exc(limit=4).replace("\n", " / ")
             ok = False
+            if rank != 0:  # said at once, from the rank it happened on: should the peers never reach the vote (a watchdog abort under RCCL) this line still exists
+                print(json.dumps({"metric": "denoising-steps/sec", "value": None, "n_gpus": world, "rank": rank, "error": sharded_error}), flush=True)
         try:
             torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
@@ -571,9 +650,23 @@ def main():
                                "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
                                "launches": sum(d["n"] for d in big.values()), "total_ms": round(fam_ms, 3), "share_of_step": round(fam_ms / tot, 4)}
 
-    single = dict(cached_rate=None, fp8_rate=None, vae_s=None, enc_s=None, edit8=None, edit50=None, edit_reasoning=None)
+    single = dict(cached_rate=None, fp8_rate=None, fp8_config4=None, vae_s=None, enc_s=None, edit8=None, edit50=None, edit_reasoning=None)
     if world == 1 and rank == 0:
         _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w, single)
+
+    # ---- N > 1: the headline is measured; say it NOW in a line marked preliminary (the legs below run whole edits and CPU baselines for minutes -
+    # should one of them take the process down, the timed figure of this run is already on stdout), then measure sec/edit with the DiT sharded
+    if world > 1 and rank == 0 and dt is not None:
+        print(json.dumps({"metric": "denoising-steps/sec", "value": round(a.steps / dt * (1 if ulysses else world), 4), "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "scaling": "strong" if ulysses else "weak", "preliminary": True,
+                          "note": "headline of this run, printed before the secondary legs; the COMPLETE line (same value + roofline, cpu_baseline, sec/edit) is the last line"}),
+              flush=True)
+    sharded_edit = None
+    if ulysses and a.reasoning_edit and not a.no_edit and not a.no_vae and T == 8:
+        try:
+            sharded_edit = _sharded_edit_leg(a, model, dev, world, max_over_ranks, test_backend)
+        except Exception as e:  # noqa: BLE001 - reported, never fatal to the line
+            sharded_edit = {"error": f"rank {rank}: {type(e).__name__}: {e}"}
 
     # ---- N > 1, Ulysses headline: the same workload on ONE GPU (rank 0) and the replica (weak-scaling) figure, both outside
     # the timed region, so the line is self-contained
@@ -643,7 +736,9 @@ def main():
                        "context_cache": bool(a.cache_context)},
             "model_tflops_per_step": round(fl / 1e12, 2),
             "achieved_tflops_per_gpu": round(per_gpu, 1),
-            "mfma_roofline_frac_whole_step": round(per_gpu / PEAK_BF16_TFLOPS, 4),
+            # against the dense peak of the arithmetic this run computes its GEMMs in (fp8 runs: the 5 PFLOP/s fp8 peak, not the bf16 one)
+            "mfma_roofline_frac_whole_step": round(per_gpu / (PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS), 4),
+            "mfma_roofline_peak_tflops": PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS,
             "finite": finite,
             **({"TEST_ONLY": f"ranks share one GPU, collectives host-staged over {test_backend}: exercises the code path, measures nothing"} if test_backend else {}),
             "launch": "hipGraph replay" if a.graph else "eager",
@@ -657,6 +752,7 @@ def main():
             "replica_mode": replica,
             "steps_per_sec_with_context_kv_cache": single["cached_rate"],
             "steps_per_sec_fp8_mode": single["fp8_rate"],
+            "fp8_mode_frac_of_fp8_peak": None if not single["fp8_rate"] else round(fl * single["fp8_rate"] / 1e12 / PEAK_FP8_TFLOPS, 4),
             "vae": vae_s,
             "encoders": enc_s,
             "sec_per_edit": {"configs[2] 8-step distilled schedule, guidance 1 (measured end to end)": single["edit8"],
@@ -666,17 +762,19 @@ def main():
             "roofline": roofline,
             "roofline_family": roofline_family,
             "kernel_breakdown": breakdown,
-            "sec_per_edit_temporal_reasoning": single.get("edit_reasoning"),
+            "sec_per_edit_temporal_reasoning": single.get("edit_reasoning") if world == 1 else sharded_edit,
+            "steps_per_sec_fp8_config4": single.get("fp8_config4"),
         }
         if a.layers != 40:
             out["invalid"] = "reduced depth (debug run)"
-        if world == 1 and not a.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(N, fwd_per_step)
+        if not a.no_cpu_baseline:
+            try:  # (rank 0 at every N, after the timed region; at N = 28 800 one call of the block is ~1 min of host time: a bounded single-run sample)
+                out["cpu_baseline"] = cpu_baseline(N, fwd_per_step, grid=(T, h // 2, w // 2))
             except Exception as e:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"error": repr(e)}
-            try:  # BASELINE.json configs[0] (N = 512, fp32 CPU plumbing): the port here; port + the reference's own class in profiles/r03_cpu_legs.json
-                out["cpu_config0"] = cpu_config0(with_reference=False, depths=(1, 2))  # (1, 2, 4) + the reference class: bench.py --cpu-only
+            try:  # BASELINE.json configs[0] (N = 512, fp32 CPU plumbing): the reference's own ChronoEditTransformer3DModel and the port, depths 1 and 2
+                if world == 1:
+                    out["cpu_config0"] = cpu_config0(with_reference=True, depths=(1, 2))  # (1, 2, 4): bench.py --cpu-only
             except Exception as e:
                 out["cpu_config0"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
@@ -685,6 +783,95 @@ def main():
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001 - a data group that failed may not shut down cleanly; the lines are already printed
             pass
+
+
+def _edit_runners(a, model, vae, te_model, ie_model, dev, after=None):
+    """Closures that run ONE whole edit through ChronoEditPipeline (token ids + pixel values + image in, video out) and return its wall time;
+    `after(seconds) -> seconds` lets the N > 1 caller take the MAX over ranks.  ONE pipeline object for all edits, as a serving process holds
+    it: hipGraph replay (where the step is capturable) and the per-edit context cache are its defaults, and a latent shape seen before is
+    captured without another warm-up step.  te_model / ie_model None: seeded random conditioning stands in for the encoders (said in the line)."""
+    from chronoedit_amd.pipeline import ChronoEditPipeline
+    from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
+    g = torch.Generator(device=dev).manual_seed(43)
+    image = torch.rand((1, 3, a.height, a.width), generator=g, device=dev) * 2 - 1
+    ids = torch.randint(2, 256384, (1, 512), generator=g, device=dev)
+    am = torch.zeros((1, 512), dtype=torch.long, device=dev)
+    am[0, :64] = 1
+    nids = torch.randint(2, 256384, (1, 512), generator=g, device=dev)
+    nam = torch.zeros((1, 512), dtype=torch.long, device=dev)
+    nam[0, :20] = 1
+    px = torch.randn((1, 3, 224, 224), generator=g, device=dev)
+    fake = None
+    if te_model is None or ie_model is None:
+        wl_ = Workload(dev, 2, 16, 16, 4343)
+        fake = (wl_.prompt, wl_.negative, wl_.image)
+    after = after or (lambda x: x)
+
+    pipe = ChronoEditPipeline(text_encoder=te_model, image_encoder=ie_model, transformer=model, vae=vae,
+                              scheduler=FlowUniPCMultistepScheduler(flow_shift=5.0))
+
+    def conditioning(guidance):
+        if fake is not None:
+            return fake[0], (fake[1] if guidance > 1 else None), fake[2]
+        pos, neg = pipe.encode_prompt(input_ids=ids, attention_mask=am, negative_input_ids=nids if guidance > 1 else None,
+                                      negative_attention_mask=nam if guidance > 1 else None)
+        return pos, neg, pipe.encode_image(px)
+
+    def edit(steps, guidance, shift):
+        pipe.scheduler = FlowUniPCMultistepScheduler(flow_shift=shift)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pos, neg, img = conditioning(guidance)
+        video = pipe.edit_tensors(image, pos, neg, img, num_frames=5, num_inference_steps=steps, guidance_scale=guidance)
+        torch.cuda.synchronize()
+        return round(after(time.perf_counter() - t0), 3), bool(torch.isfinite(video.float()).all().item())
+
+    def reasoning_edit(steps, rsteps):
+        """BASELINE configs[3], end to end: 29 pixel frames -> 8 latent frames for the first `rsteps` steps, truncated to 2 latent
+        frames for the rest (pipeline_chronoedit.py:700-709), both decodes (:776-779)."""
+        pipe.scheduler = FlowUniPCMultistepScheduler(flow_shift=5.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pos, neg, img = conditioning(5.0)
+        video = pipe.edit_tensors(image, pos, neg, img, num_frames=29, num_inference_steps=steps, guidance_scale=5.0,
+                                  enable_temporal_reasoning=True, num_temporal_reasoning_steps=rsteps)
+        torch.cuda.synchronize()
+        return round(after(time.perf_counter() - t0), 2), tuple(video.shape), bool(torch.isfinite(video.float()).all().item())
+
+    return edit, reasoning_edit
+
+
+def _sharded_edit_leg(a, model, dev, world, after, test_backend):
+    """N > 1: WHOLE temporal-reasoning edits (BASELINE configs[3]) with the DiT sharded over the ranks - run by EVERY rank, outside the timed
+    region, MAX over ranks of the wall time.  What is and is not sharded: the DiT forwards are (token axis over the Ulysses group, or the
+    guidance pair over two groups); the VAE encode of the 29 frames, the two VAE decodes and the UMT5 / CLIP encoders run REPLICATED on every
+    rank (each GPU computes the whole of them - the causal temporal cache serialises the VAE, SURVEY section 8e - so they are the serial
+    fraction of the edit), and every rank ends with the full video.  Under CE_BENCH_TEST_BACKEND the schedule is 3 steps (the code path, not a
+    measurement)."""
+    from chronoedit_amd.vae import AutoencoderKLWan
+    vae = AutoencoderKLWan.random_init(dev, seed=4321)
+    te_model = ie_model = None
+    if not a.no_encoders:
+        from chronoedit_amd.clip_vision import CLIPVisionModel
+        from chronoedit_amd.umt5 import UMT5EncoderModel
+        torch.manual_seed(0)
+        te_model, ie_model = UMT5EncoderModel(device=dev), CLIPVisionModel(device=dev)
+    _, reasoning_edit = _edit_runners(a, model, vae, te_model, ie_model, dev, after=after)
+    steps = 3 if test_backend else 50
+    out = {}
+    for rs in [int(x) for x in str(a.reasoning_steps).split(",") if x.strip()]:
+        rs = max(0, min(steps, rs if not test_backend else (1 if rs < 50 else steps)))
+        sr, shape_r, okr = reasoning_edit(steps, rs)
+        out[f"num_temporal_reasoning_steps={rs}" + (" (the reference's default: never truncates)" if rs >= steps else "")] = {
+            "seconds": sr, "finite": okr, "frames": shape_r[2], "num_temporal_reasoning_steps": rs, "num_inference_steps": steps, "n_gpus": world,
+            "includes": ("UMT5 (2 prompts) + CLIP" if te_model is not None else "(encoders skipped: seeded random conditioning)") +
+                        f" + VAE encode of 29 frames + {rs} steps x 2 forwards with 8 latent frames + {steps - rs} steps x 2 forwards with 2 latent frames + two VAE "
+                        "decodes; MAX over ranks of the wall time",
+            "sharding": "DiT forwards sharded over the ranks (as in `config.parallelism`); VAE encode / decodes and the UMT5 / CLIP encoders replicated on every rank "
+                        "(the serial fraction); launch " + ("eager (the exchanges are torch.distributed collectives)" if not getattr(getattr(model, "_sp", None), "capturable", False)
+                                                            else "hipGraph replay on the library-owned communicator")}
+    del vae, te_model, ie_model
+    return out
 
 
 def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w, out):
@@ -716,6 +903,27 @@ def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w,
             step(5 + i)
         torch.cuda.synchronize()
         out["fp8_rate"] = round(2 / (time.perf_counter() - tc), 4)
+        # BASELINE.json configs[4] itself: the same fp8 arithmetic at the upscaler shape, 1584x1056 px -> latents [1,16,2,132,198] -> N = 13 068 tokens
+        # (README.md:149-158), guidance 5: one warm step (new workspaces), then three timed; fraction against the FP8 peak
+        if (a.width, a.height, T) == (1280, 720, 2) and not a.no_fp8_config4:
+            from chronoedit_amd.flops import dit_flops_per_forward
+            wl4 = Workload(dev, 2, 1056 // 8, 1584 // 8, 44)
+            st4 = make_stepper(wl4, new_sched(6), sequential=a.sequential_cfg)
+            st4(0)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for i in range(3):
+                st4(1 + i)
+            torch.cuda.synchronize()
+            d4 = (time.perf_counter() - tc) / 3
+            fl4 = dit_flops_per_forward(wl4.N, num_layers=a.layers) * 2
+            out["fp8_config4"] = {"value": round(1.0 / d4, 4), "unit": "denoising-steps/sec", "ms_per_step": round(d4 * 1e3, 2), "steps": 3, "warmup": 1,
+                                  "workload": f"BASELINE.json configs[4]: 1584x1056, 2 latent frames (N = {wl4.N} tokens), guidance 5 (2 forwards/step batched), fp8 e4m3 GEMMs "
+                                              "(OCP-MX block scales) + MXFP8 self-attention, eager, nothing cached",
+                                  "model_tflops_per_step": round(fl4 / 1e12, 2), "achieved_tflops": round(fl4 / d4 / 1e12, 1),
+                                  "frac_of_fp8_peak": round(fl4 / d4 / 1e12 / PEAK_FP8_TFLOPS, 4), "peak": PEAK_FP8_TFLOPS,
+                                  "finite": bool(torch.isfinite(wl4.latents).all().item())}
+            del wl4, st4
         model.enable_fp8_gemms(False)
         model.enable_fp8_attention(False)
     # VAE encode + decode at the same resolution (once per edit)
@@ -772,46 +980,7 @@ def _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w,
                         "finite": bool(torch.isfinite(pe.float()).all().item() and torch.isfinite(ie.float()).all().item())}
     # MEASURED sec/edit through ChronoEditPipeline: token ids + pixel values + image in, video out
     if vae is not None and te_model is not None and not a.no_edit and (a.width, a.height, T) == (1280, 720, 2):
-        from chronoedit_amd.pipeline import ChronoEditPipeline
-        from chronoedit_amd.scheduler import FlowUniPCMultistepScheduler
-        g = torch.Generator(device=dev).manual_seed(43)
-        image = torch.rand((1, 3, a.height, a.width), generator=g, device=dev) * 2 - 1
-        ids = torch.randint(2, 256384, (1, 512), generator=g, device=dev)
-        am = torch.zeros((1, 512), dtype=torch.long, device=dev)
-        am[0, :64] = 1
-        nids = torch.randint(2, 256384, (1, 512), generator=g, device=dev)
-        nam = torch.zeros((1, 512), dtype=torch.long, device=dev)
-        nam[0, :20] = 1
-        px = torch.randn((1, 3, 224, 224), generator=g, device=dev)
-
-        # ONE pipeline object for all edits, as a serving process holds it: hipGraph replay and the per-edit context cache are its defaults,
-        # and a latent shape seen before is captured without another warm-up step
-        pipe = ChronoEditPipeline(text_encoder=te_model, image_encoder=ie_model, transformer=model, vae=vae,
-                                  scheduler=FlowUniPCMultistepScheduler(flow_shift=5.0))
-
-        def edit(steps, guidance, shift):
-            pipe.scheduler = FlowUniPCMultistepScheduler(flow_shift=shift)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            pos, neg = pipe.encode_prompt(input_ids=ids, attention_mask=am, negative_input_ids=nids if guidance > 1 else None,
-                                          negative_attention_mask=nam if guidance > 1 else None)
-            img = pipe.encode_image(px)
-            video = pipe.edit_tensors(image, pos, neg, img, num_frames=5, num_inference_steps=steps, guidance_scale=guidance)
-            torch.cuda.synchronize()
-            return round(time.perf_counter() - t0, 3), bool(torch.isfinite(video.float()).all().item())
-
-        def reasoning_edit(steps, rsteps):
-            """BASELINE configs[3] on ONE GPU, end to end: 29 pixel frames -> 8 latent frames (N = 28 800) for the first `rsteps` steps,
-            truncated to 2 latent frames for the rest (pipeline_chronoedit.py:700-709), both decodes (:776-779)."""
-            pipe.scheduler = FlowUniPCMultistepScheduler(flow_shift=5.0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            pos, neg = pipe.encode_prompt(input_ids=ids, attention_mask=am, negative_input_ids=nids, negative_attention_mask=nam)
-            img = pipe.encode_image(px)
-            video = pipe.edit_tensors(image, pos, neg, img, num_frames=29, num_inference_steps=steps, guidance_scale=5.0,
-                                      enable_temporal_reasoning=True, num_temporal_reasoning_steps=rsteps)
-            torch.cuda.synchronize()
-            return round(time.perf_counter() - t0, 2), tuple(video.shape), bool(torch.isfinite(video.float()).all().item())
+        edit, reasoning_edit = _edit_runners(a, model, vae, te_model, ie_model, dev)
 
         edit(2, 1.0, 2.0)  # warm-up of the B = 1 shapes
         s8, ok8 = edit(8, 1.0, 2.0)

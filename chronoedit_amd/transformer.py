@@ -760,6 +760,10 @@ class DiTEngine:
                 bufs = SimpleNamespace(enc_i_pad=z(B * c2, D), v1t=z(L * D, ld1), v2t=z(L * D, ld2))
                 self._ctx_bufs = dict(list(self._ctx_bufs.items())[-1:] + [((B, Tt, Ti), bufs)])  # the guided pair and the single sample
             v1t, v2t = bufs.v1t, bufs.v2t
+            # these engine-owned buffers are about to be rewritten in place, and a cached context of the same shape holds VIEWS into them
+            # (its K tensors are its own): whatever was cached is stale from here on - drop it, so a later hit cannot pair the old K with
+            # another conditioning's V^T (a call with cache_context off, key None, would otherwise leave the cached key standing)
+            self._ctx_key = self._ctx = self._ctx_refs = None
             w, b, eps_i = self.im_n2
             for bi in range(B):
                 ops.ln_affine(h_img[bi * Ti:(bi + 1) * Ti], w, b, eps_i, out=bufs.enc_i_pad[bi * c2: bi * c2 + Ti])

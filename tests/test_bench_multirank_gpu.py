@@ -5,8 +5,11 @@ anything.  Pinned here, so that the first real 8-GPU run cannot be the first run
   * W = 2 (guidance pair split over the two ranks), 4 and 8 (one Ulysses group, pair batched inside it) print ONE JSON line that carries
     `sharded_vs_single_rel_l2` (the sharded step's latents against the unsharded step on the same inputs), the per-exchange timings
     `rccl.exchange_us_per_layer` (k|v, q, output), the replica figure and the strong-scaling reference;
-  * an exception in the sharded leg (injected on one rank, and on all) still ends in parsable output: an error line, then the replica
-    line of the same run.
+  * the bare command `python bench.py --gpus 2` (no launcher) re-executes itself under torch.distributed.run and prints the same lines;
+  * the complete line carries `cpu_baseline` (rank 0; the reference's own block class where oracle/_ref/transformer_ref.bin was built) and
+    `sec_per_edit_temporal_reasoning` measured with the DiT sharded; the headline is also printed in a `preliminary` line before those legs;
+  * an exception in the sharded leg (injected on one rank, and on all) still ends in parsable output: error lines (the failing rank's own,
+    at once, and rank 0's), then the replica line of the same run.
 Reduced depth (2 blocks) and resolution (352x640, 8 latent frames = 7 040 tokens): the lines are marked invalid / TEST_ONLY by bench.py."""
 import json
 import os
@@ -28,12 +31,18 @@ def _free_port():
     return p
 
 
-def _run(world, extra=(), env_extra=None, timeout=900):
+def _run(world, extra=(), env_extra=None, timeout=900, bare=False):
     env = dict(os.environ, CE_BENCH_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CE_BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
     env.update(env_extra or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
-           "--layers", "2", "--height", "352", "--width", "640", "--no-profile", *extra]
+    bench_args = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
+                  "--layers", "2", "--height", "352", "--width", "640", "--no-profile", *extra]
+    if bare:  # `python bench.py --gpus N`, no launcher: bench.py re-executes itself under torch.distributed.run
+        cmd = [sys.executable, *bench_args]
+    else:     # the driver's form
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), *bench_args]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     lines = []
     for ln in r.stdout.splitlines():
@@ -49,9 +58,26 @@ def _run(world, extra=(), env_extra=None, timeout=900):
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_line_verifies_itself(world):
-    lines = _run(world)
-    assert len(lines) == 1, lines
-    o = lines[0]
+    # W = 2 is launched BARE (`python bench.py --gpus 2`: bench.py must re-execute itself under torch.distributed.run - VERDICT r4 #1a) and runs
+    # every leg (encoders in the sharded edit, the CPU baseline); W = 4 / 8 use the driver's launcher form and trim the legs that only cost time
+    lines = _run(world, bare=(world == 2), extra=() if world == 2 else ("--no-encoders", "--no-cpu-baseline"))
+    assert len(lines) == 2, lines  # the preliminary headline (printed before the minutes-long secondary legs), then the complete line
+    pre, o = lines
+    assert pre.get("preliminary") is True and pre["n_gpus"] == world and pre["value"] == o["value"] and pre["scaling"] == "strong"
+    assert "preliminary" not in o
+    # sec/edit with the DiT sharded (configs[3]: 8 latent frames, truncated to 2 after num_temporal_reasoning_steps; 3-step schedule under the test backend)
+    ed = o["sec_per_edit_temporal_reasoning"]
+    assert "error" not in ed and len(ed) == 2, ed
+    for name, e in ed.items():
+        assert e["seconds"] > 0 and e["finite"] is True and e["n_gpus"] == world and "replicated" in e["sharding"], (name, e)
+    assert sorted(e["frames"] for e in ed.values()) == [5, 29]  # truncated after step 1 -> 5 pixel frames; never truncated -> 29
+    if world == 2:
+        cb = o["cpu_baseline"]
+        assert "error" not in cb and cb["value"] > 0 and cb["cores"] >= 1, cb
+        assert cb["kind"] == ("reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "transformer_ref.bin")) else "port"), cb
+        assert cb["port"]["seconds_per_block"] > 0
+    else:
+        assert "cpu_baseline" not in o
     assert o["n_gpus"] == world and o["scaling"] == "strong" and o["finite"] is True and "TEST_ONLY" in o
     assert o["value"] > 0 and o["steps"] == 1
     # the sharded answer, checked against the unsharded step on the same inputs inside the same run
@@ -79,10 +105,14 @@ def test_sharded_failure_still_prints_the_replica_line(who):
     # (one rank failing alone leaves its peers inside a collective: they run into the data group's timeout, shortened here, and the
     # host-side vote then sends every rank down the replica path; under RCCL a watchdog timeout aborts the process instead - only
     # failures that every rank sees, e.g. an RCCL initialisation or a shape error, are recoverable there)
-    lines = _run(4, extra=("--no-secondary",), env_extra={"CE_BENCH_INJECT_SHARDED_FAILURE": who, "CE_BENCH_PG_TIMEOUT_S": "30"})
-    assert len(lines) == 2, lines
-    err, rep = lines
-    assert err["value"] is None and "error" in err and err["n_gpus"] == 4
+    lines = _run(4, extra=("--no-secondary", "--no-cpu-baseline"), env_extra={"CE_BENCH_INJECT_SHARDED_FAILURE": who, "CE_BENCH_PG_TIMEOUT_S": "30"})
+    errs, rest = [l for l in lines if "error" in l], [l for l in lines if "error" not in l]
+    assert errs and all(e["value"] is None and e["n_gpus"] == 4 for e in errs), lines  # rank 0's line, and the failing rank's own (said at once)
+    assert any("rank" not in e for e in errs), errs
+    if who == "1":
+        assert any(e.get("rank") == 1 for e in errs), errs
+    assert len(rest) == 2 and rest[0].get("preliminary") is True, lines
+    rep = rest[-1]
     assert rep["value"] > 0 and rep["scaling"] == "weak" and rep["n_gpus"] == 4 and rep["finite"] is True
     assert "sharded_error" in rep and "fallback" in rep
     assert rep["config"]["parallelism"] == "replica x4"

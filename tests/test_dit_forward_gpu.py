@@ -73,6 +73,17 @@ def test_forward_signature_and_errors():
     a = model(lat.cuda(), ts, text.cuda(), image.cuda()).sample
     b = model(lat.cuda(), ts, text.cuda(), image.cuda()).sample
     assert torch.equal(a, b) and torch.equal(a, out.sample)
+    # ... also after an UNCACHED call with another conditioning rewrote the engine-owned V^T buffers the cached entry had views into
+    # (the stale entry used to pair the old K with the other conditioning's V^T)
+    tx, im = text.cuda(), image.cuda()
+    a = model(lat.cuda(), ts, tx, im).sample  # cached under (tx, im)
+    model.cache_context = False
+    other = torch.randn(1, 32, 128, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16).cuda()
+    c = model(lat.cuda(), ts, other, (im * -1.5).contiguous()).sample
+    assert not torch.equal(c, a)
+    model.cache_context = True
+    b = model(lat.cuda(), ts, tx, im).sample
+    assert torch.equal(a, b)
 
 
 def test_batched_forward_equals_sequential():
