@@ -69,3 +69,31 @@ def test_flops_match_survey():
     assert abs(O.flops_per_forward(cfg, 7200) / 1e12 - 222.38) < 0.05
     assert abs(O.flops_per_forward(cfg, 28800) / 1e12 - 1389.44) < 0.1
     assert abs(O.flops_per_forward(cfg, 512) / 1e12 - 16.00) < 0.02
+
+
+def test_built_reference_block_class_equals_the_oracle_block():
+    """The reference's own ChronoEditTransformerBlock / ChronoEditRotaryPosEmbed, executed from oracle/_ref/transformer_ref.bin (what bench.py's
+    `cpu_baseline` TIMES on the GPU box, "kind": "reference"; built by oracle/build_ref.py wherever /root/reference exists), against
+    oracle/dit_oracle.block_forward on the same tensors: the fp32 results are bit-equal - the port restates the class, it is not a variant."""
+    from oracle import build_ref
+    mod = build_ref.load_transformer()
+    if mod is None:
+        pytest.skip("oracle/_ref/transformer_ref.bin not built (no /root/reference on this box)")
+    cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=1, text_dim=96, image_dim=64, added_kv_proj_dim=256)
+    p = {k: v for k, v in O.make_synthetic_params(cfg, seed=3).items() if k.startswith("blocks.0.")}
+    g = torch.Generator().manual_seed(2)
+    T, hp, wp = 2, 6, 8
+    x = torch.randn(1, T * hp * wp, cfg.inner_dim, generator=g)
+    enc = torch.randn(1, 257 + 40, cfg.inner_dim, generator=g)
+    temb6 = torch.randn(1, 6, cfg.inner_dim, generator=g) * 0.1
+    blk = mod.ChronoEditTransformerBlock(cfg.inner_dim, cfg.ffn_dim, cfg.num_attention_heads, cfg.qk_norm, cfg.cross_attn_norm, cfg.eps,
+                                         cfg.added_kv_proj_dim).eval()
+    blk.load_state_dict({k[len("blocks.0."):]: v for k, v in p.items()}, strict=True, assign=True)
+    rope = mod.ChronoEditRotaryPosEmbed(cfg.attention_head_dim, tuple(cfg.patch_size), cfg.rope_max_seq_len, temporal_skip_len=cfg.rope_temporal_skip_len)
+    rot_ref = rope(torch.empty(1, 1, T, 2 * hp, 2 * wp))
+    rot = O.rope_table(cfg, T, 2 * hp, 2 * wp)
+    assert torch.equal(rot_ref, rot)
+    with torch.no_grad():
+        want = blk(x, enc, temb6, rot_ref)
+        got = O.block_forward(p, 0, cfg, x, enc, temb6, rot)
+    assert torch.equal(got, want), float((got - want).abs().max())
