@@ -1,6 +1,8 @@
 """Launch ONE kernel shape a few times (for rocprofv3 --pmc passes).  usage:
    one_kernel.py gemm M N K epi variant [iters]  |  one_kernel.py attn Nq Nkv H [iters]  |  one_kernel.py attn8 N H B [iters]
-   |  one_kernel.py attnvt N H B [iters]   (the V^T / LDS-DMA form of the bf16 self-attention, B samples per launch)"""
+   |  one_kernel.py attnvt N H B [iters]   (the V^T / LDS-DMA form of the bf16 self-attention, B samples per launch)
+   |  one_kernel.py gemm8 M N K epi [iters]   (MX fp8 GEMM, ce_gemm_mxfp8: operands quantised once outside the counted launches; epi 7 = the
+      FFN-up form with the GELU + MX quantiser in the epilogue, ce_gemm_mxfp8_gelu_quant)"""
 import os
 import sys
 
@@ -24,6 +26,24 @@ if kind == "gemm":
     ops.set_gemm_variant(var)
     for _ in range(iters):
         ops.gemm(a, w, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+elif kind == "gemm8":
+    M, N, K, epi = map(int, sys.argv[2:6])
+    iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+    a = torch.randn(M, K, generator=g).to(BF).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
+    aq, sa = ops.quant_rows_mxfp8(a)
+    wq, sw = ops.quant_rows_mxfp8(w)
+    b = torch.zeros(N, device=dev)
+    gate = torch.ones(N, device=dev)
+    if epi == 7:
+        oq = torch.empty(M, N, dtype=torch.uint8, device=dev)
+        so = torch.empty(ops.mx_scale_bytes(M, N), dtype=torch.uint8, device=dev)
+        for _ in range(iters):
+            ops.gemm_mxfp8_gelu_quant(aq, sa, wq, sw, b, oq, so)
+    else:
+        out = torch.zeros(M, N, dtype=BF, device=dev)
+        for _ in range(iters):
+            ops.gemm_mxfp8(aq, sa, wq, sw, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
 elif kind == "attnvt":
     N, H, B = map(int, sys.argv[2:5])
     iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
