@@ -45,6 +45,27 @@ constexpr int CROW = BN * 2 + 16;             // padded epilogue staging row (52
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+// LDS-DMA issue schedule of the main loop: how many of a K-tile's 16 pieces (1 KiB per wave each) go into each group, in the order the
+// groups follow the barrier: 5, 6, 7, then 0, 1, 2, 3, 4 of the next tile.  0 = round 3/4 (all sixteen squeezed into groups 5..7: two
+// pieces per MFMA gap - an LDS-DMA piece costs its wave 60..185 cycles of issue and a 16x16x128 MFMA covers 32); the others spread them.
+#ifndef F8_DMA_SCHED
+#define F8_DMA_SCHED 1
+#endif
+// Diagnostic builds (tools/gemm_mxfp8_ab.py; results are garbage, only the time means something) - one ingredient of the main loop compiled out:
+// 1 no LDS-DMA in the loop, 2 every piece re-reads K-tile 0 (all L2 hits), 3 no fragment reads, 4 no barrier / vmcnt wait in the loop, 5 no epilogue,
+// 6 / 7 the first round's workgroups skip part of their K range (desynchronises the later rounds: what a staggered start would buy)
+#ifndef F8_ABLATE
+#define F8_ABLATE 0
+#endif
+constexpr int kDmaSched[10][8] = {{6, 5, 5, 0, 0, 0, 0, 0}, {3, 3, 3, 3, 2, 2, 0, 0}, {4, 4, 4, 4, 0, 0, 0, 0}, {2, 2, 2, 3, 3, 2, 2, 0}, {2, 2, 2, 2, 2, 2, 2, 2},
+                                  {4, 3, 3, 3, 3, 0, 0, 0}, {3, 3, 3, 3, 3, 1, 0, 0}, {2, 3, 3, 4, 4, 0, 0, 0}, {3, 3, 2, 3, 3, 2, 0, 0}, {4, 4, 4, 2, 2, 0, 0, 0}};
+constexpr int dma_sched_n(int s, int g) { return kDmaSched[s][(g + 3) & 7]; }
+constexpr int dma_sched_first(int s, int g) {
+  int n = 0;
+  for (int i = 0; i < ((g + 3) & 7); ++i) n += kDmaSched[s][i];
+  return n;
+}
+
 #define EPI_BIAS_GELU_Q 7  // (this file only) bias + tanh GELU, then MX-quantised: the next GEMM's A operand instead of a bf16 matrix
 #define X8_PIN() __builtin_amdgcn_sched_barrier(0)
 #define X8_BAR() __builtin_amdgcn_s_barrier()
@@ -109,6 +130,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     m0 = (first_m + (wg % group_sz) % gm) * BM;
     n0 = ((wg % group_sz) / gm) * BN;
   }
+#if F8_ABLATE == 6 || F8_ABLATE == 7
+  // desynchronisation probe: the workgroups of the FIRST round skip 0 / 1 / 2 / 3 quarters of their K range (6) or idle-free variant 7: only
+  // every second one skips a half - the rounds that follow then end at different times on different CUs (garbage in those tiles: timing only)
+  if (!partial && (int)blockIdx.x < 256) {
+    const int q = (F8_ABLATE == 6 ? (int)(blockIdx.x >> 3) & 3 : 2 * ((int)(blockIdx.x >> 3) & 1)) * ((ktn / 4) & ~1);
+    kt0 += q;
+    ktn -= q;
+  }
+#endif
   const int kt_last = ktn - 1;
 
   // LDS-DMA sources: piece p of this wave = rows 8 (wave + 4 p) .. + 8 of the operand tile, lane l -> row + (l >> 3), slot l & 7
@@ -122,7 +152,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xffffffffu, 0x00020000);
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xffffffffu, 0x00020000);
+#if F8_ABLATE == 2
+  auto koff = [&](int t) __attribute__((always_inline)) -> int { return (kt0 + min(t, 1)) * BKB; };
+#else
   auto koff = [&](int t) __attribute__((always_inline)) -> int { return (kt0 + min(t, kt_last)) * BKB; };
+#endif
   // piece q (0..15) of a tile: 0..7 = A, 8..15 = W
   auto dma = [&](int q, int stage_bytes, int soff) __attribute__((always_inline)) {
     if (q < 8)
@@ -140,12 +174,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     a_rd[h] = (wm * 128 + fr) * 128 + ((chunk ^ (fr >> 1)) << 4);
     w_rd[h] = TILE + (wn * 128 + fr) * 128 + ((chunk ^ (fr >> 1)) << 4);
   }
-  auto read_frag = [&](int base0, int base1, int stage_bytes, int f) __attribute__((always_inline)) -> i32x8 {
+  auto read_frag_real = [&](int base0, int base1, int stage_bytes, int f) __attribute__((always_inline)) -> i32x8 {
     const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + base0 + stage_bytes + f * 2048);
     const u32x4 hi = *reinterpret_cast<const u32x4*>(smem + base1 + stage_bytes + f * 2048);
     return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
   };
 
+#if F8_ABLATE == 3
+  i32x8 ablate_frag = read_frag_real(a_rd[0], a_rd[1], 0, 0);
+  bool in_loop = false;
+  auto read_frag = [&](int base0, int base1, int stage_bytes, int f) __attribute__((always_inline)) -> i32x8 {
+    if (in_loop) {
+      asm volatile("" : "+v"(ablate_frag));
+      return ablate_frag;
+    }
+    return read_frag_real(base0, base1, stage_bytes, f);
+  };
+#else
+  auto& read_frag = read_frag_real;
+#endif
   f32x4 acc[8][8];
 #pragma unroll
   for (int f = 0; f < 8; ++f)
@@ -197,13 +244,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (MX) mma_mx<(G) & 3, (F) & 3>(acc[F][G], (BW)[G], ring[(F) % 4], sWq[SEL_][(G) >> 2], sAq[SEL_][(F) >> 2]);                  \
     else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]));          \
   } while (0)
-  // group G of the tile in stage PAR (its W fragments in BW, the next tile's go to BN); fillers between single MFMAs
-#define X8_GROUP(G, PAR, BW, BN_, KNEXT, SEL)                                                                                 \
+  // group G of the tile in stage PAR (its W fragments in BW, the next tile's go to BN); fillers between single MFMAs.
+  // LDS-DMA schedule (F8_DMA_SCHED, table kDmaSched): piece s of the 16 is issued in the group the table gives, one piece per slot, the
+  // slots being the gaps behind MFMAs 1, 3, 5, 7 of a group.  Groups 5..7 of tile T carry the first pieces of tile T+2 (-> stage PAR, free
+  // since the barrier in group 5), groups 0..4 of the NEXT tile carry the rest (from there: tile T+1 -> the other stage); all of a tile's
+  // pieces are in flight before the vmcnt(0) + barrier in group 5 of the tile in front of it.
+#define X8_DMA(G, J, PAR, KN2, KN1)                                                                                           \
+  if constexpr (F8_ABLATE != 1 && (J) < dma_sched_n(F8_DMA_SCHED, (G))) {                                                                      \
+    if constexpr ((G) >= 5) dma(dma_sched_first(F8_DMA_SCHED, (G)) + (J), (PAR) * STAGE, KN2);                                 \
+    else dma(dma_sched_first(F8_DMA_SCHED, (G)) + (J), (1 - (PAR)) * STAGE, KN1);                                              \
+  }
+#define X8_GROUP(G, PAR, BW, BN_, KNEXT, KN1, SEL)                                                                            \
   {                                                                                                                           \
     constexpr int SEL_ = (SEL);                            /* scale register set = tile parity (MX) */                        \
     constexpr int fn_ = ((G) + 3) & 7;                     /* the A fragment fetched now ... */                                \
     constexpr int sn_ = ((G) + 3 >= 8) ? (1 - (PAR)) * STAGE : (PAR) * STAGE; /* ... from this tile or the next */             \
-    if ((G) == 5) {                                                                                                           \
+    if ((G) == 5 && F8_ABLATE != 4) {                                                                                         \
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
       if (MX) asm volatile("" : "+v"(sAq[1 - SEL_]), "+v"(sWq[1 - SEL_])); /* the next tile's scales have landed too */         \
       X8_BAR();                                                                                                               \
@@ -213,37 +269,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     ring[((G) + 3) % 4] = read_frag(a_rd[0], a_rd[1], sn_, fn_);                                                               \
     X8_PIN();                                                                                                                 \
     X8_MMA(G, 1, BW);                                                                                                         \
-    if ((G) >= 5) { dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 0, (PAR) * STAGE, KNEXT); }                                       \
+    X8_DMA(G, 0, PAR, KNEXT, KN1)                                                                                             \
     X8_PIN();                                                                                                                 \
     X8_MMA(G, 2, BW);                                                                                                         \
-    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 0] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 0); }                                    \
+    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 0] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 0); }            \
     X8_PIN();                                                                                                                 \
     X8_MMA(G, 3, BW);                                                                                                         \
-    if ((G) >= 5) { dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 1, (PAR) * STAGE, KNEXT); dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 2, (PAR) * STAGE, KNEXT); } \
+    X8_DMA(G, 1, PAR, KNEXT, KN1)                                                                                             \
+    if constexpr (dma_sched_n(F8_DMA_SCHED, (G)) > 4) { X8_DMA(G, 4, PAR, KNEXT, KN1) }                                        \
     X8_PIN();                                                                                                                 \
     X8_MMA(G, 4, BW);                                                                                                         \
-    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 1] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 1); }                                    \
+    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 1] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 1); }            \
     X8_PIN();                                                                                                                 \
     X8_MMA(G, 5, BW);                                                                                                         \
-    if ((G) >= 5) { dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 3, (PAR) * STAGE, KNEXT); dma(6 * ((G) - 5) - ((G) == 7 ? 1 : 0) + 4, (PAR) * STAGE, KNEXT); } \
+    X8_DMA(G, 2, PAR, KNEXT, KN1)                                                                                             \
+    if constexpr (dma_sched_n(F8_DMA_SCHED, (G)) > 5) { X8_DMA(G, 5, PAR, KNEXT, KN1) }                                        \
     X8_PIN();                                                                                                                 \
     X8_MMA(G, 6, BW);                                                                                                         \
     if ((G) == 5 || (G) == 6) { (BN_)[3 * ((G) - 5) + 2] = read_frag(w_rd[0], w_rd[1], (1 - (PAR)) * STAGE, 3 * ((G) - 5) + 2); } \
     X8_PIN();                                                                                                                 \
     X8_MMA(G, 7, BW);                                                                                                         \
-    if ((G) == 5) { dma(5, (PAR) * STAGE, KNEXT); }                                                                           \
+    X8_DMA(G, 3, PAR, KNEXT, KN1)                                                                                             \
     X8_PIN();                                                                                                                 \
   }
-  // pieces: group 5 -> 0..5 (six), group 6 -> 6..10 (five), group 7 -> 11..15 (five);  W fragments: group 5 -> 0,1,2, group 6 -> 3,4,5, group 7 -> 6,7
+  // W fragments: group 5 -> 0,1,2, group 6 -> 3,4,5, group 7 -> 6,7
 #define X8_TILE(PAR, T, BW, BN_, SEL)                                                                                         \
   {                                                                                                                           \
-    const int knext = koff((T) + 2);                                                                                          \
-    X8_GROUP(0, PAR, BW, BN_, knext, SEL) X8_GROUP(1, PAR, BW, BN_, knext, SEL) X8_GROUP(2, PAR, BW, BN_, knext, SEL)          \
-    X8_GROUP(3, PAR, BW, BN_, knext, SEL) X8_GROUP(4, PAR, BW, BN_, knext, SEL) X8_GROUP(5, PAR, BW, BN_, knext, SEL)          \
-    X8_GROUP(6, PAR, BW, BN_, knext, SEL) X8_GROUP(7, PAR, BW, BN_, knext, SEL)                                                \
+    const int knext = koff((T) + 2), kn1 = koff((T) + 1);                                                                     \
+    X8_GROUP(0, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(1, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(2, PAR, BW, BN_, knext, kn1, SEL) \
+    X8_GROUP(3, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(4, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(5, PAR, BW, BN_, knext, kn1, SEL) \
+    X8_GROUP(6, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(7, PAR, BW, BN_, knext, kn1, SEL)                                      \
   }
   {
     const int npairs = ktn >> 1;
+#if F8_ABLATE == 3
+    in_loop = true;
+#endif
     for (int it = 0; it < npairs; ++it) {
       const int t = 2 * it;
       if (MX) load_scales(t + 1, 1);  // (one K-tile ahead: ~1.7 us of matrix work between the request and the first MFMA that reads it)
@@ -254,9 +315,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #undef X8_TILE
 #undef X8_GROUP
+#undef X8_DMA
 #undef X8_MMA
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   X8_BAR();
+#if F8_ABLATE == 5
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) sum += acc[f][g][0] + acc[f][g][1] + acc[f][g][2] + acc[f][g][3];
+    if (sum == 123.456f) ws[0] = sum;
+    return;
+  }
+#endif
 
   // ---- epilogue: scales, bias -> bf16 -> LDS, four passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave),
   // then the row-contiguous half of ce_gemm_epi.h (activation / gated residual, 16-byte stores)

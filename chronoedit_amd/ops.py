@@ -244,9 +244,17 @@ def ensure_gemm_workspace(device: torch.device) -> None:
             _gemm_ws[("first_stream", dev)] = first = stream
         with torch.cuda.device(dev):
             _check(lib().ce_set_gemm_workspace(buf.data_ptr(), buf.numel()), "ce_set_gemm_workspace")
-            if stream != first and (dev, stream) not in _gemm_ws and not torch.cuda.is_current_stream_capturing() \
-                    and sum(1 for k in _gemm_ws if isinstance(k, tuple) and len(k) == 2 and k[0] == dev) < GEMM_WS_STREAMS:
-                own = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+            if stream != first and (dev, stream) not in _gemm_ws and not torch.cuda.is_current_stream_capturing():
+                mine = [k for k in _gemm_ws if isinstance(k, tuple) and len(k) == 2 and k[0] == dev]  # (dev, stream) keys, oldest first
+                own = None
+                if len(mine) >= GEMM_WS_STREAMS:
+                    # the cap is reached: the LEAST recently registered stream hands its scratch on (it is unregistered first, so that stream - in
+                    # practice one that no longer exists - falls back to the device default; two live streams never share a scratch silently)
+                    oldest = mine[0]
+                    own = _gemm_ws.pop(oldest)
+                    _check(lib().ce_set_gemm_workspace_stream(oldest[1], None, 0), "ce_set_gemm_workspace_stream")
+                if own is None:
+                    own = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
                 _gemm_ws[(dev, stream)] = own
                 _check(lib().ce_set_gemm_workspace_stream(stream, own.data_ptr(), own.numel()), "ce_set_gemm_workspace_stream")
     else:
@@ -844,6 +852,7 @@ def gemm_mxfp8_gelu_quant(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, 
         raise ValueError("gemm_mxfp8_gelu_quant: operand / scale shapes do not match")
     if bias is not None:
         _dev(bias, torch.float32, "bias")
+    ensure_gemm_workspace(aq.device)  # (its launcher cuts the last round along K like the others: the stream's own scratch must be registered)
     st = _prof_begin()
     _check(lib().ce_gemm_mxfp8_gelu_quant(_ptr(aq), _ptr(wq), _ptr(sa), _ptr(sw), _ptr(bias), _ptr(out), _ptr(scale), M, N, K, lda, ldw, ldq,
                                           _stream()), "ce_gemm_mxfp8_gelu_quant")

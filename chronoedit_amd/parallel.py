@@ -64,6 +64,21 @@ class OwnedComm:
     section 8b: "one ncclComm_t per process passed in".  The unique id travels over the existing process group (any backend); RCCL itself
     is the librccl.so torch ships, dlopen()ed by the library (one copy per process)."""
 
+    _cache = {}  # (id of the process group, device index) -> OwnedComm: ONE communicator per group and device for the life of the process
+
+    @classmethod
+    def get(cls, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None) -> "OwnedComm":
+        """The communicator of (group, device), created on first use and REUSED afterwards: a serving process that re-enables or re-groups
+        sequence parallelism must not leave one ncclComm_t (device buffers, proxy threads) behind per call - ncclCommDestroy cannot be
+        used on this stack (see close())."""
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        key = (id(group) if group is not None else None, dev.index)
+        comm = cls._cache.get(key)
+        if comm is None or comm.handle is None:
+            comm = cls._cache[key] = cls(group, dev)
+            comm._group_ref = group  # keeps the id() of the key unique while the entry lives
+        return comm
+
     def __init__(self, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None):
         import ctypes
         import os
@@ -118,7 +133,7 @@ class OwnedComm:
                                                 torch.cuda.current_stream().cuda_stream), "ce_comm_all_gather")
 
     def close(self):
-        """Forget the communicator.  ncclCommDestroy is NOT called: on this stack (RCCL 2.26.6 beside torch's own process group) it blocks
+        """Forget the communicator (the cache then builds a new one on the next get()).  ncclCommDestroy is NOT called: on this stack (RCCL 2.26.6 beside torch's own process group) it blocks
         for good on a one-rank communicator (tools/owned_comm_probe.py); the handle lives until the process exits, like torch's own."""
         self.handle = None
 
@@ -142,7 +157,10 @@ class Ulysses:
         self.backend = dist.get_backend(group)
         self._host_staged = self.backend == "gloo"
         self.stats = {"all_to_all_calls": 0, "all_to_all_bytes_sent_off_rank": 0, "all_gather_calls": 0}
-        self.comm = OwnedComm(group) if owned_comm else None
+        if owned_comm and self._host_staged:
+            # ranks of a gloo group may share one GPU (the one-box test backend): ncclCommInitRank on duplicate devices fails or hangs
+            raise RuntimeError("owned_comm=True needs the RCCL ('nccl') backend: under gloo the exchanges are host-staged and ranks may share a device")
+        self.comm = OwnedComm.get(group) if owned_comm else None
 
     @property
     def capturable(self) -> bool:

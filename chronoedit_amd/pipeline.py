@@ -102,6 +102,19 @@ def denoise_step(transformer: ChronoEditTransformer3DModel, scheduler: FlowUniPC
     return scheduler.step_cfg(noise_pred, noise_uncond, guidance_scale, latents)
 
 
+_WARMUP_STREAMS = {}
+
+
+def _warmup_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """The side stream the un-captured step in front of a capture runs on - one per device for the life of the process (a fresh stream per
+    GraphedDenoiser left a 64 MiB split-K scratch registered for each of them: ADVICE r4)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _WARMUP_STREAMS.get(key)
+    if st is None:
+        st = _WARMUP_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class GraphedDenoiser:
     """One denoising step captured as a hipGraph and replayed per step (north star: "the 50-step / 8-step sampling loops
     are hipGraph-captured").  Everything a step reads lives at fixed device addresses: the fp32 latents (updated in place),
@@ -151,7 +164,7 @@ class GraphedDenoiser:
             # lazy initialisations (packed weights, workspaces, function attributes) must not happen under capture: run the CURRENT step
             # eagerly, for real, on a side stream as torch asks of anything that precedes a capture
             saved = None if keep_warmup_step else (latents.clone(), [m.clone() for m in scheduler.model_outputs], scheduler.last_sample.clone())
-            side = torch.cuda.Stream(device=dev)
+            side = _warmup_stream(dev)  # ONE long-lived side stream per device: every stream GEMMs run on gets a split-K scratch of its own (ops.ensure_gemm_workspace)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._body()
@@ -192,11 +205,14 @@ class GraphedDenoiser:
         self.sch.step_cfg(c, u, self.g, self.latents, coef=self.coef_buf)
 
     def step(self, i: int) -> torch.Tensor:
-        if self._done_index is not None and i == self._done_index:  # this step ran eagerly in front of the capture
+        if self._done_index is not None:  # the constructor already ran ONE real step (index _done_index) eagerly on the live state
+            if i != self._done_index:
+                # a caller that re-seeded the latents or starts elsewhere would silently get a trajectory with one extra step
+                raise RuntimeError(f"GraphedDenoiser was built at step {self._done_index} (which it ran eagerly, keep_warmup_step=True) but step({i}) "
+                                   "was asked first: build it at the step it starts from, or with keep_warmup_step=False")
             self._done_index = None
             self.sch._step_index = i + 1
             return self.latents
-        self._done_index = None
         self._stage(i)
         self.graph.replay()
         self.sch._step_index = i + 1

@@ -78,6 +78,13 @@ int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, i
                      int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride,
                      int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
+/* ---- DIAGNOSTIC SWITCHES (ce_set_gemm_variant, ce_set_attention_waves, ce_set_gemm_fp8_variant, ce_set_attention_mxfp8_variant,
+ * ce_set_attention_mxfp8_persistent): process-wide A/B selectors of alternative kernel bodies that compute the same results, for the
+ * measurement tools under tools/ and the body-equivalence tests.  The product path (chronoedit_amd engine, pipeline, bench.py's timed
+ * region) NEVER sets them: every launcher picks its kernel from the call's own shape when they are at their defaults, so with the
+ * defaults the library keeps no state that a launch reads except the caller-registered split-K scratch.  A process
+ * that hosts several engines leaves them alone. ---- */
+
 /* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default: large shapes on the one-wave-per-SIMD
  * LDS-DMA kernels, macro tile per ce_gemm_bf16_tile_rows), 0 force the 128x128 register-staged kernel; wherever the shape allows the
  * large-tile kernels: 1 the 8-wave 256x256 main loop (csrc/ce_gemm256.hip), 2 the same staggered, 3 / 4 / 5 the one-wave-per-SIMD
@@ -420,6 +427,10 @@ int ce_comm_load(const char* librccl_path);
 int ce_comm_unique_id(void* id128);
 /* ncclCommInitRank on the CURRENT device - collective over the `world` ranks that share id128; *comm_out is the handle of the other calls. */
 int ce_comm_init(void** comm_out, const void* id128, int rank, int world);
+/* ncclCommDestroy + free of the handle.  UNSAFE on the stack this library was validated on (RCCL 2.26.6 inside torch 2.10, next to
+ * torch.distributed's own process group): the call blocks for good even on a one-rank communicator (tools/owned_comm_probe.py,
+ * profiles/r04_owned_comm_probe.txt), so the Python side never calls it - it keeps ONE communicator per (group, device) for the life of
+ * the process instead (parallel.OwnedComm.get).  Exported for hosts whose RCCL tears down cleanly. */
 int ce_comm_destroy(void* comm);
 /* send / recv: `world` chunks of bytes_per_peer bytes, chunk p to / from rank p (all_to_all_single with equal splits), as one grouped
  * batch of ncclSend / ncclRecv on `stream`.  Buffers must stay valid until the stream has passed the call. */
