@@ -398,6 +398,22 @@ def main():
         _self_launch(a.gpus)  # bare `python bench.py --gpus N`: becomes the torch.distributed.run launch the driver uses (never returns)
     else:
         torch.cuda.set_device(0)
+    # CE_BENCH_ONE_RANK_SP=1 (tests/test_bench_multirank_gpu.py only): the SHARDED code path of this file - Ulysses exchanges on real RCCL, the
+    # library-owned communicator (--owned-comm), the captured sharded step (--graph) - with a group of ONE rank on a one-GPU box.  Every
+    # exchange runs as a real RCCL call (parallel.Ulysses(force=True)); the line is marked and measures nothing but that the path works.
+    one_rank_sp = world == 1 and a.gpus == 1 and os.environ.get("CE_BENCH_ONE_RANK_SP") == "1"
+    if one_rank_sp:
+        import torch.distributed as dist
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("CE_BENCH_PG_TIMEOUT_S", "600")))
+        dist.init_process_group("nccl", rank=0, world_size=1, timeout=pg_timeout)
+        ctl = dist.new_group(backend="gloo", timeout=pg_timeout)
     dev = torch.device("cuda", local if world > 1 else 0)
 
     from chronoedit_amd import ops
@@ -420,8 +436,8 @@ def main():
             model.enable_fp8_attention()
     mode = a.parallel
     if mode == "auto":
-        mode = "ulysses" if world > 1 else "replica"
-    ulysses = world > 1 and mode == "ulysses"
+        mode = "ulysses" if (world > 1 or one_rank_sp) else "replica"
+    ulysses = (world > 1 or one_rank_sp) and mode == "ulysses"
     # Default split of the N ranks (tools/scaling_model.py): on TWO GPUs the guidance pair is split - each
     # GPU runs one of the two forwards whole, no all-to-all at all, one 3.7 MB exchange per step - because a 2-rank Ulysses group
     # talks over ONE of the seven xGMI links (predicted 0.93 vs 0.69 steps/s); from four GPUs on ONE Ulysses group over all ranks, the
@@ -436,7 +452,7 @@ def main():
         if a.cfg_parallel:
             model.enable_cfg_parallel()
         else:
-            model.enable_sequence_parallel(owned_comm=a.owned_comm)
+            model.enable_sequence_parallel(force=one_rank_sp, owned_comm=a.owned_comm)
     wl = Workload(dev, T, h, w, 42 + (0 if ulysses else rank))  # Ulysses: replicated inputs
     N = wl.N
     fwd_per_step = 2 if a.guidance > 1.0 else 1
@@ -542,6 +558,18 @@ def main():
                                 ("; one all_gather of the two predictions per step" if a.cfg_parallel else "")}
             exchange_us = time_exchanges()
             rccl["exchange_us_per_layer"] = exchange_us
+            # what the scaling model (tools/scaling_model.py) predicts for every split of these ranks - the pair batched in
+            # one group, two groups side by side, eager or as a captured loop (where the k|v exchange no longer hides behind the q projection) -
+            # next to what this run chose, so the first real multi-GPU line can be read against it.  Full-size configs[3] only.
+            if N == 28800 and a.layers == 40 and not test_backend:
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import scaling_model
+                    rccl["model_prediction"] = scaling_model.predict(world)
+                    rccl["model_prediction"]["this_run"] = (("cfg-parallel 2 x %d" % model._sp.world) if a.cfg_parallel else
+                                                            ("ulysses %d" % world + (", B=2" if pair_batched else ""))) + (", hipGraph" if a.graph else ", eager")
+                except Exception as e:  # noqa: BLE001 - a prediction must never take the line down
+                    rccl["model_prediction"] = {"error": repr(e)}
             verify = sharded_result()
 
     def time_exchanges():
@@ -651,7 +679,7 @@ def main():
                                "launches": sum(d["n"] for d in big.values()), "total_ms": round(fam_ms, 3), "share_of_step": round(fam_ms / tot, 4)}
 
     single = dict(cached_rate=None, fp8_rate=None, fp8_config4=None, vae_s=None, enc_s=None, edit8=None, edit50=None, edit_reasoning=None)
-    if world == 1 and rank == 0:
+    if world == 1 and rank == 0 and not one_rank_sp:
         _single_gpu_secondaries(a, model, wl, new_sched, make_stepper, dev, T, h, w, single)
 
     # ---- N > 1: the headline is measured; say it NOW in a line marked preliminary (the legs below run whole edits and CPU baselines for minutes -
@@ -741,6 +769,7 @@ def main():
             "mfma_roofline_peak_tflops": PEAK_FP8_TFLOPS if a.fp8 else PEAK_BF16_TFLOPS,
             "finite": finite,
             **({"TEST_ONLY": f"ranks share one GPU, collectives host-staged over {test_backend}: exercises the code path, measures nothing"} if test_backend else {}),
+            **({"TEST_ONLY": "CE_BENCH_ONE_RANK_SP: the sharded code path on a Ulysses group of ONE rank over real RCCL - exercises the path, measures nothing"} if one_rank_sp else {}),
             "launch": "hipGraph replay" if a.graph else "eager",
             "host_enqueue_ms_per_step": host_enqueue_ms,
             "rccl": rccl,
@@ -778,7 +807,7 @@ def main():
             except Exception as e:
                 out["cpu_config0"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or one_rank_sp:
         try:
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001 - a data group that failed may not shut down cleanly; the lines are already printed

@@ -116,3 +116,27 @@ def test_sharded_failure_still_prints_the_replica_line(who):
     assert rep["value"] > 0 and rep["scaling"] == "weak" and rep["n_gpus"] == 4 and rep["finite"] is True
     assert "sharded_error" in rep and "fallback" in rep
     assert rep["config"]["parallelism"] == "replica x4"
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_one_rank_rccl_owned_comm_flags(graph):
+    """`bench.py --owned-comm [--graph]` on REAL RCCL (VERDICT r4 #5a): CE_BENCH_ONE_RANK_SP puts the sharded code path of bench.py on a Ulysses group of
+    one rank (every exchange a real ncclSend / ncclRecv batch on the library-owned communicator), eager and as the captured step the flag
+    pair selects.  Pins the flag combination the first multi-GPU run would use; measures nothing."""
+    env = dict(os.environ, CE_BENCH_ONE_RANK_SP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CE_BENCH_TEST_BACKEND", "CE_BENCH_SELF_LAUNCHED"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--layers", "2", "--height", "352", "--width", "640",
+           "--no-profile", "--no-secondary", "--no-cpu-baseline", "--no-reasoning-edit", "--owned-comm", *(["--graph"] if graph else [])]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"stdout tail: {r.stdout[-1500:]}\nstderr tail: {r.stderr[-3000:]}"
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.strip().startswith("{") and ln.strip().endswith("}")]
+    assert len(lines) == 1, lines
+    o = lines[0]
+    assert o["n_gpus"] == 1 and o["finite"] is True and "ONE_RANK_SP" in o["TEST_ONLY"] and o["value"] > 0
+    assert o["launch"] == ("hipGraph replay" if graph else "eager")
+    rc = o["rccl"]
+    assert rc["backend"] == "nccl" and rc["world"] == 1 and rc["communicator"].startswith("library-owned"), rc
+    assert rc["all_to_all_per_layer_per_forward"] == 3  # k|v, q, output - also with one rank (force=True)
+    assert o["config"]["tokens"] == 8 * 22 * 40 and o["config"]["parallelism"].startswith("ulysses sp1")
+    assert o["sharded_verification"]["latents_abs_sum_spread_over_ranks"] == 0.0

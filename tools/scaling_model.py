@@ -20,7 +20,9 @@ def rounds(n_wg: float) -> float:
     return full + (0.0 if frac < 1e-9 else max(frac, 0.5))
 
 
-def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_gpu: dict, pair_batched: bool = False):
+def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_gpu: dict, pair_batched: bool = False, captured: bool = False):
+    """captured: the sharded step replayed as a hipGraph on the library-owned communicator - every exchange then sits on the capturing stream
+    (parallel.OwnedComm.all_to_all), so the k|v exchange no longer hides behind the q projection: all three exchanges are exposed."""
     sp = W // 2 if cfg_parallel else W  # ranks per Ulysses group
     # samples per forward: 1 (the two guidance passes in sequence, or side by side on two groups: cfg-parallel) or 2 (pair_batched: one
     # sharded forward of B = 2 on the blocked-layout kernels; shards rounded up to 64 tokens)
@@ -56,13 +58,34 @@ def model(W: int, cfg_parallel: bool, link_GBps: float, latency_us: float, one_g
         per_link = ntensors * rows * (D // sp) * 2  # [local rows][D / sp] bf16 to every peer
         return per_link / (link_GBps * 1e9) * 1e3 + latency_us * 1e-3
     kv, q, o = a2a_ms(2), a2a_ms(1), a2a_ms(1)
-    exposed = max(0.0, kv - q_gemm) + q + o
+    exposed = (kv if captured else max(0.0, kv - q_gemm)) + q + o
     layer = attn + xattn + g + row + exposed
     fwd = L * layer + 6.0 / sp  # + context K/V projections (3 + 3 ms on one GPU), head, patchify
     passes = 1 if (cfg_parallel or batch == 2) else 2
     step = passes * fwd + (0.1 if cfg_parallel else 0.0)  # + the 3.7 MB prediction exchange
     return dict(W=W, mode="cfg-parallel 2 x %d" % sp if cfg_parallel else ("ulysses %d, B=2" % sp if batch == 2 else "ulysses %d" % sp), rows=rows, heads=heads,
                 attn_ms=attn, gemm_ms=g, exchange_ms=kv + q + o, exposed_ms=exposed, step_ms=step, steps_per_s=1e3 / step)
+
+
+def predict(W: int, link_GBps: float = 55.0, latency_us: float = 25.0) -> dict:
+    """What `bench.py --gpus W` puts into its `rccl` block next to the measurement (full-size configs[3] only): the model's steps/s for every
+    way of splitting W ranks, eager and captured, so that the first real multi-GPU run can be read against it.  `choice` = the split and
+    the launch form the model ranks first - a captured loop only wins where the host cannot keep W ranks' queues full, which the one-GPU
+    enqueue time (8 ... 16 ms per step against >= 250 ms of GPU work per rank at W = 8) says is never the case at these shapes."""
+    one = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n28800_one_gpu.json")))
+    out = {"source": "tools/scaling_model.py on profiles/r02_bench_n28800_one_gpu.json", "link_GBps_one_way": link_GBps, "latency_us_per_collective": latency_us,
+           "one_gpu_steps_per_s": round(1e3 / one["ms_per_step"], 4), "steps_per_s": {}}
+    for cfgp, pb in ((False, False), (False, True), (True, False)):
+        if cfgp and (W < 2 or W % 2):
+            continue
+        for cap in (False, True):
+            if cap and (cfgp or W == 1):
+                continue  # the guidance-pair exchange of CFG parallelism is a torch.distributed collective: never captured
+            r = model(W, cfgp, link_GBps, latency_us, one, pair_batched=pb, captured=cap)
+            out["steps_per_s"][r["mode"] + (", hipGraph" if cap else ", eager")] = round(r["steps_per_s"], 4)
+    best = max(out["steps_per_s"], key=out["steps_per_s"].get)
+    out["choice"] = best
+    return out
 
 
 def main():
@@ -74,11 +97,14 @@ def main():
     one = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n28800_one_gpu.json")))
     base = one["ms_per_step"]
     print(f"measured on one MI355X: {base:.0f} ms/step ({1e3 / base:.3f} steps/s); link {a.link_GBps} GB/s one way, {a.latency_us} us per collective")
-    print(f"{'GPUs':>4} {'mode':>18} {'rows/rank':>9} {'heads':>5} {'attn':>7} {'GEMMs':>7} {'a2a':>6} {'exposed':>7} | {'ms/step':>8} {'steps/s':>8} {'speed-up':>8} {'eff.':>5}")
+    print(f"{'GPUs':>4} {'mode (captured loop: steps/s)':>34} {'rows/rank':>9} {'heads':>5} {'attn':>7} {'GEMMs':>7} {'a2a':>6} {'exposed':>7} | {'ms/step':>8} {'steps/s':>8} {'speed-up':>8} {'eff.':>5}")
     for W in (1, 2, 4, 8):
         for cfgp, pb in (((False, False), (False, True)) if W == 1 else ((False, False), (False, True), (True, False))):
             r = model(W, cfgp, a.link_GBps, a.latency_us, one, pair_batched=pb)
-            print(f"{W:>4} {r['mode']:>18} {r['rows']:>9} {r['heads']:>5} {r['attn_ms']:>7.2f} {r['gemm_ms']:>7.2f} {r['exchange_ms']:>6.2f} {r['exposed_ms']:>7.2f} |"
+            if W > 1 and not cfgp:
+                rc = model(W, cfgp, a.link_GBps, a.latency_us, one, pair_batched=pb, captured=True)
+                r["mode"] += " (graph: %.3f)" % rc["steps_per_s"]
+            print(f"{W:>4} {r['mode']:>34} {r['rows']:>9} {r['heads']:>5} {r['attn_ms']:>7.2f} {r['gemm_ms']:>7.2f} {r['exchange_ms']:>6.2f} {r['exposed_ms']:>7.2f} |"
                   f" {r['step_ms']:>8.1f} {r['steps_per_s']:>8.3f} {base / r['step_ms']:>8.2f} {base / r['step_ms'] / W:>5.2f}")
 
 
