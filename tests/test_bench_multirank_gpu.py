@@ -137,6 +137,7 @@ def test_one_rank_rccl_owned_comm_flags(graph):
     assert o["launch"] == ("hipGraph replay" if graph else "eager")
     rc = o["rccl"]
     assert rc["backend"] == "nccl" and rc["world"] == 1 and rc["communicator"].startswith("library-owned"), rc
-    assert rc["all_to_all_per_layer_per_forward"] == 3  # k|v, q, output - also with one rank (force=True)
+    if not graph:  # (a replay runs no Python: the call counter only sees the capture)
+        assert rc["all_to_all_per_layer_per_forward"] == 3  # k|v, q, output - also with one rank (force=True)
     assert o["config"]["tokens"] == 8 * 22 * 40 and o["config"]["parallelism"].startswith("ulysses sp1")
     assert o["sharded_verification"]["latents_abs_sum_spread_over_ranks"] == 0.0
