@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int p = 0; p < 8; ++p) dma_a(p, 2 * TILE, a2);
     }
   }
-  if (NSA == 3 && !ONEBAR) W4_VM(24); else if (NG == 8) W4_VM(16); else W4_VM(12);  // tile 0 has landed
+  if (NSA == 3 && !ONEBAR) W4_VM(24); else if (NG == 8) W4_VM(16); else if (NG == 4) W4_VM(12); else W4_VM(11);  // tile 0 has landed (8 + NG pieces of tile 1 may be in flight)
   W4_BAR();
   FragSet<NG> s0, s1, s2;
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (!ONEBAR) W4_BAR();                                                                                      \
     W4_UNIT0(0, K0, WP, wsoff) W4_UNIT0(1, K0, WP, wsoff) W4_UNIT0(2, K0, WP, wsoff) W4_UNIT0(3, K0, WP, wsoff) \
     W4_UNIT0(4, K0, WP, wsoff) W4_UNIT0(5, K0, WP, wsoff) W4_UNIT0(6, K0, WP, wsoff) W4_UNIT0(7, K0, WP, wsoff) \
-    if (NSA == 3 && !ONEBAR) W4_VM(16); else if (NG == 8) W4_VM(8); else W4_VM(4);                              \
+    if (NSA == 3 && !ONEBAR) W4_VM(16); else if (NG == 8) W4_VM(8); else if (NG == 4) W4_VM(4); else W4_VM(3);   \
     W4_BAR();                                                                                                   \
     W4_UNIT1(0, K1, K0, KN, WP) W4_UNIT1(1, K1, K0, KN, WP) W4_UNIT1(2, K1, K0, KN, WP) W4_UNIT1(3, K1, K0, KN, WP) \
     W4_UNIT1(4, K1, K0, KN, WP) W4_UNIT1(5, K1, K0, KN, WP) W4_UNIT1(6, K1, K0, KN, WP) W4_UNIT1(7, K1, K0, KN, WP) \
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results -> v_accvgpr_read (hipcc does not see the asm MFMAs)
   W4_BAR();
 
-  static_assert(NG == 8 || (NG == 4 && NSA == 2 && !ONEBAR), "the 256 x 128 tile exists for the two-stage loop only");
+  static_assert(NG == 8 || ((NG == 4 || NG == 3) && NSA == 2 && !ONEBAR), "the 256 x 128 / 256 x 96 tiles exist for the two-stage loop only");
   if (partial) {  // split-K tail piece: fp32 slab [wave][f][g][lane] for gemm256w4_reduce (the launcher splits 256 x 256 tiles only)
     float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
 #pragma unroll
@@ -240,8 +240,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         *reinterpret_cast<f32x4*>(slab + (((wave * 64 + f * 8 + g) * 64) + lane) * 4) = acc[f][g];
     return;
   }
-  constexpr int CPR = BN / 8;        // 16-byte chunks per staged row (32 | 16)
-  constexpr int CH = 64 * CPR / 256;  // chunks per thread and pass (8 | 4)
+  constexpr int CPR = BN / 8;        // 16-byte chunks per staged row (32 | 16 | 12)
+  // chunks per thread and pass: 8 | 4 when a staged row's chunk count divides 256 (thread t: chunk t % CPR of rows t / CPR + (256 / CPR) tt);
+  // the 96-wide tile (CPR = 12): threads 0..251 take chunk t % 12 of rows t / 12 + 21 tt, tt = 0..3 - rows past 63 and threads 252..255 idle
+  constexpr bool CPOW2 = (CPR & (CPR - 1)) == 0;
+  constexpr int RPT = 256 / CPR;                        // staged rows one sweep of the workgroup covers (8 | 16 | 21)
+  constexpr int CH = CPOW2 ? 64 * CPR / 256 : (64 + RPT - 1) / RPT;
+  const int my_cc = CPOW2 ? (tid & (CPR - 1)) : tid % CPR;
+  // staged row of this thread's chunk tt (clamped to a valid one) and whether the chunk exists
+  auto chunk_row = [&](int tt, bool& ok) __attribute__((always_inline)) -> int {
+    if (CPOW2) {
+      ok = true;
+      return (tid + 256 * tt) / CPR;
+    }
+    const int rl = tid / CPR + RPT * tt;
+    ok = tid < RPT * CPR && rl < 64;
+    return min(rl, 63);
+  };
 
   // ---- epilogue: four passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave = tile rows
   // wm*128 + p*32 + [0,32)), so that bias / GELU / gated-residual math and the global stores run on 16-B row-contiguous chunks
@@ -261,7 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   u32x4 rv[4][CH];
   f32x4 gA0, gA1, gB0, gB1;
   int g_switch = 0x7fffffff;  // first global row that takes the second sample's gate
-  const int my_n = n0 + (tid & (CPR - 1)) * 8, my_nc = min(my_n, N - 8);
+  const int my_n = n0 + my_cc * 8, my_nc = min(my_n, N - 8);
   const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
   if (EPI == EPI_GATE_RES && prefetch) {
     gA0 = gA1 = gB0 = gB1 = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -280,7 +295,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int tt = 0; tt < CH; ++tt) {
-        const int rl = (tid + 256 * tt) / CPR;
+        bool ok;
+        const int rl = chunk_row(tt, ok);
         const int m = min(m0 + (rl >> 5) * 128 + p * 32 + (rl & 31), M - 1);
         rv[p][tt] = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + my_nc);
       }
@@ -308,9 +324,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (EPI == EPI_GATE_RES && prefetch) {
 #pragma unroll
       for (int tt = 0; tt < CH; ++tt) {
-        const int rl = (tid + 256 * tt) / CPR;
-        const int m = m0 + (rl >> 5) * 128 + p * 32 + (rl & 31);
-        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + (tid & (CPR - 1)) * 16);
+        bool ok;
+        const int rl = chunk_row(tt, ok);
+        const int m = ok ? m0 + (rl >> 5) * 128 + p * 32 + (rl & 31) : M;  // (a chunk that does not exist: its store falls outside the buffer's range)
+        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + my_cc * 16);
         const bool second = m >= g_switch;
         const f32x4 g0 = second ? gB0 : gA0, g1 = second ? gB1 : gA1;
         const u32x4 r = rv[p][tt];
@@ -329,10 +346,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else if (EPI != EPI_GATE_RES) {
       epi_chunks<EPI, CH>(smem, CROW,
                          [&](int tt, int& rl, int& cc, int& mr) {
-                           const int c = tid + 256 * tt;
-                           rl = c / CPR;
-                           cc = c & (CPR - 1);
-                           mr = (rl >> 5) * 128 + p * 32 + (rl & 31);
+                           bool ok;
+                           rl = chunk_row(tt, ok);
+                           cc = my_cc;
+                           mr = ok ? (rl >> 5) * 128 + p * 32 + (rl & 31) : (1 << 28);  // (no such chunk: row past M, the store is skipped)
                          },
                          m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
     }
@@ -390,7 +407,7 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
                      int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride, int w_seg_k,
                      long long w_seg_stride, int a_seg2_k, long long a_seg2_stride, int nsa, int ng, hipStream_t stream) {
   const bool seg2 = a_seg2_k > 0;
-  if ((ng != 8 && ng != 4) || (ng == 4 && !seg2)) return CE_ERR_ARG;
+  if ((ng != 8 && ng != 4 && ng != 3) || (ng != 8 && !seg2)) return CE_ERR_ARG;
   if (seg2 && (a_seg_k <= 0 || a_seg2_k % a_seg_k || (epilogue != EPI_BIAS && epilogue != EPI_GATE_RES) || nsa != 2 ||
                (epilogue == EPI_GATE_RES && gate != nullptr)))
     return CE_ERR_ARG;
@@ -447,13 +464,16 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
   const int lds3 = 5 * TILE, lds2 = 4 * TILE;
   if (seg2) {
     const int lds2n = 2 * TILE + 2 * (128 * BK * 2);  // 256 x 128 tile: W stages of 16 KiB
+    const int lds2m = 2 * TILE + 2 * (96 * BK * 2);   // 256 x 96 tile: W stages of 12 KiB
     static bool seg2_done_[CE_MAX_DEVICES] = {};
     bool& seg2_done = seg2_done_[ce_device_slot()];
     if (!seg2_done) {
       if (hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_BIAS, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess ||
           hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2) != hipSuccess ||
           hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_BIAS, 2, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2n) != hipSuccess ||
-          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2n) != hipSuccess)
+          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2n) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_BIAS, 2, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2m) != hipSuccess ||
+          hipFuncSetAttribute((const void*)gemm_bf16_w4<EPI_GATE_RES, 2, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2m) != hipSuccess)
         return CE_ERR_ARG;
       seg2_done = true;
     }
@@ -462,9 +482,9 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
                      (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, a_seg_magic,   \
                      a_seg_extra, w_seg_magic, w_seg_extra, a_seg2_magic, a_seg2_extra)
     if (epilogue == EPI_BIAS) {
-      if (ng == 8) CE_LAUNCH_SEG2(EPI_BIAS, 8, lds2); else CE_LAUNCH_SEG2(EPI_BIAS, 4, lds2n);
+      if (ng == 8) CE_LAUNCH_SEG2(EPI_BIAS, 8, lds2); else if (ng == 4) CE_LAUNCH_SEG2(EPI_BIAS, 4, lds2n); else CE_LAUNCH_SEG2(EPI_BIAS, 3, lds2m);
     } else {
-      if (ng == 8) CE_LAUNCH_SEG2(EPI_GATE_RES, 8, lds2); else CE_LAUNCH_SEG2(EPI_GATE_RES, 4, lds2n);
+      if (ng == 8) CE_LAUNCH_SEG2(EPI_GATE_RES, 8, lds2); else if (ng == 4) CE_LAUNCH_SEG2(EPI_GATE_RES, 4, lds2n); else CE_LAUNCH_SEG2(EPI_GATE_RES, 3, lds2m);
     }
 #undef CE_LAUNCH_SEG2
     return (int)hipGetLastError();
@@ -517,7 +537,7 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
 
 // A with TWO nested segment levels: column k of row m lives at A + (k / a_seg2_k) a_seg2_stride + ((k % a_seg2_k) / a_seg_k) a_seg_stride +
 // m lda + k % a_seg_k (elements).  EPI_BIAS or the plain residual add (EPI_GATE_RES without a gate); no split-K.
-// n_tile: 256 or 128 (the 256 x 128 macro tile: wave tiles 128 x 64).
+// n_tile: 256, 128 (the 256 x 128 macro tile: wave tiles 128 x 64) or 96 (256 x 96: wave tiles 128 x 48 - the 96-channel convolutions).
 extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const void* res, int M, int N,
                                         int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
                                         long long a_seg2_stride, int n_tile, hipStream_t stream) {

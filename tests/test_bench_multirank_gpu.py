@@ -105,7 +105,7 @@ def test_sharded_failure_still_prints_the_replica_line(who):
     # (one rank failing alone leaves its peers inside a collective: they run into the data group's timeout, shortened here, and the
     # host-side vote then sends every rank down the replica path; under RCCL a watchdog timeout aborts the process instead - only
     # failures that every rank sees, e.g. an RCCL initialisation or a shape error, are recoverable there)
-    lines = _run(4, extra=("--no-secondary", "--no-cpu-baseline"), env_extra={"CE_BENCH_INJECT_SHARDED_FAILURE": who, "CE_BENCH_PG_TIMEOUT_S": "30"})
+    lines = _run(4, extra=("--no-secondary", "--no-cpu-baseline"), env_extra={"CE_BENCH_INJECT_SHARDED_FAILURE": who, "CE_BENCH_PG_TIMEOUT_S": "15"})
     errs, rest = [l for l in lines if "error" in l], [l for l in lines if "error" not in l]
     assert errs and all(e["value"] is None and e["n_gpus"] == 4 for e in errs), lines  # rank 0's line, and the failing rank's own (said at once)
     assert any("rank" not in e for e in errs), errs

@@ -1,5 +1,6 @@
-"""The VAE's wide stride-1 convs at the 720p decode shapes: ce_conv3d_gemm_bf16 with either macro tile (256 x 128, 256 x 256) vs the
-implicit-GEMM kernel (ce_conv_igemm_bf16), one process, interleaved.   python tools/conv_gemm_ab.py [rounds]"""
+"""The VAE's wide stride-1 convs at the 720p decode shapes: ce_conv3d_gemm_bf16 with each macro tile (256 x 96, 256 x 128, 256 x 256) vs the
+implicit-GEMM kernel (ce_conv_igemm_bf16), one process, interleaved; every tile's output is compared with the 128-wide one's (same products,
+same summation order per accumulator: bit-identical).   python tools/conv_gemm_ab.py [rounds]"""
 import os
 import sys
 
@@ -44,10 +45,19 @@ def main():
             return e0.elapsed_time(e1) / iters
 
         best = {}
+        kinds = ("old", 96, 128, 256) if Cout % 96 == 0 else ("old", 128, 256)
         for _ in range(rounds):
-            for kind in ("old", 128, 256):
+            for kind in kinds:
                 best[kind] = min(best.get(kind, 1e9), timeit(kind))
-        print(f"conv {KT}x3x3 {Cin}->{Cout} {T}x{H}x{W}: " + " | ".join(f"{k}: {v:.3f} ms {fl / v / 1e9:.0f} TF" for k, v in best.items()), flush=True)
+        run(128)
+        ref = out.data.clone()
+        same = {}
+        for kind in kinds[1:]:
+            out.data.zero_()
+            run(kind)
+            same[kind] = bool(torch.equal(out.data, ref))
+        print(f"conv {KT}x3x3 {Cin}->{Cout} {T}x{H}x{W}: " + " | ".join(f"{k}: {v:.3f} ms {fl / v / 1e9:.0f} TF" for k, v in best.items()) +
+              f" | == 128-wide: {same}", flush=True)
         del f, out
 
 
