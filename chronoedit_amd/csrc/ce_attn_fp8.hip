@@ -415,7 +415,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
                                                                   const unsigned char* __restrict__ V8T_, const unsigned char* __restrict__ SV_,
                                                                   bf16* __restrict__ O_, int Nq, int Nkv, int npad, int H, int ldq8,
                                                                   int ldk8, int ldo, int nqb, int batch, unsigned char* __restrict__ O8_,
-                                                                  unsigned char* __restrict__ S8_, int ldo8) {
+                                                                  unsigned char* __restrict__ S8_, int ldo8, const bf16* Oadd_, int ldadd) {
+  // (Oadd_: bf16 rows [batch Nq][ldadd] ADDED to this attention's bf16-rounded result before it is stored / quantised - the second
+  // segment of the cross-attention, out = bf16(SDPA_text) + bf16(SDPA_image), transformer_chronoedit.py:96-107; may alias O_)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int D32 = (H * HD) >> 5;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -425,6 +427,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
   for (int item = blockIdx.x; item < nqb * H * batch; item += gridDim.x) {
   const unsigned char *Q8 = Q8_, *SQ = SQ_, *K8 = K8_, *SK = SK_, *V8T = V8T_, *SV = SV_;
   bf16* O = O_;
+  const bf16* Oadd = Oadd_;
   // Work order (batch folded into the item index, as in the bf16 kernel): every XCD takes its heads' FULL 256-row query blocks first,
   // sample by sample, and the remainder blocks (Nq % 256 rows: only their first waves have rows, the others merely stage) last -
   // they fill the partially occupied final round of workgroups instead of heading it.  Nq = 7200, H = 40, two samples: 2320
@@ -462,6 +465,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
     V8T += b * H * HD * npad;
     SV += b * H * HD * (npad >> 5);
     O += b * Nq * ldo;
+    if (Oadd != nullptr) Oadd += b * Nq * ldadd;
   }
   const int q0 = qb * (QW * 8) + wave * QW;
   const bool active = q0 < Nq;  // wave-uniform: a wave past the last query row only stages tiles and keeps the barriers
@@ -738,7 +742,53 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
 
   const float inv = 1.0f / l_run;  // the matrix pipe summed over all 64 k-slots: every lane holds its row's full sum
   unsigned char* ost = smem + (size_t)(wave * QW + l31) * OST_ROW;
-  if (O8_ != nullptr) {
+  if (Oadd != nullptr) {
+    // Second segment of a two-segment attention: this segment's result, rounded to bf16, staged row-contiguous; every lane then takes
+    // 16-byte chunks (8 channels of one query row), adds the first segment's bf16 result (one coalesced 16-byte load) and either stores
+    // the bf16 sum or quantises it as ce_quant_rows_mxfp8 would (a 32-channel block = 4 consecutive chunks = 4 adjacent lanes).
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const u32x2 val = {pack_bf16(oacc[m][4 * a + 0] * inv, oacc[m][4 * a + 1] * inv), pack_bf16(oacc[m][4 * a + 2] * inv, oacc[m][4 * a + 3] * inv)};
+        *reinterpret_cast<u32x2*>(ost + (32 * m + 8 * a + 4 * hh) * 2) = val;
+      }
+    __syncthreads();
+    const int ktiles = (H * HD) >> 7;
+    unsigned char* O8 = O8_ != nullptr ? O8_ + (size_t)bz * Nq * ldo8 : nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + 64 * i;
+      const int rl = c >> 4, cc = c & 15;
+      const int q = min(q0 + rl, Nq - 1);
+      const bool on = q0 + rl < Nq;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (size_t)(wave * QW + rl) * OST_ROW + cc * 16);
+      const u32x4 pv = *reinterpret_cast<const u32x4*>(Oadd + (size_t)q * ldadd + hoff + cc * 8);
+      u32x4 sm;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sm[w] = pack_bf16(bf16lo(v[w]) + bf16lo(pv[w]), bf16hi(v[w]) + bf16hi(pv[w]));
+      if (O8 == nullptr) {
+        if (on) *reinterpret_cast<u32x4*>(O + (size_t)q * ldo + hoff + cc * 8) = sm;
+      } else {
+        float amax = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) amax = fmaxf(amax, fmaxf(fabsf(bf16lo(sm[w])), fabsf(bf16hi(sm[w]))));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        const int byte = mx_scale_byte_nosat(amax);
+        const float is = mx_inv_scale(byte);
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(sm[0]) * is), clamp448(bf16hi(sm[0]) * is), w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(sm[1]) * is), clamp448(bf16hi(sm[1]) * is), w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(sm[2]) * is), clamp448(bf16hi(sm[2]) * is), w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(sm[3]) * is), clamp448(bf16hi(sm[3]) * is), w1, true);
+        if (on) {
+          *reinterpret_cast<u32x2*>(O8 + (size_t)q * ldo8 + hoff + cc * 8) = u32x2{(uint32_t)w0, (uint32_t)w1};
+          if ((cc & 3) == 0) S8_[mx_gemm_scale_offset(bz * Nq + q, head * 4 + (cc >> 2), ktiles)] = (unsigned char)byte;
+        }
+      }
+    }
+  } else if (O8_ != nullptr) {
     // The out-projection's MX operand straight from the accumulators (ce_attention_mxfp8_quant): the bf16 value the plain form stores,
     // quantised as ce_quant_rows_mxfp8 would - a 32-channel block m of a query row is this lane's 16 values and the 16 of lane ^ 32.
     const int ktiles = (H * HD) >> 7;
@@ -835,7 +885,8 @@ extern "C" int ce_set_attention_mxfp8_variant(int v) {
 
 static int attention_mxfp8_launch(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
                                   int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, void* O8, void* S8,
-                                  int ldo8, hipStream_t stream) {
+                                  int ldo8, hipStream_t stream, const void* o_add = nullptr, int ldadd = 0) {
+  if (o_add && (ldadd & 7)) return CE_ERR_ALIGN;
   if (!q8 || !sq || !k8 || !sk || !v8t || !sv || (!O && !O8) || (O8 && !S8)) return CE_ERR_ARG;
   if (head_dim != HD || Nq <= 0 || Nkv <= 0 || H <= 0 || batch <= 0 || (npad & 63) || npad < Nkv || npad - Nkv >= KVB) return CE_ERR_SHAPE;
   if ((ldq8 & 15) || (ldk8 & 15) || (O && (ldo & 7)) || (O8 && (ldo8 & 15))) return CE_ERR_ALIGN;
@@ -847,7 +898,7 @@ static int attention_mxfp8_launch(const void* q8, const void* sq, const void* k8
     (void)hipFuncSetAttribute((const void*)attn_fwd_mxfp8_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_SP);
     attr = true;
   }
-  if (g_mxfp8_variant == 0 && !O8)
+  if (g_mxfp8_variant == 0 && !O8 && !o_add)
     hipLaunchKernelGGL(attn_fwd_mxfp8_kernel, dim3(H * nqb, batch), dim3(512), SMEM, stream, (const unsigned char*)q8, (const unsigned char*)sq,
                        (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t, (const unsigned char*)sv, (bf16*)O, Nq, Nkv,
                        npad, H, ldq8, ldk8, ldo, nqb);
@@ -855,8 +906,18 @@ static int attention_mxfp8_launch(const void* q8, const void* sq, const void* k8
     hipLaunchKernelGGL(attn_fwd_mxfp8_sp_kernel, dim3(g_mxfp8_persist > 0 && H * nqb * batch > g_mxfp8_persist ? g_mxfp8_persist : H * nqb * batch), dim3(512), SMEM_SP, stream, (const unsigned char*)q8,
                        (const unsigned char*)sq, (const unsigned char*)k8, (const unsigned char*)sk, (const unsigned char*)v8t,
                        (const unsigned char*)sv, (bf16*)O, Nq, Nkv, npad, H, ldq8, ldk8, ldo, nqb, batch, (unsigned char*)O8, (unsigned char*)S8,
-                       ldo8);
+                       ldo8, (const bf16*)o_add, ldadd);
   return (int)hipGetLastError();
+}
+
+// Second segment of a two-segment attention (the cross-attention's image segment, transformer_chronoedit.py:96-107): as ce_attention_mxfp8 /
+// ce_attention_mxfp8_quant, with the bf16 rows o_add [batch Nq][ldadd] - the first segment's result - added to this segment's bf16-rounded
+// result; the sum is stored as bf16 (O; may be o_add itself) or as the out-projection's MX operand (o8 + scale8; exactly one of the two).
+extern "C" int ce_attention_mxfp8_add(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv,
+                                      const void* o_add, int ldadd, void* O, int ldo, void* o8, void* scale8, int ldo8, int Nq, int Nkv, int npad,
+                                      int H, int head_dim, int ldq8, int ldk8, int batch, hipStream_t stream) {
+  if (!o_add || (O == nullptr) == (o8 == nullptr)) return CE_ERR_ARG;
+  return attention_mxfp8_launch(q8, sq, k8, sk, v8t, sv, O, Nq, Nkv, npad, H, head_dim, ldq8, ldk8, ldo, batch, o8, scale8, ldo8, stream, o_add, ldadd);
 }
 
 extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,

@@ -490,12 +490,24 @@ extern "C" int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int
   if (ldw < kpad || (ldw & 7)) return CE_ERR_SHAPE;
   const long long rows = (long long)T_out * Hp * Wp - 2ll * (Wp + 1);
   if (rows <= 0 || rows * Cin * 2 >= (1ll << 32) || rows * out_cstride * 2 >= (1ll << 32)) return CE_ERR_SHAPE;
-  if (n_tile == 0) {  // the narrower tile where it wastes less of the N axis (its loop reads 1.5 x the LDS bytes per MFMA)
-    const int w256 = (Cout + 255) / 256 * 256, w128 = (Cout + 127) / 128 * 128;
-    n_tile = w128 * 9 < w256 * 8 ? 128 : 256;
-    // 96 output channels (the full-resolution layers of the VAE): a 128-wide tile idles a quarter of every MFMA - the 96-wide one (wave
-    // tiles 128 x 48: 11 fragment reads per 24 MFMAs against 12 per 32) does a quarter fewer of them
-    if (Cout == 96) n_tile = 96;
+  if (n_tile == 0) {
+    // Priced per macro tile from the A/B of the 720p decode shapes (profiles/r05_conv_gemm_tile96_ab.txt): a 256 x 96 / 256 x 128 / 256 x 256 tile
+    // costs 0.82 : 1 : 1.6 (the narrower ones read more LDS bytes per MFMA); a grid of a few rounds of 256 CUs pays whole rounds.  96 output
+    // channels -> the 96-wide tile (a 128-wide one idles a quarter of every MFMA); 384 channels at 90 x 160 -> 96 too (four tile columns
+    // fill the chip where three leave a third of it idle); the big 192 / 384-channel layers stay on 256 / 128.
+    const long long tiles_m = (rows + 255) / 256;
+    const int widths[3] = {96, 128, 256};
+    const double cost[3] = {0.82, 1.0, 1.6};
+    double best = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      const long long tiles = tiles_m * ((Cout + widths[i] - 1) / widths[i]);
+      const double rounds = tiles >= 1024 ? (double)tiles / 256.0 : (double)((tiles + 255) / 256);
+      const double t = rounds * cost[i];
+      if (n_tile == 0 || t < best) {
+        best = t;
+        n_tile = widths[i];
+      }
+    }
   }
   const size_t shift = (size_t)(Wp + 1);
   bf16* c0 = (bf16*)out_stack + shift * out_cstride;

@@ -35,6 +35,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_v_mxfp8_transpose": [_P, _I, _P, _P, _I, _I, _I, _I, _P],
     "ce_attention_mxfp8": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_attention_mxfp8_quant": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ce_attention_mxfp8_add": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_set_attention_mxfp8_variant": [_I],
     "ce_set_attention_mxfp8_persistent": [_I],
     "ce_rope_scatter_bf16": [_P, _I, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _I, _P],

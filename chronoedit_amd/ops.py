@@ -957,10 +957,12 @@ def set_attention_mxfp8_variant(v: int) -> int:
 
 def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: torch.Tensor, v8t: torch.Tensor, sv: torch.Tensor,
                     heads: int, out: Optional[torch.Tensor] = None, batch: int = 1, out8: Optional[torch.Tensor] = None,
-                    scale8: Optional[torch.Tensor] = None):
-    """Self-attention on the MX-fp8 matrix instruction from the operands the two producers above write (q with post_scale =
+                    scale8: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None):
+    """Attention on the MX-fp8 matrix instruction from the operands the two producers above write (q with post_scale =
     MXFP8_Q_SCALE); out [batch*Nq, heads*128] bf16 - or, with out8 / scale8, the same values as the MX fp8 operand of the out-projection
-    (e4m3 rows + tiled E8M0 block scales, bit-identical to quant_rows_mxfp8 of the bf16 output)."""
+    (e4m3 rows + tiled E8M0 block scales, bit-identical to quant_rows_mxfp8 of the bf16 output).
+    add: bf16 rows [batch*Nq, heads*128] added to this call's bf16-rounded result before it is stored / quantised - the second segment of the
+    cross-attention (`add` = the text segment's result; `out` may be `add` itself)."""
     for n, t in (("q8", q8), ("sq", sq), ("k8", k8), ("sk", sk), ("v8t", v8t), ("sv", sv)):
         _dev(t, torch.uint8, n)
     Mq, D, ldq = _rows(q8, "q8")
@@ -970,6 +972,27 @@ def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: to
     npad = v8t.shape[-1]
     assert sq.is_contiguous() and sk.is_contiguous() and v8t.is_contiguous() and sv.is_contiguous()
     assert sq.shape == (Mq, D // 32) and sk.shape == (Mk, D // 32) and v8t.shape == (batch, heads, 128, npad) and sv.shape == (batch, heads, npad // 64, 128, 2)
+    if add is not None:
+        _dev(add, torch.bfloat16, "add")
+        Ma, Da, lda = _rows(add, "add")
+        assert (Ma, Da) == (Mq, D)
+        ld8 = ldo = 0
+        if out8 is not None:
+            _dev(out8, torch.uint8, "out8"), _dev(scale8, torch.uint8, "scale8")
+            _, D8, ld8 = _rows(out8, "out8")
+            assert out8.shape[0] == Mq and D8 == D and scale8.is_contiguous() and scale8.numel() >= mx_scale_bytes(Mq, D)
+        else:
+            if out is None:
+                out = add
+            _dev(out, torch.bfloat16, "out")
+            _, _, ldo = _rows(out, "out")
+        st = _prof_begin()
+        _check(lib().ce_attention_mxfp8_add(_ptr(q8), _ptr(sq), _ptr(k8), _ptr(sk), _ptr(v8t), _ptr(sv), _ptr(add), lda, _ptr(out) if out8 is None else None,
+                                            ldo, _ptr(out8), _ptr(scale8) if out8 is not None else None, ld8, nq, nkv, npad, heads, 128, ldq, ldk, batch,
+                                            _stream()), "ce_attention_mxfp8_add")
+        _prof_end(st, f"attention_mxfp8_{nq}x{nkv}_h{heads}" + (f"_b{batch}" if batch > 1 else "") + "_add" + ("_mxq" if out8 is not None else ""),
+                  4.0 * nq * nkv * 128 * heads * batch)
+        return out8 if out8 is not None else out
     if out8 is not None:
         _dev(out8, torch.uint8, "out8"), _dev(scale8, torch.uint8, "scale8")
         _, D8, ld8 = _rows(out8, "out8")

@@ -330,16 +330,16 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self._engine = None
         return self
 
-    def enable_fp8_attention(self, on: bool = True):
-        """BASELINE.json configs[4] "fp8 weights+attn": the self-attention of every block under the MXFP8 contract of
+    def enable_fp8_attention(self, on: bool = True, cross: bool = True):
+        """BASELINE.json configs[4] "fp8 weights+attn": the attention of every block under the MXFP8 contract of
         csrc/ce_attn_fp8.hip - q / k (after RMSNorm + RoPE) in e4m3 with one E8M0 scale per 32 head channels, v per 32 keys,
-        Q.K^T and P.V on v_mfma_scale_f32_32x32x64_f8f6f4, P in e4m3, fp32 accumulation.  Cross-attention (769 keys, 3 % of the
-        attention flops) and everything else are unchanged; independent of enable_fp8_gemms."""
+        Q.K^T and P.V on v_mfma_scale_f32_32x32x64_f8f6f4, P in e4m3, fp32 accumulation.  cross (round 5): the cross-attention too - the
+        text and the image segment each as one MXFP8 attention over the context's quantised K / V^T (made once per context: cached per
+        edit), the image segment adding the text segment's bf16 result (`ce_attention_mxfp8_add`); cross=False keeps it on the bf16
+        two-segment kernel (3 % of the attention flops).  Everything else is unchanged; independent of enable_fp8_gemms."""
         self.attn_dtype = "mxfp8" if on else "bf16"
-        if self._engine is not None:
-            self._engine.fp8_attn = on
-            self._engine._ws = {}
-            self._engine.ws_generation += 1
+        self.fp8_cross = bool(on and cross)
+        self._engine = None  # (the context operands and the workspaces depend on it)
         return self
 
     def attention_path(self) -> str:
@@ -513,6 +513,7 @@ class DiTEngine:
             tables.append(f32(blk.scale_shift_table).reshape(6, self.D))
             self.blk.append(p)
         self.fp8_attn = model.attn_dtype == "mxfp8"
+        self.fp8_cross = self.fp8_attn and bool(getattr(model, "fp8_cross", False))  # cross-attention under the MXFP8 contract too
         self.fp8 = model.gemm_dtype in ("fp8", "mxfp8")
         self.mx = model.gemm_dtype == "mxfp8"  # MX block scales on both GEMM operands (ce_gemm_mxfp8)
         self.fuse_quant = bool(getattr(model, "fp8_fuse_quant", True)) and self.F % 128 == 0  # MX: quantisation fused into the FFN-up epilogue
@@ -743,7 +744,8 @@ class DiTEngine:
         eps = self.cfg.eps
         hd = self.cfg.attention_head_dim
         L = self.L
-        use_vt = self.cross_vt and enc_i is not None and self.all_img and Tt % 8 == 0
+        f8 = self.fp8_cross and (self.model._sp is None or not self.model._sp.sharded) and getattr(self.model, "_cfgp", None) is None
+        use_vt = self.cross_vt and enc_i is not None and self.all_img and Tt % 8 == 0 and not f8
         k_t_all = ops.gemm(enc_t, self.w_k_t_all, self.b_k_t_all)  # [B*Tt, L*D]
         k_i_all = v_t_all = v_i_all = v1t = v2t = None
         c1 = c2 = 0
@@ -774,7 +776,7 @@ class DiTEngine:
             if k_i_all is not None:
                 v_i_all = ops.gemm(enc_i, self.w_v_i_all, self.b_v_i_all)
         kv = []
-        for li, p in enumerate(self.blk):
+        for li, p in enumerate(self.blk if not f8 else ()):
             cols = slice(li * D, (li + 1) * D)
             k_t = k_t_all[:, cols]
             ops.rmsnorm_rope_(k_t, p.nk2, None, hd, eps)
@@ -786,7 +788,17 @@ class DiTEngine:
                 kv.append((k_t, v1t[cols], k_i, v2t[cols]))
             else:
                 kv.append((k_t, v_t_all[:, cols], k_i, None if v_i_all is None else v_i_all[:, cols]))
-        ctx = SimpleNamespace(kv=kv, Tt=Tt, Ti=Ti, vt=use_vt, c1=c1, c2=c2)
+        if f8:
+            # MXFP8 operands of both segments, per layer: K (RMS-normed, no RoPE) quantised along the head channels, V^T tiles quantised along
+            # the keys (ce_rmsnorm_rope_mxfp8 reads the un-normed projection: the bf16 loop above, which norms in place, did not run)
+            for li, p in enumerate(self.blk):
+                cols = slice(li * D, (li + 1) * D)
+                seg_t = ops.rmsnorm_rope_mxfp8(k_t_all[:, cols], p.nk2, None, hd, eps) + ops.v_mxfp8_transpose(v_t_all[:, cols], Tt, B, self.H)
+                seg_i = None
+                if k_i_all is not None:
+                    seg_i = ops.rmsnorm_rope_mxfp8(k_i_all[:, cols], p.nk_i, None, hd, eps) + ops.v_mxfp8_transpose(v_i_all[:, cols], Ti, B, self.H)
+                kv.append((seg_t, seg_i))
+        ctx = SimpleNamespace(kv=kv, Tt=Tt, Ti=Ti, vt=use_vt, c1=c1, c2=c2, f8=f8)
         if key is not None:
             self._ctx_key, self._ctx, self._ctx_refs = key, ctx, keyed
         return ctx
@@ -908,9 +920,27 @@ class DiTEngine:
                 self._ln_linear(ws, x, p.n2w, p.n2b, p, "q2", ws.q2)
             else:
                 self._linear(ws, x, p, "q2", ws.q2)
-            ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
-            k_t, v_t, k_i, v_i = ctx.kv[li]
-            if ctx.vt and fuse_o:
+            q_o2 = bool(ctx.vt and fuse_o)
+            if ctx.f8:  # MXFP8 (round 5): text segment -> bf16, image segment adds it and emits bf16 or the out-projection's MX operand
+                seg_t, seg_i = ctx.kv[li]
+                ops.rmsnorm_rope_mxfp8(ws.q2, p.nq2, None, hd, eps, out=ws.q8, scale=ws.sq, post_scale=ops.MXFP8_Q_SCALE)
+                if seg_i is None and fuse_o:
+                    ops.attention_mxfp8(ws.q8, ws.sq, *seg_t, H, batch=B, out8=ws.a8[:, :D], scale8=ws.s8)
+                else:
+                    ops.attention_mxfp8(ws.q8, ws.sq, *seg_t, H, out=ws.att, batch=B)
+                    if seg_i is not None and fuse_o:
+                        ops.attention_mxfp8(ws.q8, ws.sq, *seg_i, H, batch=B, out8=ws.a8[:, :D], scale8=ws.s8, add=ws.att)
+                    elif seg_i is not None:
+                        ops.attention_mxfp8(ws.q8, ws.sq, *seg_i, H, out=ws.att, batch=B, add=ws.att)
+                q_o2 = fuse_o
+                self._linear(ws, ws.att, p, "o2", x, quantised=q_o2, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
+                k_t = None
+            else:
+                ops.rmsnorm_rope_(ws.q2, p.nq2, None, hd, eps)
+                k_t, v_t, k_i, v_i = ctx.kv[li]
+            if k_t is None:
+                pass
+            elif ctx.vt and fuse_o:
                 ops.attention_2seg_vt(ws.q2, k_t, v_t, Tt, k_i, v_i, Ti, H, batch=B, cols1=ctx.c1, cols2=ctx.c2, out8=ws.a8[:, :D], scale8=ws.s8)
             elif ctx.vt:  # both segments' K and V^T tiles by LDS-DMA (v_t / v_i are V^T row blocks of this layer)
                 ops.attention_2seg_vt(ws.q2, k_t, v_t, Tt, k_i, v_i, Ti, H, out=ws.att, batch=B, cols1=ctx.c1, cols2=ctx.c2)
@@ -918,7 +948,8 @@ class DiTEngine:
                 ops.attention(ws.q2, k_t, v_t, H, out=ws.att, k2=k_i, v2=v_i, batch=B)
             else:
                 ops.attention(ws.q2, k_t, v_t, H, out=ws.att, batch=B)
-            self._linear(ws, ws.att, p, "o2", x, quantised=bool(ctx.vt and fuse_o), epilogue=ops.EPI_GATE_RES, gate=None, res=x)
+            if k_t is not None:
+                self._linear(ws, ws.att, p, "o2", x, quantised=q_o2, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
             if self.mx and self.fuse_quant:
                 # MX: the up-projection's bias + GELU epilogue emits the down-projection's fp8 operand and its block scales directly (a

@@ -380,6 +380,15 @@ int ce_attention_mxfp8_quant(const void* q8, const void* sq, const void* k8, con
                              void* scale8, int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo8, int batch,
                              hipStream_t stream);
 
+/* Second segment of a TWO-segment attention under the same contract - the cross-attention, out = bf16(SDPA(q, k_text, v_text)) +
+ * bf16(SDPA(q, k_image, v_image)) (transformer_chronoedit.py:96-107): as ce_attention_mxfp8 / ce_attention_mxfp8_quant on the second
+ * segment's operands, with the bf16 rows o_add [batch Nq][ldadd] (the first segment's result, from a plain ce_attention_mxfp8 call) added to
+ * this segment's bf16-rounded result.  The sum goes to O (bf16 [batch Nq][ldo]; may be o_add itself) or, quantised exactly as
+ * ce_quant_rows_mxfp8 would quantise it, to o8 / scale8 (the out-projection's MX operand) - exactly one of O and o8 is non-NULL. */
+int ce_attention_mxfp8_add(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, const void* o_add,
+                           int ldadd, void* O, int ldo, void* o8, void* scale8, int ldo8, int Nq, int Nkv, int npad, int H, int head_dim,
+                           int ldq8, int ldk8, int batch, hipStream_t stream);
+
 /* Loop body of ce_attention_mxfp8 (returns the previous value): 0 plain (exact running maximum every tile), 1 software-pipelined
  * with a speculative integer offset, row sums on the matrix pipe and an exact repair route per tile (default).  Other values are
  * ignored.  Host-side tuning knob. */

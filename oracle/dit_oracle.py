@@ -343,7 +343,8 @@ def attention_mxfp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, lazy_offs
 def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=None, fp8=False, fp8_attn=False):
     """ChronoEditAttnProcessor2_0.__call__ (transformer_chronoedit.py:43-108).  fp8: the projections that chronoedit_amd runs on
     the fp8 path (q, the self-attention k / v, the output projection) follow linear_fp8; the context k / v stay as they are.
-    fp8_attn: the SELF-attention product under the MXFP8 contract (attention_mxfp8); cross-attention stays SDPA."""
+    fp8_attn: True - the SELF-attention product under the MXFP8 contract (attention_mxfp8), cross-attention stays SDPA; "all" (round 5) -
+    the two segments of the cross-attention under the same contract too, each rounded to the activation dtype before the add (:96-107)."""
     self_attn = encoder is None
     H = cfg.num_attention_heads
     lin_q = _fp8_linear(fp8)
@@ -374,9 +375,9 @@ def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=No
         v_img = linear(enc_img, p, pre + ".add_v_proj")
         k_img = k_img.unflatten(2, (H, -1)).transpose(1, 2)
         v_img = v_img.unflatten(2, (H, -1)).transpose(1, 2)
-        out_img = F.scaled_dot_product_attention(q, k_img, v_img)
+        out_img = attention_mxfp8(q, k_img, v_img) if fp8_attn == "all" else F.scaled_dot_product_attention(q, k_img, v_img)
         out_img = out_img.transpose(1, 2).flatten(2, 3).type_as(q)
-    out = attention_mxfp8(q, k, v) if (fp8_attn and self_attn) else F.scaled_dot_product_attention(q, k, v)
+    out = attention_mxfp8(q, k, v) if (fp8_attn and (self_attn or fp8_attn == "all")) else F.scaled_dot_product_attention(q, k, v)
     out = out.transpose(1, 2).flatten(2, 3).type_as(q)
     if out_img is not None:
         out = out + out_img
@@ -452,7 +453,7 @@ def dit_forward(
 ) -> torch.Tensor:
     """ChronoEditTransformer3DModel.forward (transformer_chronoedit.py:397-476).  fp8 restates chronoedit_amd's fp8 GEMM modes (the six
     large Linears of every block under linear_fp8 - fp8=True / "row": per-row scales - or linear_mxfp8 - fp8="mx": MX block scales; everything
-    else unchanged); fp8_attn=True its MXFP8 self-attention."""
+    else unchanged); fp8_attn=True its MXFP8 self-attention, fp8_attn="all" the cross-attention under that contract as well."""
     B, C, T, Hh, Ww = hidden_states.shape
     pt, ph, pw = cfg.patch_size
     ppf, pph, ppw = T // pt, Hh // ph, Ww // pw

@@ -272,6 +272,53 @@ def test_mxfp8_attention_kernel_vs_contract(N, H, B, spread):
     assert torch.isfinite(out).all() and e_k < 1.5e-2 and e_k0 < 1.5e-2
 
 
+@pytest.mark.parametrize("Nq,Tt,Ti,H,B", [(200, 40, 257, 2, 1), (333, 512, 257, 8, 2), (96, 64, 65, 2, 2)])
+def test_mxfp8_two_segment_attention_vs_contract(Nq, Tt, Ti, H, B):
+    """The cross-attention under the MXFP8 contract (round 5): out = bf16(attention_mxfp8(q, k_text, v_text)) + bf16(attention_mxfp8(q,
+    k_image, v_image)) as two launches - the text segment plain, the image segment through ce_attention_mxfp8_add (also in place, and as
+    the out-projection's MX operand: bit-identical to quant_rows_mxfp8 of the bf16 sum).  vs the oracle's two calls: rel-L2 <= 1.5e-2."""
+    from chronoedit_amd import ops
+    from oracle import dit_oracle as O
+    D = H * 128
+    g = torch.Generator().manual_seed(35)
+    one = torch.ones(D).cuda()
+    qd = torch.randn(B * Nq, D, generator=g).to(torch.bfloat16).cuda()
+    segs = []
+    for n in (Tt, Ti):
+        kv = torch.randn(B * n, 2 * D, generator=g).to(torch.bfloat16).cuda()
+        k8, sk = ops.rmsnorm_rope_mxfp8(kv[:, :D], one, None, 128, 1e-6)
+        v8t, sv = ops.v_mxfp8_transpose(kv[:, D:], n, B, H)
+        segs.append((kv, (k8, sk, v8t, sv)))
+    q8, sq = ops.rmsnorm_rope_mxfp8(qd, one, None, 128, 1e-6, post_scale=ops.MXFP8_Q_SCALE)
+    o_t = ops.attention_mxfp8(q8, sq, *segs[0][1], H, batch=B)
+    o_sum = ops.attention_mxfp8(q8, sq, *segs[1][1], H, batch=B, out=torch.empty_like(o_t), add=o_t)
+    o_inplace = o_t.clone()
+    ops.attention_mxfp8(q8, sq, *segs[1][1], H, batch=B, out=o_inplace, add=o_inplace)
+    assert torch.equal(o_inplace, o_sum)
+    o_i = ops.attention_mxfp8(q8, sq, *segs[1][1], H, batch=B)
+    assert torch.equal(o_sum, (o_t.float() + o_i.float()).to(torch.bfloat16))  # each segment rounded to bf16, then a bf16 add
+    # the fused MX operand of the out-projection == the row quantiser on the bf16 sum
+    o8 = torch.empty(B * Nq, D, dtype=torch.uint8, device="cuda")
+    s8 = torch.zeros(ops.mx_scale_bytes(B * Nq, D), dtype=torch.uint8, device="cuda")
+    ops.attention_mxfp8(q8, sq, *segs[1][1], H, batch=B, out8=o8, scale8=s8, add=o_t)
+    q_ref, s_ref = ops.quant_rows_mxfp8(o_sum)
+    assert torch.equal(o8, q_ref)
+    assert torch.equal(ops.mx_scales_to_rows(s8, B * Nq, D), ops.mx_scales_to_rows(s_ref, B * Nq, D))
+    # the oracle on the same normalised operands
+    qn = qd.clone()
+    ops.rmsnorm_rope_(qn, one, None, 128, 1e-6)
+    f = lambda t, n: t.float().cpu().view(B, n, H, 128).permute(0, 2, 1, 3)
+    want = None
+    for (kv, _), n in zip(segs, (Tt, Ti)):
+        kn = kv[:, :D].clone()
+        ops.rmsnorm_rope_(kn, one, None, 128, 1e-6)
+        w = O.attention_mxfp8(f(qn, Nq), f(kn, n), f(kv[:, D:], n)).permute(0, 2, 1, 3).reshape(B * Nq, D).to(torch.bfloat16)
+        want = w if want is None else (want.float() + w.float()).to(torch.bfloat16)
+    e = rel_l2(o_sum.float().cpu(), want.float())
+    print(f"two-segment MXFP8 attention Nq={Nq} Tt={Tt} Ti={Ti} H={H} B={B}: kernel vs contract {e:.3e}")
+    assert torch.isfinite(o_sum.float()).all() and e < 1.5e-2
+
+
 @pytest.mark.parametrize("mx", [False, True], ids=["row-scales", "mx-block-scales"])
 def test_dit_forward_with_mxfp8_attention_vs_contract_oracle(mx):
     """fp8 GEMMs + MXFP8 self-attention (bench.py --fp8) through the whole DiT: vs the oracle restating both contracts (<= 2.5e-2), and
@@ -295,7 +342,7 @@ def test_dit_forward_with_mxfp8_attention_vs_contract_oracle(mx):
     with torch.no_grad():
         a32 = (lat.float(), torch.tensor([500]), text.float(), image.float())
         exact = O.dit_forward(pf, cfg, *a32)
-        contract = O.dit_forward(pf, cfg, *a32, fp8="mx" if mx else True, fp8_attn=True)
+        contract = O.dit_forward(pf, cfg, *a32, fp8="mx" if mx else True, fp8_attn="all")  # (enable_fp8_attention(): self- AND cross-attention, round 5)
     e_bf16, e_fp8, e_attn = rel_l2(out_bf16, exact), rel_l2(out_fp8, exact), rel_l2(out_attn_only, exact)
     e_contract = rel_l2(out_fp8, contract)
     print(f"DiT 4 blocks: bf16 path vs exact {e_bf16:.3e} | fp8 GEMMs + MXFP8 attention vs exact {e_fp8:.3e} (attention only: {e_attn:.3e}) | "

@@ -59,12 +59,13 @@ def test_one_wave_per_simd_gemm_keeps_its_accumulators_in_place():
         assert r[2] <= 512, r
     loops = isa_lint.inner_loops(src, "gemm_bf16_w4")
     # 5 epilogues x (3 stages, 3 stages + one barrier, 2 stages) + the two instantiations with a two-level segmented A operand (the
-    # convolutions of the VAE: ce_conv3d_gemm_bf16), each also as the 256 x 128 tile (NG = 4) - template arguments <EPI, NSA, ONEBAR, SEG2, NG>
-    assert len(loops) == 19
+    # convolutions of the VAE: ce_conv3d_gemm_bf16), each also as the 256 x 128 tile (NG = 4) and the 256 x 96 tile (NG = 3, round 5) -
+    # template arguments <EPI, NSA, ONEBAR, SEG2, NG>
+    assert len(loops) == 21
     for name, c in loops:
-        narrow = "ELi4EEE" in name  # 256 x 128: half the MFMAs and W pieces, 8 + 4 fragments per k-step
-        assert c.get("v_mfma_f32_16x16x32_bf16", 0) == (128 if narrow else 256), (name, c)
-        assert c.get("ds_read_b128", 0) == (48 if narrow else 64) and c.get("buffer_load_dwordx4", 0) == (24 if narrow else 32), (name, c)
+        ng = 4 if "ELi4EEE" in name else 3 if "ELi3EEE" in name else 8  # column fragments per wave: MFMAs and W pieces scale with it, 8 + NG fragments per k-step
+        assert c.get("v_mfma_f32_16x16x32_bf16", 0) == 32 * ng, (name, c)
+        assert c.get("ds_read_b128", 0) == 4 * (8 + ng) and c.get("buffer_load_dwordx4", 0) == 2 * (8 + ng), (name, c)
         assert c.get("s_barrier", 0) == (2 if re.search(r"ELi\dELb1ELb", name) else 4), (name, c)
         assert not any(op.startswith("v_accvgpr") or op.startswith("scratch") for op in c), (name, c)
 
