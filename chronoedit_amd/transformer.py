@@ -330,13 +330,17 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self._engine = None
         return self
 
-    def enable_fp8_attention(self, on: bool = True, cross: bool = True):
+    def enable_fp8_attention(self, on: bool = True, cross: bool = False):
         """BASELINE.json configs[4] "fp8 weights+attn": the attention of every block under the MXFP8 contract of
         csrc/ce_attn_fp8.hip - q / k (after RMSNorm + RoPE) in e4m3 with one E8M0 scale per 32 head channels, v per 32 keys,
         Q.K^T and P.V on v_mfma_scale_f32_32x32x64_f8f6f4, P in e4m3, fp32 accumulation.  cross (round 5): the cross-attention too - the
         text and the image segment each as one MXFP8 attention over the context's quantised K / V^T (made once per context: cached per
-        edit), the image segment adding the text segment's bf16 result (`ce_attention_mxfp8_add`); cross=False keeps it on the bf16
-        two-segment kernel (3 % of the attention flops).  Everything else is unchanged; independent of enable_fp8_gemms."""
+        edit), the image segment adding the text segment's bf16 result (`ce_attention_mxfp8_add`).  OFF by default - measured on MI355X at
+        the full width (tools/fp8_cross_probe.py, profiles/r05_fp8_cross_attention_probe.txt): with 512 + 257 keys the two MXFP8 launches
+        are prologue / epilogue bound (0.199 + 0.209 ms + 0.06 ms more producer work against 0.315 ms for the bf16 two-segment kernel with
+        the fused MX output) and the block's error against fp32 rises from 7.85 x to 8.75 x the bf16 path's: slower AND less accurate, so
+        the default keeps the 3 % of the attention flops that are cross-attention in bf16.  Everything else is unchanged; independent of
+        enable_fp8_gemms."""
         self.attn_dtype = "mxfp8" if on else "bf16"
         self.fp8_cross = bool(on and cross)
         self._engine = None  # (the context operands and the workspaces depend on it)

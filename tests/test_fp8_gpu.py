@@ -319,8 +319,8 @@ def test_mxfp8_two_segment_attention_vs_contract(Nq, Tt, Ti, H, B):
     assert torch.isfinite(o_sum.float()).all() and e < 1.5e-2
 
 
-@pytest.mark.parametrize("mx", [False, True], ids=["row-scales", "mx-block-scales"])
-def test_dit_forward_with_mxfp8_attention_vs_contract_oracle(mx):
+@pytest.mark.parametrize("mx,cross", [(False, False), (True, False), (True, True)], ids=["row-scales", "mx-block-scales", "mx-block-scales+fp8-cross-attention"])
+def test_dit_forward_with_mxfp8_attention_vs_contract_oracle(mx, cross):
     """fp8 GEMMs + MXFP8 self-attention (bench.py --fp8) through the whole DiT: vs the oracle restating both contracts (<= 2.5e-2), and
     the mode's distance from exact fp32 bounded against the bf16 path's as SURVEY section 8c prescribes (<= 10 x the bf16 error)."""
     from chronoedit_amd.transformer import ChronoEditTransformer3DModel
@@ -334,7 +334,7 @@ def test_dit_forward_with_mxfp8_attention_vs_contract_oracle(mx):
     ts = torch.tensor([500], device="cuda:0")
     args = (lat.cuda(), ts, text.cuda(), image.cuda())
     out_bf16 = m(*args).sample.float().cpu()
-    m.enable_fp8_gemms(mx=mx).enable_fp8_attention()
+    m.enable_fp8_gemms(mx=mx).enable_fp8_attention(cross=cross)  # cross=True: the opt-in MXFP8 cross-attention (round 5; off by default)
     out_fp8 = m(*args).sample.float().cpu()
     m.enable_fp8_gemms(False)
     out_attn_only = m(*args).sample.float().cpu()
@@ -342,7 +342,7 @@ def test_dit_forward_with_mxfp8_attention_vs_contract_oracle(mx):
     with torch.no_grad():
         a32 = (lat.float(), torch.tensor([500]), text.float(), image.float())
         exact = O.dit_forward(pf, cfg, *a32)
-        contract = O.dit_forward(pf, cfg, *a32, fp8="mx" if mx else True, fp8_attn="all")  # (enable_fp8_attention(): self- AND cross-attention, round 5)
+        contract = O.dit_forward(pf, cfg, *a32, fp8="mx" if mx else True, fp8_attn="all" if cross else True)
     e_bf16, e_fp8, e_attn = rel_l2(out_bf16, exact), rel_l2(out_fp8, exact), rel_l2(out_attn_only, exact)
     e_contract = rel_l2(out_fp8, contract)
     print(f"DiT 4 blocks: bf16 path vs exact {e_bf16:.3e} | fp8 GEMMs + MXFP8 attention vs exact {e_fp8:.3e} (attention only: {e_attn:.3e}) | "
