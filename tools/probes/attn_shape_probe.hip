@@ -1,0 +1,139 @@
+// Which bf16 MFMA geometry carries the flash-attention tile loop better on gfx950?  A SYNTHETIC loop with the self-attention kernel's per-tile
+// instruction mix (csrc/ce_attn.hip: 8 waves x 32 query rows, 64-key tiles, head dim 128) - per wave and tile: S^T = K.Q^T (524 kflop), P = exp2(S)
+// packed to bf16 (32 v_exp_f32 + 16 v_cvt_pk_bf16_f32 per lane), O^T += V^T.P^T (524 kflop), 32 ds_read_b128 of K / V^T fragments, 2 LDS-DMA
+// pieces of the next tile, one workgroup barrier - once on v_mfma_f32_32x32x16_bf16 (16 + 16 MFMAs per tile and wave, the production geometry) and
+// once on v_mfma_f32_16x16x32_bf16 (32 + 32).  Same bytes, same flops, same fillers, compiler-scheduled in both arms; the data is random bf16 (the
+// power-limited clock sees toggling operands).  Not the production kernel: the row statistics, the rescale and the output are left out in both arms.
+// build: hipcc --offload-arch=gfx950 -O3 tools/probes/attn_shape_probe.hip -o tools/probes/attn_shape_probe
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ uint32_t pk(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(512, 2) void k(const unsigned char* __restrict__ src, float* __restrict__ out, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // two stages of [K 16 KiB | V^T 16 KiB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Q fragments (registers, as in the kernel): 32 query rows x 128 d per wave = 8 x bf16x8 per lane
+  bf16x8 qf[8];
+  for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const bf16x8*>(src + ((blockIdx.x * 512 + tid) * 8 + i) % 4096 * 16);
+  auto stage = [&](int t, int s) {
+    // 32 KiB per tile and workgroup = 4 KiB per wave = 4 pieces of 1 KiB... the kernel moves 2 (K) + 2 (V^T) per wave
+    for (int p = 0; p < 4; ++p)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(src + (((t * 8 + wave) * 4 + p) % 512) * 1024 + lane * 16), (lds_void*)(smem + s * 32768 + (wave * 4 + p) * 1024), 16, 0, 0);
+  };
+  float acc_sink = 0.f;
+  f32x16 o32[4];
+  f32x4 o16[16];
+  for (int m = 0; m < 4; ++m)
+    for (int r = 0; r < 16; ++r) o32[m][r] = 0.f;
+  for (int m = 0; m < 16; ++m) o16[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  stage(0, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(t + 1, (t + 1) & 1);
+    const unsigned char* st = smem + (t & 1) * 32768;
+    const unsigned char* kb = st + lane * 16;          // conflict-free lane-linear reads (the swizzle of the real kernel achieves the same)
+    const unsigned char* vb = st + 16384 + lane * 16;
+    if (SHAPE == 32) {
+      f32x16 s[2];
+      _Pragma("unroll") for (int f = 0; f < 2; ++f) {
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) s[f][r] = 0.f;
+        _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (f * 8 + ks) * 1024);
+          s[f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[f], 0, 0, 0);
+        }
+      }
+      u32x4 pw[4];
+      _Pragma("unroll") for (int f = 0; f < 2; ++f)
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+          const float a = __builtin_amdgcn_exp2f(s[f][2 * i]), b = __builtin_amdgcn_exp2f(s[f][2 * i + 1]);
+          pw[(f * 8 + i) >> 2][(f * 8 + i) & 3] = pk(a, b);
+        }
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw[ks]);
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + (ks * 4 + m) * 1024);
+          o32[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o32[m], 0, 0, 0);
+        }
+      }
+    } else {
+      // 16 x 16 x 32: keys in 4 blocks of 16, queries in 2 blocks of 16, 4 k-steps of 32 channels; Q fragment (qb, ks) = qf[qb * 4 + ks]
+      f32x4 s[4][2];
+      _Pragma("unroll") for (int kbk = 0; kbk < 4; ++kbk) {
+        _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) s[kbk][qb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (kbk * 4 + ks) * 1024);
+          _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) s[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb * 4 + ks], s[kbk][qb], 0, 0, 0);
+        }
+      }
+      u32x4 pw[2][2];  // [query block][key half of 32]: 8 bf16 = one B fragment (32 keys)
+      _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)
+        _Pragma("unroll") for (int kbk = 0; kbk < 4; ++kbk) {
+          const float a = __builtin_amdgcn_exp2f(s[kbk][qb][0]), b = __builtin_amdgcn_exp2f(s[kbk][qb][1]);
+          const float c = __builtin_amdgcn_exp2f(s[kbk][qb][2]), d = __builtin_amdgcn_exp2f(s[kbk][qb][3]);
+          pw[qb][kbk >> 1][(kbk & 1) * 2] = pk(a, b);
+          pw[qb][kbk >> 1][(kbk & 1) * 2 + 1] = pk(c, d);
+        }
+      _Pragma("unroll") for (int h = 0; h < 2; ++h)
+        _Pragma("unroll") for (int d = 0; d < 8; ++d) {  // 8 channel blocks of 16, key half h: one V^T fragment against the two query blocks
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + (h * 8 + d) * 1024);
+          _Pragma("unroll") for (int qb = 0; qb < 2; ++qb)
+            o16[d * 2 + qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[qb][h]), o16[d * 2 + qb], 0, 0, 0);
+        }
+    }
+  }
+  for (int m = 0; m < 4; ++m) acc_sink += o32[m][0] + o32[m][15];
+  for (int m = 0; m < 16; ++m) acc_sink += o16[m][0] + o16[m][3];
+  if (acc_sink == 123.456f) out[blockIdx.x * 512 + tid] = acc_sink;
+}
+
+int main() {
+  const int nbytes = 512 * 1024;
+  unsigned char* h = new unsigned char[nbytes];
+  uint32_t x = 12345;
+  for (int i = 0; i < nbytes; i += 2) {  // bf16 values in (-0.25, 0.25): exp2 of their dot products stays finite
+    x = x * 1664525u + 1013904223u;
+    const uint16_t v = (uint16_t)(((x >> 16) & 0x807fu) | 0x3d00u);
+    h[i] = v & 0xff;
+    h[i + 1] = v >> 8;
+  }
+  unsigned char* d;
+  float* out;
+  hipMalloc(&d, nbytes);
+  hipMalloc(&out, 512 * 512 * 4);
+  hipMemcpy(d, h, nbytes, hipMemcpyHostToDevice);
+  hipFuncSetAttribute((const void*)k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int ntiles = 2000, nwg = 512;  // two workgroups per CU, as the kernel runs
+  const double flop = 2.0 * 2.0 * 32 * 64 * 128 * 8.0 * ntiles * nwg;
+  for (int rep = 0; rep < 3; ++rep)
+    for (int shape : {32, 16}) {
+      hipEventRecord(e0);
+      if (shape == 32) hipLaunchKernelGGL(k<32>, dim3(nwg), dim3(512), 65536, 0, d, out, ntiles);
+      else hipLaunchKernelGGL(k<16>, dim3(nwg), dim3(512), 65536, 0, d, out, ntiles);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("rep %d  %s : %8.3f ms  %7.1f TFLOP/s  (%5.0f cycles per tile and wave pair at 2.0 GHz)\n", rep, shape == 32 ? "32x32x16" : "16x16x32", ms, flop / ms / 1e9,
+             ms * 1e-3 * 2.0e9 / ntiles / (nwg / 256 / 2 > 0 ? nwg / 256 / 2 : 1));
+    }
+  return 0;
+}
