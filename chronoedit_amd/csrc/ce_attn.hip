@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict
 static int g_attn_nwave = 0;
 extern "C" int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
-  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 64 || nwave == 128 || nwave == 129) g_attn_nwave = nwave;
+  if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16 || nwave == 64 || nwave == 128 || nwave == 129) g_attn_nwave = nwave;
   return old;
 }
 
@@ -1538,6 +1538,10 @@ extern "C" int ce_v_transpose_blocked_bf16(const void* v, int ldv, void* vt, int
   return (int)hipGetLastError();
 }
 
+// the 16 x 16 x 32 body of the plain-layout V^T attention (ce_attn16.hip; ce_set_attention_waves(16))
+extern "C" int ce_attn16_launch(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int ldq, int ldo,
+                                float sl2, int batch, int cus, hipStream_t stream);
+
 /* Self-attention with V handed over TRANSPOSED (V^T [H * 128][ldvt]): both K and V^T tiles reach LDS by LDS-DMA, no register
  * staging.  One KV segment, software-pipelined kernel only.  blk_rows == 0: plain layout (sample b's token g in row b N + g of Q / K / O,
  * its keys in columns [b len, (b + 1) len) of V^T).  blk_rows > 0 (a multiple of 64): the BLOCKED layout an all-to-all leaves behind -
@@ -1580,6 +1584,10 @@ static int attention_vt_launch(const void* Q, const void* K, const void* Vt, int
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
   const int items = nqb * H * batch;
+  if (g_attn_nwave == 16 && blk_rows == 0) {  // the 16 x 16 x 32 geometry (plain layout; unaligned operands fall through to the default body)
+    const int rc = ce_attn16_launch(Q, K, Vt, len, ldk, ldvt, O, Nq, H, ldq, ldo, sl2, batch, cus, stream);
+    if (rc != CE_ERR_ALIGN) return rc;
+  }
   if (g_attn_nwave == 128 || g_attn_nwave == 129) {  // one wave per SIMD (attn_fwd_w4_kernel): 128 = one workgroup per item, 129 = #CUs persistent workgroups
     static bool done4_[CE_MAX_DEVICES] = {};
     bool& done4 = done4_[ce_device_slot()];

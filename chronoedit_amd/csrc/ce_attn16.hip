@@ -1,0 +1,251 @@
+// Self-attention forward on v_mfma_f32_16x16x32_bf16 (round 5): the 16 x 16 x 32 geometry for the V^T / LDS-DMA form of the DiT's self-attention
+// (ce_attention_vt_bf16, plain row layout), selected with ce_set_attention_waves(16).  Same contract as attn_fwd_sp_kernel<false, true> in
+// ce_attn.hip: O = softmax(Q K^T / sqrt(128)) V per head, head_dim 128, bf16 in / out, fp32 accumulation, Q pre-multiplied by
+// softmax_scale * log2(e) and rounded to bf16 once (scores leave the matrix pipe in the exp2 domain), P rounded to bf16 for the second product,
+// row sums in fp32 of the un-rounded P.  Replaces F.scaled_dot_product_attention at transformer_chronoedit.py:91-104.
+//
+// Why a second geometry: tools/probes/attn_shape_probe.hip (profiles/r05_attn_shape_probe.txt) - the attention tile loop with the kernel's
+// filler load runs 6 ... 7 % faster on 16x16x32 than on 32x32x16 (the same ratio the bare MFMA streams show: profiles/r01_mfma_rate_probe.txt).
+//
+//  * workgroup = 8 waves x 32 query rows = 256 query rows of one head; 64-key tiles; two stages of [K 16 KiB | V^T 16 KiB] filled by LDS-DMA
+//    (global_load_lds, 16 B per lane, source-side chunk swizzles), one barrier per tile, the next tile in flight under the current one.
+//  * S^T = K.Q^T: first operand = K fragment [16 keys x 32 d] (one ds_read_b128 per lane: chunk (4 ks + g) ^ (key & 15) of the key's 256-byte
+//    row), second = Q fragment [32 d x 16 queries] held in registers (2 query blocks x 4 k-steps).  Lane (n, g) of accumulator s[kb][qb] owns
+//    query 16 qb + n and the four keys 16 kb + 4 g + j: a query's statistics live in 4 lanes (n, n + 16, n + 32, n + 48).
+//  * O^T += V^T.P^T: the P operand comes straight out of the S registers (k-slots 8 g .. 8 g + 7 of k-step h = this lane's values of
+//    s[2 h][.] and s[2 h + 1][.]).  The K ROWS of a tile are placed in LDS in the order that makes those eight slots eight CONSECUTIVE keys -
+//    LDS row 16 kb + 4 g + j holds key 32 (kb >> 1) + 8 g + 4 (kb & 1) + j; the DMA's per-lane source row does the permutation for nothing -
+//    so the V^T fragment [16 d x 32 keys] of a lane is ONE 16-byte read of natural-order V^T (unit 4 h + g of the channel's 128-byte row, in
+//    slot (4 h + g) ^ ((row >> 1) & 7): conflict-free reads, a whole-16-byte permutation on the DMA's source side).
+//  * online softmax with a LAZY running maximum: the offset of a row moves only when a tile's maximum exceeds it by more than 2^8 (P stays
+//    below 2^8 in fp32 / bf16: no precision is lost by an offset that lags), so the accumulators are rescaled on the first tiles only.
+//  * work order: attn_fwd_sp_kernel's (an XCD keeps its heads; batch folded into the item index; persistent workgroups).
+#include "ce_common.h"
+
+namespace {
+
+constexpr int HD = 128, QW = 32, KVB = 64;
+constexpr int K_TILE = KVB * HD * 2;   // 16 KiB: 64 key rows of 256 B
+constexpr int V_TILE = HD * KVB * 2;   // 16 KiB: 128 channel rows of 128 B
+constexpr int STAGE = K_TILE + V_TILE;
+constexpr int NST = 2;
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LAZY = 8.0f;  // exp2 domain: the running offset moves when a tile maximum exceeds it by more than this
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_x16_kernel(const bf16* __restrict__ Q_, const bf16* __restrict__ K_, const bf16* __restrict__ Vt_,
+                                                              bf16* __restrict__ O_, int Nq, int Nkv, int H, int ldq, int ldk, int ldvt, int ldo,
+                                                              int nqb, float sl2, int batch, int vt_cols) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int ntiles = (Nkv + KVB - 1) / KVB;
+#pragma clang loop unroll(disable)
+  for (int item = blockIdx.x; item < nqb * H * batch; item += gridDim.x) {
+    int head, qb, bz;
+    {
+      const int nqb_full = Nq / (QW * 8);
+      if ((H & 7) == 0) {
+        const int xcd = item & 7, local = item >> 3, hx_n = H >> 3;
+        const int full = batch * hx_n * nqb_full;
+        if (local < full) {
+          bz = local / (hx_n * nqb_full);
+          const int r = local % (hx_n * nqb_full);
+          head = xcd + 8 * (r / nqb_full);
+          qb = r % nqb_full;
+        } else {
+          const int l2 = local - full;
+          bz = l2 / hx_n;
+          head = xcd + 8 * (l2 % hx_n);
+          qb = nqb_full;
+        }
+      } else {
+        bz = item / (nqb * H);
+        const int r = item % (nqb * H);
+        head = r / nqb;
+        qb = r % nqb;
+      }
+    }
+    const bf16* Q = Q_ + (size_t)bz * Nq * ldq;
+    const bf16* K = K_ + (size_t)bz * Nkv * ldk;
+    const bf16* Vt = Vt_ + (size_t)bz * vt_cols;  // sample b's keys: columns [b vt_cols, ...)
+    bf16* O = O_ + (size_t)bz * Nq * ldo;
+    const int hoff = head * HD;
+    const int q0 = qb * (QW * 8) + wave * QW;
+    const bool active = q0 < Nq;  // wave-uniform: a wave past the last query row only stages tiles and keeps the barriers
+
+    // Q fragments, pre-scaled: qf[qblk][ks] = Q[q0 + 16 qblk + n][32 ks + 8 g .. + 8] * sl2, rounded to bf16
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qblk = 0; qblk < 2; ++qblk) {
+      const bf16* qrow = Q + (size_t)min(q0 + 16 * qblk + n, Nq - 1) * ldq + hoff + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(qrow + 32 * ks);
+        u32x4 sc;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sc[w] = pack_bf16(bf16lo(raw[w]) * sl2, bf16hi(raw[w]) * sl2);
+        qf[qblk][ks] = __builtin_bit_cast(bf16x8, sc);
+      }
+    }
+
+    // LDS-DMA sources.  K tile: piece p of wave w = LDS rows 8 w + 4 p + (lane >> 4) <- key key_of(row), 16-byte slot lane & 15 <- source chunk
+    // slot ^ (row & 15).
+    // V^T tile: piece p of wave w = channel rows 16 w + 8 p + (lane >> 3), 16-byte slot lane & 7 <- source unit slot ^ ((row >> 1) & 7).
+    const int k_row0 = 8 * wave + (lane >> 4), k_slot = lane & 15;
+    const int v_row0 = 16 * wave + (lane >> 3), v_slot = lane & 7;
+    auto stage_tile = [&](int t, int s) __attribute__((always_inline)) {
+      unsigned char* st = smem + s * STAGE;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = k_row0 + 4 * p;
+        const int key = 32 * (row >> 5) + 8 * ((row >> 2) & 3) + 4 * ((row >> 4) & 1) + (row & 3);  // the key LDS row `row` holds (see the header)
+        const int kr = min(t * KVB + key, Nkv - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(K + (size_t)kr * ldk + hoff + ((k_slot ^ (row & 15)) << 3)), (lds_void*)(st + (2 * wave + p) * 1024), 16, 0,
+                                         0);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = v_row0 + 8 * p;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(Vt + (size_t)(hoff + row) * ldvt + t * KVB + ((v_slot ^ ((row >> 1) & 7)) << 3)),
+                                         (lds_void*)(st + K_TILE + (2 * wave + p) * 1024), 16, 0, 0);
+      }
+    };
+    // fragment read offsets inside a stage
+    //   K fragment (kb, ks): row 16 kb + n, chunk (4 ks + g) ^ n                       -> kb * 4096 + n * 256 + (((4 ks + g) ^ n) << 4)
+    //   V^T fragment (h, d): row 16 d + n, 16-byte unit 4 h + g in slot (4 h + g) ^ ((n >> 1) & 7)   ((row >> 1) & 7 == (n >> 1) & 7)
+    const int v_sw = (n >> 1) & 7;
+    const int v_rd = K_TILE + n * 128;
+
+    f32x4 o[8][2];
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+      for (int qblk = 0; qblk < 2; ++qblk) o[d][qblk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+
+    stage_tile(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
+      __builtin_amdgcn_s_barrier();                     // ... everybody's have, and everybody is done reading tile t-1's stage
+      stage_tile(min(t + 1, ntiles - 1), (t + 1) & 1);  // (the last iteration re-stages the last tile into the free stage: never read)
+      if (!active) continue;
+      const unsigned char* st = smem + (t & 1) * STAGE;
+
+      // ---- S^T = K.Q^T: 4 key blocks x 2 query blocks x 4 k-steps
+      f32x4 s[4][2];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int qblk = 0; qblk < 2; ++qblk) s[kb][qblk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + kb * 4096 + n * 256 + (((4 * ks + g) ^ n) << 4));
+#pragma unroll
+          for (int qblk = 0; qblk < 2; ++qblk) s[kb][qblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qblk][ks], s[kb][qblk], 0, 0, 0);
+        }
+      }
+      // ---- key tail of the last tile: s[kb][.][j] belongs to key 64 t + 32 (kb >> 1) + 8 g + 4 (kb & 1) + j
+      if ((t + 1) * KVB > Nkv) {
+        const int base = t * KVB + 8 * g;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (base + 32 * (kb >> 1) + 4 * (kb & 1) + j >= Nkv) {
+              s[kb][0][j] = NEG_BIG;
+              s[kb][1][j] = NEG_BIG;
+            }
+      }
+      // ---- online softmax, lazy offset; a query's 64 scores of this tile sit in lanes n, n + 16, n + 32, n + 48
+      u32x4 pw[2][2];  // [query block][key half]: 8 bf16 = the P operand of one k-step
+#pragma unroll
+      for (int qblk = 0; qblk < 2; ++qblk) {
+        float mx = fmaxf(fmaxf(s[0][qblk][0], s[0][qblk][1]), fmaxf(s[0][qblk][2], s[0][qblk][3]));
+#pragma unroll
+        for (int kb = 1; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(s[kb][qblk][0], s[kb][qblk][1]), fmaxf(s[kb][qblk][2], s[kb][qblk][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (__any(mx > m_run[qblk] + LAZY)) {  // the offset moves (first tiles; afterwards rarely): rescale this lane's rows
+          const float m_new = fmaxf(m_run[qblk], mx);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[qblk] - m_new);
+          m_run[qblk] = m_new;
+          l_run[qblk] *= alpha;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) o[d][qblk] *= alpha;
+        }
+        const float mo = m_run[qblk];
+        float psum = 0.f;
+        float p[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            p[kb][j] = __builtin_amdgcn_exp2f(s[kb][qblk][j] - mo);
+            psum += p[kb][j];
+          }
+        l_run[qblk] += psum;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          pw[qblk][h] = u32x4{pack_bf16(p[2 * h][0], p[2 * h][1]), pack_bf16(p[2 * h][2], p[2 * h][3]), pack_bf16(p[2 * h + 1][0], p[2 * h + 1][1]),
+                              pack_bf16(p[2 * h + 1][2], p[2 * h + 1][3])};
+      }
+      // ---- O^T += V^T.P^T: 2 key halves x 8 channel blocks x 2 query blocks
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(st + v_rd + d * 2048 + (((4 * h + g) ^ v_sw) << 4));
+#pragma unroll
+          for (int qblk = 0; qblk < 2; ++qblk)
+            o[d][qblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[qblk][h]), o[d][qblk], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus prefetch must land before the next item stages over it
+    // ---- normalise and store: lane (n, g) of o[d][qblk] owns query 16 qblk + n, channels 16 d + 4 g + [0, 4)
+    if (active) {
+#pragma unroll
+      for (int qblk = 0; qblk < 2; ++qblk) {
+        float l = l_run[qblk];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + 16 * qblk + n;
+        if (q < Nq) {
+          bf16* orow = O + (size_t)q * ldo + hoff + 4 * g;
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            const u32x2 v = {pack_bf16(o[d][qblk][0] * inv, o[d][qblk][1] * inv), pack_bf16(o[d][qblk][2] * inv, o[d][qblk][3] * inv)};
+            *reinterpret_cast<u32x2*>(orow + 16 * d) = v;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();  // nobody stages the next item's tile 0 over a stage a slower wave still reads
+  }
+}
+
+}  // namespace
+
+// The plain-layout single-segment V^T attention on the 16 x 16 x 32 geometry (called by ce_attention_vt_bf16 under ce_set_attention_waves(16)).
+// Requirements beyond attention_vt_launch's: the DMA moves 16-byte pieces - ldk, ldvt multiples of 8 elements and, with batch > 1, a sample
+// column stride (= len) that is a multiple of 8; returns CE_ERR_ALIGN otherwise (the caller falls back to the 32 x 32 x 16 kernel).
+extern "C" int ce_attn16_launch(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int ldq, int ldo,
+                                float sl2, int batch, int cus, hipStream_t stream) {
+  if ((ldk & 7) || (ldvt & 7) || (ldq & 7) || (ldo & 3) || (batch > 1 && (len & 7))) return CE_ERR_ALIGN;
+  static bool done_[CE_MAX_DEVICES] = {};
+  bool& done = done_[ce_device_slot()];
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_x16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST * STAGE);
+    done = true;
+  }
+  const int nqb = (Nq + 8 * QW - 1) / (8 * QW);
+  const int items = nqb * H * batch;
+  const int grid = items <= 2 * cus ? items : ((2 * cus) & ~7);
+  hipLaunchKernelGGL(attn_fwd_x16_kernel, dim3(grid), dim3(512), NST * STAGE, stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, Nq, len, H,
+                     ldq, ldk, ldvt, ldo, nqb, sl2, batch, len);
+  return (int)hipGetLastError();
+}

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
 HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
 
-SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_gemm256w4.hip", "ce_gemm384.hip", "ce_attn.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip", "ce_gemm_fp8w4.hip", "ce_comm.hip"]
+SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_gemm256w4.hip", "ce_gemm384.hip", "ce_attn.hip", "ce_attn16.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip", "ce_gemm_fp8w4.hip", "ce_comm.hip"]
 
 _c = ctypes
 _P, _I, _F = _c.c_void_p, _c.c_int, _c.c_float

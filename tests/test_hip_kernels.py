@@ -313,6 +313,42 @@ def test_attention_vt_one_wave_per_simd_body_is_bit_identical_to_the_eight_wave_
         assert rel_l2(outs[128][b * Nq:(b + 1) * Nq], ref) < (1e-2 if slope == 0 else 1.5e-2)
 
 
+@pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (7200, 7200, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2),
+                                         (2000, 200, 40, 3), (1090, 1090, 8, 2)])  # the last: sample offsets not 16-byte aligned -> the default body runs
+@pytest.mark.parametrize("slope", [0.0, 10.0])
+def test_attention_vt_16x16x32_body(Nq, Nkv, H, B, slope):
+    """attn_fwd_x16_kernel (csrc/ce_attn16.hip, round 5; ce_set_attention_waves(16)): the V^T self-attention on v_mfma_f32_16x16x32_bf16 - K rows
+    permuted inside the tile so that a lane's P operand meets one 16-byte read of natural-order V^T, online softmax with a lazily moved offset -
+    against torch SDPA (<= 1e-2; spiked scores, which move the offset in every tile, <= 1.5e-2) and against the default 32x32x16 body (<= 3e-3:
+    same products, other summation orders); query blocks with empty waves, key tails, many work items per persistent workgroup."""
+    from chronoedit_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(37)
+    D = H * 128
+    q = torch.randn(B * Nq, D, generator=g).to(BF).to(dev)
+    k = torch.randn(B * Nkv, D, generator=g).to(BF).to(dev)
+    v = torch.randn(B * Nkv, D, generator=g).to(BF).to(dev)
+    v.mul_(torch.linspace(0.5, 1.5, D, device=dev).to(BF)).add_((torch.arange(B * Nkv, device=dev) % 7).to(BF)[:, None] * 0.25)  # a permuted P.V shows up
+    if slope:
+        for b in range(B):
+            for t in range((Nkv + 63) // 64):
+                k[b * Nkv + min(t * 64 + 5, Nkv - 1)] = q[b * Nq + min(7, Nq - 1)] * (0.5 + slope * t)
+    vt = ops.v_transpose(v, H)
+    base = ops.attention_vt(q, k, vt, H, batch=B).clone()
+    old = ops.set_attention_waves(16)
+    try:
+        out = ops.attention_vt(q, k, vt, H, batch=B).clone()
+    finally:
+        ops.set_attention_waves(old)
+    assert torch.isfinite(out.float()).all()
+    if slope == 0:
+        assert rel_l2(out, base) < 3e-3, rel_l2(out, base)
+    for b in range(B):
+        ref = _sdpa_ref(q[b * Nq:(b + 1) * Nq], k[b * Nkv:(b + 1) * Nkv], v[b * Nkv:(b + 1) * Nkv], H)
+        e = rel_l2(out[b * Nq:(b + 1) * Nq], ref)
+        assert e < (1e-2 if slope == 0 else 1.5e-2), (b, e, rel_l2(base[b * Nq:(b + 1) * Nq], ref))
+
+
 @pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (512, 104, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2),
                                          (7200, 7200, 8, 2), (1056, 1056, 5, 2), (1090, 1090, 8, 2), (330, 3270, 8, 3),   # these two: sample offsets only 4-byte aligned
                                          (2000, 200, 40, 3), (3000, 64, 24, 2)])  # many work items per persistent workgroup
