@@ -7,18 +7,22 @@
 // Why a second geometry: tools/probes/attn_shape_probe.hip (profiles/r05_attn_shape_probe.txt) - the attention tile loop with the kernel's
 // filler load runs 6 ... 7 % faster on 16x16x32 than on 32x32x16 (the same ratio the bare MFMA streams show: profiles/r01_mfma_rate_probe.txt).
 //
-//  * workgroup = 8 waves x 32 query rows = 256 query rows of one head; 64-key tiles; two stages of [K 16 KiB | V^T 16 KiB] filled by LDS-DMA
-//    (global_load_lds, 16 B per lane, source-side chunk swizzles), one barrier per tile, the next tile in flight under the current one.
+//  * workgroup = 8 waves x 32 query rows = 256 query rows of one head; 64-key tiles; three stages of [K 16 KiB | V^T 16 KiB] filled by LDS-DMA
+//    (global_load_lds, 16 B per lane, source-side chunk swizzles) two tiles ahead, one barrier per tile.
+//  * a wave alternates ONE matrix block per tile - O += V^T(t).P^T(t), the row sums, S(t+1) = K(t+1).Q^T: 68 MFMAs back to back - with ONE vector
+//    block (mask, row maxima, exponentials, packing); the two waves of a SIMD run the two in antiphase.
 //  * S^T = K.Q^T: first operand = K fragment [16 keys x 32 d] (one ds_read_b128 per lane: chunk (4 ks + g) ^ (key & 15) of the key's 256-byte
 //    row), second = Q fragment [32 d x 16 queries] held in registers (2 query blocks x 4 k-steps).  Lane (n, g) of accumulator s[kb][qb] owns
-//    query 16 qb + n and the four keys 16 kb + 4 g + j: a query's statistics live in 4 lanes (n, n + 16, n + 32, n + 48).
+//    query 16 qb + n and LDS rows 16 kb + 4 g + j of the tile: a query's statistics live in 4 lanes (n, n + 16, n + 32, n + 48).
 //  * O^T += V^T.P^T: the P operand comes straight out of the S registers (k-slots 8 g .. 8 g + 7 of k-step h = this lane's values of
 //    s[2 h][.] and s[2 h + 1][.]).  The K ROWS of a tile are placed in LDS in the order that makes those eight slots eight CONSECUTIVE keys -
 //    LDS row 16 kb + 4 g + j holds key 32 (kb >> 1) + 8 g + 4 (kb & 1) + j; the DMA's per-lane source row does the permutation for nothing -
 //    so the V^T fragment [16 d x 32 keys] of a lane is ONE 16-byte read of natural-order V^T (unit 4 h + g of the channel's 128-byte row, in
 //    slot (4 h + g) ^ ((row >> 1) & 7): conflict-free reads, a whole-16-byte permutation on the DMA's source side).
-//  * online softmax with a LAZY running maximum: the offset of a row moves only when a tile's maximum exceeds it by more than 2^8 (P stays
-//    below 2^8 in fp32 / bf16: no precision is lost by an offset that lags), so the accumulators are rescaled on the first tiles only.
+//  * online softmax with a LAZY offset: the S accumulators START at minus the row's offset (scores arrive as "score - offset": no subtract),
+//    the offset is the exact maximum of tile 0 and moves afterwards only when a tile's maximum exceeds it by more than 2^8 (P stays below 2^8
+//    in fp32 / bf16: no precision is lost by an offset that lags), so accumulators are rescaled on the first tiles only; the row sums of the
+//    rounded P come off the matrix pipe (an all-ones operand against P: 4 MFMAs per tile instead of 32 adds per lane).
 //  * work order: attn_fwd_sp_kernel's (an XCD keeps its heads; batch folded into the item index; persistent workgroups).
 #include "ce_common.h"
 
@@ -28,7 +32,7 @@ constexpr int HD = 128, QW = 32, KVB = 64;
 constexpr int K_TILE = KVB * HD * 2;   // 16 KiB: 64 key rows of 256 B
 constexpr int V_TILE = HD * KVB * 2;   // 16 KiB: 128 channel rows of 128 B
 constexpr int STAGE = K_TILE + V_TILE;
-constexpr int NST = 2;
+constexpr int NST = 3;
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LAZY = 8.0f;  // exp2 domain: the running offset moves when a tile maximum exceeds it by more than this
 
@@ -120,99 +124,132 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x16_kernel(const bf16* __rest
     const int v_sw = (n >> 1) & 7;
     const int v_rd = K_TILE + n * 128;
 
-    f32x4 o[8][2];
+    f32x4 o[8][2], lacc[2];
 #pragma unroll
-    for (int d = 0; d < 8; ++d)
+    for (int qblk = 0; qblk < 2; ++qblk) {
+      lacc[qblk] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int qblk = 0; qblk < 2; ++qblk) o[d][qblk] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {NEG_BIG, NEG_BIG}, l_run[2] = {0.f, 0.f};
+      for (int d = 0; d < 8; ++d) o[d][qblk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // all-ones A operand: ones.P^T leaves every lane the sum over the 32 key slots of a k-step for its query - the row sums of the ROUNDED P
+    // come off the matrix pipe (4 MFMAs per tile) instead of 32 adds per lane, and need no cross-lane reduction at the end
+    u32x4 ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+v"(ones_w));
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
+    float m_run[2] = {0.f, 0.f};  // offset (exp2 domain) the scores of a row are taken against; S accumulators START at -m_run
+    float mx_cur[2] = {0.f, 0.f}; // maximum of s_cur (already relative to m_run), identical in the 4 lanes of a query
 
-    stage_tile(0, 0);
-    for (int t = 0; t < ntiles; ++t) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t have landed
-      __builtin_amdgcn_s_barrier();                     // ... everybody's have, and everybody is done reading tile t-1's stage
-      stage_tile(min(t + 1, ntiles - 1), (t + 1) & 1);  // (the last iteration re-stages the last tile into the free stage: never read)
-      if (!active) continue;
-      const unsigned char* st = smem + (t & 1) * STAGE;
-
-      // ---- S^T = K.Q^T: 4 key blocks x 2 query blocks x 4 k-steps
-      f32x4 s[4][2];
+    // S^T(t) = K(t).Q^T - m_run, masked; returns the row maxima (relative to m_run)
+    auto scores = [&](int t, f32x4 (&sx)[4][2], float (&mx)[2]) __attribute__((always_inline)) {
+      const unsigned char* st = smem + (t % NST) * STAGE;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
-        for (int qblk = 0; qblk < 2; ++qblk) s[kb][qblk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qblk = 0; qblk < 2; ++qblk) sx[kb][qblk] = f32x4{-m_run[qblk], -m_run[qblk], -m_run[qblk], -m_run[qblk]};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(st + kb * 4096 + n * 256 + (((4 * ks + g) ^ n) << 4));
 #pragma unroll
-          for (int qblk = 0; qblk < 2; ++qblk) s[kb][qblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qblk][ks], s[kb][qblk], 0, 0, 0);
+          for (int qblk = 0; qblk < 2; ++qblk) sx[kb][qblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qblk][ks], sx[kb][qblk], 0, 0, 0);
         }
       }
-      // ---- key tail of the last tile: s[kb][.][j] belongs to key 64 t + 32 (kb >> 1) + 8 g + 4 (kb & 1) + j
-      if ((t + 1) * KVB > Nkv) {
+    };
+    auto mask_and_max = [&](int t, f32x4 (&sx)[4][2], float (&mx)[2]) __attribute__((always_inline)) {
+      if ((t + 1) * KVB > Nkv) {  // key tail of the last tile: sx[kb][.][j] belongs to key 64 t + 32 (kb >> 1) + 8 g + 4 (kb & 1) + j
         const int base = t * KVB + 8 * g;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (base + 32 * (kb >> 1) + 4 * (kb & 1) + j >= Nkv) {
-              s[kb][0][j] = NEG_BIG;
-              s[kb][1][j] = NEG_BIG;
+              sx[kb][0][j] = NEG_BIG;
+              sx[kb][1][j] = NEG_BIG;
             }
       }
-      // ---- online softmax, lazy offset; a query's 64 scores of this tile sit in lanes n, n + 16, n + 32, n + 48
-      u32x4 pw[2][2];  // [query block][key half]: 8 bf16 = the P operand of one k-step
 #pragma unroll
       for (int qblk = 0; qblk < 2; ++qblk) {
-        float mx = fmaxf(fmaxf(s[0][qblk][0], s[0][qblk][1]), fmaxf(s[0][qblk][2], s[0][qblk][3]));
+        float v = fmaxf(fmaxf(sx[0][qblk][0], sx[0][qblk][1]), fmaxf(sx[0][qblk][2], sx[0][qblk][3]));
 #pragma unroll
-        for (int kb = 1; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(s[kb][qblk][0], s[kb][qblk][1]), fmaxf(s[kb][qblk][2], s[kb][qblk][3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (__any(mx > m_run[qblk] + LAZY)) {  // the offset moves (first tiles; afterwards rarely): rescale this lane's rows
-          const float m_new = fmaxf(m_run[qblk], mx);
-          const float alpha = __builtin_amdgcn_exp2f(m_run[qblk] - m_new);
-          m_run[qblk] = m_new;
-          l_run[qblk] *= alpha;
-#pragma unroll
-          for (int d = 0; d < 8; ++d) o[d][qblk] *= alpha;
-        }
-        const float mo = m_run[qblk];
-        float psum = 0.f;
-        float p[4][4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            p[kb][j] = __builtin_amdgcn_exp2f(s[kb][qblk][j] - mo);
-            psum += p[kb][j];
-          }
-        l_run[qblk] += psum;
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-          pw[qblk][h] = u32x4{pack_bf16(p[2 * h][0], p[2 * h][1]), pack_bf16(p[2 * h][2], p[2 * h][3]), pack_bf16(p[2 * h + 1][0], p[2 * h + 1][1]),
-                              pack_bf16(p[2 * h + 1][2], p[2 * h + 1][3])};
+        for (int kb = 1; kb < 4; ++kb) v = fmaxf(v, fmaxf(fmaxf(sx[kb][qblk][0], sx[kb][qblk][1]), fmaxf(sx[kb][qblk][2], sx[kb][qblk][3])));
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        mx[qblk] = fmaxf(v, __shfl_xor(v, 32, 64));
       }
-      // ---- O^T += V^T.P^T: 2 key halves x 8 channel blocks x 2 query blocks
+    };
+
+    // prologue: tiles 0 and 1 on their way; S(0) against offset 0
+    stage_tile(0, 0);
+    stage_tile(min(1, ntiles - 1), 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4 s_cur[4][2];
+    if (active) {
+      scores(0, s_cur, mx_cur);
+      mask_and_max(0, s_cur, mx_cur);
+    }
+    for (int t = 0; t < ntiles; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile t+1 have landed (nothing else of its is in flight)
+      __builtin_amdgcn_s_barrier();                     // ... everybody's have; everybody is through iteration t-1: stage (t+2) % 3 is free
+      stage_tile(min(t + 2, ntiles - 1), (t + 2) % NST);
+      if (!active) continue;
+      // ---- the offset of a row moves when its tile maximum outgrows it by more than 2^LAZY (tile 0: always, to the exact maximum)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int qblk = 0; qblk < 2; ++qblk) {
+        if (t == 0 || __any(mx_cur[qblk] > LAZY)) {
+          const float delta = t == 0 ? mx_cur[qblk] : fmaxf(mx_cur[qblk], 0.f);
+          m_run[qblk] += delta;
+          if (t > 0) {
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            lacc[qblk] *= alpha;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(st + v_rd + d * 2048 + (((4 * h + g) ^ v_sw) << 4));
+            for (int d = 0; d < 8; ++d) o[d][qblk] *= alpha;
+          }
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_cur[kb][qblk][j] -= delta;
+        }
+      }
+      // ---- VALU block: P(t) = exp2(s_cur) packed to bf16 (the other wave of the SIMD is in its matrix block meanwhile)
+      u32x4 pw[2][2];  // [query block][key half]: 8 bf16 = the P operand of one k-step
+#pragma unroll
+      for (int qblk = 0; qblk < 2; ++qblk)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float p[2][4];
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[e][j] = __builtin_amdgcn_exp2f(s_cur[2 * h + e][qblk][j]);
+          pw[qblk][h] = u32x4{pack_bf16(p[0][0], p[0][1]), pack_bf16(p[0][2], p[0][3]), pack_bf16(p[1][0], p[1][1]), pack_bf16(p[1][2], p[1][3])};
+        }
+      // ---- matrix block: O^T += V^T(t).P^T(t), the row sums, then S(t+1) into the registers P(t) came from - 68 MFMAs back to back
+      {
+        const unsigned char* st = smem + (t % NST) * STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(st + v_rd + d * 2048 + (((4 * h + g) ^ v_sw) << 4));
+#pragma unroll
+            for (int qblk = 0; qblk < 2; ++qblk)
+              o[d][qblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[qblk][h]), o[d][qblk], 0, 0, 0);
+          }
 #pragma unroll
           for (int qblk = 0; qblk < 2; ++qblk)
-            o[d][qblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, __builtin_bit_cast(bf16x8, pw[qblk][h]), o[d][qblk], 0, 0, 0);
+            lacc[qblk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, pw[qblk][h]), lacc[qblk], 0, 0, 0);
         }
+      }
+      if (t + 1 < ntiles) {
+        scores(t + 1, s_cur, mx_cur);
+        mask_and_max(t + 1, s_cur, mx_cur);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus prefetch must land before the next item stages over it
-    // ---- normalise and store: lane (n, g) of o[d][qblk] owns query 16 qblk + n, channels 16 d + 4 g + [0, 4)
+    // ---- normalise and store: lane (n, g) of o[d][qblk] owns query 16 qblk + n, channels 16 d + 4 g + [0, 4); every lane holds its row's sum
     if (active) {
 #pragma unroll
       for (int qblk = 0; qblk < 2; ++qblk) {
-        float l = l_run[qblk];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
+        const float inv = 1.0f / lacc[qblk][0];
         const int q = q0 + 16 * qblk + n;
         if (q < Nq) {
           bf16* orow = O + (size_t)q * ldo + hoff + 4 * g;

@@ -121,13 +121,17 @@ int main() {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  const int ntiles = 2000, nwg = 512;  // two workgroups per CU, as the kernel runs
+  hipFuncSetAttribute((const void*)k<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)k<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  const int ntiles = 2000, nwg = 512;
   const double flop = 2.0 * 2.0 * 32 * 64 * 128 * 8.0 * ntiles * nwg;
   for (int rep = 0; rep < 3; ++rep)
+   for (int lds : {65536, 131072})  // 64 KiB: two workgroups per CU = four waves per SIMD; 128 KiB: one per CU = two waves per SIMD (the production kernel's occupancy)
     for (int shape : {32, 16}) {
+      printf("LDS %3d KiB (%d workgroup(s) per CU)  ", lds >> 10, lds > 81920 ? 1 : 2);
       hipEventRecord(e0);
-      if (shape == 32) hipLaunchKernelGGL(k<32>, dim3(nwg), dim3(512), 65536, 0, d, out, ntiles);
-      else hipLaunchKernelGGL(k<16>, dim3(nwg), dim3(512), 65536, 0, d, out, ntiles);
+      if (shape == 32) hipLaunchKernelGGL(k<32>, dim3(nwg), dim3(512), lds, 0, d, out, ntiles);
+      else hipLaunchKernelGGL(k<16>, dim3(nwg), dim3(512), lds, 0, d, out, ntiles);
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms;
