@@ -4,8 +4,11 @@
 // softmax_scale * log2(e) and rounded to bf16 once (scores leave the matrix pipe in the exp2 domain), P rounded to bf16 for the second product,
 // row sums in fp32 of the un-rounded P.  Replaces F.scaled_dot_product_attention at transformer_chronoedit.py:91-104.
 //
-// Why a second geometry: tools/probes/attn_shape_probe.hip (profiles/r05_attn_shape_probe.txt) - the attention tile loop with the kernel's
-// filler load runs 6 ... 7 % faster on 16x16x32 than on 32x32x16 (the same ratio the bare MFMA streams show: profiles/r01_mfma_rate_probe.txt).
+// Why a second geometry, and what it measured (profiles/r05_attention_16x16x32.txt): the bare MFMA streams (profiles/r01_mfma_rate_probe.txt) and a
+// synthetic tile loop with this kernel's filler load (tools/probes/attn_shape_probe.hip) run 6 ... 8 % faster on 16x16x32 than on 32x32x16 - but only
+// at FOUR waves per SIMD.  At the two waves per SIMD the register budget of a head_dim-128 kernel allows (O^T 64 + Q 32 + S 32 registers per lane) the
+// geometries are level, and this compiler-scheduled body runs 0.93 ... 1.05 PFLOP/s against the hand-scheduled 32x32x16 body's 1.21 ... 1.28: it is
+// an OPT-IN (ce_set_attention_waves(16)), parity-tested record of that result, not the production path.
 //
 //  * workgroup = 8 waves x 32 query rows = 256 query rows of one head; 64-key tiles; three stages of [K 16 KiB | V^T 16 KiB] filled by LDS-DMA
 //    (global_load_lds, 16 B per lane, source-side chunk swizzles) two tiles ahead, one barrier per tile.

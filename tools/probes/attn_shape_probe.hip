@@ -4,6 +4,8 @@
 // pieces of the next tile, one workgroup barrier - once on v_mfma_f32_32x32x16_bf16 (16 + 16 MFMAs per tile and wave, the production geometry) and
 // once on v_mfma_f32_16x16x32_bf16 (32 + 32).  Same bytes, same flops, same fillers, compiler-scheduled in both arms; the data is random bf16 (the
 // power-limited clock sees toggling operands).  Not the production kernel: the row statistics, the rescale and the output are left out in both arms.
+// Run at two occupancies: 64 KiB of LDS per workgroup (two workgroups per CU = four waves per SIMD) and 128 KiB (one per CU = two waves per SIMD, the
+// occupancy the production kernel's 190+ registers allow).  Result: profiles/r05_attention_16x16x32.txt.
 // build: hipcc --offload-arch=gfx950 -O3 tools/probes/attn_shape_probe.hip -o tools/probes/attn_shape_probe
 #include <hip/hip_runtime.h>
 #include <cstdint>
