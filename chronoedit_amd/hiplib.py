@@ -16,7 +16,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libchronoedit_hip.so")
+# CE_HIPLIB_PATH: A/B tooling only (tools/sessions_r05/gpu_r5_l.sh runs the same bench against two BUILDS of the library); the product loads the in-tree build
+LIB_PATH = os.environ.get("CE_HIPLIB_PATH") or os.path.join(LIB_DIR, "libchronoedit_hip.so")
 HEADER = os.path.join(ROOT, "include", "chronoedit_hip.h")
 
 SOURCES = ["ce_rowops.hip", "ce_gemm.hip", "ce_gemm256.hip", "ce_gemm256w4.hip", "ce_gemm384.hip", "ce_attn.hip", "ce_attn16.hip", "ce_attn_fp8.hip", "ce_sched.hip", "ce_conv.hip", "ce_enc.hip", "ce_gemm_fp8.hip", "ce_gemm_fp8w4.hip", "ce_comm.hip"]

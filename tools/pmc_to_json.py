@@ -14,10 +14,10 @@ SPECS = [
     ("r05_pmc_attn8_7200_b2.txt", "attn_fwd_mxfp8_sp_kernel", ["attention_mxfp8_7200x7200_h40_b2", "attention_mxfp8_7200x7200_h40_b2_mxq"],
      2 * 7200 * 5120 * (1 + 1 + 1 + 2) + 3 * 2 * 7200 * 5120 // 32,
      "attn_fwd_mxfp8_sp_kernel, 7200 keys x 40 heads x 2 samples (q8 + k8 + v8t e4m3, bf16 output, E8M0 scales)", "tools/one_kernel.py attn8 7200 40 2"),
-    ("r05_pmc_gemm8_outproj.txt", "gemm_fp8_w4ILi2E", ["gemm_mxfp8_14400x5120x5120_epi2"],
+    ("r05_pmc_gemm8_outproj_sched1.txt", "gemm_fp8_w4ILi2E", ["gemm_mxfp8_14400x5120x5120_epi2"],
      14400 * 5120 + 5120 * 5120 + 2 * 2 * 14400 * 5120 + (14400 + 5120) * 5120 // 32,
      "gemm_fp8_w4<EPI_GATE_RES, MX> 14400 x 5120 x 5120 (e4m3 operands, bf16 residual in, bf16 out)", "tools/one_kernel.py gemm8 14400 5120 5120 2"),
-    ("r05_pmc_gemm8_ffnup.txt", "gemm_fp8_w4ILi7E", ["gemm_mxfp8_14400x13824x5120_gelu_quant"],
+    ("r05_pmc_gemm8_ffnup_sched1.txt", "gemm_fp8_w4ILi7E", ["gemm_mxfp8_14400x13824x5120_gelu_quant"],
      14400 * 5120 + 13824 * 5120 + 14400 * 13824 + (14400 * 5120 + 13824 * 5120 + 14400 * 13824) // 32,
      "gemm_fp8_w4<EPI_BIAS_GELU_Q, MX> 14400 x 13824 x 5120 (e4m3 operands, e4m3 + E8M0 output)", "tools/one_kernel.py gemm8 14400 13824 5120 7"),
 ]
