@@ -53,7 +53,8 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #endif
 // Diagnostic builds (tools/gemm_mxfp8_ab.py; results are garbage, only the time means something) - one ingredient of the main loop compiled out:
 // 1 no LDS-DMA in the loop, 2 every piece re-reads K-tile 0 (all L2 hits), 3 no fragment reads, 4 no barrier / vmcnt wait in the loop, 5 no epilogue,
-// 6 / 7 the first round's workgroups skip part of their K range (desynchronises the later rounds: what a staggered start would buy)
+// 6 / 7 the first round's workgroups skip part of their K range (desynchronises the later rounds: what a staggered start would buy),
+// 8 / 9 / 10 (FFN-up form) the epilogue without its GELU + block maximum / without its global stores / without its LDS staging and barriers
 #ifndef F8_ABLATE
 #define F8_ABLATE 0
 #endif
@@ -388,9 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    if (p > 0) __syncthreads();
+    if (p > 0 && F8_ABLATE != 10) __syncthreads();
 #pragma unroll
-    for (int ff = 0; ff < 2; ++ff) {
+    for (int ff = 0; ff < (F8_ABLATE == 10 ? 0 : 2); ++ff) {  /* (10: no staging writes, no barriers: the chunk phase reads stale LDS) */
       const int f = 2 * p + ff;
       const float sav = MX ? 1.0f : sa[min(m0 + wm * 128 + f * 16 + fr, M - 1)];
       const int rl = wm * 32 + ff * 16 + fr;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
       }
     }
-    __syncthreads();
+    if (F8_ABLATE != 10) __syncthreads();
     if (prefetch) {
 #pragma unroll
       for (int tt = 0; tt < 8; ++tt) {
@@ -436,11 +437,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float am = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+#if F8_ABLATE == 8  /* (epilogue ablation: no GELU, no block maximum) */
+          o[q] = y[q];
+          am = 1.0f;
+        }
+#else
           o[q] = pack_bf16(gelu_tanh(bf16lo(y[q])), gelu_tanh(bf16hi(y[q])));
           am = fmaxf(am, fmaxf(fabsf(bf16lo(o[q])), fabsf(bf16hi(o[q]))));
         }
         am = fmaxf(am, __shfl_xor(am, 1, 64));
         am = fmaxf(am, __shfl_xor(am, 2, 64));
+#endif
         const int byte = mx_scale_byte_nosat(am);
         const float inv = mx_inv_scale(byte);
         int w0 = 0, w1 = 0;
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[1]) * inv), clamp448(bf16hi(o[1]) * inv), w0, true);
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[2]) * inv), clamp448(bf16hi(o[2]) * inv), w1, false);
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[3]) * inv), clamp448(bf16hi(o[3]) * inv), w1, true);
-        if (m < M && n < N) {
+        if (m < M && n < N && (F8_ABLATE != 9 || w0 == 0x12345677)) {  /* (9: no stores) */
           *reinterpret_cast<u32x2*>(q_out + (size_t)m * ldc + n) = u32x2{(uint32_t)w0, (uint32_t)w1};
           if ((cc & 3) == 0) qs_out[mx_gemm_scale_offset(m, n >> 5, N >> 7)] = (unsigned char)byte;
         }
