@@ -181,10 +181,20 @@ class GraphedDenoiser:
                 transformer.prime_context(self.cfg_inputs[0], self.cfg_inputs[1])
             elif not self.guided:
                 transformer.prime_context(prompt_embeds, image_embeds)
+        # The capture: at once when every step() must be a replay (warm shape, or keep_warmup_step=False); LAZILY - at the first step() that needs a
+        # replay - when the constructor already ran the trajectory's current step eagerly: if that was the last step of this shape (truncation lands
+        # there, or a callback replaces the latents every step) nothing is ever replayed and a whole capture would be thrown away
+        self.graph = None
+        if self._done_index is None:
+            self._capture()
+        scheduler._step_index = idx0  # step_cfg counts on the host, also while being captured
+
+    def _capture(self):
+        idx = self.sch._step_index
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):  # (a capture executes nothing: the device state stays what the eager step left)
             self._body()
-        scheduler._step_index = idx0  # step_cfg counts on the host, also while being captured
+        self.sch._step_index = idx
 
     def _stage(self, i):
         self.t_buf.copy_(self.sch.timesteps[i])
@@ -213,6 +223,8 @@ class GraphedDenoiser:
             self._done_index = None
             self.sch._step_index = i + 1
             return self.latents
+        if self.graph is None:
+            self._capture()
         self._stage(i)
         self.graph.replay()
         self.sch._step_index = i + 1

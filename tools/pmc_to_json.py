@@ -11,6 +11,12 @@ P = os.path.join(ROOT, "profiles")
 
 # file, kernel-name fragment, bench labels that map to it, algorithmic bytes per launch, description
 SPECS = [
+    ("r05_pmc_attention_vt_7200_b2.txt", "attn_fwd_sp_kernel", ["attention_7200x7200+0_h40_b2"], 589824000,
+     "attn_fwd_sp_kernel<false, VT = true> (ce_attention_vt_bf16: K and V^T by LDS-DMA), 7200 keys x 40 heads x 2 samples", "tools/one_kernel.py attnvt 7200 40 2"),
+    ("r05_pmc_gemm_outproj.txt", "gemm_bf16_384ILi2E", ["gemm_14400x5120x5120_epi2"], 494796800,
+     "gemm_bf16_384<EPI_GATE_RES> (384 x 256 macro tile, one wave per SIMD) 14400 x 5120 x 5120", "tools/one_kernel.py gemm 14400 5120 5120 2 -1"),
+    ("r05_pmc_gemm_ffnup.txt", "gemm_bf16_w4ILi1E", ["gemm_14400x13824x5120_epi1"], 687144960,
+     "gemm_bf16_w4<EPI_BIAS_GELU> (256 x 256 tile, one wave per SIMD; its split-K reduce launch not included) 14400 x 13824 x 5120", "tools/one_kernel.py gemm 14400 13824 5120 1 -1"),
     ("r05_pmc_attn8_7200_b2.txt", "attn_fwd_mxfp8_sp_kernel", ["attention_mxfp8_7200x7200_h40_b2", "attention_mxfp8_7200x7200_h40_b2_mxq"],
      2 * 7200 * 5120 * (1 + 1 + 1 + 2) + 3 * 2 * 7200 * 5120 // 32,
      "attn_fwd_mxfp8_sp_kernel, 7200 keys x 40 heads x 2 samples (q8 + k8 + v8t e4m3, bf16 output, E8M0 scales)", "tools/one_kernel.py attn8 7200 40 2"),
@@ -44,7 +50,7 @@ def parse(path, frag):
 
 
 def main():
-    out = {"_comment": "HBM-side traffic per launch of the fp8 kernels from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only; round-5 sessions "
+    out = {"_comment": "HBM-side traffic per launch of the dominant bf16 and fp8 kernels from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only; round-5 sessions "
                        "tools/sessions_r05/gpu_r5_*.sh; raw summaries: the r05_pmc_*.txt files next to this one).  fetch_bytes = FETCH_SIZE x 1024 x 2 (gfx950 tallies "
                        "128-byte requests at 64), write_bytes = WRITE_SIZE x 1024; Infinity-Cache hits are included: traffic past the L2, an upper bound on HBM bytes.  "
                        "Shapes not listed fall back to r04_pmc_traffic.json / r02_pmc_traffic.json (bench.py::_pmc_traffic)."}
