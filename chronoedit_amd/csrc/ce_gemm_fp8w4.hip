@@ -41,6 +41,8 @@ constexpr int BM = 256, BN = 256, BKB = 128;  // K-tile in bytes (= fp8 elements
 constexpr int TILE = 256 * BKB;               // one operand K-tile, 32 KiB
 constexpr int STAGE = 2 * TILE;               // [A | W]
 constexpr int CROW = BN * 2 + 16;             // padded epilogue staging row (528 B)
+constexpr int W_RING = 3 * TILE;              // (F8_A3) A stages at 0, TILE, 2 TILE; W stages at W_RING, W_RING + TILE
+constexpr int LDS_BYTES = F8_A3 ? 5 * TILE : 2 * STAGE;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -50,6 +52,12 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // pieces per MFMA gap - an LDS-DMA piece costs its wave 60..185 cycles of issue and a 16x16x128 MFMA covers 32); the others spread them.
 #ifndef F8_DMA_SCHED
 #define F8_DMA_SCHED 1
+#endif
+// F8_A3 = 1: an A ring of THREE K-tile stages beside the W ring of two (160 KiB of LDS, as ce_gemm256w4.hip).  The A pieces of tile T+2 then go out in
+// groups 1..4 of tile T (nine groups of flight) and the W pieces of tile T+2 in groups 5, 6, 7 of T and group 0 of T+1 (five): TWO pieces per group
+// everywhere, none with less than five groups to land (the two-stage loop: three pieces per group and three groups).
+#ifndef F8_A3
+#define F8_A3 0
 #endif
 // Diagnostic builds (tools/gemm_mxfp8_ab.py; results are garbage, only the time means something) - one ingredient of the main loop compiled out:
 // 1 no LDS-DMA in the loop, 2 every piece re-reads K-tile 0 (all L2 hits), 3 no fragment reads, 4 no barrier / vmcnt wait in the loop, 5 no epilogue,
@@ -220,6 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   if (MX) load_scales(0, 0);
 
+#if !F8_A3
   // prologue: tiles 0 and 1 on their way, tile 0 landed; its W fragments and its first three A fragments read
   {
     const int k0 = koff(0), k1 = koff(1);
@@ -314,6 +323,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       X8_TILE(1, t + 1, bw1, bw0, 1)
     }
   }
+#else
+  // ---- F8_A3: A ring of three stages, W ring of two ----
+  auto dma_a = [&](int q, int a_off, int soff) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + a_off + (wave + 4 * q) * 1024), 16, a_voff[q & 7], soff, 0, 0);
+  };
+  auto dma_w = [&](int q, int par, int soff) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + W_RING + par * TILE + (wave + 4 * q) * 1024), 16, w_voff[q & 7], soff, 0, 0);
+  };
+  auto read_a = [&](const int (&base)[2], int f) __attribute__((always_inline)) -> i32x8 {
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + base[0] + f * 2048);
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(smem + base[1] + f * 2048);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  auto read_w = [&](int par, int f) __attribute__((always_inline)) -> i32x8 {  // (w_rd already carries TILE: the W half of the two-stage layout)
+    const u32x4 lo = *reinterpret_cast<const u32x4*>(smem + w_rd[0] - TILE + W_RING + par * TILE + f * 2048);
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(smem + w_rd[1] - TILE + W_RING + par * TILE + f * 2048);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  // prologue: tiles 0 and 1 on their way (A stages 0, 1; W stages 0, 1), tile 0 landed; its W fragments and its first three A fragments read
+  {
+    const int k0 = koff(0), k1 = koff(1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_a(q, 0, k0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_w(q, 0, k0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_a(q, TILE, k1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma_w(q, 1, k1);
+  }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  if (MX) asm volatile("" : "+v"(sAq[0]), "+v"(sWq[0]));
+  X8_BAR();
+  i32x8 ring[4], bw0[8], bw1[8];
+  int arc[2] = {a_rd[0], a_rd[1]}, arn[2] = {a_rd[0] + TILE, a_rd[1] + TILE};  // fragment read bases of the tile being multiplied / of the next one
+  int a_c = 0, a_n = TILE, a_nn = 2 * TILE;                                     // A stages (bytes, wave-uniform) of tiles T, T+1 and the one tile T+2 lands in
+#pragma unroll
+  for (int g = 0; g < 8; ++g) bw0[g] = read_w(0, g);
+#pragma unroll
+  for (int f = 0; f < 3; ++f) ring[f] = read_a(arc, f);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  X8_PIN();
+
+#define X8_MMA(F, G, BW)                                                                                                          \
+  do {                                                                                                                            \
+    if (MX) mma_mx<(G) & 3, (F) & 3>(acc[F][G], (BW)[G], ring[(F) % 4], sWq[SEL_][(G) >> 2], sAq[SEL_][(F) >> 2]);                  \
+    else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]));          \
+  } while (0)
+  // the two LDS-DMA pieces of group G (J = 0, 1): group 0 - the last two W pieces of tile T+1; groups 1..4 - the eight A pieces of tile T+2 (-> the
+  // stage tile T-1 left at the barrier of T-1); groups 5..7 - the first six W pieces of tile T+2 (-> W stage PAR, free since this tile's barrier)
+#define X8_DMA(G, J, PAR, KN2, KN1)                                                                                           \
+  if constexpr (F8_ABLATE != 1) {                                                                                             \
+    if constexpr ((G) == 0) dma_w(6 + (J), 1 - (PAR), KN1);                                                                   \
+    else if constexpr ((G) <= 4) dma_a(2 * ((G) - 1) + (J), a_nn, KN2);                                                        \
+    else dma_w(2 * ((G) - 5) + (J), (PAR), KN2);                                                                              \
+  }
+#define X8_GROUP(G, PAR, BW, BN_, KNEXT, KN1, SEL)                                                                            \
+  {                                                                                                                           \
+    constexpr int SEL_ = (SEL);                                                                                               \
+    constexpr int fn_ = ((G) + 3) & 7;                                                                                        \
+    if ((G) == 5 && F8_ABLATE != 4) {                                                                                         \
+      /* everything older than the eight A pieces of tile T+2 (groups 1..4) has landed: tile T+1 whole, its scales */          \
+      asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+      if (MX) asm volatile("" : "+v"(sAq[1 - SEL_]), "+v"(sWq[1 - SEL_]));                                                     \
+      X8_BAR();                                                                                                               \
+      X8_PIN();                                                                                                               \
+    }                                                                                                                         \
+    X8_MMA(G, 0, BW);                                                                                                         \
+    if constexpr ((G) + 3 >= 8) ring[((G) + 3) % 4] = read_a(arn, fn_); else ring[((G) + 3) % 4] = read_a(arc, fn_);          \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 1, BW);                                                                                                         \
+    X8_DMA(G, 0, PAR, KNEXT, KN1)                                                                                             \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 2, BW);                                                                                                         \
+    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 0] = read_w(1 - (PAR), 3 * ((G) - 5) + 0); }                                         \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 3, BW);                                                                                                         \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 4, BW);                                                                                                         \
+    if ((G) >= 5) { (BN_)[3 * ((G) - 5) + 1] = read_w(1 - (PAR), 3 * ((G) - 5) + 1); }                                         \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 5, BW);                                                                                                         \
+    X8_DMA(G, 1, PAR, KNEXT, KN1)                                                                                             \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 6, BW);                                                                                                         \
+    if ((G) == 5 || (G) == 6) { (BN_)[3 * ((G) - 5) + 2] = read_w(1 - (PAR), 3 * ((G) - 5) + 2); }                             \
+    X8_PIN();                                                                                                                 \
+    X8_MMA(G, 7, BW);                                                                                                         \
+    X8_PIN();                                                                                                                 \
+  }
+#define X8_TILE(PAR, T, BW, BN_, SEL)                                                                                         \
+  {                                                                                                                           \
+    const int knext = koff((T) + 2), kn1 = koff((T) + 1);                                                                     \
+    X8_GROUP(0, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(1, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(2, PAR, BW, BN_, knext, kn1, SEL) \
+    X8_GROUP(3, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(4, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(5, PAR, BW, BN_, knext, kn1, SEL) \
+    X8_GROUP(6, PAR, BW, BN_, knext, kn1, SEL) X8_GROUP(7, PAR, BW, BN_, knext, kn1, SEL)                                      \
+    /* rotate the A ring: the next tile becomes the current one, tile T+2's stage the next one, this tile's stage takes tile T+3 */ \
+    {                                                                                                                         \
+      const int freed = a_c;                                                                                                  \
+      a_c = a_n; a_n = a_nn; a_nn = freed;                                                                                    \
+      arc[0] = arn[0]; arc[1] = arn[1];                                                                                       \
+      arn[0] = a_rd[0] + a_n; arn[1] = a_rd[1] + a_n;                                                                         \
+    }                                                                                                                         \
+  }
+  {
+    const int npairs = ktn >> 1;
+    for (int it = 0; it < npairs; ++it) {
+      const int t = 2 * it;
+      if (MX) load_scales(t + 1, 1);
+      X8_TILE(0, t, bw0, bw1, 0)
+      if (MX) load_scales(t + 2, 0);
+      X8_TILE(1, t + 1, bw1, bw0, 1)
+    }
+  }
+#endif
 #undef X8_TILE
 #undef X8_GROUP
 #undef X8_DMA
@@ -575,7 +699,7 @@ static int fp8w4_launch(bool mx, const void* Aq, const void* Wq, void* C, const 
   if (split == 1) tail = 0;
   const int t_full = nwg - tail;
   dim3 grid(t_full + tail * split), block(256);
-  const int lds = 2 * STAGE;
+  const int lds = LDS_BYTES;
   static bool attr_done_[CE_MAX_DEVICES][3] = {};
   bool* attr_done = attr_done_[ce_device_slot()];
 #define F8_LAUNCH(E)                                                                                                          \
@@ -664,10 +788,10 @@ extern "C" int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const vo
   static bool done_[CE_MAX_DEVICES] = {};
   bool& done = done_[ce_device_slot()];
   if (!done) {
-    if (hipFuncSetAttribute((const void*)gemm_fp8_w4<EPI_BIAS_GELU_Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE) != hipSuccess) return CE_ERR_ARG;
+    if (hipFuncSetAttribute((const void*)gemm_fp8_w4<EPI_BIAS_GELU_Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return CE_ERR_ARG;
     done = true;
   }
-  hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true>), dim3(t_full + tail * split), dim3(256), 2 * STAGE, stream, (const unsigned char*)Aq,
+  hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true>), dim3(t_full + tail * split), dim3(256), LDS_BYTES, stream, (const unsigned char*)Aq,
                      (const unsigned char*)Wq, (bf16*)q_out, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, nullptr,
                      nullptr, M, N, K, lda, ldw, ldq, 0, 0, tiles_m, tiles_n, t_full, split, g_ws, (unsigned char*)qs_out);
   if (tail)
