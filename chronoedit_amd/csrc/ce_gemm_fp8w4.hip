@@ -35,6 +35,13 @@
 #include "ce_common.h"
 #include "ce_gemm_epi.h"
 
+// F8_A3 = 1: an A ring of THREE K-tile stages beside the W ring of two (160 KiB of LDS, as ce_gemm256w4.hip).  The A pieces of tile T+2 then go out in
+// groups 1..4 of tile T (nine groups of flight) and the W pieces of tile T+2 in groups 5, 6, 7 of T and group 0 of T+1 (five): TWO pieces per group
+// everywhere, none with less than five groups to land (the two-stage loop: three pieces per group and three groups).
+#ifndef F8_A3
+#define F8_A3 0
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BKB = 128;  // K-tile in bytes (= fp8 elements)
@@ -52,12 +59,6 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // pieces per MFMA gap - an LDS-DMA piece costs its wave 60..185 cycles of issue and a 16x16x128 MFMA covers 32); the others spread them.
 #ifndef F8_DMA_SCHED
 #define F8_DMA_SCHED 1
-#endif
-// F8_A3 = 1: an A ring of THREE K-tile stages beside the W ring of two (160 KiB of LDS, as ce_gemm256w4.hip).  The A pieces of tile T+2 then go out in
-// groups 1..4 of tile T (nine groups of flight) and the W pieces of tile T+2 in groups 5, 6, 7 of T and group 0 of T+1 (five): TWO pieces per group
-// everywhere, none with less than five groups to land (the two-stage loop: three pieces per group and three groups).
-#ifndef F8_A3
-#define F8_A3 0
 #endif
 // Diagnostic builds (tools/gemm_mxfp8_ab.py; results are garbage, only the time means something) - one ingredient of the main loop compiled out:
 // 1 no LDS-DMA in the loop, 2 every piece re-reads K-tile 0 (all L2 hits), 3 no fragment reads, 4 no barrier / vmcnt wait in the loop, 5 no epilogue,
