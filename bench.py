@@ -24,9 +24,15 @@ The JSON line carries:
   roofline         the single largest kernel launch shape (the batched self-attention at 7200 tokens), algorithmic FLOPs / mean
                    launch duration measured with HIP events on the launch stream in one extra profiled step after the timed
                    region, vs 2.5 PFLOP/s dense bf16; `traffic` from the committed rocprofv3 --pmc passes under profiles/;
-  roofline_family  the same accounting for ALL launches of the 256x256x64 GEMM kernel together (72 % of a step);
-  cpu_baseline     the CPU oracle (oracle/dit_oracle.py, "port") timed on this host's cores on ONE transformer block at the
-                   same token count (rank 0, N=1 only; one warm-up + median of three), extrapolated to steps/sec;
+                   RULE: `roofline.kernel` = the launch LABEL (shape) with the largest total time in the profiled step - the batched self-attention;
+                   the largest kernel SYMBOL (gemm_bf16_384<EPI_GATE_RES>, three shapes) is covered by roofline_family;
+  roofline_family  the same accounting for ALL launches of the large-tile GEMM kernels together (72 % of a step);
+  cpu_baseline     the reference's OWN ChronoEditTransformerBlock (transformer_chronoedit.py:215-295, executed from the build output
+                   oracle/_ref/transformer_ref.bin: "kind": "reference"; the oracle port beside it, and alone - "kind": "port" - where that file
+                   was not built) timed on this host's granted cores on ONE transformer block at the same token count (rank 0, at every N; one
+                   warm-up + median of three, a single bounded run at 28 800 tokens), extrapolated to steps/sec; cpu_config0 = BASELINE configs[0];
+  N > 1            `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run; the headline is printed at once in a
+                   "preliminary" line, the complete line (sharded sec/edit of the temporal-reasoning edits, cpu_baseline, rccl.model_prediction) last;
   sec_per_edit     MEASURED end to end through ChronoEditPipeline for configs[2] (8-step distilled schedule, guidance 1) and,
                    with --full-edit, configs[1] (50 steps); the composed 50-step figure is labelled as composed.
 """
