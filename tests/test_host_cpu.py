@@ -304,3 +304,23 @@ def test_bench_median_time_bounded_sample():
     calls.clear()
     dt, ts = bench._median_time(lambda: (calls.append(1), _t.sleep(0.05)), runs=3, warm=1, budget_s=0.1)
     assert len(calls) == 1 and len(ts) == 1 and dt >= 0.05
+
+
+def test_scaling_model_prediction_block():
+    """tools/scaling_model.predict (what bench.py puts into `rccl.model_prediction`): every split of the ranks priced eager and captured; a captured
+    loop exposes the k|v exchange it hides when eager, so it never ranks above its eager twin; the guidance-pair split is never offered captured."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import scaling_model as m
+    for W in (2, 4, 8):
+        p = m.predict(W)
+        sps = p["steps_per_s"]
+        assert p["choice"] in sps and sps[p["choice"]] == max(sps.values())
+        assert not any("cfg-parallel" in k and "hipGraph" in k for k in sps)
+        for k, v in sps.items():
+            if k.endswith(", hipGraph"):
+                assert v <= sps[k.replace(", hipGraph", ", eager")], (W, k)
+        assert max(sps.values()) > p["one_gpu_steps_per_s"]
+    assert m.predict(2)["choice"].startswith("cfg-parallel")       # one xGMI link between two ranks: split the guidance pair instead
+    assert m.predict(8)["choice"] == "ulysses 8, B=2, eager"
