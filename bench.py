@@ -306,6 +306,39 @@ def cpu_config0(with_reference: bool = True, depths=(1, 2, 4)):
     return out
 
 
+def _power_sample(step_fn, first_index: int, n_steps: int = 6):
+    """Package power and shader clock WHILE the step runs (best effort, one GPU, outside the timed region): enqueue `n_steps` more steps, ask rocm-smi
+    once half a second in, then synchronise.  profiles/r05_power_clock_trace.txt is the same reading sampled every 0.5 s: both the bf16 and the fp8 step
+    sit at ~1.35 kW of the 1.4 kW cap with the shader clock pulled to 1.9 / 2.2 GHz of 2.4 - the step time is energy per step over the cap.
+    None when rocm-smi is missing or says nothing parsable."""
+    import re
+    import shutil
+    import subprocess
+    smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if smi is None:
+        return None
+    try:
+        for i in range(n_steps):
+            step_fn(first_index + i)
+        time.sleep(0.5)
+        txt = subprocess.run([smi, "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+        torch.cuda.synchronize()
+        pw = re.search(r"GPU\[0\].*?Current Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
+        cap = re.search(r"GPU\[0\].*?Max Graphics Package Power \(W\): ([0-9.]+)", txt)
+        ck = re.search(r"GPU\[0\].*?sclk clock level: \w+: \((\d+)Mhz\)", txt)
+        if not pw or not ck:
+            return None
+        return {"package_power_w": float(pw.group(1)), "power_cap_w": float(cap.group(1)) if cap else None, "sclk_mhz": int(ck.group(1)), "sclk_max_mhz": 2400,
+                "how": "one rocm-smi reading 0.5 s into six more steps after the timed region (device 0)",
+                "see": "profiles/r05_power_clock_trace.txt: the step runs at the package's power cap; its time is energy per step over the cap"}
+    except Exception:  # noqa: BLE001 - a diagnostic must never take the line down
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+        return None
+
+
 def _pmc_traffic(kernel_label: str):
     """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
     are collected in their own runs, tools/gpu_pmc.sh; they cannot be read live from inside this process).  None when the
@@ -656,6 +689,10 @@ def main():
     else:
         headline_leg()
 
+    power = None
+    if world == 1 and not one_rank_sp and not a.no_profile and not a.graph and total >= a.warmup + a.steps + 2:
+        # (its own seeded inputs and scheduler: the timed workload's latents and schedule are left as the timed region left them)
+        power = _power_sample(make_stepper(Workload(dev, T, h, w, 4343), new_sched(8), sequential=a.sequential_cfg), 0)
     # ---- per-kernel HIP-event profile of ONE more step (outside the timed region) -> roofline of the dominant kernel
     roofline = roofline_family = breakdown = None
     if not a.no_profile and ulysses and rank != 0:
@@ -799,6 +836,7 @@ def main():
                              "configs[1] 50 steps, guidance 5 (measured end to end)": single["edit50"],
                              "configs[1] 50 steps, composed = 50 x ms_per_step + VAE + encoders": None if vae_s is None else round(
                                  50 * dt / a.steps + vae_s["encode_s"] + vae_s["decode_s"] + (0.0 if enc_s is None else enc_s["text_s"] + enc_s["image_s"]), 2)},
+            "power": power,
             "roofline": roofline,
             "roofline_family": roofline_family,
             "kernel_breakdown": breakdown,
