@@ -1443,18 +1443,20 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict
 // 4 / 8 = the plain kernel with 4 / 8 waves per workgroup (the readable statement of the algorithm; kept as the A/B partner
 // of the parity tests).  The other loop bodies of round 1 (XOR-swizzled pipeline, ping-pong, one wave per SIMD) and their
 // ablation build lost every A/B and were removed in round 2; git history has them.
-static int g_attn_nwave = 0;
-extern "C" int ce_set_attention_waves(int nwave) {
+CE_KNOB g_attn_nwave = 0;
+#ifdef CE_DIAGNOSTICS
+CE_API int ce_set_attention_waves(int nwave) {
   const int old = g_attn_nwave;
   if (nwave == 0 || nwave == 4 || nwave == 8 || nwave == 16 || nwave == 64 || nwave == 128 || nwave == 129) g_attn_nwave = nwave;
   return old;
 }
+#endif
 
 // Q [Nq][ldq], K*/V* [len][ld*], O [Nq][ldo]; all bf16, head h occupies columns [128 h, 128 h + 128).
 // Second kv segment optional (k2 == nullptr or len2 == 0): O = bf16(attn(seg1)) + bf16(attn(seg2)).
 // batch > 1: `batch` samples stacked along the rows of every operand (sample b: rows [b Nq, (b+1) Nq) of Q/O, rows
 // [b len, (b+1) len) of each K/V segment), one launch - more workgroups per launch, smaller last-round tail.
-extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1,
+CE_API int ce_attention_batched_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1,
                                          const void* K2, const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H,
                                          int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
   if (!Q || !K1 || !V1 || !O) return CE_ERR_ARG;
@@ -1507,7 +1509,7 @@ extern "C" int ce_attention_batched_bf16(const void* Q, const void* K1, const vo
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
+CE_API int ce_attention_bf16(const void* Q, const void* K1, const void* V1, int len1, int ldk1, int ldv1, const void* K2,
                                  const void* V2, int len2, int ldk2, int ldv2, void* O, int Nq, int H, int head_dim, int ldq,
                                  int ldo, float softmax_scale, hipStream_t stream) {
   return ce_attention_batched_bf16(Q, K1, V1, len1, ldk1, ldv1, K2, V2, len2, ldk2, ldv2, O, Nq, H, head_dim, ldq, ldo,
@@ -1515,7 +1517,7 @@ extern "C" int ce_attention_bf16(const void* Q, const void* K1, const void* V1, 
 }
 
 /* V [batch * n_tokens][ldv] -> V^T [H * 128][ldvt]: see v_transpose_kernel. */
-extern "C" int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, hipStream_t stream) {
+CE_API int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, hipStream_t stream) {
   if (!v || !vt) return CE_ERR_ARG;
   if (n_keys <= 0 || H <= 0 || ldvt < n_keys) return CE_ERR_SHAPE;
   if ((ldv & 3) || (ldvt & 7)) return CE_ERR_ALIGN;
@@ -1526,7 +1528,7 @@ extern "C" int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, i
 /* The same from the BLOCKED row layout (ce_attention_vt_blocked_bf16): key g of sample b in row (g / blk_rows) blk_stride + b blk_rows +
  * g % blk_rows of v; output plain per sample, sample b's n_keys keys at columns [b vt_sample_cols, ...), the rest of its vt_sample_cols
  * columns zeroed.  vt_sample_cols: a multiple of 64, >= 64 ceil(n_keys / 64); ldvt >= batch * vt_sample_cols. */
-extern "C" int ce_v_transpose_blocked_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, int batch, int blk_rows, int blk_stride,
+CE_API int ce_v_transpose_blocked_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, int batch, int blk_rows, int blk_stride,
                                            int vt_sample_cols, hipStream_t stream) {
   if (!v || !vt) return CE_ERR_ARG;
   if (n_keys <= 0 || H <= 0 || batch <= 0 || blk_rows <= 0 || (blk_rows & 63) || blk_stride < batch * blk_rows || (vt_sample_cols & 63) ||
@@ -1539,8 +1541,10 @@ extern "C" int ce_v_transpose_blocked_bf16(const void* v, int ldv, void* vt, int
 }
 
 // the 16 x 16 x 32 body of the plain-layout V^T attention (ce_attn16.hip; ce_set_attention_waves(16))
+#ifdef CE_DIAGNOSTICS
 extern "C" int ce_attn16_launch(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H, int ldq, int ldo,
                                 float sl2, int batch, int cus, hipStream_t stream);
+#endif
 
 /* Self-attention with V handed over TRANSPOSED (V^T [H * 128][ldvt]): both K and V^T tiles reach LDS by LDS-DMA, no register
  * staging.  One KV segment, software-pipelined kernel only.  blk_rows == 0: plain layout (sample b's token g in row b N + g of Q / K / O,
@@ -1584,10 +1588,12 @@ static int attention_vt_launch(const void* Q, const void* K, const void* Vt, int
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
   const int items = nqb * H * batch;
+#ifdef CE_DIAGNOSTICS
   if (g_attn_nwave == 16 && blk_rows == 0) {  // the 16 x 16 x 32 geometry (plain layout; unaligned operands fall through to the default body)
     const int rc = ce_attn16_launch(Q, K, Vt, len, ldk, ldvt, O, Nq, H, ldq, ldo, sl2, batch, cus, stream);
     if (rc != CE_ERR_ALIGN) return rc;
   }
+#endif
   if (g_attn_nwave == 128 || g_attn_nwave == 129) {  // one wave per SIMD (attn_fwd_w4_kernel): 128 = one workgroup per item, 129 = #CUs persistent workgroups
     static bool done4_[CE_MAX_DEVICES] = {};
     bool& done4 = done4_[ce_device_slot()];
@@ -1606,12 +1612,12 @@ static int attention_vt_launch(const void* Q, const void* K, const void* Vt, int
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
+CE_API int ce_attention_vt_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
                                     int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
   return attention_vt_launch(Q, K, Vt, len, ldk, ldvt, O, Nq, H, head_dim, ldq, ldo, softmax_scale, batch, 0, 0, 0, stream);
 }
 
-extern "C" int ce_attention_vt_blocked_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
+CE_API int ce_attention_vt_blocked_bf16(const void* Q, const void* K, const void* Vt, int len, int ldk, int ldvt, void* O, int Nq, int H,
                                             int head_dim, int ldq, int ldo, float softmax_scale, int batch, int blk_rows, int blk_stride,
                                             int vt_sample_cols, hipStream_t stream) {
   if (blk_rows <= 0) return CE_ERR_SHAPE;
@@ -1665,7 +1671,7 @@ static int attention_2seg_vt_launch(const void* Q, const void* K1, const void* V
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
+CE_API int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
                                          const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* O, int Nq,
                                          int H, int head_dim, int ldq, int ldo, float softmax_scale, int batch, hipStream_t stream) {
   if (!O) return CE_ERR_ARG;
@@ -1676,7 +1682,7 @@ extern "C" int ce_attention_2seg_vt_bf16(const void* Q, const void* K1, const vo
 /* The same attention with the output written as the MX fp8 operand of the out-projection that follows it in the fp8 mode: o8 e4m3
  * [batch Nq][ldo8] + E8M0 scales per 32 channels in the tiled layout of ce_gemm_mxfp8 (rows = batch Nq, K = H head_dim) - bit-identical to
  * ce_attention_2seg_vt_bf16 followed by ce_quant_rows_mxfp8. */
-extern "C" int ce_attention_2seg_vt_quant_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
+CE_API int ce_attention_2seg_vt_quant_bf16(const void* Q, const void* K1, const void* V1t, int len1, int ldk1, int ldv1t, int vt_cols1,
                                                const void* K2, const void* V2t, int len2, int ldk2, int ldv2t, int vt_cols2, void* o8,
                                                void* scale8, int Nq, int H, int head_dim, int ldq, int ldo8, float softmax_scale, int batch,
                                                hipStream_t stream) {

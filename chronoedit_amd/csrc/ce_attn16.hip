@@ -27,6 +27,9 @@
 //    in fp32 / bf16: no precision is lost by an offset that lags), so accumulators are rescaled on the first tiles only; the row sums of the
 //    rounded P come off the matrix pipe (an all-ones operand against P: 4 MFMAs per tile instead of 32 adds per lane).
 //  * work order: attn_fwd_sp_kernel's (an XCD keeps its heads; batch folded into the item index; persistent workgroups).
+//  * PRECONDITION on V^T: the padded columns [len, ceil64(len)) of every channel row must hold FINITE values (the callers zero-fill the buffer;
+//    ce_v_transpose_bf16 and the CE_EPI_BIAS_ROW projection write zeros there): masked keys get P = 0, and 0 x NaN garbage would still be NaN.
+//  * Built into libchronoedit_hip_diag.so ONLY (round 6): the product library neither contains nor dispatches to this body.
 #include "ce_common.h"
 
 namespace {
@@ -284,7 +287,9 @@ extern "C" int ce_attn16_launch(const void* Q, const void* K, const void* Vt, in
   }
   const int nqb = (Nq + 8 * QW - 1) / (8 * QW);
   const int items = nqb * H * batch;
-  const int grid = items <= 2 * cus ? items : ((2 * cus) & ~7);
+  // NST * STAGE = 96 KiB of LDS: ONE workgroup fits on a CU, so the persistent grid is one per CU (2 x cus ran as two serial rounds with no
+  // tail balancing: ADVICE r5)
+  const int grid = items <= cus ? items : (cus & ~7);
   hipLaunchKernelGGL(attn_fwd_x16_kernel, dim3(grid), dim3(512), NST * STAGE, stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, Nq, len, H,
                      ldq, ldk, ldvt, ldo, nqb, sl2, batch, len);
   return (int)hipGetLastError();

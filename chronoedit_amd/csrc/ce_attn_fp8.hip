@@ -849,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
 
 }  // namespace
 
-extern "C" int ce_rmsnorm_rope_mxfp8(const void* x, const float* w, const float* cos_sin, void* q8, void* scale8, int M, int D, int ldx,
+CE_API int ce_rmsnorm_rope_mxfp8(const void* x, const float* w, const float* cos_sin, void* q8, void* scale8, int M, int D, int ldx,
                                      int ldq, int head_dim, float eps, int rope_rows, float post_scale, hipStream_t stream) {
   if (!x || !w || !q8 || !scale8) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 31) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (head_dim & 31) || D % head_dim) return CE_ERR_SHAPE;
@@ -862,7 +862,7 @@ extern "C" int ce_rmsnorm_rope_mxfp8(const void* x, const float* w, const float*
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv, int n_tokens, int batch, int H, int npad, hipStream_t stream) {
+CE_API int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv, int n_tokens, int batch, int H, int npad, hipStream_t stream) {
   if (!v || !v8t || !sv) return CE_ERR_ARG;
   if (n_tokens <= 0 || batch <= 0 || H <= 0 || (ldv & 7) || (npad & 63) || npad < n_tokens) return CE_ERR_SHAPE;
   hipLaunchKernelGGL(v_mxfp8_transpose_kernel, dim3(npad / KVB, H, batch), dim3(256), 0, stream, (const bf16*)v, ldv, (unsigned char*)v8t,
@@ -870,18 +870,20 @@ extern "C" int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv,
   return (int)hipGetLastError();
 }
 
-static int g_mxfp8_persist = 512;  // workgroups of the persistent form (0: one workgroup per work item); a multiple of 8
-extern "C" int ce_set_attention_mxfp8_persistent(int n) {
+CE_KNOB g_mxfp8_persist = 512;  // workgroups of the persistent form (0: one workgroup per work item); a multiple of 8
+CE_KNOB g_mxfp8_variant = 1;    // 0: plain kernel (exact running maximum every tile), 1: software-pipelined (default)
+#ifdef CE_DIAGNOSTICS
+CE_API int ce_set_attention_mxfp8_persistent(int n) {
   const int old = g_mxfp8_persist;
   if (n >= 0 && (n & 7) == 0) g_mxfp8_persist = n;
   return old;
 }
-static int g_mxfp8_variant = 1;  // 0: plain kernel (exact running maximum every tile), 1: software-pipelined (default)
-extern "C" int ce_set_attention_mxfp8_variant(int v) {
+CE_API int ce_set_attention_mxfp8_variant(int v) {
   const int old = g_mxfp8_variant;
   if (v == 0 || v == 1) g_mxfp8_variant = v;
   return old;
 }
+#endif
 
 static int attention_mxfp8_launch(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
                                   int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, void* O8, void* S8,
@@ -913,14 +915,14 @@ static int attention_mxfp8_launch(const void* q8, const void* sq, const void* k8
 // Second segment of a two-segment attention (the cross-attention's image segment, transformer_chronoedit.py:96-107): as ce_attention_mxfp8 /
 // ce_attention_mxfp8_quant, with the bf16 rows o_add [batch Nq][ldadd] - the first segment's result - added to this segment's bf16-rounded
 // result; the sum is stored as bf16 (O; may be o_add itself) or as the out-projection's MX operand (o8 + scale8; exactly one of the two).
-extern "C" int ce_attention_mxfp8_add(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv,
+CE_API int ce_attention_mxfp8_add(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv,
                                       const void* o_add, int ldadd, void* O, int ldo, void* o8, void* scale8, int ldo8, int Nq, int Nkv, int npad,
                                       int H, int head_dim, int ldq8, int ldk8, int batch, hipStream_t stream) {
   if (!o_add || (O == nullptr) == (o8 == nullptr)) return CE_ERR_ARG;
   return attention_mxfp8_launch(q8, sq, k8, sk, v8t, sv, O, Nq, Nkv, npad, H, head_dim, ldq8, ldk8, ldo, batch, o8, scale8, ldo8, stream, o_add, ldadd);
 }
 
-extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
+CE_API int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv, void* O,
                                   int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo, int batch, hipStream_t stream) {
   if (!O) return CE_ERR_ARG;
   return attention_mxfp8_launch(q8, sq, k8, sk, v8t, sv, O, Nq, Nkv, npad, H, head_dim, ldq8, ldk8, ldo, batch, nullptr, nullptr, 0, stream);
@@ -929,7 +931,7 @@ extern "C" int ce_attention_mxfp8(const void* q8, const void* sq, const void* k8
 // The same attention with its output written as the out-projection's MX operand: o8 e4m3 [batch Nq][ldo8] + E8M0 block scales in the
 // tiled layout of ce_gemm_mxfp8 (rows = batch Nq, K = H head_dim) - bit-identical to ce_attention_mxfp8 followed by ce_quant_rows_mxfp8
 // (the software-pipelined kernel whatever ce_set_attention_mxfp8_variant says).
-extern "C" int ce_attention_mxfp8_quant(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv,
+CE_API int ce_attention_mxfp8_quant(const void* q8, const void* sq, const void* k8, const void* sk, const void* v8t, const void* sv,
                                         void* o8, void* scale8, int Nq, int Nkv, int npad, int H, int head_dim, int ldq8, int ldk8, int ldo8,
                                         int batch, hipStream_t stream) {
   if (!o8 || !scale8) return CE_ERR_ARG;

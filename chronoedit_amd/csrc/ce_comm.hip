@@ -44,7 +44,7 @@ int fail(const char* what, ncclResult_t r) {
 
 }  // namespace
 
-extern "C" int ce_comm_load(const char* librccl_path) {
+CE_API int ce_comm_load(const char* librccl_path) {
   std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.handle) return CE_OK;
   if (!librccl_path) return CE_ERR_ARG;
@@ -76,7 +76,7 @@ extern "C" int ce_comm_load(const char* librccl_path) {
   return CE_OK;
 }
 
-extern "C" int ce_comm_unique_id(void* id128) {
+CE_API int ce_comm_unique_id(void* id128) {
   if (!g_rccl.handle || !id128) return CE_ERR_ARG;
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   ncclUniqueId id;
@@ -86,7 +86,7 @@ extern "C" int ce_comm_unique_id(void* id128) {
   return CE_OK;
 }
 
-extern "C" int ce_comm_init(void** comm_out, const void* id128, int rank, int world) {
+CE_API int ce_comm_init(void** comm_out, const void* id128, int rank, int world) {
   if (!g_rccl.handle || !comm_out || !id128 || world < 1 || rank < 0 || rank >= world) return CE_ERR_ARG;
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof id);
@@ -97,7 +97,7 @@ extern "C" int ce_comm_init(void** comm_out, const void* id128, int rank, int wo
   return CE_OK;
 }
 
-extern "C" int ce_comm_destroy(void* comm) {
+CE_API int ce_comm_destroy(void* comm) {
   if (!comm) return CE_OK;
   CeComm* c = static_cast<CeComm*>(comm);
   const ncclResult_t r = g_rccl.handle ? g_rccl.CommDestroy(c->comm) : ncclSuccess;
@@ -107,7 +107,7 @@ extern "C" int ce_comm_destroy(void* comm) {
 
 // send / recv: `world` chunks of bytes_per_peer bytes each, chunk p going to / coming from rank p (the layout of
 // torch.distributed.all_to_all_single with equal splits).  One grouped batch of ncclSend / ncclRecv pairs on `stream`.
-extern "C" int ce_comm_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream) {
+CE_API int ce_comm_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream) {
   if (!g_rccl.handle || !comm || !send || !recv || bytes_per_peer == 0) return CE_ERR_ARG;
   CeComm* c = static_cast<CeComm*>(comm);
   ncclResult_t r = g_rccl.GroupStart();
@@ -123,7 +123,7 @@ extern "C" int ce_comm_all_to_all(void* comm, const void* send, void* recv, size
 }
 
 // recv = the ranks' `bytes_per_rank`-byte blocks in rank order.
-extern "C" int ce_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) {
+CE_API int ce_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) {
   if (!g_rccl.handle || !comm || !send || !recv || bytes_per_rank == 0) return CE_ERR_ARG;
   CeComm* c = static_cast<CeComm*>(comm);
   const ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank, ncclInt8, c->comm, stream);

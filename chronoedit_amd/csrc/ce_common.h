@@ -16,6 +16,16 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 #define CE_WAVE 64
 
+// The shared library is built with -fvisibility=hidden: CE_API marks the entry points include/chronoedit_hip.h declares (and, in the
+// -DCE_DIAGNOSTICS build, the selectors of include/chronoedit_hip_diag.h); cross-TU helpers stay `extern "C"` and hidden.
+#define CE_API extern "C" __attribute__((visibility("default")))
+// A kernel-body selector: a constant at its default in the product build, a process-wide variable with an exported setter in the diagnostic build
+#ifdef CE_DIAGNOSTICS
+#define CE_KNOB static int
+#else
+#define CE_KNOB static constexpr int
+#endif
+
 // error codes returned by every extern "C" launcher (include/chronoedit_hip.h)
 #define CE_OK 0
 #define CE_ERR_ARG (-1)

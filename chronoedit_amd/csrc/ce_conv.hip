@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias,
+CE_API int ce_conv_igemm_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias,
                                   void* const* out_frames, int n_out_frames, const void* const* res_frames, int Cin, int Cout,
                                   int KT, int KH, int KW, int st, int ss, int H_out, int W_out, int in_Wp, int in_off_h,
                                   int in_off_w, int out_Wp, int out_border, int out_cstride, int out_coff, hipStream_t stream) {
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void conv_head_kernel(ConvParams p, int H_tile
 // 3 x 3 x 3 (KT = 3) or 1 x 3 x 3 (KT = 1) stride-1 conv of 96 input channels onto Cout <= 4 channels (weight [>= Cout][KT*9][96]).
 // Frames, addressing and result as ce_conv_igemm_bf16 with st = ss = 1, in_off = 0 and no residual; channels Cout .. 3 (and .. 7 when the
 // pixel stride leaves room for them) are written as zeros.
-extern "C" int ce_conv3d_head_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias,
+CE_API int ce_conv3d_head_bf16(const void* const* in_frames, int n_in_frames, const void* weight, const float* bias,
                                    void* const* out_frames, int n_out_frames, int Cin, int Cout, int KT, int H_out, int W_out, int in_Wp,
                                    int out_Wp, int out_border, int out_cstride, int out_coff, hipStream_t stream) {
   if (!in_frames || !weight || !out_frames) return CE_ERR_ARG;
@@ -477,7 +477,7 @@ extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, c
                                         int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
                                         long long a_seg2_stride, int n_tile, hipStream_t stream);
 
-extern "C" int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
+CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
                                    int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream) {
   if (!in_stack || !weight || !out_stack) return CE_ERR_ARG;
   if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3) || (n_tile != 0 && n_tile != 96 && n_tile != 128 && n_tile != 256)) return CE_ERR_SHAPE;
@@ -522,7 +522,7 @@ extern "C" int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,
+CE_API int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,
                                 int out_border, int apply_silu, hipStream_t stream) {
   if (!x || !y || !gamma || npix <= 0) return CE_ERR_ARG;
   if ((C & 7) || C > 512 || H <= 0 || W <= 0 || npix % ((long long)H * W)) return CE_ERR_SHAPE;
@@ -549,7 +549,7 @@ extern "C" int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long
 
 /* Zero the one-pixel border of T frames [H+2][W+2][ld] (channels [0, C)): what a producer that writes interiors only leaves to do on a
  * buffer that was not zero-filled. */
-extern "C" int ce_zero_border_bf16(void* frames, int T, int H, int W, int C, int ld, hipStream_t stream) {
+CE_API int ce_zero_border_bf16(void* frames, int T, int H, int W, int C, int ld, hipStream_t stream) {
   if (!frames || T <= 0 || H <= 0 || W <= 0 || (C & 7) || (ld & 7) || ld < C) return CE_ERR_ARG;
   const int Hp = H + 2, Wp = W + 2;
   const long long n = (long long)T * (2 * Wp + 2 * (Hp - 2)) * (C / 8);
@@ -557,7 +557,7 @@ extern "C" int ce_zero_border_bf16(void* frames, int T, int H, int W, int C, int
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipStream_t stream) {
+CE_API int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipStream_t stream) {
   if (!x || !y || (C & 7) || T <= 0) return CE_ERR_ARG;
   const long long n = (long long)T * (2 * H) * (2 * W) * (C / 8);
   hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16*)x, (bf16*)y, n, C / 8,
@@ -565,7 +565,7 @@ extern "C" int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, i
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int npad, int ld, int ldp, float scale,
+CE_API int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int n, int npad, int ld, int ldp, float scale,
                                         hipStream_t stream) {
   if (!scores || !probs || M <= 0 || n <= 0 || npad < n || npad > ldp) return CE_ERR_ARG;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, stream, scores, (bf16*)probs, n, npad, ld, ldp, scale);
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void attn_1head_kernel(const bf16* __restrict_
 // O [Nq][ldo] = softmax(Q K^T * scale) V for ONE head of dimension C (128 or 384): Q [Nq][ldq], K [Nk][ldk] bf16 rows, Vt [C][ldvt] =
 // V transposed (keys contiguous; columns [Nk, 64 ceil(Nk / 64)) must be finite - zero them).  Replaces the q.k^T / softmax / .v of the
 // VAE's AttentionBlock (chronoedit/_src/tokenizers/wan2pt1.py:247-255, F.scaled_dot_product_attention on [b t, 1, h w, c]).
-extern "C" int ce_attention_1head_bf16(const void* Q, const void* K, const void* Vt, void* O, int Nq, int Nk, int C, int ldq, int ldk, int ldvt,
+CE_API int ce_attention_1head_bf16(const void* Q, const void* K, const void* Vt, void* O, int Nq, int Nk, int C, int ldq, int ldk, int ldvt,
                                        int ldo, float softmax_scale, hipStream_t stream) {
   if (!Q || !K || !Vt || !O || Nq <= 0 || Nk <= 0) return CE_ERR_ARG;
   if ((C != 128 && C != 384) || (ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3) || ldvt < (Nk + 63) / 64 * 64) return CE_ERR_SHAPE;

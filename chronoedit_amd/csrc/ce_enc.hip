@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void softmax_t5_kernel(const float* __restrict
 
 }  // namespace
 
-extern "C" int ce_im2col_patch2d_bf16(const void* img, void* cols, int B, int C, int H, int W, int P, int Kpad, hipStream_t stream) {
+CE_API int ce_im2col_patch2d_bf16(const void* img, void* cols, int B, int C, int H, int W, int P, int Kpad, hipStream_t stream) {
   if (!img || !cols) return CE_ERR_ARG;
   if (B <= 0 || C <= 0 || P <= 0 || H % P || W % P || Kpad < C * P * P) return CE_ERR_SHAPE;
   const long long total = (long long)B * (H / P) * (W / P) * Kpad;
@@ -137,7 +137,7 @@ extern "C" int ce_im2col_patch2d_bf16(const void* img, void* cols, int B, int C,
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_gather_rows_bf16(const void* table, const long long* ids, void* out, int n, int D, int ldt, int ldo, int vocab,
+CE_API int ce_gather_rows_bf16(const void* table, const long long* ids, void* out, int n, int D, int ldt, int ldo, int vocab,
                                    hipStream_t stream) {
   if (!table || !ids || !out) return CE_ERR_ARG;
   if (n <= 0 || D <= 0 || vocab <= 0) return CE_ERR_SHAPE;
@@ -147,7 +147,7 @@ extern "C" int ce_gather_rows_bf16(const void* table, const long long* ids, void
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_rmsnorm_bf16(const void* x, void* y, const void* w, int M, int D, int ldx, int ldy, float eps, hipStream_t stream) {
+CE_API int ce_rmsnorm_bf16(const void* x, void* y, const void* w, int M, int D, int ldx, int ldy, float eps, hipStream_t stream) {
   if (!x || !y || !w) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || D > 64 * 8 * RMS_MAXC) return CE_ERR_SHAPE;
   if ((D & 7) || (ldx & 7) || (ldy & 7)) return CE_ERR_ALIGN;
@@ -155,7 +155,7 @@ extern "C" int ce_rmsnorm_bf16(const void* x, void* y, const void* w, int M, int
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_softmax_t5_bf16(const float* scores, void* probs, int batch, int heads, int Lq, int Lk, int ld, int ldp,
+CE_API int ce_softmax_t5_bf16(const float* scores, void* probs, int batch, int heads, int Lq, int Lk, int ld, int ldp,
                                   const int* bucket_lut, const float* table, const int* valid_len, hipStream_t stream) {
   if (!scores || !probs || ((table != nullptr) != (bucket_lut != nullptr))) return CE_ERR_ARG;
   if (batch <= 0 || heads <= 0 || Lq <= 0 || Lk <= 0 || Lk > 64 * SM_MAXK || ldp < Lk || ldp > 64 * SM_MAXK || ld < Lk) return CE_ERR_SHAPE;

@@ -19,6 +19,8 @@
 //   EPI_BIAS_GELU_ERF  same with the exact (erf) GELU                         (image MLP, K3)
 //   EPI_GATE_RES   C = bf16(float(res) + float(bf16(acc + bias)) * gate[n])   (K10/K15/K17;
 //                  gate == nullptr -> 1.0, i.e. the plain bf16 residual add of :286)
+#include <cmath>
+
 #include "ce_common.h"
 
 #define EPI_BIAS 0
@@ -239,13 +241,15 @@ extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const 
 // 128-tile kernel; whenever the shape allows the 256-tile kernel: 1 = its 8-wave / 8-phase main loop, 2 = the same staggered (two
 // wave groups one barrier apart), 3 / 4 = the one-wave-per-SIMD main loop of ce_gemm256w4.hip with an A ring of 3 / 2 stages, 5 = 3 stages and one barrier per K-tile,
 // 6 = the 384 x 256 macro tile of ce_gemm384.hip (4 waves, 192 x 128 wave tiles, one barrier per K-tile)
-static int g_gemm_variant = -1;
-extern "C" int ce_set_gemm_variant(int v) {
+CE_KNOB g_gemm_variant = -1;
+#ifdef CE_DIAGNOSTICS
+CE_API int ce_set_gemm_variant(int v) {
   const int old = g_gemm_variant;
   g_gemm_variant = v;
   ce_gemm256_set_staggered(v == 2);
   return old;
 }
+#endif
 
 // Column k of A lives at A + (k / a_seg_k) * a_seg_stride + m * lda + k % a_seg_k: the layout an all-to-all leaves the
 // attention output in ([source rank][local row][D / W], chronoedit_amd/parallel.py), consumed by the out-projection
@@ -262,14 +266,24 @@ extern "C" void ce_gemm256_workspace(hipStream_t stream, float** ws, size_t* byt
 // half round + reduce against 760 tiles of 384 x 256 = 2.97 rounds (measured +3 ... +4 %); N = 13824: 12.02 against 8.02 rounds
 // (256 x 256 wins by 2.6 %); the V^T product (M = 5120 = 13.3 tiles of 384 rows: 5 % of padding) stays on 256 x 256.
 // Exported as a pure function of the shape, the CU count and the split-K workspace size (tests/test_host_cpu.py pins the step's choices).
-extern "C" int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_bytes) {
+CE_API int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_bytes) {
   if (M <= 0 || N <= 0 || K < 64 || cus <= 0) return 0;
   const int kt = K / 64;
+  // Round 6: refitted on the 41 (shape, tile) timings of profiles/r06_gemm_tile_choice.txt - the five large GEMMs of a block at every row count
+  // the engine runs them on: M = 7 200 (distilled B = 1 step, BASELINE configs[2]), 14 400 (configs[1]), 13 068 / 26 136 (configs[4]), 28 800 /
+  // 57 600 (configs[3] on one GPU), 3 648 / 7 296 (a rank of the 8-GPU split); the round-3 form was fitted at M = 14 400 only and left 2.1 ms
+  // per forward on the table at M = 7 200.  In microseconds: a K-tile of a 256 x 256 tile costs 1.40 us on a busy chip, of a 384 x 256 tile
+  // 1.5 x that x 0.96 (a sixth fewer operand bytes per flop), x 1.04 when the A operand does not stay in the 256 MB last-level cache beside W
+  // (M K 2 B > 128 MiB: the M = 14 400 FFN-up runs the large tile 2.3 % slower, the M = 7 200 one 3.0 % faster).  A partial last round that
+  // cannot be cut along K costs fill^0.3 of a round (measured 0.6 ... 0.8 of a round at 48 ... 59 % fill: fewer tiles share the L2 and the
+  // power budget); one that can costs its K share plus the fp32 slabs, written and read back at ~6 TB/s (the round-3 form charged an eighth of
+  // a round whatever K and the slab volume were).  On the 41 shapes the picks lose 0.4 % of the summed best-tile time (round-3 form: 2.3 %).
   auto cost = [&](int bm) -> double {
     const long long nwg = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
     const long long full = nwg / cus;
     const int tail = (int)(nwg % cus);
-    double last = 0.0;
+    const double c = bm == 256 ? 1.40 : 1.40 * 1.5 * 0.96 * ((double)M * K * 2.0 > 128.0 * 1048576.0 ? 1.04 : 1.0);
+    double t = (double)full * kt * c;
     if (tail > 0) {
       int split = 1;
       for (int sp = cus / tail < 8 ? cus / tail : 8; sp >= 2; --sp)
@@ -277,9 +291,10 @@ extern "C" int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws
           split = sp;
           break;
         }
-      last = split > 1 ? 1.0 / split + 0.125 : 1.0;
+      if (split > 1) t += (double)kt / split * c + (double)tail * split * bm * 256.0 * 8.0 / 6.0e6;
+      else t += (double)kt * c * pow((double)tail / cus, 0.3);
     }
-    return ((double)full + last) * bm * 256.0;
+    return t;
   };
   return cost(384) <= cost(256) ? 384 : 256;
 }
@@ -292,7 +307,7 @@ static bool prefer_tile384(int M, int N, int K, hipStream_t stream) {
   return ce_gemm_bf16_tile_rows(M, N, K, cus, ws != nullptr ? (long long)ws_bytes : 0) == 384;
 }
 
-extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+CE_API int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
   if (!A || !W || !C) return CE_ERR_ARG;
@@ -343,13 +358,13 @@ extern "C" int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const flo
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+CE_API int ce_gemm_aseg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  int a_seg_k, long long a_seg_stride, hipStream_t stream) {
   return ce_gemm_seg_bf16(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, 0, 0, stream);
 }
 
-extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+CE_API int ce_gemm_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                             const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                             hipStream_t stream) {
   return ce_gemm_seg_bf16(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, 0, 0, 0, 0, stream);
@@ -358,7 +373,7 @@ extern "C" int ce_gemm_bf16(const void* A, const void* W, void* C, const float* 
 // batch0 x batch1 independent products with two-level element strides (e.g. head within sample): operand z = (z0, z1) is
 // A + z0 sA0 + z1 sA1, W + z0 sW0 + z1 sW1, C + z0 sC0 + z1 sC1 (C strides in elements of C's type).  Epilogues EPI_BIAS
 // and EPI_F32 only; always the 128-tile kernel (these are the per-head attention products of the encoders).
-extern "C" int ce_gemm_batched_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, int M, int N, int K,
+CE_API int ce_gemm_batched_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, int M, int N, int K,
                                     int lda, int ldw, int ldc, int batch0, int batch1, long long sA0, long long sA1, long long sW0,
                                     long long sW1, long long sC0, long long sC1, hipStream_t stream) {
   if (!A || !W || !C) return CE_ERR_ARG;

@@ -447,8 +447,12 @@ extern "C" int ce_gemm256_supported(int M, int N, int K, int lda, int ldw) {
   return 1;
 }
 
+#ifdef CE_DIAGNOSTICS
 static bool staggered = false;
 extern "C" void ce_gemm256_set_staggered(int on) { staggered = on != 0; }
+#else
+static constexpr bool staggered = false;
+#endif
 
 // Scratch for the split-K tail (fp32 slabs); without it every tile runs whole.  Host-side registry, not on the data path: one DEFAULT
 // scratch per device (ce_set_gemm_workspace, registered for the current device) and, for callers that run GEMMs on several streams of
@@ -479,7 +483,7 @@ int device_cus(int slot) {
 }
 }  // namespace
 
-extern "C" int ce_set_gemm_workspace(void* ptr, size_t bytes) {
+CE_API int ce_set_gemm_workspace(void* ptr, size_t bytes) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   const int slot = ce_device_slot();
   g_ws_dev[slot].ptr = reinterpret_cast<float*>(ptr);
@@ -488,7 +492,7 @@ extern "C" int ce_set_gemm_workspace(void* ptr, size_t bytes) {
   return CE_OK;
 }
 
-extern "C" int ce_set_gemm_workspace_stream(hipStream_t stream, void* ptr, size_t bytes) {
+CE_API int ce_set_gemm_workspace_stream(hipStream_t stream, void* ptr, size_t bytes) {
   std::lock_guard<std::mutex> lock(g_ws_mutex);
   const int slot = ce_device_slot();
   int at = -1;

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void quant_rows_mxfp8_kernel(const bf16* __res
 /* x bf16 [M][ldx] -> q e4m3 bytes [M][ldq] + E8M0 block scales (one per 32 consecutive elements of a row, scale = 2^(floor(log2 amax) - 8),
  * elements RNE(x / scale) clamped to +-448: the OCP MX contract of oracle.dit_oracle.mx_quant) in the tiled layout of ce_gemm_mxfp8:
  * scale8 holds ceil(M / 128) * (K / 128) * 512 bytes.  K % 128 == 0. */
-extern "C" int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream) {
+CE_API int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream) {
   if (!x || !q || !scale8) return CE_ERR_ARG;
   if (M <= 0 || K <= 0 || (K & 127)) return CE_ERR_SHAPE;
   if ((ldx & 7) || (ldq & 7)) return CE_ERR_ALIGN;
@@ -360,7 +360,7 @@ extern "C" int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, 
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, int K, int ldx, int ldq, hipStream_t stream) {
+CE_API int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, int K, int ldx, int ldq, hipStream_t stream) {
   if (!x || !q || !scale) return CE_ERR_ARG;
   if (M <= 0 || K <= 0) return CE_ERR_SHAPE;
   if ((K & 7) || (ldx & 7) || (ldq & 7)) return CE_ERR_ALIGN;
@@ -379,14 +379,16 @@ extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, con
 
 // main loop of ce_gemm_fp8: 1 = one wave per SIMD (ce_gemm_fp8w4.hip; the default: +2 ... +8 % on the step's shapes,
 // profiles/r03_gemm_fp8_variants_ab.txt), 0 = the 8-wave / 4-phase loop of this file
-static int g_fp8_variant = 1;
-extern "C" int ce_set_gemm_fp8_variant(int v) {
+CE_KNOB g_fp8_variant = 1;
+#ifdef CE_DIAGNOSTICS
+CE_API int ce_set_gemm_fp8_variant(int v) {
   const int old = g_fp8_variant;
   if (v == 0 || v == 1) g_fp8_variant = v;
   return old;
 }
+#endif
 
-extern "C" int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias, int epilogue,
+CE_API int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const float* sw, const float* bias, int epilogue,
                            const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
                            int gate_rows, hipStream_t stream) {
   if (!Aq || !Wq || !C || !sa || !sw) return CE_ERR_ARG;

@@ -745,7 +745,7 @@ extern "C" int ce_gemm_fp8w4_launch(const void* Aq, const void* Wq, void* C, con
 /* The MX form (header of this file): Aq [M][lda], Wq [N][ldw] e4m3 bytes; sa8 / sw8 E8M0 bytes in the tiled order
  * [ceil(rows / 128)][K / 128][4][16][8] (byte of row r, elements [128 t + 32 g, + 32): ((r / 128 * K/128 + t) * 4 + g) * 128 + (r % 16) * 8 +
  * (r / 16) % 8 = exponent + 127), as ce_quant_rows_mxfp8 / ce_ln_affine_mxfp8 write them. */
-extern "C" int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void* sa8, const void* sw8, const float* bias, int epilogue,
+CE_API int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void* sa8, const void* sw8, const float* bias, int epilogue,
                              const float* gate, const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                              hipStream_t stream) {
   if (!Aq || !Wq || !C || !sa8 || !sw8) return CE_ERR_ARG;
@@ -760,7 +760,7 @@ extern "C" int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void
 
 /* bias + tanh GELU with the MX quantisation of the result fused into the epilogue (include/chronoedit_hip.h); the split-K tail of a
  * partially filled last round goes through gemm_fp8w4_reduce_gelu_q. */
-extern "C" int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* sa8, const void* sw8, const float* bias, void* q_out, void* qs_out,
+CE_API int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* sa8, const void* sw8, const float* bias, void* q_out, void* qs_out,
                                         int M, int N, int K, int lda, int ldw, int ldq, hipStream_t stream) {
   if (!Aq || !Wq || !sa8 || !sw8 || !q_out || !qs_out) return CE_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (K % (2 * BKB)) || (N & 127)) return CE_ERR_SHAPE;
@@ -799,4 +799,16 @@ extern "C" int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const vo
     hipLaunchKernelGGL(gemm_fp8w4_reduce_gelu_q, dim3(4 * tail), dim3(256), 0, stream, (unsigned char*)q_out, (unsigned char*)qs_out, bias, M, N, ldq,
                        tiles_m, tiles_n, t_full, split, g_ws);
   return (int)hipGetLastError();
+}
+
+/* How this library was compiled (include/chronoedit_hip.h): bit 0 the diagnostic build (-DCE_DIAGNOSTICS), bit 1 F8_A3, bits 4-7
+ * F8_DMA_SCHED, bits 8-15 F8_ABLATE (non-zero: a timing-only build of the MX fp8 GEMM whose RESULTS ARE GARBAGE - the loader refuses it
+ * unless asked for by name). */
+CE_API int ce_build_info(void) {
+  int v = 0;
+#ifdef CE_DIAGNOSTICS
+  v |= 1;
+#endif
+  v |= (F8_A3 ? 2 : 0) | ((F8_DMA_SCHED & 15) << 4) | ((F8_ABLATE & 255) << 8);
+  return v;
 }

@@ -419,7 +419,7 @@ __global__ void unpatchify_kernel(const bf16* __restrict__ y, bf16* __restrict__
 // ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
-extern "C" int ce_ln_affine_bf16(const void* x, void* y, const float* a, const float* b, int M, int D, int ldx, int ldy,
+CE_API int ce_ln_affine_bf16(const void* x, void* y, const float* a, const float* b, int M, int D, int ldx, int ldy,
                                  float eps, int ab_rows, int ab_stride, hipStream_t stream) {
   if (!x || !y || !a || !b) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldy & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
@@ -437,7 +437,7 @@ extern "C" int ce_ln_affine_bf16(const void* x, void* y, const float* a, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_ln_affine_fp8(const void* x, void* q, float* scale, const float* a, const float* b, int M, int D, int ldx, int ldq,
+CE_API int ce_ln_affine_fp8(const void* x, void* q, float* scale, const float* a, const float* b, int M, int D, int ldx, int ldq,
                                 float eps, int ab_rows, int ab_stride, hipStream_t stream) {
   if (!x || !q || !scale || !a || !b) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
@@ -453,7 +453,7 @@ extern "C" int ce_ln_affine_fp8(const void* x, void* q, float* scale, const floa
 
 /* ce_ln_affine_bf16 followed by ce_quant_rows_mxfp8 in one pass (q: e4m3 bytes, scale8: E8M0 block scales in the tiled layout of
  * ce_gemm_mxfp8, ceil(M / 128) * (D / 128) * 512 bytes).  D % 128 == 0. */
-extern "C" int ce_ln_affine_mxfp8(const void* x, void* q, void* scale8, const float* a, const float* b, int M, int D, int ldx, int ldq, float eps,
+CE_API int ce_ln_affine_mxfp8(const void* x, void* q, void* scale8, const float* a, const float* b, int M, int D, int ldx, int ldq, float eps,
                                   int ab_rows, int ab_stride, hipStream_t stream) {
   if (!x || !q || !scale8 || !a || !b) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 127) || D > 64 * 8 * ROW_MAXC || (ldx & 7) || (ldq & 7) || (ab_rows > 0 && (ab_stride & 3))) return CE_ERR_SHAPE;
@@ -466,7 +466,7 @@ extern "C" int ce_ln_affine_mxfp8(const void* x, void* q, void* scale8, const fl
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_rmsnorm_rope_bf16(void* x, const float* w, void* x2, const float* w2, const float* cos_sin, int M, int D, int ld,
+CE_API int ce_rmsnorm_rope_bf16(void* x, const float* w, void* x2, const float* w2, const float* cos_sin, int M, int D, int ld,
                                     int head_dim, float eps, int rope_rows, hipStream_t stream) {
   if (!x || !w || (x2 && !w2)) return CE_ERR_ARG;
   if (M <= 0 || D <= 0 || (D & 7) || D > 64 * 8 * ROW_MAXC || (ld & 7) || (head_dim & 7) || D % head_dim) return CE_ERR_SHAPE;
@@ -479,19 +479,19 @@ extern "C" int ce_rmsnorm_rope_bf16(void* x, const float* w, void* x2, const flo
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_timestep_sinusoid(const int64_t* t, float* out, int dim, hipStream_t stream) {
+CE_API int ce_timestep_sinusoid(const int64_t* t, float* out, int dim, hipStream_t stream) {
   if (!t || !out || dim <= 0 || (dim & 1)) return CE_ERR_ARG;
   hipLaunchKernelGGL(timestep_sinusoid_kernel<int64_t>, dim3((dim + 255) / 256), dim3(256), 0, stream, t, out, dim);
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_timestep_sinusoid_f32(const float* t, float* out, int dim, hipStream_t stream) {
+CE_API int ce_timestep_sinusoid_f32(const float* t, float* out, int dim, hipStream_t stream) {
   if (!t || !out || dim <= 0 || (dim & 1)) return CE_ERR_ARG;
   hipLaunchKernelGGL(timestep_sinusoid_kernel<float>, dim3((dim + 255) / 256), dim3(256), 0, stream, t, out, dim);
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_gemv(const void* W, int w_is_bf16, const float* x, const float* bias, float* y, int N, int K, int flags,
+CE_API int ce_gemv(const void* W, int w_is_bf16, const float* x, const float* bias, float* y, int N, int K, int flags,
                        hipStream_t stream) {
   if (!W || !x || !y || N <= 0 || K <= 0) return CE_ERR_ARG;
   if (K > 16384) return CE_ERR_SHAPE;  // pre(x) is staged in LDS (64 KiB)
@@ -504,7 +504,7 @@ extern "C" int ce_gemv(const void* W, int w_is_bf16, const float* x, const float
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_modulation(const float* table, const float* v, float* mod, int L, int J, int D, int v_rows, int one_mask,
+CE_API int ce_modulation(const float* table, const float* v, float* mod, int L, int J, int D, int v_rows, int one_mask,
                              hipStream_t stream) {
   if (!table || !v || !mod || L <= 0 || J <= 0 || D <= 0 || (v_rows != 1 && v_rows != J)) return CE_ERR_ARG;
   const size_t total = (size_t)L * J * D;
@@ -513,7 +513,7 @@ extern "C" int ce_modulation(const float* table, const float* v, float* mod, int
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_patchify_rows_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, int row0, int nrows,
+CE_API int ce_patchify_rows_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, int row0, int nrows,
                                      hipStream_t stream) {
   if (!x || !cols || (H & 1) || (W & 1) || Kpad < C * 4 || row0 < 0 || nrows <= 0) return CE_ERR_ARG;
   const size_t total = (size_t)nrows * Kpad;
@@ -522,12 +522,12 @@ extern "C" int ce_patchify_rows_bf16(const void* x, void* cols, int C, int T, in
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_patchify_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, hipStream_t stream) {
+CE_API int ce_patchify_bf16(const void* x, void* cols, int C, int T, int H, int W, int Kpad, hipStream_t stream) {
   if ((H & 1) || (W & 1)) return CE_ERR_ARG;
   return ce_patchify_rows_bf16(x, cols, C, T, H, W, Kpad, 0, T * (H / 2) * (W / 2), stream);
 }
 
-extern "C" int ce_rope_scatter_bf16(const void* x, int ldx, void* send, int M, int D, int W, int nt, int col0, const float* w0,
+CE_API int ce_rope_scatter_bf16(const void* x, int ldx, void* send, int M, int D, int W, int nt, int col0, const float* w0,
                                     int col1, const float* w1, int col2, const float* w2, const float* cos_sin, int head_dim,
                                     float eps, int rope_rows, hipStream_t stream) {
   if (!x || !send || nt < 1 || nt > 3 || W < 1) return CE_ERR_ARG;
@@ -543,7 +543,7 @@ extern "C" int ce_rope_scatter_bf16(const void* x, int ldx, void* send, int M, i
   return (int)hipGetLastError();
 }
 
-extern "C" int ce_unpatchify_bf16(const void* y, void* out, int Cout, int T, int H, int W, int ldy, hipStream_t stream) {
+CE_API int ce_unpatchify_bf16(const void* y, void* out, int Cout, int T, int H, int W, int ldy, hipStream_t stream) {
   if (!y || !out || (H & 1) || (W & 1) || ldy < 4 * Cout) return CE_ERR_ARG;
   const size_t total = (size_t)Cout * T * H * W;
   hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16*)y, (bf16*)out,

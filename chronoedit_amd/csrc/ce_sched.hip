@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void cfg_unipc_kernel(const bf16* __restrict__
   }
 }
 
-extern "C" int ce_cfg_unipc_step(const void* v_cond, const void* v_uncond, float* x, float* x_last, float* m0, float* m1,
+CE_API int ce_cfg_unipc_step(const void* v_cond, const void* v_uncond, float* x, float* x_last, float* m0, float* m1,
                                  float* x0_out, const float* coef, const void* reserved, long long n, int flags,
                                  hipStream_t stream) {
   (void)reserved;

@@ -16,21 +16,42 @@ from . import hiplib
 EPI_BIAS, EPI_BIAS_GELU, EPI_GATE_RES, EPI_BIAS_GELU_ERF = 0, 1, 2, 3
 EPI_F32, EPI_MUL, EPI_BIAS_ROW = 4, 5, 6
 
-_lib = None
+_lib = None      # the library launches go through: the product library unless a diagnostic selector is away from its default
+_product = None
+
+# The alternative kernel bodies are selectable only in libchronoedit_hip_diag.so (include/chronoedit_hip_diag.h): while every selector is at
+# its default, launches go through the product library; the first non-default value moves them to the diagnostic build, the last reset moves
+# them back.  Tools and body-equivalence tests only - the engine, the pipeline and bench.py's timed region never call set_*.
+_KNOB_DEFAULTS = {"ce_set_gemm_variant": -1, "ce_set_attention_waves": 0, "ce_set_gemm_fp8_variant": 1,
+                  "ce_set_attention_mxfp8_variant": 1, "ce_set_attention_mxfp8_persistent": 512}
+_knobs = dict(_KNOB_DEFAULTS)
 
 
 def lib():
-    global _lib
+    global _lib, _product
     if _lib is None:
-        _lib = hiplib.load()
+        _lib = _product = hiplib.load()
         import os
-        v8 = os.environ.get("CE_GEMM_FP8_VARIANT")  # the same for the fp8 GEMM (ce_set_gemm_fp8_variant)
+        v8 = os.environ.get("CE_GEMM_FP8_VARIANT")  # A/B knobs for whole-step runs (bench.py under another main loop): the diagnostic build
         if v8 is not None:
-            _lib.ce_set_gemm_fp8_variant(int(v8))
-        v = os.environ.get("CE_GEMM_VARIANT")  # A/B knob for whole-step runs (bench.py under another main loop): see ce_set_gemm_variant
+            _set_knob("ce_set_gemm_fp8_variant", int(v8))
+        v = os.environ.get("CE_GEMM_VARIANT")
         if v is not None:
-            _lib.ce_set_gemm_variant(int(v))
+            _set_knob("ce_set_gemm_variant", int(v))
     return _lib
+
+
+def _set_knob(symbol: str, v: int) -> int:
+    global _lib
+    lib()
+    diag = hiplib.load_diagnostics()
+    prev = getattr(diag, symbol)(int(v))
+    _knobs[symbol] = getattr(diag, symbol)(int(v))  # (setters ignore values they do not know: read back what is in force)
+    want = diag if any(_knobs[k] != _KNOB_DEFAULTS[k] for k in _knobs) else _product
+    if want is not _lib:
+        _lib = want
+        _gemm_ws.pop("active", None)  # the split-K scratch registry is per library: re-register with the one launches now go through
+    return prev
 
 
 class HipKernelError(RuntimeError):
@@ -219,7 +240,8 @@ def rope_scatter(x: torch.Tensor, cols, weights, D: int, world: int, cos_sin: Op
 
 _gemm_ws = {}
 _gemm_split = True
-GEMM_WS_BYTES = 256 * 256 * 256 * 4  # one fp32 256x256 slab per CU
+GEMM_WS_BYTES = 256 * 384 * 256 * 4  # one fp32 slab of the LARGEST macro tile (384 x 256) per CU: any split-K tail the dispatcher may choose fits (96 MiB; round 6 - with 64 MiB the
+# 384-row tile could not cut its tail at M = 7 200 and lost FFN-down by 13 %: profiles/r06_gemm_tile_choice_m7200.txt)
 
 
 GEMM_WS_STREAMS = 8  # streams per device that get a scratch of their own; further ones share the device default
@@ -244,17 +266,19 @@ def ensure_gemm_workspace(device: torch.device) -> None:
             _gemm_ws[("first_stream", dev)] = first = stream
         with torch.cuda.device(dev):
             _check(lib().ce_set_gemm_workspace(buf.data_ptr(), buf.numel()), "ce_set_gemm_workspace")
-            if stream != first and (dev, stream) not in _gemm_ws and not torch.cuda.is_current_stream_capturing():
-                mine = [k for k in _gemm_ws if isinstance(k, tuple) and len(k) == 2 and k[0] == dev]  # (dev, stream) keys, oldest first
-                own = None
+            if stream != first and (dev, stream) in _gemm_ws:
+                _gemm_ws[(dev, stream)] = _gemm_ws.pop((dev, stream))  # most recently used last (dicts keep insertion order)
+            elif stream != first and not torch.cuda.is_current_stream_capturing():
+                mine = [k for k in _gemm_ws if isinstance(k, tuple) and len(k) == 2 and k[0] == dev]  # (dev, stream) keys, least recently used first
                 if len(mine) >= GEMM_WS_STREAMS:
-                    # the cap is reached: the LEAST recently registered stream hands its scratch on (it is unregistered first, so that stream - in
-                    # practice one that no longer exists - falls back to the device default; two live streams never share a scratch silently)
+                    # the cap is reached: the LEAST RECENTLY USED stream is unregistered (it falls back to the device default if it ever comes
+                    # back) and its scratch is DROPPED, not handed on: split-K partials of GEMMs still queued on that stream may be in it, and
+                    # nothing orders the new stream behind them.  The caching allocator returns the block to the pool of the stream it was
+                    # allocated on, so whatever reuses it is ordered behind that stream's queued work.
                     oldest = mine[0]
-                    own = _gemm_ws.pop(oldest)
+                    del _gemm_ws[oldest]
                     _check(lib().ce_set_gemm_workspace_stream(oldest[1], None, 0), "ce_set_gemm_workspace_stream")
-                if own is None:
-                    own = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
+                own = torch.empty(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
                 _gemm_ws[(dev, stream)] = own
                 _check(lib().ce_set_gemm_workspace_stream(stream, own.data_ptr(), own.numel()), "ce_set_gemm_workspace_stream")
     else:
@@ -275,13 +299,13 @@ def set_gemm_split(on: bool) -> bool:
 
 def set_gemm_variant(v: int) -> int:
     """-1 auto, 0 force the 128-tile kernel, 1 force the 256-tile LDS-DMA kernel; returns the previous setting."""
-    return lib().ce_set_gemm_variant(int(v))
+    return _set_knob("ce_set_gemm_variant", v)
 
 
 def set_attention_waves(n: int) -> int:
     """Attention loop body: 0 auto (= 64), 4 / 8 plain kernel with that many waves, 64 software-pipelined (default), 128 / 129 the
     one-wave-per-SIMD body of the V^T form (one workgroup per item / persistent); returns the previous value (include/chronoedit_hip.h)."""
-    return lib().ce_set_attention_waves(int(n))
+    return _set_knob("ce_set_attention_waves", n)
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
@@ -862,7 +886,7 @@ def gemm_mxfp8_gelu_quant(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, 
 
 def set_gemm_fp8_variant(v: int) -> int:
     """Main loop of `gemm_fp8`: 0 = 8 waves / 4 phases, 1 = one wave per SIMD (ce_gemm_fp8w4.hip); returns the previous setting."""
-    return lib().ce_set_gemm_fp8_variant(int(v))
+    return _set_knob("ce_set_gemm_fp8_variant", v)
 
 
 def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor],
@@ -952,7 +976,12 @@ def set_attention_mxfp8_variant(v: int) -> int:
     """0: plain loop (exact running maximum every tile), 1: software-pipelined with the speculative offset (default); returns the
     previous setting.  (A one-wave-per-SIMD form, 4 waves x 64 rows, measured 1.20 vs 1.71 PFLOP/s at 28 800 keys and was removed:
     profiles/r02_microbench_attn_mxfp8.txt.)"""
-    return lib().ce_set_attention_mxfp8_variant(int(v))
+    return _set_knob("ce_set_attention_mxfp8_variant", v)
+
+
+def set_attention_mxfp8_persistent(n: int) -> int:
+    """(diagnostic build) workgroups of the persistent MXFP8 attention form: 0 = one workgroup per work item, default 512; returns the previous value."""
+    return _set_knob("ce_set_attention_mxfp8_persistent", n)
 
 
 def attention_mxfp8(q8: torch.Tensor, sq: torch.Tensor, k8: torch.Tensor, sk: torch.Tensor, v8t: torch.Tensor, sv: torch.Tensor,

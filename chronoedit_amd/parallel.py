@@ -64,19 +64,33 @@ class OwnedComm:
     section 8b: "one ncclComm_t per process passed in".  The unique id travels over the existing process group (any backend); RCCL itself
     is the librccl.so torch ships, dlopen()ed by the library (one copy per process)."""
 
-    _cache = {}  # (id of the process group, device index) -> OwnedComm: ONE communicator per group and device for the life of the process
+    _cache = {}  # (id of the process group OBJECT, device index) -> OwnedComm: ONE communicator per group and device for the life of the group
 
     @classmethod
     def get(cls, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None) -> "OwnedComm":
         """The communicator of (group, device), created on first use and REUSED afterwards: a serving process that re-enables or re-groups
         sequence parallelism must not leave one ncclComm_t (device buffers, proxy threads) behind per call - ncclCommDestroy cannot be
-        used on this stack (see close())."""
+        used on this stack (see close()).
+
+        COLLECTIVE over `group` (every rank of the group calls it, as every rank constructs its Ulysses): the ranks first agree - one
+        all_reduce(MIN) of a "my cached handle is usable" flag - whether ALL of them hold a communicator made for THIS group object with
+        this world size and rank.  Only then is the cached one reused; otherwise every rank builds a new one together (a rank that called
+        close(), or a process group that was destroyed and re-initialised with another world or rank, can therefore neither reuse a stale
+        ncclComm_t nor enter ncclCommInitRank alone)."""
         dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        key = (id(group) if group is not None else None, dev.index)
+        grp = group if group is not None else dist.group.WORLD  # the default group as an OBJECT: a re-initialised one is a different key
+        key = (id(grp), dev.index)
         comm = cls._cache.get(key)
-        if comm is None or comm.handle is None:
+        usable = (comm is not None and comm.handle is not None and comm._group_ref is grp
+                  and comm.world == dist.get_world_size(group) and comm.rank == dist.get_rank(group))
+        flag = torch.tensor([1 if usable else 0], dtype=torch.int32, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.handle = None  # (never destroyed: see close())
+            for k in [k for k, c in cls._cache.items() if c._group_ref is not grp and k[1] == dev.index and c.handle is None]:
+                del cls._cache[k]   # closed communicators of groups that are gone
             comm = cls._cache[key] = cls(group, dev)
-            comm._group_ref = group  # keeps the id() of the key unique while the entry lives
         return comm
 
     def __init__(self, group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None):
@@ -106,6 +120,7 @@ class OwnedComm:
             if self.lib.ce_comm_init(ctypes.byref(handle), idb, self.rank, self.world) != 0:
                 raise RuntimeError("ce_comm_init (ncclCommInitRank) failed")
         self.handle = handle
+        self._group_ref = group if group is not None else dist.group.WORLD  # (also keeps the id() in the cache key unique while the entry lives)
         self.side = torch.cuda.Stream(device=self.device)  # the stream asynchronous exchanges run on (created outside any capture)
 
     def _check(self, rc, what):

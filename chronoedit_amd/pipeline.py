@@ -120,7 +120,11 @@ class GraphedDenoiser:
     are hipGraph-captured").  Everything a step reads lives at fixed device addresses: the fp32 latents (updated in place),
     the condition, the stacked CFG conditioning, the scheduler history, and two small staging buffers that receive the
     step's timestep and UniPC coefficient row (device-to-device copies enqueued in front of the replay - no host sync).
-    A new graph is needed when the latent shape changes (temporal-reasoning truncation 8 -> 2 frames)."""
+    A new graph is needed when the latent shape changes (temporal-reasoning truncation 8 -> 2 frames).
+    `step(i)` raises RuntimeError when the object was built at one step index with keep_warmup_step=True (that step ran eagerly in the
+    constructor) and the first `step()` asks for another index: build it at the index it starts from.  Between construction and the last
+    `step()` the transformer's modes (fp8, sequence parallelism, cache_context) must not change; other forwards of the same transformer
+    are allowed (the lazy capture re-primes its context entry)."""
 
     def __init__(self, transformer, scheduler, latents, condition, prompt_embeds, negative_prompt_embeds, image_embeds,
                  guidance_scale: float, batch_cfg: bool = True, warm: bool = False, keep_warmup_step: bool = True):
@@ -176,11 +180,8 @@ class GraphedDenoiser:
                 for m, sv in zip(scheduler.model_outputs, saved[1]):
                     m.copy_(sv)
                 scheduler.last_sample.copy_(saved[2])
-        elif getattr(transformer, "cache_context", False) and hasattr(transformer, "prime_context"):
-            if self.cfg_inputs is not None:
-                transformer.prime_context(self.cfg_inputs[0], self.cfg_inputs[1])
-            elif not self.guided:
-                transformer.prime_context(prompt_embeds, image_embeds)
+        else:
+            self._prime_context()
         # The capture: at once when every step() must be a replay (warm shape, or keep_warmup_step=False); LAZILY - at the first step() that needs a
         # replay - when the constructor already ran the trajectory's current step eagerly: if that was the last step of this shape (truncation lands
         # there, or a callback replaces the latents every step) nothing is ever replayed and a whole capture would be thrown away
@@ -189,7 +190,23 @@ class GraphedDenoiser:
             self._capture()
         scheduler._step_index = idx0  # step_cfg counts on the host, also while being captured
 
+    def _prime_context(self):
+        """With `cache_context`: the step-invariant context projections of THIS conditioning computed eagerly now, so that the capture
+        records the cache hit and not the projections."""
+        tr = self.tr
+        if getattr(tr, "cache_context", False) and hasattr(tr, "prime_context"):
+            if self.cfg_inputs is not None:
+                tr.prime_context(self.cfg_inputs[0], self.cfg_inputs[1])
+            elif not self.guided:
+                tr.prime_context(self.prompt, self.image)
+
     def _capture(self):
+        # The LAZY capture (first replayed step()) runs at an arbitrary later point of the caller's program: another forward of the same
+        # transformer in between (another conditioning of the same shape) may have replaced the context-cache entry and the engine-owned
+        # context buffers the eager step left, so the entry is re-primed here (a hit costs nothing) - ADVICE r5.  torch.cuda.graph() itself
+        # synchronises the device and runs a gc pass: callers that cannot afford that inside their loop build with keep_warmup_step=False
+        # (capture in the constructor).
+        self._prime_context()
         idx = self.sch._step_index
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):  # (a capture executes nothing: the device state stays what the eager step left)

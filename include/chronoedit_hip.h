@@ -78,19 +78,11 @@ int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, i
                      int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride,
                      int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
-/* ---- DIAGNOSTIC SWITCHES (ce_set_gemm_variant, ce_set_attention_waves, ce_set_gemm_fp8_variant, ce_set_attention_mxfp8_variant,
- * ce_set_attention_mxfp8_persistent): process-wide A/B selectors of alternative kernel bodies that compute the same results, for the
- * measurement tools under tools/ and the body-equivalence tests.  The product path (chronoedit_amd engine, pipeline, bench.py's timed
- * region) NEVER sets them: every launcher picks its kernel from the call's own shape when they are at their defaults, so with the
- * defaults the library keeps no state that a launch reads except the caller-registered split-K scratch.  A process
- * that hosts several engines leaves them alone. ---- */
+/* ---- The alternative kernel bodies (A/B partners of the measurement tools and the body-equivalence tests) are NOT selectable through this
+ * library: libchronoedit_hip.so picks every kernel from the call's own shape and keeps no state a launch reads except the caller-registered
+ * split-K scratch below.  The selectors live in a second build of the same sources, libchronoedit_hip_diag.so
+ * (include/chronoedit_hip_diag.h, -DCE_DIAGNOSTICS), which tools/ and tests/ load beside this one. ---- */
 
-/* Kernel selection for ce_gemm_bf16 (returns the previous setting): -1 automatic (default: large shapes on the one-wave-per-SIMD
- * LDS-DMA kernels, macro tile per ce_gemm_bf16_tile_rows), 0 force the 128x128 register-staged kernel; wherever the shape allows the
- * large-tile kernels: 1 the 8-wave 256x256 main loop (csrc/ce_gemm256.hip), 2 the same staggered, 3 / 4 / 5 the one-wave-per-SIMD
- * 256x256 main loop (csrc/ce_gemm256w4.hip; A ring of 3 stages / 2 stages / 3 stages and one barrier per K-tile), 6 the 384x256 macro
- * tile (csrc/ce_gemm384.hip).  Host-side test/bench knob. */
-int ce_set_gemm_variant(int variant);
 
 /* Which macro tile ce_gemm_bf16 runs a LARGE product on when the choice is automatic: 384 (x 256, ce_gemm384.hip) or 256 (x 256,
  * ce_gemm256w4.hip) rows - the one whose tile count falls better on `cus` compute units (full rounds + the last round, which is cut
@@ -172,13 +164,6 @@ int ce_v_transpose_blocked_bf16(const void* v, int ldv, void* vt, int ldvt, int 
  * [n_keys, ldvt) zeroed): the producer of ce_attention_vt_bf16's V operand. */
 int ce_v_transpose_bf16(const void* v, int ldv, void* vt, int ldvt, int n_keys, int H, hipStream_t stream);
 
-/* Loop body behind ce_attention_bf16 / ce_attention_batched_bf16 (returns the previous value; all are tested against the
- * same reference): 0 automatic (= 64); 4 / 8 the plain kernel with 4 / 8 waves per workgroup; 64 software-pipelined, K by
- * LDS-DMA, pre-scaled Q, speculative softmax with an exact fall-back route per tile (default); 128 / 129: as 64, but the V^T form
- * (ce_attention_vt_bf16, ce_attention_vt_blocked_bf16) runs its one-wave-per-SIMD body (4 waves x 64 query rows, Q and O^T in the
- * accumulator file; bit-identical results) with one workgroup per work item / with one persistent workgroup per CU.  Other values
- * are ignored.  Host-side tuning knob. */
-int ce_set_attention_waves(int nwave);
 
 /* out[dim] = [cos(t f_i), sin(t f_i)], f_i = 1e4^(-i/(dim/2)), fp32; t is a device int64.
  * Replaces diffusers Timesteps(flip_sin_to_cos=True, downscale_freq_shift=0)
@@ -346,10 +331,6 @@ int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void* sa8, cons
 int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* sa8, const void* sw8, const float* bias, void* q_out, void* qs_out,
                              int M, int N, int K, int lda, int ldw, int ldq, hipStream_t stream);
 
-/* Main loop of ce_gemm_fp8 (returns the previous setting): 0 = 8 waves / 4 phases per K-tile (csrc/ce_gemm_fp8.hip), 1 = one wave per
- * SIMD (csrc/ce_gemm_fp8w4.hip: 4 waves, 128 x 128 wave tiles, accumulators in AGPRs, one barrier per K-tile).  Same results bit for
- * bit (same products, same summation order per accumulator).  Host-side test / bench knob. */
-int ce_set_gemm_fp8_variant(int variant);
 
 /* ---- MXFP8 self-attention of the fp8 mode ("fp8 weights+attn", BASELINE.json configs[4]).  Contract (csrc/ce_attn_fp8.hip,
  * oracle/dit_oracle.py::attention_mxfp8): Q, K quantised to OCP MXFP8 - e4m3 elements, one E8M0 scale per 32 head channels - V per
@@ -389,15 +370,7 @@ int ce_attention_mxfp8_add(const void* q8, const void* sq, const void* k8, const
                            int ldadd, void* O, int ldo, void* o8, void* scale8, int ldo8, int Nq, int Nkv, int npad, int H, int head_dim,
                            int ldq8, int ldk8, int batch, hipStream_t stream);
 
-/* Loop body of ce_attention_mxfp8 (returns the previous value): 0 plain (exact running maximum every tile), 1 software-pipelined
- * with a speculative integer offset, row sums on the matrix pipe and an exact repair route per tile (default).  Other values are
- * ignored.  Host-side tuning knob. */
-int ce_set_attention_mxfp8_variant(int variant);
 
-/* Workgroups of the persistent form of the software-pipelined MXFP8 kernel (returns the previous value): n > 0 (a multiple of 8) -
- * n workgroups walk the work order with stride n (default 512 = 2 x #CUs: +2 % at 7 200 keys, +0.3 ... 0.5 % above); 0 - one
- * workgroup per (head, query block, sample).  Host-side tuning knob. */
-int ce_set_attention_mxfp8_persistent(int n);
 
 /* ---- conditioning encoders (run once per edit, outside the loop: pipeline_chronoedit.py:205-254; the arithmetic is
  * transformers==4.57.1 CLIPVisionModel / UMT5EncoderModel, restated in oracle/clip_oracle.py, oracle/umt5_oracle.py) ---- */
@@ -446,6 +419,11 @@ int ce_comm_destroy(void* comm);
 int ce_comm_all_to_all(void* comm, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream);
 /* recv = every rank's bytes_per_rank-byte block, in rank order (ncclAllGather on `stream`). */
 int ce_comm_all_gather(void* comm, const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream);
+
+/* How the loaded library was compiled - a constant, no device is touched: bit 0 = the diagnostic build (libchronoedit_hip_diag.so,
+ * include/chronoedit_hip_diag.h), bit 1 = -DF8_A3, bits 4-7 = F8_DMA_SCHED, bits 8-15 = F8_ABLATE (non-zero: a timing-only build of the MX fp8
+ * GEMM with one ingredient compiled out; its results are garbage and chronoedit_amd.hiplib.load refuses it).  The product build returns 0x10. */
+int ce_build_info(void);
 
 #ifdef __cplusplus
 }

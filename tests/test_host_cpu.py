@@ -11,15 +11,43 @@ from oracle import dit_oracle as O
 
 
 def test_library_builds_and_exports_header_symbols():
+    """The dynamic symbol table of the product library IS include/chronoedit_hip.h - no more (cross-TU launch helpers, kernel stubs and
+    the kernel-body selectors are not ABI), no less; the diagnostic build adds exactly include/chronoedit_hip_diag.h."""
     from chronoedit_amd import hiplib
     path = hiplib.build()
-    assert os.path.exists(path)
+    assert os.path.exists(path) and os.path.exists(hiplib.DIAG_LIB_PATH)
     lib = ctypes.CDLL(path)
     syms = hiplib.header_symbols()
-    assert len(syms) >= 10
+    assert len(syms) >= 50
     for s in syms:
         assert hasattr(lib, s), s
     assert set(hiplib.SIGNATURES) == set(syms)
+    assert set(hiplib.exported_symbols(path)) == set(syms)                      # `nm -D --defined-only` == the header
+    diag = hiplib.header_symbols(diag=True)
+    assert set(diag) == set(hiplib.DIAG_SIGNATURES) and all(d.startswith("ce_set_") for d in diag)
+    assert set(hiplib.exported_symbols(hiplib.DIAG_LIB_PATH)) == set(syms) | set(diag)
+    for d in diag:                                                              # two engines in one process cannot fight over a selector:
+        assert not hasattr(lib, d), d                                           # the product library has none
+    lib.ce_build_info.restype = ctypes.c_int
+    assert lib.ce_build_info() == 0x10                                          # product build: no diagnostics, F8_DMA_SCHED 1, no ablation
+    dl = ctypes.CDLL(hiplib.DIAG_LIB_PATH)
+    dl.ce_build_info.restype = ctypes.c_int
+    assert dl.ce_build_info() == 0x11
+
+
+def test_loader_refuses_a_diagnostic_build_as_the_product_library(monkeypatch):
+    """CE_HIPLIB_PATH only redirects load() (with a warning), and a build that says of itself that it is not the product is refused."""
+    from chronoedit_amd import hiplib
+    hiplib.build()
+    monkeypatch.setattr(hiplib, "_LIB", None)
+    monkeypatch.setenv("CE_HIPLIB_PATH", hiplib.DIAG_LIB_PATH)
+    with pytest.warns(RuntimeWarning, match="CE_HIPLIB_PATH"):
+        with pytest.raises(RuntimeError, match="diagnostic build"):
+            hiplib.load()
+    monkeypatch.setenv("CE_HIPLIB_ALLOW_DIAGNOSTIC_BUILD", "1")
+    with pytest.warns(RuntimeWarning):
+        assert hiplib.load().ce_build_info() & 1
+    monkeypatch.setattr(hiplib, "_LIB", None)
 
 
 def test_param_tree_matches_reference_names():
@@ -171,21 +199,29 @@ def test_conv3d_gemm_address_map_reproduces_the_convolution(KT, T_out, H, W, Cin
 
 def test_macro_tile_choice_of_the_step_shapes():
     """ce_gemm_bf16_tile_rows: the automatic 384 x 256 / 256 x 256 macro-tile choice is a pure function of the shape, the CU count and
-    the split-K workspace - pinned here for the five large GEMMs of a batched-CFG step at 720p on 256 CUs with the engine's 64 MiB
-    workspace (what the same-box A/B measured as the faster tile for each)."""
+    the split-K workspace - pinned here for the five large GEMMs of a block at BOTH row counts of the 720p step (M = 14 400: guidance pair
+    batched, BASELINE configs[1]; M = 7 200: the distilled B = 1 step, configs[2]) on 256 CUs with the engine's 96 MiB workspace: what the
+    same-box A/B measured as the faster tile for each (profiles/r06_gemm_tile_choice.txt; round 6 refit)."""
     from chronoedit_amd import hiplib, ops
     lib = hiplib.load()
     ws = ops.GEMM_WS_BYTES
+    assert ws == 256 * 384 * 256 * 4  # one slab of the largest macro tile per CU: every split the dispatcher may choose fits
     pick = lambda M, N, K: lib.ce_gemm_bf16_tile_rows(M, N, K, 256, ws)
-    assert pick(14400, 10240, 5120) == 384   # q | k: 1520 tiles = 5.94 rounds (2280 = 8.9)
-    assert pick(5120, 14400, 5120) == 256    # V^T: M = 13.3 tiles of 384 rows would pad 5 %
-    assert pick(14400, 5120, 5120) == 384    # out-projections, q of the cross-attention: 760 tiles = 2.97 rounds (1140 = 4.45)
-    assert pick(14400, 13824, 5120) == 256   # FFN-up: 12.02 rounds against 8.02 x 1.5
-    assert pick(14400, 5120, 13824) == 384   # FFN-down
+    assert pick(14400, 10240, 5120) == 384   # q | k (level)
+    assert pick(5120, 14400, 5120) == 256    # V^T: measured 256 by 10 %
+    assert pick(14400, 5120, 5120) == 384    # out-projections, q of the cross-attention: 384 by 6 %
+    assert pick(14400, 13824, 5120) == 256   # FFN-up: 256 by 2.3 %
+    assert pick(14400, 5120, 13824) == 384   # FFN-down: 384 by 3.6 %
+    assert pick(7200, 10240, 5120) == 384    # q | k: 384 by 11.5 %
+    assert pick(5120, 7200, 5120) == 256     # V^T: 256 by 4.5 %
+    assert pick(7200, 5120, 5120) == 384     # out-projections: 384 by 1.2 %
+    assert pick(7200, 13824, 5120) == 384    # FFN-up: 384 by 3.0 % (the round-3 model said 256)
+    assert pick(7200, 5120, 13824) == 384    # FFN-down: 384 by 2.8 % - needs the 96 MiB scratch: 124 tail tiles x 2 slabs of 384 rows
     assert pick(0, 5120, 5120) == 0 and pick(256, 256, 32) == 0
-    # without a workspace a partial last round cannot be cut along K: it costs a whole round
-    assert lib.ce_gemm_bf16_tile_rows(14400, 5120, 5120, 256, 0) == 384    # 3 rounds x 1.5 against 5
-    assert lib.ce_gemm_bf16_tile_rows(14400, 13824, 5120, 256, 0) == 256   # 9 rounds x 1.5 against 13
+    # without a workspace a partial last round cannot be cut along K
+    assert lib.ce_gemm_bf16_tile_rows(14400, 5120, 5120, 256, 0) == 384
+    assert lib.ce_gemm_bf16_tile_rows(14400, 13824, 5120, 256, 0) == 256
+    assert lib.ce_gemm_bf16_tile_rows(7200, 5120, 13824, 256, 64 << 20) == 256  # the 64 MiB scratch of rounds 1-5: 384 cannot cut its tail (-13 %)
 
 
 def test_mx_scale_layout_helpers_agree_with_the_kernels_offset_formula():

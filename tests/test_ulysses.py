@@ -496,9 +496,25 @@ def _owned_comm_graph_worker(rank, world, port, q):
     except NotImplementedError:
         accepted = False
     torch.cuda.synchronize()
+    # the communicator cache.  A second get() for the SAME live group reuses the handle; after the process group was destroyed
+    # and re-initialised the default group is another object - the stale ncclComm_t (old world / rank) must not be handed out again
+    from chronoedit_amd.parallel import OwnedComm
+    c1 = m._sp.comm
+    reused = OwnedComm.get() is c1
+    c1.close()
+    rebuilt_after_close = OwnedComm.get() is not c1
+    dist.destroy_process_group()
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    c3 = OwnedComm.get()
+    fresh = c3 is not c1 and c3.handle is not None and c3.world == world and c3._group_ref is dist.group.WORLD
+    snd = torch.arange(64, dtype=torch.float32, device="cuda")
+    rcv = torch.zeros_like(snd)
+    c3.all_to_all(snd, rcv, async_op=False)
+    torch.cuda.synchronize()
+    fresh = fresh and bool(torch.equal(snd, rcv))
     q.put((rank, accepted, bool(torch.equal(graphed, eager)), bool(torch.equal(again, eager)), float((eager - ref).norm() / ref.norm()),
-           calls_eager, bool(torch.isfinite(graphed).all())))
-    m._sp.comm.close()
+           calls_eager, bool(torch.isfinite(graphed).all()), reused, rebuilt_after_close, fresh))
     dist.destroy_process_group()
 
 
@@ -509,8 +525,9 @@ def test_sharded_loop_is_captured_on_the_library_owned_communicator():
     the k|v exchange forked onto the communicator's side stream and joined by an event) - no Work objects, no watchdog.  One rank over
     RCCL, the most a one-GPU box allows: the sharded 4-step temporal-reasoning loop as TWO captured graphs (8 -> 2 latent frames),
     replayed, equals the eager sharded loop bit for bit, twice in one process; GraphedDenoiser accepts the sharded step."""
-    (rank, accepted, same, same_again, err, calls, finite), = _spawn(_owned_comm_graph_worker, 1, timeout=150)
+    (rank, accepted, same, same_again, err, calls, finite, reused, rebuilt, fresh), = _spawn(_owned_comm_graph_worker, 1, timeout=200)
     assert accepted and finite, (accepted, finite)
+    assert reused and rebuilt and fresh, (reused, rebuilt, fresh)  # OwnedComm.get: hit on the live group, never a closed or a stale communicator
     assert same and same_again, (same, same_again)
     assert err < 5e-3, err   # sharded vs un-sharded (different GEMM M splits)
     assert calls == 4 * 2 * 3  # eager loop: 4 steps x ONE batched pass x 2 layers x 3 exchanges

@@ -1,7 +1,8 @@
 """A/B of the main loops of the 256-tile bf16 GEMM in ONE process (ce_set_gemm_variant: 1 = 8 waves / 8 phases, 2 = staggered,
 3 / 4 = one wave per SIMD with an A ring of 3 / 2 stages) on the shapes of one batched-CFG denoising step (M = 2 x 7200) and of the
 N = 28 800 mode; random operands (zero-filled ones clock ~20 % higher on this chip), interleaved rounds, best and median of each.
-    python tools/gemm_variants.py [variants, e.g. 1,3,4] [rounds]"""
+    python tools/gemm_variants.py [variants, e.g. 1,3,4] [rounds]
+CE_GEMM_AB_M=7200: the B = 1 shapes of the distilled configuration (BASELINE configs[2]); CE_GEMM_WS_MB=n: split-K scratch of n MiB (default 64)."""
 import os
 import statistics
 import sys
@@ -20,9 +21,14 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
+    if os.environ.get("CE_GEMM_WS_MB"):
+        ops.GEMM_WS_BYTES = int(os.environ["CE_GEMM_WS_MB"]) << 20
+    MM = int(os.environ.get("CE_GEMM_AB_M", "14400"))
     shapes = [(14400, 10240, 5120, ops.EPI_BIAS, "q|k"), (5120, 14400, 5120, ops.EPI_BIAS_ROW, "V^T"),
               (14400, 5120, 5120, ops.EPI_GATE_RES, "out-proj"), (14400, 13824, 5120, ops.EPI_BIAS_GELU, "ffn-up"),
               (14400, 5120, 13824, ops.EPI_GATE_RES, "ffn-down"), (28800, 13824, 5120, ops.EPI_BIAS_GELU, "ffn-up 28800")]
+    if MM != 14400:
+        shapes = [(MM if m == 14400 else m, MM if n == 14400 else n, k, e, t) for (m, n, k, e, t) in shapes[:5]] + [(MM, 5120, 5120, ops.EPI_BIAS, "cross q")]
     tot = {v: 0.0 for v in variants}
     for (M, N, K, epi, tag) in shapes:
         a = torch.randn(M, K, generator=g).to(BF).to(dev)
@@ -59,7 +65,7 @@ def main():
             best, med = min(times[v]), statistics.median(times[v])
             d = (outs[base].float() - outs[v].float()).norm().item() / outs[base].float().norm().item()
             line += f" | {NAMES.get(v, v)} best {best:.3f} ms {fl/best/1e9:.0f} TF, median {fl/med/1e9:.0f} TF ({(min(times[base])/best-1)*100:+.1f} %, rel {d:.1e})"
-            if M == 14400 or M == 5120:
+            if M in (14400, MM) or M == 5120:
                 tot[v] += best * (2 if tag == "out-proj" else 1)  # two 5120x5120 projections per block
         print(line, flush=True)
         del a, w, res, outs

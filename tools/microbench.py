@@ -168,13 +168,12 @@ def main():
                 ops.set_attention_mxfp8_variant(1)
                 t8 = min(t8, timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3))
             tpers = {}
-            L = ops.lib()
-            if hasattr(L, "ce_set_attention_mxfp8_persistent"):
-                L.ce_set_attention_mxfp8_variant(1)
+            if True:
+                ops.set_attention_mxfp8_variant(1)
                 for nwg in (0, 256, 512, 768):
-                    old = L.ce_set_attention_mxfp8_persistent(nwg)
+                    old = ops.set_attention_mxfp8_persistent(nwg)
                     tpers[nwg] = min(timeit(lambda: ops.attention_mxfp8(q8, sq, k8, sk, v8t, sv, H, out=out, batch=B), iters=3) for _ in range(3))
-                    L.ce_set_attention_mxfp8_persistent(old)
+                    ops.set_attention_mxfp8_persistent(old)
                 print(f"attn N={N} B={B} mxfp8 persistent workgroups: " + ", ".join(f"{k or 'per-item'}: {v*1e3:.3f} ms" for k, v in tpers.items()), flush=True)
             fl = 4.0 * N * N * 128 * H * B
             res[f"attn8_{N}x{H}_b{B}"] = {"mxfp8_ms": t8 * 1e3, "mxfp8_tflops": fl / t8 / 1e12, "bf16_ms": t16 * 1e3, "bf16_tflops": fl / t16 / 1e12,
