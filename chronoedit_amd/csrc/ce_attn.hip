@@ -347,6 +347,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned pp_u2;
 // ------------------------------------------------------------------------------------------------
 constexpr int K_GRP = 1088;  // LDS-DMA K image: 4 rows (1 KiB) + 64 B pad per group; 16 groups = PK_TILE
 typedef __attribute__((address_space(3))) void lds_void;
+#ifdef CE_DIAGNOSTICS
+__device__ unsigned long long g_sp_exact_hits = 0ull;
+#endif
 constexpr float SP_SPEC_THR = 1024.0f;  // a lane's partial row sum above this sends the tile through the exact route
 constexpr int SP_V0 = 2 * PK_TILE;                       // V^T buffers follow the two K buffers
 constexpr int SP_TILE_BYTES = 2 * PK_TILE + 3 * PV_TILE;  // 90112 (also holds the 69632-B O staging)
@@ -761,6 +764,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_sp_kernel(const bf16* __restr
       }
       if (__builtin_expect(t > 0 && __any(psum > SP_SPEC_THR), 0)) {
         // exact_tile: S(t) again (K(t) is untouched until the next barrier), true row max, plain softmax
+        CE_DIAG_COUNT_EXACT(g_sp_exact_hits);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(kb + k_eo[(i >> 1) & 1] + (i & 1) * 8 * K_GRP + (i >> 2) * 64);
@@ -1283,6 +1287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
       for (int sb = 0; sb < NSB; ++sb) {
         if (__builtin_expect(W4_ABLATE == 0 && t > 0 && __any(psum[sb] > SP_SPEC_THR), 0)) {
+          CE_DIAG_COUNT_EXACT(g_sp_exact_hits);
           // exact_tile: S(t) again (K(t) stays in its buffer until barrier t + 1), true row max, plain softmax
           st[sb][0] = zero16;
           st[sb][1] = zero16;
@@ -1443,6 +1448,20 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16* __restrict
 // 4 / 8 = the plain kernel with 4 / 8 waves per workgroup (the readable statement of the algorithm; kept as the A/B partner
 // of the parity tests).  The other loop bodies of round 1 (XOR-swizzled pipeline, ping-pong, one wave per SIMD) and their
 // ablation build lost every A/B and were removed in round 2; git history has them.
+#ifdef CE_DIAGNOSTICS
+extern "C" int ce_diag_mx_exact_hits(unsigned long long* out, int reset);
+// hits[0] = waves x key tiles that took the exact route in the bf16 software-pipelined kernels (attn_fwd_sp_kernel, attn_fwd_w4_kernel) since
+// the last reset, hits[1] = the same for the MXFP8 kernel; reset != 0 zeroes both.  Synchronises the device (a diagnostic, not a launcher).
+CE_API int ce_diag_attention_exact_route_hits(unsigned long long* hits, int reset) {
+  if (!hits) return CE_ERR_ARG;
+  unsigned long long v = 0ull, z = 0ull;
+  if (hipDeviceSynchronize() != hipSuccess) return CE_ERR_ARG;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sp_exact_hits), sizeof(v)) != hipSuccess) return CE_ERR_ARG;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_sp_exact_hits), &z, sizeof(z)) != hipSuccess) return CE_ERR_ARG;
+  hits[0] = v;
+  return ce_diag_mx_exact_hits(hits + 1, reset);
+}
+#endif
 CE_KNOB g_attn_nwave = 0;
 #ifdef CE_DIAGNOSTICS
 CE_API int ce_set_attention_waves(int nwave) {

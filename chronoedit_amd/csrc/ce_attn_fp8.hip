@@ -24,6 +24,10 @@
 #include "ce_common.h"
 
 namespace {
+#ifdef CE_DIAGNOSTICS
+__device__ unsigned long long g_mx_exact_hits = 0ull;
+#endif
+
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(2))) short s16x2;
@@ -612,6 +616,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_mxfp8_sp_kernel(const unsigne
   // P (exp2 of the score minus the offset: no fp32 overflow whatever the score) and its row sums redone
   auto exact_tile = [&](int tt) __attribute__((always_inline)) {
     const unsigned char* st = smem + (tt % NSTAGE_SP) * STAGE;
+    CE_DIAG_COUNT_EXACT(g_mx_exact_hits);
     f32x16 sacc[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -870,6 +875,16 @@ CE_API int ce_v_mxfp8_transpose(const void* v, int ldv, void* v8t, void* sv, int
   return (int)hipGetLastError();
 }
 
+#ifdef CE_DIAGNOSTICS
+// (diagnostic build) exact-route count of the MXFP8 kernel since the last reset; called by ce_diag_attention_exact_route_hits (ce_attn.hip)
+extern "C" int ce_diag_mx_exact_hits(unsigned long long* out, int reset) {
+  unsigned long long v = 0ull, z = 0ull;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_mx_exact_hits), sizeof(v)) != hipSuccess) return CE_ERR_ARG;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_mx_exact_hits), &z, sizeof(z)) != hipSuccess) return CE_ERR_ARG;
+  *out = v;
+  return CE_OK;
+}
+#endif
 CE_KNOB g_mxfp8_persist = 512;  // workgroups of the persistent form (0: one workgroup per work item); a multiple of 8
 CE_KNOB g_mxfp8_variant = 1;    // 0: plain kernel (exact running maximum every tile), 1: software-pipelined (default)
 #ifdef CE_DIAGNOSTICS

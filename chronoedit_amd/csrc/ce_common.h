@@ -22,8 +22,15 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // A kernel-body selector: a constant at its default in the product build, a process-wide variable with an exported setter in the diagnostic build
 #ifdef CE_DIAGNOSTICS
 #define CE_KNOB static int
+// (diagnostic build) how often a wave took the EXACT route of an attention kernel's speculative softmax for one key tile: counted per wave and
+// tile, read and reset through ce_diag_attention_exact_route_hits (include/chronoedit_hip_diag.h; tools/attn_peaked.py)
+#define CE_DIAG_COUNT_EXACT(counter)                                        \
+  do {                                                                      \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&(counter), 1ull);               \
+  } while (0)
 #else
 #define CE_KNOB static constexpr int
+#define CE_DIAG_COUNT_EXACT(counter) do { } while (0)
 #endif
 
 // error codes returned by every extern "C" launcher (include/chronoedit_hip.h)
@@ -122,4 +129,10 @@ __device__ __forceinline__ float clamp448(float x) { return __builtin_amdgcn_fme
 // ([ceil(rows / 128)][K / 128][4][16][8]; ce_gemm_fp8w4.hip reads 8 consecutive bytes - the 8 row fragments of a wave tile - per lane)
 __device__ __forceinline__ size_t mx_gemm_scale_offset(int row, int blk, int ktiles) {
   return ((size_t)(row >> 7) * ktiles + (blk >> 2)) * 512 + (blk & 3) * 128 + (row & 15) * 8 + ((row >> 4) & 7);
+}
+// The same for the W operand (weights, quantised once): [ceil(rows / 128)][K / 128][4][128 rows in order].  The register-direct epilogue of
+// ce_gemm_fp8w4.hip (round 6) feeds fragment G of a wave tile with W rows G + 8 i (i = fragment row), so the eight scale bytes ONE lane needs -
+// rows 8 i .. 8 i + 7 - are eight consecutive bytes of this order (the A order keeps rows i, i + 16, ... together: the A fragments are unpermuted).
+__device__ __forceinline__ size_t mx_gemm_wscale_offset(int row, int blk, int ktiles) {
+  return ((size_t)(row >> 7) * ktiles + (blk >> 2)) * 512 + (blk & 3) * 128 + (row & 127);
 }

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16* __restr
 // one is issued: the generic form ran at 60 % of the per-row kernel's rate on the step's widths); NCHL == 0: any K, four chunks in flight.
 template <int NCHL>
 __global__ __launch_bounds__(256) void quant_rows_mxfp8_kernel(const bf16* __restrict__ x, unsigned char* __restrict__ q,
-                                                               unsigned char* __restrict__ sc, int M, int K, int ldx, int ldq) {
+                                                               unsigned char* __restrict__ sc, int M, int K, int ldx, int ldq, int w_order) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void quant_rows_mxfp8_kernel(const bf16* __res
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(v[3]) * inv), clamp448(bf16hi(v[3]) * inv), w1, true);
         const u32x2 o = {(uint32_t)w0, (uint32_t)w1};
         *reinterpret_cast<u32x2*>(qr + c * 8) = o;
-        if ((lane & 3) == 0) sc[mx_gemm_scale_offset(row, c >> 2, ktiles)] = (unsigned char)byte;
+        if ((lane & 3) == 0) sc[w_order ? mx_gemm_wscale_offset(row, c >> 2, ktiles) : mx_gemm_scale_offset(row, c >> 2, ktiles)] = (unsigned char)byte;
       }
     }
   }
@@ -345,19 +345,26 @@ __global__ __launch_bounds__(256) void quant_rows_mxfp8_kernel(const bf16* __res
 }  // namespace
 
 /* x bf16 [M][ldx] -> q e4m3 bytes [M][ldq] + E8M0 block scales (one per 32 consecutive elements of a row, scale = 2^(floor(log2 amax) - 8),
- * elements RNE(x / scale) clamped to +-448: the OCP MX contract of oracle.dit_oracle.mx_quant) in the tiled layout of ce_gemm_mxfp8:
+ * elements RNE(x / scale) clamped to +-448: the OCP MX contract of oracle.dit_oracle.mx_quant) in the tiled layout of ce_gemm_mxfp8's A
+ * operand (ce_quant_rows_mxfp8: activations) or of its W operand (ce_quant_rows_mxfp8_w: weights, once at load time):
  * scale8 holds ceil(M / 128) * (K / 128) * 512 bytes.  K % 128 == 0. */
-CE_API int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream) {
+static int quant_rows_mxfp8_launch(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, int w_order, hipStream_t stream) {
   if (!x || !q || !scale8) return CE_ERR_ARG;
   if (M <= 0 || K <= 0 || (K & 127)) return CE_ERR_SHAPE;
   if ((ldx & 7) || (ldq & 7)) return CE_ERR_ALIGN;
 #define MX_QUANT(NC) \
-  hipLaunchKernelGGL(quant_rows_mxfp8_kernel<NC>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (unsigned char*)q, (unsigned char*)scale8, M, K, ldx, ldq)
+  hipLaunchKernelGGL(quant_rows_mxfp8_kernel<NC>, dim3((M + 3) / 4), dim3(256), 0, stream, (const bf16*)x, (unsigned char*)q, (unsigned char*)scale8, M, K, ldx, ldq, w_order)
   if (K == 64 * 8 * 10) MX_QUANT(10);       // 5120
   else if (K == 64 * 8 * 27) MX_QUANT(27);  // 13824
   else MX_QUANT(0);
 #undef MX_QUANT
   return (int)hipGetLastError();
+}
+CE_API int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream) {
+  return quant_rows_mxfp8_launch(x, q, scale8, M, K, ldx, ldq, 0, stream);
+}
+CE_API int ce_quant_rows_mxfp8_w(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream) {
+  return quant_rows_mxfp8_launch(x, q, scale8, M, K, ldx, ldq, 1, stream);
 }
 
 CE_API int ce_quant_rows_fp8(const void* x, void* q, float* scale, int M, int K, int ldx, int ldq, hipStream_t stream) {

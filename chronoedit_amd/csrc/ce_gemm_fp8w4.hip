@@ -41,6 +41,11 @@
 #ifndef F8_A3
 #define F8_A3 0
 #endif
+// F8_EPI_LDS = 1: the round-3..5 epilogue (accumulators hold C^T, rows staged through LDS for row-contiguous stores; W scales in the A order) -
+// kept as the A/B partner of tools/gemm_mxfp8_ab.py.  0 (round 6, default): the REGISTER-DIRECT epilogue, see "epilogue" below.
+#ifndef F8_EPI_LDS
+#define F8_EPI_LDS 0
+#endif
 
 namespace {
 
@@ -158,7 +163,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int row = 8 * (wave + 4 * p) + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_voff[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)lda + chunk * 16;
-    w_voff[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)ldw + chunk * 16;
+#if F8_EPI_LDS
+    const int wrow = row;
+#else
+    // register-direct epilogue: LDS row 16 G + i of a wave's 128 W rows (fragment G, fragment row i) holds W row 8 i + G, so that lane i of an
+    // accumulator quad-row owns the 8 CONSECUTIVE output columns 8 i .. 8 i + 7 over its eight G accumulators (a permutation of whole 128-byte
+    // rows on the DMA's source side: free)
+    const int wrow = (row & 128) | ((row & 15) << 3) | ((row & 127) >> 4);
+#endif
+    w_voff[p] = (uint32_t)min(n0 + wrow, N - 1) * (uint32_t)ldw + chunk * 16;
   }
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xffffffffu, 0x00020000);
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xffffffffu, 0x00020000);
@@ -249,11 +262,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   X8_PIN();
 
-  // W fragment first: the accumulator holds C^T, lane (fr, fg) of acc[F][G] owns row F*16 + fr and the columns G*16 + fg*4 + [0,4)
+  // F8_EPI_LDS: W fragment first - the accumulator holds C^T, lane (fr, fg) of acc[F][G] owns row F*16 + fr and the columns G*16 + fg*4 + [0,4)
 #define X8_MMA(F, G, BW)                                                                                                          \
   do {                                                                                                                            \
-    if (MX) mma_mx<(G) & 3, (F) & 3>(acc[F][G], (BW)[G], ring[(F) % 4], sWq[SEL_][(G) >> 2], sAq[SEL_][(F) >> 2]);                  \
-    else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]));          \
+    if (F8_EPI_LDS) {                                                                                                             \
+      if (MX) mma_mx<(G) & 3, (F) & 3>(acc[F][G], (BW)[G], ring[(F) % 4], sWq[SEL_][(G) >> 2], sAq[SEL_][(F) >> 2]);                \
+      else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]));        \
+    } else { /* A fragment first: the accumulator holds C, lane (fr, fg) owns rows F*16 + fg*4 + [0,4) and W fragment row fr */     \
+      if (MX) mma_mx<(F) & 3, (G) & 3>(acc[F][G], ring[(F) % 4], (BW)[G], sAq[SEL_][(F) >> 2], sWq[SEL_][(G) >> 2]);                \
+      else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"(ring[(F) % 4]), "v"((BW)[G]));        \
+    }                                                                                                                             \
   } while (0)
   // group G of the tile in stage PAR (its W fragments in BW, the next tile's go to BN); fillers between single MFMAs.
   // LDS-DMA schedule (F8_DMA_SCHED, table kDmaSched): piece s of the 16 is issued in the group the table gives, one piece per slot, the
@@ -369,8 +387,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 #define X8_MMA(F, G, BW)                                                                                                          \
   do {                                                                                                                            \
-    if (MX) mma_mx<(G) & 3, (F) & 3>(acc[F][G], (BW)[G], ring[(F) % 4], sWq[SEL_][(G) >> 2], sAq[SEL_][(F) >> 2]);                  \
-    else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]));          \
+    if (F8_EPI_LDS) {                                                                                                             \
+      if (MX) mma_mx<(G) & 3, (F) & 3>(acc[F][G], (BW)[G], ring[(F) % 4], sWq[SEL_][(G) >> 2], sAq[SEL_][(F) >> 2]);                \
+      else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"((BW)[G]), "v"(ring[(F) % 4]));        \
+    } else { /* A fragment first: the accumulator holds C, lane (fr, fg) owns rows F*16 + fg*4 + [0,4) and W fragment row fr */     \
+      if (MX) mma_mx<(F) & 3, (G) & 3>(acc[F][G], ring[(F) % 4], (BW)[G], sAq[SEL_][(F) >> 2], sWq[SEL_][(G) >> 2]);                \
+      else asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(acc[F][G]) : "v"(ring[(F) % 4]), "v"((BW)[G]));        \
+    }                                                                                                                             \
   } while (0)
   // the two LDS-DMA pieces of group G (J = 0, 1): group 0 - the last two W pieces of tile T+1; groups 1..4 - the eight A pieces of tile T+2 (-> the
   // stage tile T-1 left at the barrier of T-1); groups 5..7 - the first six W pieces of tile T+2 (-> W stage PAR, free since this tile's barrier)
@@ -444,7 +467,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef X8_DMA
 #undef X8_MMA
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  X8_BAR();
+#if F8_EPI_LDS
+  X8_BAR();  // (the staged epilogue reuses the LDS stages)
+#endif
 #if F8_ABLATE == 5
   {
     float sum = 0.f;
@@ -457,6 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #endif
 
+#if F8_EPI_LDS
   // ---- epilogue: scales, bias -> bf16 -> LDS, four passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave),
   // then the row-contiguous half of ce_gemm_epi.h (activation / gated residual, 16-byte stores)
   f32x4 swv[8], bvv[8];
@@ -596,6 +622,174 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                          m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
     }
   }
+
+#else
+  // ---- epilogue, REGISTER-DIRECT (round 6).  With the A fragment as the FIRST operand the accumulator holds C: lane (fr, fg) of acc[F][G]
+  // owns rows F*16 + fg*4 + [0,4) of the wave tile and the output column of W fragment row fr - and the DMA's source-side row permutation
+  // (LDS row 16 G + i <- W row 8 i + G) makes that column 8 fr + G.  So for a fixed row (F, jj) a lane's eight G accumulators are EIGHT
+  // CONSECUTIVE COLUMNS: one 16-byte bf16 (8-byte e4m3) store per lane, the sixteen fr lanes of a quad-row cover 256 (128) contiguous bytes of
+  // the row - the row-contiguous stores the LDS staging existed for, without the LDS round trip, its eight barriers and the 24 KiB of LDS
+  // traffic per pass; an MX block of 32 output columns is the four lanes of a DPP quad.  Same arithmetic, same roundings, same order as the
+  // staged form (tests: bit-identical to ce_gemm_mxfp8 / ce_quant_rows_mxfp8 compositions and to the F8_EPI_LDS build).
+  const int col0 = n0 + wn * 128 + fr * 8;  // this lane's 8 output columns
+  const bool col_ok = col0 < N;
+  const int colc = min(col0, N - 8);
+  const int row_base = m0 + wm * 128 + fg * 4;  // + F*16 + jj
+  f32x4 swv[2], bvv[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    swv[h] = MX ? f32x4{1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(sw + colc + 4 * h);  // (MX: the matrix pipe applied the scales)
+    bvv[h] = bias != nullptr ? *reinterpret_cast<const f32x4*>(bias + colc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (partial) {
+    // fp32 slab, already scaled, in the [wave][f][g][lane'] order gemm256w4_reduce / gemm_fp8w4_reduce_gelu_q read (the C^T accumulator order of
+    // the staged form: lane' (fr', fg') of [f][g] = row f*16 + fr', columns g*16 + fg'*4 + [0,4)): this lane's (F, jj, G = 4 h .. 4 h + 3) is row
+    // F*16 + fg*4 + jj, columns fr*8 + 4 h + [0,4) -> f = F, fr' = fg*4 + jj, g = fr >> 1, fg' = 2 (fr & 1) + h
+    float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
+#pragma unroll
+    for (int F = 0; F < 8; ++F) {
+      f32x4 av[8];
+#pragma unroll
+      for (int G = 0; G < 8; ++G) {
+        asm volatile("" : "+a"(acc[F][G]));  // (pins the read-out of fragment row F here, as in the main path below)
+        av[G] = acc[F][G];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float sav = MX ? 1.0f : sa[min(row_base + F * 16 + jj, M - 1)];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 o = {av[4 * h + 0][jj] * (sav * swv[h][0]), av[4 * h + 1][jj] * (sav * swv[h][1]),
+                           av[4 * h + 2][jj] * (sav * swv[h][2]), av[4 * h + 3][jj] * (sav * swv[h][3])};
+          const int lane_o = fg * 4 + jj + 16 * (2 * (fr & 1) + h);
+          *reinterpret_cast<f32x4*>(slab + (((wave * 64 + F * 8 + (fr >> 1)) * 64) + lane_o) * 4) = o;
+        }
+      }
+    }
+    return;
+  }
+  // Gated residual: this lane's 32 residual chunks (8 F x 4 rows x 16 B) and its gate values are requested HERE, in front of the first
+  // row (the main loop's fragment registers are dead); stores are predicated by the buffer descriptor's range check.
+  // (GP = false - gate rows shorter than a tile, or a C beyond 32-bit byte offsets: per-row loads and 64-bit addresses)
+  constexpr bool prefetch = EPI == EPI_GATE_RES && GP;
+  u32x4 rv[8][4];
+  f32x4 gA[2], gB[2];
+  int g_switch = 0x7fffffff;
+  const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * (EPI == EPI_BIAS_GELU_Q ? 1 : 2)) +
+                                                                        (uint32_t)N * (EPI == EPI_BIAS_GELU_Q ? 1u : 2u), 0x00020000);
+  if (prefetch) {
+    gA[0] = gA[1] = gB[0] = gB[1] = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (gate != nullptr) {
+      const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
+      const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
+      const float* ga = gate + (size_t)s0 * N + colc;
+      const float* gb = gate + (size_t)s1 * N + colc;
+      gA[0] = *reinterpret_cast<const f32x4*>(ga);
+      gA[1] = *reinterpret_cast<const f32x4*>(ga + 4);
+      gB[0] = *reinterpret_cast<const f32x4*>(gb);
+      gB[1] = *reinterpret_cast<const f32x4*>(gb + 4);
+      if (s1 != s0) g_switch = s1 * gate_rows;
+    }
+#pragma unroll
+    for (int F = 0; F < 8; ++F)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        rv[F][jj] = *reinterpret_cast<const u32x4*>(res + (size_t)min(row_base + F * 16 + jj, M - 1) * ldres + colc);
+  }
+  f32x4 sarow[8];  // (per-row-scale form: this lane's 32 row scales, requested together - not beside the gated residual's 128 prefetch registers)
+  constexpr bool sa_ahead = !MX && EPI != EPI_GATE_RES;
+  if (sa_ahead) {
+#pragma unroll
+    for (int F = 0; F < 8; ++F)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) sarow[F][jj] = sa[min(row_base + F * 16 + jj, M - 1)];
+  }
+#pragma unroll
+  for (int F = 0; F < 8; ++F) {
+    f32x4 av[8];  // the eight accumulators of this fragment row out of the accumulator file, whole
+#pragma unroll
+    for (int G = 0; G < 8; ++G) {
+      asm volatile("" : "+a"(acc[F][G]));  // (pins the read-out of fragment row F here: nothing of it is hoisted above the rows in front of it)
+      av[G] = acc[F][G];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int m = row_base + F * 16 + jj;
+      const float sav = MX ? 1.0f : sa_ahead ? sarow[F][jj] : sa[min(m, M - 1)];
+      u32x4 y;  // bf16(acc * scales + bias), 8 columns
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int h = q >> 1, e = 2 * (q & 1);
+        y[q] = pack_bf16(av[2 * q][jj] * (sav * swv[h][e]) + bvv[h][e], av[2 * q + 1][jj] * (sav * swv[h][e + 1]) + bvv[h][e + 1]);
+      }
+      const bool ok = m < M && col_ok;
+      if (EPI == EPI_BIAS_GELU_Q) {
+        // GELU on the bf16 row piece, then ce_quant_rows_mxfp8's contract on the bf16 result: the block's other three 8-column pieces sit in
+        // the lanes fr ^ 1, fr ^ 2, fr ^ 3 of the same quad
+        unsigned char* q_out = reinterpret_cast<unsigned char*>(C);
+        u32x4 o;
+        float am = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[q] = pack_bf16(gelu_tanh(bf16lo(y[q])), gelu_tanh(bf16hi(y[q])));
+          am = fmaxf(am, fmaxf(fabsf(bf16lo(o[q])), fabsf(bf16hi(o[q]))));
+        }
+        am = fmaxf(am, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(am), 0xB1, 0xf, 0xf, true)));  // quad_perm [1,0,3,2]
+        am = fmaxf(am, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(am), 0x4E, 0xf, 0xf, true)));  // quad_perm [2,3,0,1]
+        const int byte = mx_scale_byte_nosat(am);
+        const float inv = mx_inv_scale(byte);
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[0]) * inv), clamp448(bf16hi(o[0]) * inv), w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[1]) * inv), clamp448(bf16hi(o[1]) * inv), w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[2]) * inv), clamp448(bf16hi(o[2]) * inv), w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(bf16lo(o[3]) * inv), clamp448(bf16hi(o[3]) * inv), w1, true);
+        if (GP) {
+          const uint32_t qoff = ok ? (uint32_t)m * (uint32_t)ldc + (uint32_t)col0 : 0xffffffffu;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)w0, (uint32_t)w1}, c_rsrc, qoff, 0, 0);
+        } else if (ok) {
+          *reinterpret_cast<u32x2*>(q_out + (size_t)m * ldc + col0) = u32x2{(uint32_t)w0, (uint32_t)w1};
+        }
+        if (ok && (fr & 3) == 0) qs_out[mx_gemm_scale_offset(m, col0 >> 5, N >> 7)] = (unsigned char)byte;
+      } else {
+        u32x4 o = y;
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_tanh(bf16lo(y[q])), gelu_tanh(bf16hi(y[q])));
+        } else if (EPI == EPI_GATE_RES) {
+          u32x4 r;
+          f32x4 g0, g1;
+          if (prefetch) {
+            r = rv[F][jj];
+            const bool second = m >= g_switch;
+            g0 = second ? gB[0] : gA[0];
+            g1 = second ? gB[1] : gA[1];
+          } else {
+            const int mc = min(m, M - 1);
+            r = *reinterpret_cast<const u32x4*>(res + (size_t)mc * ldres + colc);
+            g0 = g1 = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (gate != nullptr) {
+              const float* gp = gate + (gate_rows > 0 ? (size_t)(mc / gate_rows) * N : 0) + colc;
+              g0 = *reinterpret_cast<const f32x4*>(gp);
+              g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
+            // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
+            o[q] = pack_bf16(mul_then_add(bf16lo(y[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(y[q]), gb, bf16hi(r[q])));
+          }
+        }
+        if (GP) {
+          const uint32_t coff = ok ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)col0 * 2u : 0xffffffffu;
+          __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
+        } else if (ok) {
+          *reinterpret_cast<u32x4*>(C + (size_t)m * ldc + col0) = o;
+        }
+      }
+    }
+  }
+#endif
 }
 
 // Split-K tail of the FFN-up form: sums the `split` fp32 slabs of one quadrant (= one producer wave's 128 x 128 accumulators, layout
@@ -677,7 +871,12 @@ static int fp8w4_launch(bool mx, const void* Aq, const void* Wq, void* C, const 
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n, kt = K / BKB;
   // (the prefetched gated-residual epilogue holds ONE or TWO samples' gate rows per tile and stores through 32-bit offsets)
+#if F8_EPI_LDS
   const bool gate_prefetch = epilogue != EPI_GATE_RES || ((gate == nullptr || gate_rows <= 0 || gate_rows >= BM) && (long long)M * ldc * 2 < (1ll << 32));
+#else
+  // (register-direct epilogue: every form stores through a buffer descriptor's 32-bit offsets when C fits them)
+  const bool gate_prefetch = (long long)M * ldc * 2 < (1ll << 32) && (epilogue != EPI_GATE_RES || gate == nullptr || gate_rows <= 0 || gate_rows >= BM);
+#endif
   float* g_ws = nullptr;
   size_t g_ws_bytes = 0;
   int g_cus = 256;
@@ -790,11 +989,17 @@ CE_API int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* 
   bool& done = done_[ce_device_slot()];
   if (!done) {
     if (hipFuncSetAttribute((const void*)gemm_fp8_w4<EPI_BIAS_GELU_Q, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return CE_ERR_ARG;
+    if (hipFuncSetAttribute((const void*)gemm_fp8_w4<EPI_BIAS_GELU_Q, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return CE_ERR_ARG;
     done = true;
   }
-  hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true>), dim3(t_full + tail * split), dim3(256), LDS_BYTES, stream, (const unsigned char*)Aq,
-                     (const unsigned char*)Wq, (bf16*)q_out, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, nullptr,
-                     nullptr, M, N, K, lda, ldw, ldq, 0, 0, tiles_m, tiles_n, t_full, split, g_ws, (unsigned char*)qs_out);
+  if ((long long)M * ldq < (1ll << 32))
+    hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true>), dim3(t_full + tail * split), dim3(256), LDS_BYTES, stream, (const unsigned char*)Aq,
+                       (const unsigned char*)Wq, (bf16*)q_out, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, nullptr,
+                       nullptr, M, N, K, lda, ldw, ldq, 0, 0, tiles_m, tiles_n, t_full, split, g_ws, (unsigned char*)qs_out);
+  else  // (a q_out beyond 32-bit byte offsets: 64-bit store addresses)
+    hipLaunchKernelGGL((gemm_fp8_w4<EPI_BIAS_GELU_Q, true, false>), dim3(t_full + tail * split), dim3(256), LDS_BYTES, stream, (const unsigned char*)Aq,
+                       (const unsigned char*)Wq, (bf16*)q_out, reinterpret_cast<const float*>(sa8), reinterpret_cast<const float*>(sw8), bias, nullptr,
+                       nullptr, M, N, K, lda, ldw, ldq, 0, 0, tiles_m, tiles_n, t_full, split, g_ws, (unsigned char*)qs_out);
   if (tail)
     hipLaunchKernelGGL(gemm_fp8w4_reduce_gelu_q, dim3(4 * tail), dim3(256), 0, stream, (unsigned char*)q_out, (unsigned char*)qs_out, bias, M, N, ldq,
                        tiles_m, tiles_n, t_full, split, g_ws);
@@ -802,13 +1007,13 @@ CE_API int ce_gemm_mxfp8_gelu_quant(const void* Aq, const void* Wq, const void* 
 }
 
 /* How this library was compiled (include/chronoedit_hip.h): bit 0 the diagnostic build (-DCE_DIAGNOSTICS), bit 1 F8_A3, bits 4-7
- * F8_DMA_SCHED, bits 8-15 F8_ABLATE (non-zero: a timing-only build of the MX fp8 GEMM whose RESULTS ARE GARBAGE - the loader refuses it
+ * F8_DMA_SCHED, bit 2 F8_EPI_LDS (the staged epilogue of rounds 3-5: W scales in the A order), bits 8-15 F8_ABLATE (non-zero: a timing-only build of the MX fp8 GEMM whose RESULTS ARE GARBAGE - the loader refuses it
  * unless asked for by name). */
 CE_API int ce_build_info(void) {
   int v = 0;
 #ifdef CE_DIAGNOSTICS
   v |= 1;
 #endif
-  v |= (F8_A3 ? 2 : 0) | ((F8_DMA_SCHED & 15) << 4) | ((F8_ABLATE & 255) << 8);
+  v |= (F8_A3 ? 2 : 0) | (F8_EPI_LDS ? 4 : 0) | ((F8_DMA_SCHED & 15) << 4) | ((F8_ABLATE & 255) << 8);
   return v;
 }

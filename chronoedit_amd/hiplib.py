@@ -57,6 +57,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_quant_rows_fp8": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ce_gemm_fp8": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_quant_rows_mxfp8": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "ce_quant_rows_mxfp8_w": [_P, _P, _P, _I, _I, _I, _I, _P],
     "ce_ln_affine_mxfp8": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "ce_gemm_mxfp8": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ce_gemm_mxfp8_gelu_quant": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -98,6 +99,7 @@ DIAG_SIGNATURES: Dict[str, List] = {
     "ce_set_gemm_fp8_variant": [_I],
     "ce_set_attention_mxfp8_variant": [_I],
     "ce_set_attention_mxfp8_persistent": [_I],
+    "ce_diag_attention_exact_route_hits": [_P, _I],
 }
 
 

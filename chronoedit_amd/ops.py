@@ -41,13 +41,35 @@ def lib():
     return _lib
 
 
+_force_diag = False
+
+
+def force_diagnostics(on: bool = True) -> None:
+    """(tools) send launches through libchronoedit_hip_diag.so even with every selector at its default - e.g. to read the exact-route counters
+    of the attention kernels (ce_diag_attention_exact_route_hits) for launches that run the DEFAULT bodies."""
+    global _lib, _force_diag
+    lib()
+    _force_diag = bool(on)
+    want = hiplib.load_diagnostics() if (_force_diag or any(_knobs[k] != _KNOB_DEFAULTS[k] for k in _knobs)) else _product
+    if want is not _lib:
+        _lib = want
+        _gemm_ws.pop("active", None)
+
+
+def attention_exact_route_hits(reset: bool = True):
+    """(diagnostic build) (bf16 kernels, MXFP8 kernel): waves x key tiles that took the exact route of the speculative softmax since the last reset."""
+    buf = (ctypes.c_ulonglong * 2)()
+    _check(hiplib.load_diagnostics().ce_diag_attention_exact_route_hits(buf, 1 if reset else 0), "ce_diag_attention_exact_route_hits")
+    return int(buf[0]), int(buf[1])
+
+
 def _set_knob(symbol: str, v: int) -> int:
     global _lib
     lib()
     diag = hiplib.load_diagnostics()
     prev = getattr(diag, symbol)(int(v))
     _knobs[symbol] = getattr(diag, symbol)(int(v))  # (setters ignore values they do not know: read back what is in force)
-    want = diag if any(_knobs[k] != _KNOB_DEFAULTS[k] for k in _knobs) else _product
+    want = diag if (_force_diag or any(_knobs[k] != _KNOB_DEFAULTS[k] for k in _knobs)) else _product
     if want is not _lib:
         _lib = want
         _gemm_ws.pop("active", None)  # the split-K scratch registry is per library: re-register with the one launches now go through
@@ -792,16 +814,21 @@ def mx_scale_bytes(rows: int, K: int) -> int:
     return (rows + 127) // 128 * (K // 128) * 512
 
 
-def mx_scales_to_rows(scale8: torch.Tensor, rows: int, K: int) -> torch.Tensor:
-    """The tiled scale buffer as a plain [rows, K/32] uint8 matrix (E8M0 bytes; for tests and tools - not on the hot path)."""
+def mx_scales_to_rows(scale8: torch.Tensor, rows: int, K: int, w_order: bool = False) -> torch.Tensor:
+    """The tiled scale buffer as a plain [rows, K/32] uint8 matrix (E8M0 bytes; for tests and tools - not on the hot path).
+    w_order: the buffer is in the W order ([rb][kt][g][128 rows], `quant_rows_mxfp8(..., w_order=True)`), else in the A order."""
     rb, kt = (rows + 127) // 128, K // 128
+    if w_order:
+        t = scale8[: rb * kt * 512].view(rb, kt, 4, 128)            # [rb][kt][g][row % 128]
+        return t.permute(0, 3, 1, 2).reshape(rb * 128, kt * 4)[:rows]
     t = scale8[: rb * kt * 512].view(rb, kt, 4, 16, 8)          # [rb][kt][g][fr][F]
     return t.permute(0, 4, 3, 1, 2).reshape(rb * 128, kt * 4)[:rows]  # row = rb*128 + F*16 + fr, block = kt*4 + g
 
 
-def quant_rows_mxfp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+def quant_rows_mxfp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None, w_order: bool = False):
     """x [M,K] bf16 -> (q [M,K] uint8 holding e4m3, scale8 uint8: one E8M0 byte per 32 consecutive elements of a row, tiled layout of
-    `gemm_mxfp8`): the OCP MX contract of oracle.dit_oracle.mx_quant.  K % 128 == 0."""
+    `gemm_mxfp8`): the OCP MX contract of oracle.dit_oracle.mx_quant.  K % 128 == 0.  w_order=True: the scale order of the GEMM's WEIGHT
+    operand (ce_quant_rows_mxfp8_w; weights are quantised once at load time), else of its activation operand."""
     _dev(x, torch.bfloat16, "x")
     M, K, ldx = _rows(x, "x")
     if out is None:
@@ -812,7 +839,9 @@ def quant_rows_mxfp8(x: torch.Tensor, out: Optional[torch.Tensor] = None, scale:
     assert scale.is_contiguous() and scale.numel() >= mx_scale_bytes(M, K)
     _, _, ldq = _rows(out, "out")
     st = _prof_begin()
-    _check(lib().ce_quant_rows_mxfp8(_ptr(x), _ptr(out), _ptr(scale), M, K, ldx, ldq, _stream()), "ce_quant_rows_mxfp8")
+    # (an A/B build with the staged epilogue of rounds 3-5, -DF8_EPI_LDS=1 = ce_build_info bit 2, reads the W scales in the A order)
+    fn = lib().ce_quant_rows_mxfp8_w if (w_order and not lib().ce_build_info() & 4) else lib().ce_quant_rows_mxfp8
+    _check(fn(_ptr(x), _ptr(out), _ptr(scale), M, K, ldx, ldq, _stream()), "ce_quant_rows_mxfp8")
     _prof_end(st, f"quant_mxfp8_{M}x{K}", 3.0 * M * K)
     return out, scale
 
@@ -835,7 +864,8 @@ def ln_affine_mxfp8(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, eps: floa
 def gemm_mxfp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, bias: Optional[torch.Tensor],
                out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None,
                res: Optional[torch.Tensor] = None, gate_rows: int = 0):
-    """out[M,N] (bf16) = epilogue(MX-scaled aq @ wq^T + bias); aq [M,K], wq [N,K] uint8 (e4m3) with their tiled E8M0 scale buffers."""
+    """out[M,N] (bf16) = epilogue(MX-scaled aq @ wq^T + bias); aq [M,K], wq [N,K] uint8 (e4m3) with their tiled E8M0 scale buffers: sa in the
+    A order (every activation producer writes it), sw in the W order (`quant_rows_mxfp8(w, w_order=True)`)."""
     _dev(aq, torch.uint8, "aq"), _dev(wq, torch.uint8, "wq"), _dev(sa, torch.uint8, "sa"), _dev(sw, torch.uint8, "sw")
     M, K, lda = _rows(aq, "aq")
     N, K2, ldw = _rows(wq, "wq")

@@ -195,6 +195,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         self._gen = next(_GENERATION)  # engine_generation(): see there
         self.cache_context = False  # reuse K3/K13 results while the conditioning tensors are unchanged
         self.gemm_dtype = "bf16"    # "fp8": the six large Linears of every block on the OCP-e4m3 MX matrix path
+        self.fp8_linears = self.FP8_LINEARS  # which of them, once the fp8 mode is on (enable_fp8_gemms(linears= / policy=))
         self.attn_dtype = "bf16"    # "mxfp8": self-attention on the MX-fp8 matrix instruction (csrc/ce_attn_fp8.hip)
         self.v_transposed = True    # bf16 self-attention takes V^T straight from the projection (swapped GEMM) and stages it by LDS-DMA
         self.sp_batch_cfg = True    # sequence-parallel forwards take the guidance pair as one batch of two (blocked-layout kernels)
@@ -298,14 +299,36 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         """Call after changing parameters in place (LoRA fuse, load_state_dict): re-packs on next forward."""
         self._engine = None
 
-    def enable_fp8_gemms(self, on: bool = True, mx: bool = True):
+    FP8_LINEARS = ("qkv", "o1", "q2", "o2", "f1", "f2")  # fused q|k|v, self-attention out, cross-attention q, cross-attention out, FFN up, FFN down
+    # Mixed-precision policies of the fp8 mode (round 6): which of the six large Linears of a block run on the MX fp8 GEMM - the others stay
+    # on the bf16 GEMM.  From the measurement in profiles/r06_fp8_sensitivity.txt (one full-width block at N = 7 200 against the fp32 oracle,
+    # one Linear in fp8 at a time): the UNGATED cross-attention out-projection `o2` alone carries 3.3e-2 of the 3.7e-2 the fp8 mode adds to
+    # the bf16 path's 4.8e-3 (its result enters the residual stream at full scale; `o1` and `f2` are multiplied by their AdaLN gates first,
+    # `qkv` feeds a softmax); the MXFP8 self-attention adds 1.0e-3.  "fast" = all six (7.8 x the bf16 error per block); "accurate" = all but
+    # `o2` (4.0 x) for one 5120 x 5120 GEMM per block back on the bf16 kernel.
+    FP8_POLICIES = {"fast": ("qkv", "o1", "q2", "o2", "f1", "f2"), "accurate": ("qkv", "o1", "q2", "f1", "f2")}
+
+    def enable_fp8_gemms(self, on: bool = True, mx: bool = True, linears=None, policy: Optional[str] = None):
         """BASELINE.json configs[4]: run the six large Linears of every block (fused q|k|v, the two output projections, the
         cross-attention query, FFN up / down) in fp8 e4m3 with fp32 accumulation on the MX matrix instruction.
         mx=True (default since round 4): OCP MXFP8 operands - one E8M0 scale per 32 consecutive input channels of every activation row and
         of every weight row, applied inside the matrix pipe (`ce_gemm_mxfp8`; quantisers `ce_quant_rows_mxfp8` / `ce_ln_affine_mxfp8`);
         mx=False: one fp32 scale per token row / per output channel (`ce_gemm_fp8`, the round-1..3 contract).  Weights are quantised once;
-        attention, norms, the residual stream, the conditioning projections and the head stay bf16 / fp32.  The bf16 parameters are kept."""
-        self.gemm_dtype = ("mxfp8" if mx else "fp8") if on else "bf16"
+        attention, norms, the residual stream, the conditioning projections and the head stay bf16 / fp32.  The bf16 parameters are kept.
+        linears / policy (round 6): a subset of FP8_LINEARS, or the name of one of FP8_POLICIES ("fast" = all six, the default; "accurate" = all but the
+        ungated cross-attention out-projection, 4.0 x instead of 7.8 x the bf16 path's error per block) - Linears not named run the bf16 GEMM on bf16 activations."""
+        if policy is not None:
+            if linears is not None:
+                raise ValueError("enable_fp8_gemms: give `linears` or `policy`, not both")
+            if policy not in self.FP8_POLICIES:
+                raise ValueError(f"enable_fp8_gemms: unknown policy {policy!r} (one of {sorted(self.FP8_POLICIES)})")
+            linears = self.FP8_POLICIES[policy]
+        linears = tuple(self.FP8_LINEARS if linears is None else linears)
+        bad = [n for n in linears if n not in self.FP8_LINEARS]
+        if bad:
+            raise ValueError(f"enable_fp8_gemms: unknown Linear name(s) {bad} (of {self.FP8_LINEARS})")
+        self.fp8_linears = tuple(n for n in self.FP8_LINEARS if n in linears)
+        self.gemm_dtype = ("mxfp8" if mx else "fp8") if (on and self.fp8_linears) else "bf16"
         self._engine = None
         return self
 
@@ -374,7 +397,7 @@ class ChronoEditTransformer3DModel(LoraMixin, nn.Module):
         first-time initialisation.  (Process-unique, unlike id(): a recycled address cannot alias an earlier model.)"""
         eng = self._engine
         sp = self._sp
-        return (self._gen, None if eng is None else eng.ws_generation, self.gemm_dtype, self.attn_dtype, self.v_transposed, self.cross_vt,
+        return (self._gen, None if eng is None else eng.ws_generation, self.gemm_dtype, self.fp8_linears, self.attn_dtype, self.v_transposed, self.cross_vt,
                 self.sp_batch_cfg, bool(getattr(self, "rope_plain_temporal", False)), self.cache_context,
                 None if sp is None else (sp.world, sp.rank), self._cfgp is not None)
 
@@ -520,6 +543,7 @@ class DiTEngine:
         self.fp8_cross = self.fp8_attn and bool(getattr(model, "fp8_cross", False))  # cross-attention under the MXFP8 contract too
         self.fp8 = model.gemm_dtype in ("fp8", "mxfp8")
         self.mx = model.gemm_dtype == "mxfp8"  # MX block scales on both GEMM operands (ce_gemm_mxfp8)
+        self.fp8_set = frozenset(getattr(model, "fp8_linears", model.FP8_LINEARS)) if self.fp8 else frozenset()  # which Linears (mixed precision)
         self.fuse_quant = bool(getattr(model, "fp8_fuse_quant", True)) and self.F % 128 == 0  # MX: quantisation fused into the FFN-up epilogue
         self.fuse_attn_quant = self.fuse_quant and bool(getattr(model, "fp8_fuse_attn_quant", True))
         self.v_transposed = bool(getattr(model, "v_transposed", True))
@@ -527,8 +551,9 @@ class DiTEngine:
             if self.D % 256 or self.F % 256:
                 raise NotImplementedError("fp8 GEMMs need inner and ffn dims that are multiples of 256")
             for p in self.blk:  # per-output-channel e4m3 copies of the six large weights (the bf16 originals stay)
-                for name in ("qkv", "o1", "q2", "o2", "f1", "f2"):
-                    setattr(p, "q_" + name, (ops.quant_rows_mxfp8 if self.mx else ops.quant_rows_fp8)(getattr(p, "w_" + name)))
+                for name in sorted(self.fp8_set):
+                    w = getattr(p, "w_" + name)  # (MX: the weight operand's scale order, ce_quant_rows_mxfp8_w)
+                    setattr(p, "q_" + name, ops.quant_rows_mxfp8(w, w_order=True) if self.mx else ops.quant_rows_fp8(w))
         # K13 for ALL layers as one GEMM per context stream and operand: the per-layer to_k (to_v, add_k_proj, add_v_proj) weights are
         # re-homed, layer after layer, in one [L*D, D] buffer each (the step-invariant projections of 769 context rows are 160 small
         # GEMMs otherwise: 0.5-1.0 PFLOP/s at M = 514 / 1024 against 1.35 for one [M, L*D] product).  K and V apart (round 4): the V
@@ -572,7 +597,7 @@ class DiTEngine:
         """LayerNorm (+ affine / AdaLN rows) followed by one of the large projections.  fp8 mode: the LN kernel emits the fp8
         operand and its row scales directly (no bf16 round trip through HBM, no separate quantisation pass)."""
         eps = self.cfg.eps
-        if not self.fp8:
+        if name not in self.fp8_set:
             ops.ln_affine(x, a_row, b_row, eps, out=ws.h, ab_rows=ab_rows, ab_stride=ab_stride)
             return ops.gemm(ws.h, getattr(p, "w_" + name), getattr(p, "b_" + name), out=out, **kw)
         aq = ws.a8[:, : x.shape[1]]
@@ -587,7 +612,8 @@ class DiTEngine:
         """One of the six large projections of a block: bf16 GEMM, or (fp8 mode) row-quantise the activations and run the MX GEMM.
         quantised: the producer already wrote the MX operand into ws.a8 / ws.s8 (an attention kernel's fused output)."""
         w, b = getattr(p, "w_" + name), getattr(p, "b_" + name)
-        if not self.fp8:
+        if name not in self.fp8_set:
+            assert not quantised, name  # (a bf16 Linear takes bf16 activations: the caller did not ask its producer for the MX operand)
             return ops.gemm(a, w, b, out=out, **kw)
         K = a.shape[1]
         aq = ws.a8[:, :K]
@@ -607,7 +633,7 @@ class DiTEngine:
         all-to-all send layout; the attention kernel and the out-projection read the receive buffers in place."""
         D, H, hd, eps, W = self.D, self.H, self.cfg.attention_head_dim, self.cfg.eps, sp.world
         Dl = D // W
-        if not self.fp8:
+        if "qkv" not in self.fp8_set:
             ops.ln_affine(x, a_row, b_row, eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
             lin = lambda lo, hi, out: ops.gemm(ws.h, p.w_qkv[lo:hi], p.b_qkv[lo:hi], out=out)
         else:
@@ -641,7 +667,7 @@ class DiTEngine:
         else:
             ops.attention(sp.gathered_view(ws.recv_q), kv[:N, :Dl], kv[:N, Dl:], H // W, out=ws.att_g)
         y, _ = sp.all_to_all(ws.att_g.view(W, B * Nl, Dl), ws.att_seg)  # [head group][local row][Dl]
-        if self.fp8:  # the row quantiser wants plain rows: secondary mode, one gather pass
+        if "o1" in self.fp8_set:  # the row quantiser wants plain rows: secondary mode, one gather pass
             ws.att.copy_(sp.merge_heads_reference(y))
             return ws.att
         return y  # K-segmented A operand of the out-projection (ce_gemm_aseg_bf16)
@@ -883,6 +909,7 @@ class DiTEngine:
 
         x = ws.x
         fuse_o = self.mx and self.fuse_attn_quant and D % 128 == 0  # MX: both attention kernels emit the out-projections' fp8 operands themselves
+        fuse_o1, fuse_o2 = fuse_o and "o1" in self.fp8_set, fuse_o and "o2" in self.fp8_set  # (only for an out-projection that runs in fp8)
         for li, p in enumerate(self.blk):
             q_o1 = False
             # 1. self-attention
@@ -893,13 +920,13 @@ class DiTEngine:
                 if ws.v8t is None or ws.v8t.shape[0] != B:
                     ws.v8t = ws.sv = None
                 ws.v8t, ws.sv = ops.v_mxfp8_transpose(ws.qkv[:, 2 * D :], Nl, B, H, out=ws.v8t, scale=ws.sv)
-                if fuse_o:  # the out-projection's MX operand straight from the attention epilogue (no bf16 output, no quantisation pass)
+                if fuse_o1:  # the out-projection's MX operand straight from the attention epilogue (no bf16 output, no quantisation pass)
                     ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, batch=B, out8=ws.a8[:, :D], scale8=ws.s8)
                     q_o1 = True
                 else:
                     ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, out=ws.att, batch=B)
                 att = ws.att
-            elif sp is None and self.v_transposed and not self.fp8 and (B * Nl) % 8 == 0 and (B == 1 or Nl % 2 == 0):
+            elif sp is None and self.v_transposed and "qkv" not in self.fp8_set and (B * Nl) % 8 == 0 and (B == 1 or Nl % 2 == 0):
                 # q | k as one GEMM, V^T = W_v.h^T as the same GEMM with the operand roles swapped (bias along rows): the attention
                 # kernel's V^T operand [D][keys of all samples] without a transpose pass; K and V^T tiles both go by LDS-DMA
                 if getattr(ws, "vt", None) is None:
@@ -924,19 +951,19 @@ class DiTEngine:
                 self._ln_linear(ws, x, p.n2w, p.n2b, p, "q2", ws.q2)
             else:
                 self._linear(ws, x, p, "q2", ws.q2)
-            q_o2 = bool(ctx.vt and fuse_o)
+            q_o2 = bool(ctx.vt and fuse_o2)
             if ctx.f8:  # MXFP8 (round 5): text segment -> bf16, image segment adds it and emits bf16 or the out-projection's MX operand
                 seg_t, seg_i = ctx.kv[li]
                 ops.rmsnorm_rope_mxfp8(ws.q2, p.nq2, None, hd, eps, out=ws.q8, scale=ws.sq, post_scale=ops.MXFP8_Q_SCALE)
-                if seg_i is None and fuse_o:
+                if seg_i is None and fuse_o2:
                     ops.attention_mxfp8(ws.q8, ws.sq, *seg_t, H, batch=B, out8=ws.a8[:, :D], scale8=ws.s8)
                 else:
                     ops.attention_mxfp8(ws.q8, ws.sq, *seg_t, H, out=ws.att, batch=B)
-                    if seg_i is not None and fuse_o:
+                    if seg_i is not None and fuse_o2:
                         ops.attention_mxfp8(ws.q8, ws.sq, *seg_i, H, batch=B, out8=ws.a8[:, :D], scale8=ws.s8, add=ws.att)
                     elif seg_i is not None:
                         ops.attention_mxfp8(ws.q8, ws.sq, *seg_i, H, out=ws.att, batch=B, add=ws.att)
-                q_o2 = fuse_o
+                q_o2 = fuse_o2
                 self._linear(ws, ws.att, p, "o2", x, quantised=q_o2, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
                 k_t = None
             else:
@@ -944,7 +971,7 @@ class DiTEngine:
                 k_t, v_t, k_i, v_i = ctx.kv[li]
             if k_t is None:
                 pass
-            elif ctx.vt and fuse_o:
+            elif ctx.vt and fuse_o2:
                 ops.attention_2seg_vt(ws.q2, k_t, v_t, Tt, k_i, v_i, Ti, H, batch=B, cols1=ctx.c1, cols2=ctx.c2, out8=ws.a8[:, :D], scale8=ws.s8)
             elif ctx.vt:  # both segments' K and V^T tiles by LDS-DMA (v_t / v_i are V^T row blocks of this layer)
                 ops.attention_2seg_vt(ws.q2, k_t, v_t, Tt, k_i, v_i, Ti, H, out=ws.att, batch=B, cols1=ctx.c1, cols2=ctx.c2)
@@ -955,7 +982,7 @@ class DiTEngine:
             if k_t is not None:
                 self._linear(ws, ws.att, p, "o2", x, quantised=q_o2, epilogue=ops.EPI_GATE_RES, gate=None, res=x)
             # 3. feed-forward
-            if self.mx and self.fuse_quant:
+            if self.mx and self.fuse_quant and "f1" in self.fp8_set and "f2" in self.fp8_set:
                 # MX: the up-projection's bias + GELU epilogue emits the down-projection's fp8 operand and its block scales directly (a
                 # block = 32 consecutive output columns: no row-wide reduction) - no bf16 [N, F] matrix, no quantisation pass
                 aq = ws.a8[:, :D]

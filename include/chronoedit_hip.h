@@ -306,19 +306,27 @@ int ce_gemm_fp8(const void* Aq, const void* Wq, void* C, const float* sa, const 
 /* ---- the MX form of the fp8 GEMMs (round 4; BASELINE.json configs[4] "fp8 weights"): OCP MXFP8 operands - e4m3 elements with one E8M0
  * scale per 32 consecutive K elements of a row, scale = the smallest power of two with amax / scale <= 448 (2^-126 for an all-zero block:
  * the non-saturating choice - with the OCP floor rule 2^(floor(log2 amax) - 8) an eighth of the blocks have their largest elements clipped),
- * elements RNE(x / scale) - and the block scales applied INSIDE the matrix pipe by v_mfma_scale_f32_16x16x128_f8f6f4.  Scale bytes are stored in the order the GEMM reads them:
- * [ceil(rows / 128)][K / 128][4][16][8], i.e. the scale of elements [128 t + 32 g, + 32) of row r at byte
- * ((r / 128 * (K / 128) + t) * 4 + g) * 128 + (r % 16) * 8 + (r / 16) % 8; a scale buffer holds ceil(rows / 128) * (K / 128) * 512 bytes.
+ * elements RNE(x / scale) - and the block scales applied INSIDE the matrix pipe by v_mfma_scale_f32_16x16x128_f8f6f4.
+ * Scale bytes are stored in the order the GEMM reads them.
+ * A operand (activations; every producer of this library writes it): [ceil(rows / 128)][K / 128][4][16][8], i.e. the scale of elements
+ * [128 t + 32 g, + 32) of row r at byte ((r / 128 * (K / 128) + t) * 4 + g) * 128 + (r % 16) * 8 + (r / 16) % 8.
+ * W operand (weights; round 6): [ceil(rows / 128)][K / 128][4][128], the same byte with r % 128 in place of (r % 16) * 8 + (r / 16) % 8 - the
+ * GEMM feeds fragment G of a wave tile with the weight rows G + 8 i, so that a lane's eight accumulators are eight CONSECUTIVE output columns
+ * (the epilogue stores straight from registers, csrc/ce_gemm_fp8w4.hip), and a lane's eight scale bytes are consecutive in this order.
+ * A scale buffer holds ceil(rows / 128) * (K / 128) * 512 bytes in either order.
  * The reference has no fp8 path: the contract is oracle.dit_oracle.mx_quant / linear_mxfp8. ---- */
 
-/* x bf16 [M][ldx] -> q e4m3 bytes [M][ldq] + scale8 (above).  K % 128 == 0.  Activations (per token row) and, at load time, weights. */
+/* x bf16 [M][ldx] -> q e4m3 bytes [M][ldq] + scale8 in the A order (above).  K % 128 == 0.  Activations (per token row). */
 int ce_quant_rows_mxfp8(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream);
+
+/* The same with scale8 in the W order: the weight operand of ce_gemm_mxfp8 / ce_gemm_mxfp8_gelu_quant, quantised once at load time. */
+int ce_quant_rows_mxfp8_w(const void* x, void* q, void* scale8, int M, int K, int ldx, int ldq, hipStream_t stream);
 
 /* ce_ln_affine_bf16 followed by ce_quant_rows_mxfp8 in one pass (the quantisation of the bf16 row ce_ln_affine_bf16 would have written). */
 int ce_ln_affine_mxfp8(const void* x, void* q, void* scale8, const float* a, const float* b, int M, int D, int ldx, int ldq, float eps,
                        int ab_rows, int ab_stride, hipStream_t stream);
 
-/* C = epilogue(sum_blocks 2^(ea + ew) (Aq Wq^T)_block + bias[n]); Aq [M][lda], Wq [N][ldw] e4m3 bytes with their scale buffers sa8 / sw8,
+/* C = epilogue(sum_blocks 2^(ea + ew) (Aq Wq^T)_block + bias[n]); Aq [M][lda], Wq [N][ldw] e4m3 bytes with their scale buffers sa8 (A order) / sw8 (W order),
  * C bf16; K % 256 == 0, N % 8 == 0.  Epilogues 0 (bias), 1 (bias + tanh GELU), 2 (gated residual; gate rows per sample >= 256 or one gate)
  * as ce_gemm_bf16; the one-wave-per-SIMD main loop of csrc/ce_gemm_fp8w4.hip, split-K tail through the ce_set_gemm_workspace scratch. */
 int ce_gemm_mxfp8(const void* Aq, const void* Wq, void* C, const void* sa8, const void* sw8, const float* bias, int epilogue, const float* gate,

@@ -44,6 +44,11 @@ int ce_set_attention_mxfp8_variant(int variant);
  * workgroup per (head, query block, sample).  Host-side tuning knob. */
 int ce_set_attention_mxfp8_persistent(int n);
 
+/* How often the attention kernels' speculative softmax fell back to its exact route: hits[0] = (wave, key tile) pairs of the bf16
+ * software-pipelined kernels since the last reset, hits[1] = of the MXFP8 kernel; reset != 0 zeroes both counters.  Synchronises the
+ * device.  tools/attn_peaked.py: the kernels' rate on peaked score rows. */
+int ce_diag_attention_exact_route_hits(unsigned long long* hits, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -340,15 +340,21 @@ def attention_mxfp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, lazy_offs
 # --------------------------------------------------------------------------------------
 
 
-def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=None, fp8=False, fp8_attn=False):
+FP8_LINEARS = ("qkv", "o1", "q2", "o2", "f1", "f2")  # the names chronoedit_amd.transformer gives the six large Linears of a block
+
+
+def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=None, fp8=False, fp8_attn=False, fp8_linears=FP8_LINEARS):
     """ChronoEditAttnProcessor2_0.__call__ (transformer_chronoedit.py:43-108).  fp8: the projections that chronoedit_amd runs on
     the fp8 path (q, the self-attention k / v, the output projection) follow linear_fp8; the context k / v stay as they are.
     fp8_attn: True - the SELF-attention product under the MXFP8 contract (attention_mxfp8), cross-attention stays SDPA; "all" (round 5) -
     the two segments of the cross-attention under the same contract too, each rounded to the activation dtype before the add (:96-107)."""
     self_attn = encoder is None
     H = cfg.num_attention_heads
-    lin_q = _fp8_linear(fp8)
-    lin_kv = _fp8_linear(fp8) if encoder is None else linear
+    # mixed precision (round 6): fp8_linears names which of the Linears follow the fp8 contract - self-attention: "qkv" (to_q / to_k / to_v) and
+    # "o1" (to_out); cross-attention: "q2" (to_q) and "o2" (to_out); the rest are plain
+    lin_q = _fp8_linear(fp8 if ("qkv" if self_attn else "q2") in fp8_linears else False)
+    lin_kv = _fp8_linear(fp8 if "qkv" in fp8_linears else False) if encoder is None else linear
+    lin_o = _fp8_linear(fp8 if ("o1" if self_attn else "o2") in fp8_linears else False)
     enc_img = None
     has_added = (pre + ".add_k_proj.weight") in p
     if has_added and encoder is not None:
@@ -383,26 +389,26 @@ def attention(p, pre, cfg: DiTConfig, hidden, encoder=None, rotary=None, taps=No
         out = out + out_img
     if taps is not None:
         taps[pre + ".sdpa"] = out
-    return lin_q(out, p, pre + ".to_out.0")
+    return lin_o(out, p, pre + ".to_out.0")
 
 
-def feed_forward(p, pre, x, approximate: str, fp8=False):
+def feed_forward(p, pre, x, approximate: str, fp8=False, fp8_linears=FP8_LINEARS):
     """diffusers FeedForward: net.0 = GELU(proj + gelu), net.1 = Dropout(0), net.2 = Linear.
     "gelu-approximate" -> tanh (block FFN, transformer_chronoedit.py:262);
     "gelu" -> erf (image MLP, :116).  Sibling: wan_video_dit_chronoedit.py:224-225,251-257."""
-    lin = _fp8_linear(fp8)
-    h = F.gelu(lin(x, p, pre + ".net.0.proj"), approximate=approximate)
-    return lin(h, p, pre + ".net.2")
+    lin1, lin2 = _fp8_linear(fp8 if "f1" in fp8_linears else False), _fp8_linear(fp8 if "f2" in fp8_linears else False)
+    h = F.gelu(lin1(x, p, pre + ".net.0.proj"), approximate=approximate)
+    return lin2(h, p, pre + ".net.2")
 
 
-def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=None, fp8=False, fp8_attn=False):
+def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=None, fp8=False, fp8_attn=False, fp8_linears=FP8_LINEARS):
     """ChronoEditTransformerBlock.forward (transformer_chronoedit.py:267-295)."""
     b = f"blocks.{i}"
     shift, scale, gate, c_shift, c_scale, c_gate = (p[b + ".scale_shift_table"] + temb6.float()).chunk(6, dim=1)
     h = (fp32_layer_norm(x.float(), None, None, cfg.eps) * (1 + scale) + shift).type_as(x)
     if taps is not None:
         taps[b + ".ln1"] = h
-    a = attention(p, b + ".attn1", cfg, h, None, rotary, taps, fp8=fp8, fp8_attn=fp8_attn)
+    a = attention(p, b + ".attn1", cfg, h, None, rotary, taps, fp8=fp8, fp8_attn=fp8_attn, fp8_linears=fp8_linears)
     x = (x.float() + a * gate).type_as(x)
     if taps is not None:
         taps[b + ".x_after_attn1"] = x
@@ -410,12 +416,12 @@ def block_forward(p, i: int, cfg: DiTConfig, x, encoder, temb6, rotary, taps=Non
         h = fp32_layer_norm(x.float(), p[b + ".norm2.weight"], p[b + ".norm2.bias"], cfg.eps).type_as(x)
     else:
         h = x
-    a = attention(p, b + ".attn2", cfg, h, encoder, None, taps, fp8=fp8)
+    a = attention(p, b + ".attn2", cfg, h, encoder, None, taps, fp8=fp8, fp8_linears=fp8_linears)
     x = x + a
     if taps is not None:
         taps[b + ".x_after_attn2"] = x
     h = (fp32_layer_norm(x.float(), None, None, cfg.eps) * (1 + c_scale) + c_shift).type_as(x)
-    f = feed_forward(p, b + ".ffn", h, "tanh", fp8=fp8)
+    f = feed_forward(p, b + ".ffn", h, "tanh", fp8=fp8, fp8_linears=fp8_linears)
     x = (x.float() + f.float() * c_gate).type_as(x)
     return x
 
@@ -450,10 +456,12 @@ def dit_forward(
     taps: Optional[dict] = None,
     fp8=False,
     fp8_attn: bool = False,
+    fp8_linears=FP8_LINEARS,
 ) -> torch.Tensor:
     """ChronoEditTransformer3DModel.forward (transformer_chronoedit.py:397-476).  fp8 restates chronoedit_amd's fp8 GEMM modes (the six
     large Linears of every block under linear_fp8 - fp8=True / "row": per-row scales - or linear_mxfp8 - fp8="mx": MX block scales; everything
-    else unchanged); fp8_attn=True its MXFP8 self-attention, fp8_attn="all" the cross-attention under that contract as well."""
+    else unchanged); fp8_attn=True its MXFP8 self-attention, fp8_attn="all" the cross-attention under that contract as well; fp8_linears: the
+    subset of the six that follow the fp8 contract (the engine's mixed-precision policies, ChronoEditTransformer3DModel.FP8_POLICIES)."""
     B, C, T, Hh, Ww = hidden_states.shape
     pt, ph, pw = cfg.patch_size
     ppf, pph, ppw = T // pt, Hh // ph, Ww // pw
@@ -471,7 +479,7 @@ def dit_forward(
     if taps is not None:
         taps["temb"], taps["tproj"], taps["enc"] = temb, tproj, enc
     for i in range(cfg.num_layers):
-        x = block_forward(p, i, cfg, x, enc, tproj, rotary, taps, fp8=fp8, fp8_attn=fp8_attn)
+        x = block_forward(p, i, cfg, x, enc, tproj, rotary, taps, fp8=fp8, fp8_attn=fp8_attn, fp8_linears=fp8_linears)
         if taps is not None:
             taps[f"blocks.{i}.out"] = x
     shift, scale = (p["scale_shift_table"] + temb.unsqueeze(1)).chunk(2, dim=1)

@@ -115,6 +115,49 @@ def test_dit_forward_fp8_mode_vs_fp8_contract_oracle(mx):
     assert rel_l2(out8, out16) > 1e-3
 
 
+@pytest.mark.parametrize("linears", [("qkv",), ("o1",), ("q2",), ("o2",), ("f1",), ("f2",), ("f1", "f2"), "accurate", ("qkv", "o2", "f2")],
+                         ids=lambda v: v if isinstance(v, str) else "+".join(v))
+def test_dit_forward_mixed_precision_vs_contract_oracle(linears):
+    """Round 6 - enable_fp8_gemms(linears= / policy=): any subset of the six large Linears on the MX fp8 GEMM, the rest on the bf16 GEMM (every
+    producer / consumer pairing: LayerNorm -> fp8 or bf16, attention -> fused MX operand or bf16, the FFN pair fused / split), with the MXFP8
+    self-attention on.  Against the oracle restating the SAME subset (dit_forward(fp8="mx", fp8_linears=...)): contract-level agreement, and the
+    selection really is per Linear (a subset differs from both the bf16 path and the all-six mode)."""
+    from chronoedit_amd.transformer import ChronoEditTransformer3DModel
+    from oracle import dit_oracle as O
+    cfg = O.DiTConfig(num_attention_heads=2, ffn_dim=512, num_layers=3, text_dim=128, image_dim=64, added_kv_proj_dim=256)
+    p_bf = O.make_synthetic_params(cfg, seed=5, dtype=BF)
+    lat, text, image = O.make_synthetic_inputs(cfg, 2, 16, 24, dtype=BF)
+    m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=3, text_dim=128, image_dim=64,
+                                     added_kv_proj_dim=256, device="cuda:0")
+    m.load_synthetic_({k: v.cuda() for k, v in p_bf.items()})
+    ts = torch.tensor([400], device="cuda:0")
+    args = (lat.cuda(), ts, text.cuda(), image.cuda())
+    out16 = m(*args, return_dict=False)[0].clone()
+    m.enable_fp8_gemms().enable_fp8_attention()
+    out_all = m(*args, return_dict=False)[0].clone()
+    if isinstance(linears, str):
+        m.enable_fp8_gemms(policy=linears)
+        names = m.FP8_POLICIES[linears]
+    else:
+        m.enable_fp8_gemms(linears=linears)
+        names = linears
+    assert m.fp8_linears == tuple(n for n in m.FP8_LINEARS if n in names)
+    out = m(*args, return_dict=False)[0].clone()
+    again = m(*args, return_dict=False)[0]
+    assert torch.equal(out, again) and torch.isfinite(out.float()).all()
+    p32 = {k: v.float() for k, v in p_bf.items()}
+    with torch.no_grad():
+        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([400]), text.float(), image.float(), fp8="mx", fp8_attn=True, fp8_linears=names)
+    e = rel_l2(out, ref)
+    print(f"mixed precision {names}: hip vs the same-subset contract oracle {e:.3e}; vs bf16 path {rel_l2(out, out16):.3e}; vs all six {rel_l2(out, out_all):.3e}")
+    assert e <= 2.5e-2
+    assert not torch.equal(out, out16) and not torch.equal(out, out_all)
+    with pytest.raises(ValueError):
+        m.enable_fp8_gemms(linears=("qkv", "nope"))
+    with pytest.raises(ValueError):
+        m.enable_fp8_gemms(policy="fast", linears=("qkv",))
+
+
 def test_ln_affine_fp8_equals_two_launch_form():
     """The fused LayerNorm -> fp8 kernel == ln_affine followed by quant_rows_fp8, bit for bit (bytes and scales)."""
     from chronoedit_amd import ops

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_header_symbols():
     assert set(hiplib.SIGNATURES) == set(syms)
     assert set(hiplib.exported_symbols(path)) == set(syms)                      # `nm -D --defined-only` == the header
     diag = hiplib.header_symbols(diag=True)
-    assert set(diag) == set(hiplib.DIAG_SIGNATURES) and all(d.startswith("ce_set_") for d in diag)
+    assert set(diag) == set(hiplib.DIAG_SIGNATURES) and all(d.startswith(("ce_set_", "ce_diag_")) for d in diag)
     assert set(hiplib.exported_symbols(hiplib.DIAG_LIB_PATH)) == set(syms) | set(diag)
     for d in diag:                                                              # two engines in one process cannot fight over a selector:
         assert not hasattr(lib, d), d                                           # the product library has none

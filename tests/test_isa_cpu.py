@@ -96,8 +96,8 @@ def test_fp8_one_wave_per_simd_gemm_loop():
         assert r[2] <= 512 and r[3] <= 16, r
     loops = isa_lint.inner_loops(src, "gemm_fp8_w4")
     # template arguments <EPI, MX, GP>: three epilogues x {per-row scales: the plain instruction | MX: the block-scaled one, with the gated
-    # residual's prefetching epilogue (GP) or the generic per-pass one} + the fused bias + GELU + MX-quantising epilogue (EPI 7) of FFN-up
-    assert len(loops) == 10
+    # residual's prefetching epilogue (GP) or the generic per-pass one} + the fused bias + GELU + MX-quantising epilogue (EPI 7) of FFN-up (32- and 64-bit store offsets)
+    assert len(loops) == 11
     for name, c in loops:
         mfma = c.get("v_mfma_f32_16x16x128_f8f6f4", 0) + c.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0)
         assert mfma == 128 and (c.get("v_mfma_f32_16x16x128_f8f6f4", 0) == 0 or c.get("v_mfma_scale_f32_16x16x128_f8f6f4", 0) == 0), (name, c)

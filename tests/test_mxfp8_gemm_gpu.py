@@ -85,11 +85,11 @@ def test_gemm_mxfp8_matches_fp32_on_dequantised_operands(M, N, K, epi):
     res = torch.randn(M, N, generator=g).to(BF).cuda()
     gate = torch.randn(N, generator=g).cuda()
     aq, sa = ops.quant_rows_mxfp8(a)
-    wq, sw = ops.quant_rows_mxfp8(w)
+    wq, sw = ops.quant_rows_mxfp8(w, w_order=True)
     kw = {"bias": dict(), "gelu": dict(epilogue=ops.EPI_BIAS_GELU), "gate": dict(epilogue=ops.EPI_GATE_RES, gate=gate, res=res)}[epi]
     out = ops.gemm_mxfp8(aq, sa, wq, sw, bias, **kw)
     ad = _deq(aq, ops.mx_scales_to_rows(sa, M, K))   # what the kernel is defined to compute, in fp32 on the GPU
-    wd = _deq(wq, ops.mx_scales_to_rows(sw, N, K))
+    wd = _deq(wq, ops.mx_scales_to_rows(sw, N, K, w_order=True))
     lin = ad @ wd.t() + bias
     ref = {"bias": lin, "gelu": torch.nn.functional.gelu(lin.to(BF).float(), approximate="tanh"),
            "gate": res.float() + lin.to(BF).float() * gate}[epi]
@@ -117,7 +117,7 @@ def test_gemm_mxfp8_gelu_quant_equals_gemm_then_quant(M, N, K):
     w = (_spread(N, K, g, -3, 3).float() * 0.03).to(BF).cuda()
     bias = torch.randn(N, generator=g).cuda()
     aq, sa = ops.quant_rows_mxfp8(a)
-    wq, sw = ops.quant_rows_mxfp8(w)
+    wq, sw = ops.quant_rows_mxfp8(w, w_order=True)
     h = ops.gemm_mxfp8(aq, sa, wq, sw, bias, epilogue=ops.EPI_BIAS_GELU)  # (both forms cut the same tail tiles along K and sum the slabs in the same order)
     q_ref, s_ref = ops.quant_rows_mxfp8(h)
     q = torch.empty((M, N), dtype=torch.uint8, device="cuda")

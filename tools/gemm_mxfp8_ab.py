@@ -27,6 +27,12 @@ def bind(path):
     ws = lib.ce_set_gemm_workspace
     ws.restype = I
     ws.argtypes = [P, ctypes.c_size_t]
+    # round 6: the register-direct epilogue takes the W scales in the W order (ce_quant_rows_mxfp8_w); a -DF8_EPI_LDS=1 build (ce_build_info bit 2)
+    # or a library from before round 6 (no ce_build_info / no _w entry) takes them in the A order
+    lib.w_order = hasattr(lib, "ce_quant_rows_mxfp8_w") and not (lib.ce_build_info() & 4)
+    if lib.w_order:
+        lib.ce_quant_rows_mxfp8_w.restype = I
+        lib.ce_quant_rows_mxfp8_w.argtypes = q.argtypes
     return lib, g, gq, q, ws
 
 
@@ -48,7 +54,7 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     st = torch.cuda.current_stream().cuda_stream
-    scratch = [torch.empty(64 << 20, dtype=torch.uint8, device=dev) for _ in libs]
+    scratch = [torch.empty(96 << 20, dtype=torch.uint8, device=dev) for _ in libs]
     for (_, _, _, _, ws), buf in zip(libs, scratch):
         assert ws(buf.data_ptr(), buf.numel()) == 0
     u8 = lambda *s: torch.empty(s, dtype=torch.uint8, device=dev)
@@ -61,8 +67,14 @@ def main():
         aq, wq, sa, sw = u8(M, K), u8(N, K), u8(scale_bytes(M, K)), u8(scale_bytes(N, K))
         assert libs[0][3](a.data_ptr(), aq.data_ptr(), sa.data_ptr(), M, K, K, K, st) == 0
         assert libs[0][3](w.data_ptr(), wq.data_ptr(), sw.data_ptr(), N, K, K, K, st) == 0
+        sw_w = u8(scale_bytes(N, K))  # the same scales in the W order, for the libraries that want them there
+        for L in libs:
+            if L[0].w_order:
+                assert L[0].ce_quant_rows_mxfp8_w(w.data_ptr(), wq.data_ptr(), sw_w.data_ptr(), N, K, K, K, st) == 0
+                break
         ncopy = max(1, -(-(600 << 20) // (N * K))) if cold else 1
         wqs, sws = [wq] + [wq.clone() for _ in range(ncopy - 1)], [sw] + [sw.clone() for _ in range(ncopy - 1)]
+        sws_w = [sw_w] + [sw_w.clone() for _ in range(ncopy - 1)]
         turn = [0]
         b = torch.randn(N, generator=g).to(dev)
         gate = torch.randn(N, generator=g).to(dev)
@@ -76,7 +88,7 @@ def main():
         def run(i):
             _, f, fq, _, _ = libs[i]
             turn[0] = (turn[0] + 1) % ncopy
-            wq_, sw_ = wqs[turn[0]], sws[turn[0]]
+            wq_, sw_ = wqs[turn[0]], (sws_w if libs[i][0].w_order else sws)[turn[0]]
             if epi == 7:
                 rc = fq(aq.data_ptr(), wq_.data_ptr(), sa.data_ptr(), sw_.data_ptr(), b.data_ptr(), outs[i].data_ptr(), osc[i].data_ptr(), M, N, K, K, K, N, st)
             else:

@@ -71,11 +71,11 @@ vt = ops.v_transpose(qkv[:, 2 * D:], H)
 o_att = torch.empty(M, D, dtype=BF, device=dev)
 measure("bf16 self-attention 7200 keys x 40 heads x 2 (V^T form)", lambda: ops.attention_vt(qkv[:, :D], qkv[:, D:2 * D], vt, H, out=o_att, batch=2), 4.0 * 7200 * 7200 * 128 * H * 2)
 aq, sa = ops.quant_rows_mxfp8(a)
-wq, sw = ops.quant_rows_mxfp8(w_up)
+wq, sw = ops.quant_rows_mxfp8(w_up, w_order=True)
 oq = torch.empty(M, F, dtype=torch.uint8, device=dev)
 so = torch.empty(ops.mx_scale_bytes(M, F), dtype=torch.uint8, device=dev)
 measure("MX fp8 GEMM FFN-up (bias + GELU + MX quantiser)", lambda: ops.gemm_mxfp8_gelu_quant(aq, sa, wq, sw, b_up, oq, so), 2.0 * M * F * D)
-wdq, swd = ops.quant_rows_mxfp8(w_dn)
+wdq, swd = ops.quant_rows_mxfp8(w_dn, w_order=True)
 measure("MX fp8 GEMM FFN-down (gated residual)", lambda: ops.gemm_mxfp8(oq, so, wdq, swd, b_d, out=o_d, epilogue=ops.EPI_GATE_RES, gate=gate, res=o_d), 2.0 * M * F * D)
 one = torch.ones(D, device=dev)
 q8, sq = ops.rmsnorm_rope_mxfp8(qkv[:, :D], one, None, 128, 1e-6, post_scale=ops.MXFP8_Q_SCALE)

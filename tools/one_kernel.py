@@ -32,7 +32,7 @@ elif kind == "gemm8":
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
     w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
     aq, sa = ops.quant_rows_mxfp8(a)
-    wq, sw = ops.quant_rows_mxfp8(w)
+    wq, sw = ops.quant_rows_mxfp8(w, w_order=True)
     b = torch.zeros(N, device=dev)
     gate = torch.ones(N, device=dev)
     if epi == 7:

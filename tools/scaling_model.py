@@ -85,7 +85,27 @@ def predict(W: int, link_GBps: float = 55.0, latency_us: float = 25.0) -> dict:
             out["steps_per_s"][r["mode"] + (", hipGraph" if cap else ", eager")] = round(r["steps_per_s"], 4)
     best = max(out["steps_per_s"], key=out["steps_per_s"].get)
     out["choice"] = best
+    out["expected_driver_wall_s"] = expected_wall_s(W, 1e3 / out["steps_per_s"][best])
     return out
+
+
+def expected_wall_s(W: int, step_ms: float, steps: int = 20, warmup: int = 5, reasoning_steps=(10, 50)) -> dict:
+    """How long the DEFAULT `bench.py --gpus W --steps 20 --warmup 5` line should take end to end on W real GPUs: the
+    legs of bench.py priced with the model's sharded step time and the one-GPU measurements of profiles/r05_bench.json - so that a first
+    multi-GPU run that exceeds it by more than ~2x can be called a hang and not a slow run.  Seconds; an estimate (+-30 %)."""
+    sp_up = 2103.0 / step_ms                      # the model's strong-scaling speed-up at 8 latent frames
+    step2_ms = max(339.0 / (0.8 * sp_up), 45.0)   # the 2-frame step (N = 7 200) sharded: ~80 % of that speed-up (smaller per-rank shapes)
+    legs = {
+        "import torch + model build (40 blocks, 30.5 GiB of random weights per rank) + process-group init": 60.0,
+        "timed region: (warmup + steps) sharded steps": (warmup + steps) * step_ms / 1e3,
+        "profile step + sharded-vs-single verification (one sharded step, one unsharded on rank 0) + exchange timing": 2 * step_ms / 1e3 + 2.2 + 1.0,
+        "secondaries on rank 0: 4 unsharded steps at 8 frames + 3 replica steps at 2 frames": 4 * 2.1 + 3 * 0.34,
+        "sharded temporal-reasoning edits (VAE of 29 frames + two decodes + encoders replicated: ~1.5 s each)":
+            sum(rs * step_ms / 1e3 + (50 - rs) * step2_ms / 1e3 + 1.5 for rs in reasoning_steps) + 12.0,  # + encoder / VAE weight build
+        "cpu_baseline on rank 0 (the reference's block at N = 28 800 on the host cores, one bounded run) + cpu_config0": 110.0,
+    }
+    return {"total": round(sum(legs.values()), 0), "legs": {k: round(v, 1) for k, v in legs.items()},
+            "note": "estimate from tools/scaling_model.py (+-30 %); one GPU measured 224 s for its (different) set of legs in round 5"}
 
 
 def main():
