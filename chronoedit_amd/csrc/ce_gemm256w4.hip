@@ -61,8 +61,16 @@ struct FragSet {
 // accumulators, shuffles every result back through VGPRs (hundreds of v_accvgpr_* per K-tile).  Hazards: the operands come from
 // ds_reads the compiler waits for; consecutive MFMAs never share an accumulator; the first reader of the accumulators after the
 // loop sits behind explicit wait states.
+// REGEPI (round 6; the 256 x 256 tile with plain / singly segmented operands): the A fragment is the FIRST operand instead - the accumulator
+// holds C (lane (fr, fg): rows 16 F + 4 fg + [0,4), the output column of W fragment row fr) and, with the W rows permuted on the DMA's source
+// side, a lane's eight G accumulators of a row are eight consecutive columns: the register-direct epilogue below.  Same products, same sums.
 #define W4_MMA(F, G, S)                                                                                                      \
-  if ((G) < NG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][(G) < NG ? (G) : 0]) : "v"((S).b[(G) < NG ? (G) : 0]), "v"((S).a[F]))
+  if ((G) < NG) {                                                                                                            \
+    if constexpr (REGEPI)                                                                                                    \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][(G) < NG ? (G) : 0]) : "v"((S).a[F]), "v"((S).b[(G) < NG ? (G) : 0])); \
+    else                                                                                                                     \
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[F][(G) < NG ? (G) : 0]) : "v"((S).b[(G) < NG ? (G) : 0]), "v"((S).a[F])); \
+  }
 
 // SEG2: the A operand is K-segmented on TWO nested levels (`ce_gemm256w4_seg2_launch`: the taps of a 3 x 3 x 3 convolution over
 // channels-last frames - kw runs on contiguously, kh jumps a pixel row, kt a frame; ce_conv.hip) - one more scalar multiply per K-tile.
@@ -76,6 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra, uint32_t a_seg2_magic, uint32_t a_seg2_extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BN = 32 * NG;          // tile width
+  constexpr bool REGEPI = NG == 8 && !SEG2;  // register-direct epilogue (round 6): see W4_MMA and the epilogue
   constexpr int NW = NG;               // W pieces (32 rows each) per K-tile and wave
   constexpr int WTILE = BN * BK * 2;   // one W K-tile stage
   constexpr int CROW = BN * 2 + 16;    // padded epilogue staging row
@@ -106,7 +115,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int row = 8 * (wave + 4 * p) + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     a_voff[p] = (uint32_t)min(m0 + row, M - 1) * (uint32_t)(lda * 2) + chunk * 16;
-    w_voff[p] = (uint32_t)min(n0 + row, N - 1) * (uint32_t)(ldw * 2) + chunk * 16;
+    // REGEPI: LDS row 16 G + i of a wave's 128 W rows (fragment G, fragment row i) holds W row 8 i + G (whole 128-byte rows: free on the source side)
+    const int wrow = REGEPI ? ((row & 128) | ((row & 15) << 3) | ((row & 127) >> 4)) : row;
+    w_voff[p] = (uint32_t)min(n0 + wrow, N - 1) * (uint32_t)(ldw * 2) + chunk * 16;
   }
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xffffffffu, 0x00020000);
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xffffffffu, 0x00020000);
@@ -228,9 +239,113 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   W4_VM(0);  // surplus prefetches must retire before the epilogue reuses the LDS
   W4_LGKM0();
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results -> v_accvgpr_read (hipcc does not see the asm MFMAs)
+  static_assert(NG == 8 || ((NG == 4 || NG == 3) && NSA == 2 && !ONEBAR), "the 256 x 128 / 256 x 96 tiles exist for the two-stage loop only");
+  if constexpr (REGEPI) {
+    // ---- epilogue, REGISTER-DIRECT (round 6; as csrc/ce_gemm384.hip and csrc/ce_gemm_fp8w4.hip): lane (fr, fg) of acc[f][g] owns rows f*16 + fg*4 +
+    // [0,4) of the wave tile and output column 8 fr + g - eight consecutive columns per row over its eight g accumulators: one 16-byte store per
+    // lane, 256 contiguous bytes of a row per quad-row of lanes, four rows per wave instruction; no LDS round trip, no barrier.  Bit-identical
+    // to the staged form (same arithmetic, same roundings).
+    const int col0 = n0 + wn * 128 + fr * 8;
+    const bool col_ok = col0 < N;
+    const int colc = min(col0, N - 8);
+    const int row_base = m0 + wm * 128 + fg * 4;  // + f*16 + jj
+    if (partial) {
+      // split-K tail piece: fp32 slab in the [wave][f][g][lane'] order gemm256w4_reduce reads (the C^T accumulator order): this lane's
+      // (f, jj, g = 4 h .. 4 h + 3) -> lane' = fg*4 + jj + 16 (2 (fr & 1) + h) of [f][fr >> 1]
+      float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        f32x4 av[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          asm volatile("" : "+a"(acc[f][g]));  // (pins the read-out of fragment row f here)
+          av[g] = acc[f][g];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 o = {av[4 * h + 0][jj], av[4 * h + 1][jj], av[4 * h + 2][jj], av[4 * h + 3][jj]};
+            const int lane_o = fg * 4 + jj + 16 * (2 * (fr & 1) + h);
+            *reinterpret_cast<f32x4*>(slab + (((wave * 64 + f * 8 + (fr >> 1)) * 64) + lane_o) * 4) = o;
+          }
+      }
+      return;
+    }
+    f32x4 bvv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      bvv[h] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + colc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // (the launcher sends C beyond 32-bit byte offsets, gate rows shorter than a tile and row biases with M % 4 != 0 to the 8-wave kernel)
+    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
+    f32x4 gA[2], gB[2];
+    int g_switch = 0x7fffffff;
+    u32x4 rv[8][4];  // gated residual: all 32 residual pieces of this lane requested in front of the first row (the fragment registers are free)
+    if (EPI == EPI_GATE_RES) {
+      gA[0] = gA[1] = gB[0] = gB[1] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if (gate != nullptr) {
+        const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
+        const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
+        const float* ga = gate + (size_t)s0 * N + colc;
+        const float* gb = gate + (size_t)s1 * N + colc;
+        gA[0] = *reinterpret_cast<const f32x4*>(ga);
+        gA[1] = *reinterpret_cast<const f32x4*>(ga + 4);
+        gB[0] = *reinterpret_cast<const f32x4*>(gb);
+        gB[1] = *reinterpret_cast<const f32x4*>(gb + 4);
+        if (s1 != s0) g_switch = s1 * gate_rows;
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          rv[f][jj] = *reinterpret_cast<const u32x4*>(res + (size_t)min(row_base + f * 16 + jj, M - 1) * ldres + colc);
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      f32x4 av[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        asm volatile("" : "+a"(acc[f][g]));  // (pins the read-out of fragment row f here)
+        av[g] = acc[f][g];
+      }
+      f32x4 brow4 = {0.f, 0.f, 0.f, 0.f};
+      if (EPI == EPI_BIAS_ROW) brow4 = *reinterpret_cast<const f32x4*>(bias + min(row_base + f * 16, M - 4));
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int m = row_base + f * 16 + jj;
+        u32x4 y;  // bf16(acc + bias), 8 columns
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int h = q >> 1, e = 2 * (q & 1);
+          const float b0 = EPI == EPI_BIAS_ROW ? brow4[jj] : bvv[h][e], b1 = EPI == EPI_BIAS_ROW ? brow4[jj] : bvv[h][e + 1];
+          y[q] = pack_bf16(av[2 * q][jj] + b0, av[2 * q + 1][jj] + b1);
+        }
+        u32x4 o = y;
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_tanh(bf16lo(y[q])), gelu_tanh(bf16hi(y[q])));
+        } else if (EPI == EPI_BIAS_GELU_ERF) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_erf(bf16lo(y[q])), gelu_erf(bf16hi(y[q])));
+        } else if (EPI == EPI_GATE_RES) {
+          const u32x4 r = rv[f][jj];
+          const bool second = m >= g_switch;
+          const f32x4 g0 = second ? gB[0] : gA[0], g1 = second ? gB[1] : gA[1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
+            // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
+            o[q] = pack_bf16(mul_then_add(bf16lo(y[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(y[q]), gb, bf16hi(r[q])));
+          }
+        }
+        const uint32_t coff = (m < M && col_ok) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)col0 * 2u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
+      }
+    }
+    return;
+  }
   W4_BAR();
 
-  static_assert(NG == 8 || ((NG == 4 || NG == 3) && NSA == 2 && !ONEBAR), "the 256 x 128 / 256 x 96 tiles exist for the two-stage loop only");
   if (partial) {  // split-K tail piece: fp32 slab [wave][f][g][lane] for gemm256w4_reduce (the launcher splits 256 x 256 tiles only)
     float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
 #pragma unroll
@@ -414,6 +529,10 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
   // the prefetched gated-residual epilogue holds ONE or TWO samples' gate rows per tile: gate rows shorter than a tile -> 8-wave kernel
   // ... and stores through a 32-bit-offset buffer descriptor
   if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32)))
+    return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
+                             w_seg_stride, stream);
+  // (the register-direct epilogue of the plain 256 x 256 tile stores through 32-bit buffer offsets and reads four row biases at once)
+  if (ng == 8 && !seg2 && ((long long)M * ldc * 2 >= (1ll << 32) || (epilogue == EPI_BIAS_ROW && (M & 3))))
     return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
                              w_seg_stride, stream);
   const int bn = 32 * ng;

@@ -46,13 +46,15 @@ __device__ __forceinline__ void tile_origin_384(int wg, int tiles_m, int tiles_n
   n0 = ((wg % group_sz) / gm) * BN;
 }
 
-// one MFMA: row fragment F (operand a) against column fragment G (operand b); rows 0..7 accumulate in AGPRs, 8..11 in VGPRs
+// one MFMA: row fragment F (operand a) against column fragment G (operand b); rows 0..7 accumulate in AGPRs, 8..11 in VGPRs.
+// Round 6: the A fragment is the FIRST operand - the accumulator holds C (lane (fr, fg): rows 16 F + 4 fg + [0,4), the output column of W
+// fragment row fr), not C^T: see the register-direct epilogue.  (Same products, same k order: bit-identical sums.)
 template <int F>
 __device__ __forceinline__ void mma1(f32x4& acc, const bf16x8& b, const bf16x8& a) {
   if constexpr (F < 8)
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(b), "v"(a));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
   else
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(b), "v"(a));
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
 template <int EPI>
@@ -95,8 +97,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int prow = 8 * wave + (lane >> 3);
   const uint32_t pchunk = (uint32_t)(((lane & 7) ^ ((prow >> 1) & 7)) << 4);
   const uint32_t a_off0 = (uint32_t)(m0 + prow) * (uint32_t)(lda * 2) + pchunk, a_lim = (uint32_t)(M - 1) * (uint32_t)(lda * 2) + pchunk;
-  const uint32_t w_off0 = (uint32_t)(n0 + prow) * (uint32_t)(ldw * 2) + pchunk, w_lim = (uint32_t)(N - 1) * (uint32_t)(ldw * 2) + pchunk;
-  const uint32_t a_pstride = (uint32_t)(32 * lda * 2), w_pstride = (uint32_t)(32 * ldw * 2);
+  // W rows are PERMUTED on the source side (round 6): LDS row 16 G + i of a wave's 128 W rows (fragment G, fragment row i) holds W row 8 i + G,
+  // so that a lane's eight G accumulators of one output row are eight CONSECUTIVE columns.  LDS row r = 32 j + prow of the tile (piece j) <-
+  // W row (r & 128) + 8 (r & 15) + ((r & 127) >> 4) = 128 (j >> 2) + 2 (j & 3) + [8 (prow & 15) + (prow >> 4)]: a per-lane base + a per-piece constant
+  const uint32_t w_rowb = (uint32_t)(ldw * 2);
+  const uint32_t w_off0 = (uint32_t)(n0 + ((prow & 15) << 3) + (prow >> 4)) * w_rowb + pchunk, w_lim = (uint32_t)(N - 1) * w_rowb + pchunk;
+  const uint32_t a_pstride = (uint32_t)(32 * lda * 2);
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0xffffffffu, 0x00020000);
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0xffffffffu, 0x00020000);
   auto koff = [&](int t, uint32_t magic, uint32_t extra) __attribute__((always_inline)) -> int {
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const uint32_t v = min(a_off0 + (uint32_t)q * a_pstride, a_lim);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + stage_bytes + (wave + 4 * q) * 1024), 16, v, a_soff, 0, 0);
     } else {
-      const uint32_t v = min(w_off0 + (uint32_t)(q - 12) * w_pstride, w_lim);
+      const uint32_t v = min(w_off0 + (uint32_t)(128 * ((q - 12) >> 2) + 2 * ((q - 12) & 3)) * w_rowb, w_lim);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + stage_bytes + A_TILE + (wave + 4 * (q - 12)) * 1024), 16, v, w_soff, 0, 0);
     }
   };
@@ -215,192 +221,115 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef X_TILE
 #undef X_GROUP
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-  X_BAR();
 
-  if (partial) {  // split-K tail piece: fp32 slab [wave][f][g][lane] for gemm384_reduce
+  // ---- epilogue, REGISTER-DIRECT (round 6; the fp8 GEMM's, csrc/ce_gemm_fp8w4.hip).  The accumulator holds C: lane (fr, fg) of acc[f][g] owns rows
+  // f*16 + fg*4 + [0,4) of the wave tile and - by the DMA's source-side row permutation - output column 8 fr + g.  For one row (f, jj) a lane's eight
+  // g accumulators are EIGHT CONSECUTIVE COLUMNS: one 16-byte store per lane, the sixteen fr lanes of a quad-row cover 256 contiguous bytes of the
+  // row (two whole cache lines), four rows per wave instruction - the row-contiguous stores the LDS staging of rounds 3-5 existed for, without the
+  // LDS round trip and its twelve barriers.  (Round 4's direct form kept C^T and stored 16 rows x 64 bytes per instruction: level.)  Same
+  // arithmetic and roundings as the staged form: bit-identical results.
+  const int col0 = n0 + wn * 128 + fr * 8;  // this lane's 8 output columns
+  const bool col_ok = col0 < N;
+  const int colc = min(col0, N - 8);
+  const int row_base = m0 + wm * 192 + fg * 4;  // + f*16 + jj
+  if (partial) {
+    // split-K tail piece: fp32 slab in the [wave][f][g][lane'] order gemm384_reduce reads (the C^T accumulator order of the staged form: lane'
+    // (fr', fg') of [f][g] = row f*16 + fr', columns g*16 + fg'*4 + [0,4)): this lane's (f, jj, g = 4 h .. 4 h + 3) is row f*16 + fg*4 + jj,
+    // columns fr*8 + 4 h + [0,4) -> fr' = fg*4 + jj, g' = fr >> 1, fg' = 2 (fr & 1) + h
     float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
 #pragma unroll
-    for (int f = 0; f < 12; ++f)
+    for (int f = 0; f < 12; ++f) {
+      f32x4 av[8];
 #pragma unroll
-      for (int g = 0; g < 8; ++g)
-        *reinterpret_cast<f32x4*>(slab + (((wave * 96 + f * 8 + g) * 64) + lane) * 4) = acc[f][g];
+      for (int g = 0; g < 8; ++g) {
+        if (f < 8) asm volatile("" : "+a"(acc[f][g])); else asm volatile("" : "+v"(acc[f][g]));  // (pins the read-out of fragment row f here)
+        av[g] = acc[f][g];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 o = {av[4 * h + 0][jj], av[4 * h + 1][jj], av[4 * h + 2][jj], av[4 * h + 3][jj]};
+          const int lane_o = fg * 4 + jj + 16 * (2 * (fr & 1) + h);
+          *reinterpret_cast<f32x4*>(slab + (((wave * 96 + f * 8 + (fr >> 1)) * 64) + lane_o) * 4) = o;
+        }
+    }
     return;
   }
-
 #ifdef G384_ABLATE_EPILOGUE  // diagnostic builds only (tools/gemm_ab.py): what the tile costs without its epilogue (results are not written)
   if (M > 0) return;
 #endif
-#ifdef G384_DIRECT_EPILOGUE
-  // ---- epilogue straight from the accumulators (round 4 A/B build, tools/gemm_ab.py; bit-identical to the LDS-staged form below and
-  // level with it - profiles/r04_gemm384_epilogue_ablation_and_stagger.txt: the epilogue's time is its memory traffic, not its instructions).
-  // A lane holds 4 consecutive columns of one row per fragment: cols 4 fg .. of fragment g.  One v_permlane16_swap per packed dword
-  // between the fragments of a pair (g, g + 1) - lane rows 1 / 3 of the first operand change places with rows 0 / 2 of the second -
-  // leaves every lane with 8 CONSECUTIVE columns of its row: fg 0 / 2 the lower / upper half of fragment g, fg 1 / 3 of g + 1, i.e.
-  // column 32 gp + 16 (fg & 1) + 8 (fg >> 1) of the wave's 128.  A wave instruction then stores 16 rows x 64 contiguous bytes; no LDS
-  // round trip, no barrier, half the instructions of the staged form, and the same arithmetic on the same bf16-rounded values.
-  // (The erf GELU of the CLIP tower keeps the staged form: its libm call spills beside 384 live accumulators.)
-  if constexpr (EPI != EPI_BIAS_GELU_ERF) {
-    f32x4 bcol[8];
+  f32x4 bvv[2];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      const int n = n0 + wn * 128 + g * 16 + fg * 4;
-      bcol[g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int ccol = wn * 128 + (fg & 1) * 16 + (fg >> 1) * 8;  // + 32 gp: this lane's 8 columns of pair gp inside the tile
-    const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
-    const auto r_rsrc = EPI == EPI_GATE_RES ? __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, (uint32_t)(M - 1) * (uint32_t)(ldres * 2) + (uint32_t)N * 2u, 0x00020000)
-                                            : c_rsrc;
-    int g_switch = 0x7fffffff;  // first global row that takes the second sample's gate
-    float* gtab = reinterpret_cast<float*>(smem);  // gate values of the tile's 256 columns: [first sample | second sample] (LDS is free now)
-    if (EPI == EPI_GATE_RES) {
-      const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
-      const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
-      const int nc = min(n0 + tid, N - 1);
-      gtab[tid] = gate != nullptr ? gate[(size_t)s0 * N + nc] : 1.0f;
-      gtab[256 + tid] = gate != nullptr ? gate[(size_t)s1 * N + nc] : 1.0f;
-      if (s1 != s0) g_switch = s1 * gate_rows;
-      __syncthreads();
-    }
-#ifndef G384_RES_AHEAD
-#define G384_RES_AHEAD 1
-#endif
-    constexpr int RA = G384_RES_AHEAD;  // row fragments of residual in flight ahead of the one being finished
-    u32x4 rv[RA + 1][4];
-    auto res_load = [&](int f, u32x4* dst) __attribute__((always_inline)) {
-      const int m = m0 + wm * 192 + f * 16 + fr;
-#pragma unroll
-      for (int gp = 0; gp < 4; ++gp) {
-        const int n = n0 + ccol + gp * 32;
-        const uint32_t off = (m < M && n < N) ? (uint32_t)m * (uint32_t)(ldres * 2) + (uint32_t)n * 2u : 0xffffffffu;
-        dst[gp] = __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, off, 0, 0);
-      }
-    };
-    if (EPI == EPI_GATE_RES) {
-#pragma unroll
-      for (int f = 0; f < RA; ++f) res_load(f, rv[f % (RA + 1)]);
-    }
-#pragma unroll
-    for (int f = 0; f < 12; ++f) {
-      if (EPI == EPI_GATE_RES && f + RA < 12) res_load(f + RA, rv[(f + RA) % (RA + 1)]);
-      const int m = m0 + wm * 192 + f * 16 + fr;
-      float brow = 0.f;
-      if (EPI == EPI_BIAS_ROW) brow = bias[min(m, M - 1)];
-      const float* gsel = gtab + (m >= g_switch ? 256 : 0) + ccol;
-#pragma unroll
-      for (int gp = 0; gp < 4; ++gp) {
-        f32x4 b0 = bcol[2 * gp], b1 = bcol[2 * gp + 1];
-        if (EPI == EPI_BIAS_ROW) b0 = b1 = f32x4{brow, brow, brow, brow};
-        const f32x4 v0 = acc[f][2 * gp], v1 = acc[f][2 * gp + 1];
-        uint32_t a0 = pack_bf16(v0[0] + b0[0], v0[1] + b0[1]), a1 = pack_bf16(v0[2] + b0[2], v0[3] + b0[3]);
-        uint32_t c0 = pack_bf16(v1[0] + b1[0], v1[1] + b1[1]), c1 = pack_bf16(v1[2] + b1[2], v1[3] + b1[3]);
-        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, c1, false, false);
-        u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // this lane's 8 consecutive columns of row m
-        if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_tanh(bf16lo(o[q])), gelu_tanh(bf16hi(o[q])));
-        } else if (EPI == EPI_GATE_RES) {
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gsel + gp * 32), g1 = *reinterpret_cast<const f32x4*>(gsel + gp * 32 + 4);
-          const u32x4 r = rv[f % (RA + 1)][gp];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
-            // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
-            o[q] = pack_bf16(mul_then_add(bf16lo(o[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(o[q]), gb, bf16hi(r[q])));
-          }
-        }
-        const int n = n0 + ccol + gp * 32;
-        const uint32_t coff = (m < M && n < N) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)n * 2u : 0xffffffffu;
-        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
-      }
-    }
-    return;
-  }
-#endif
-  // ---- epilogue: six passes of 64 staged rows (pass p: accumulator rows f = 2p, 2p+1 of every wave = tile rows wm*192 + p*32 + [0,32))
-  f32x4 bcol[8];
-#pragma unroll
-  for (int g = 0; g < 8; ++g) {
-    const int n = n0 + wn * 128 + g * 16 + fg * 4;
-    bcol[g] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  constexpr bool prefetch = EPI == EPI_GATE_RES;  // (the launcher sends 0 < gate_rows < BM to the 8-wave kernel)
-  u32x4 rv[3][8];
-  f32x4 gA0, gA1, gB0, gB1;
-  int g_switch = 0x7fffffff;
-  const int my_n = n0 + (tid & 31) * 8, my_nc = min(my_n, N - 8);
+  for (int h = 0; h < 2; ++h)
+    bvv[h] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + colc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+  // (the launcher sends C beyond 32-bit byte offsets, and gate rows shorter than a tile, to the 8-wave kernel)
   const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
-  if (EPI == EPI_GATE_RES && prefetch) {
-    gA0 = gA1 = gB0 = gB1 = f32x4{1.f, 1.f, 1.f, 1.f};
+  f32x4 gA[2], gB[2];
+  int g_switch = 0x7fffffff;
+  constexpr int RA = 2;  // row fragments of residual in flight ahead of the one being finished (4 x 16 B per lane each)
+  u32x4 rv[RA + 1][4];
+  auto res_load = [&](int f, u32x4* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dst[jj] = *reinterpret_cast<const u32x4*>(res + (size_t)min(row_base + f * 16 + jj, M - 1) * ldres + colc);
+  };
+  if (EPI == EPI_GATE_RES) {
+    gA[0] = gA[1] = gB[0] = gB[1] = f32x4{1.f, 1.f, 1.f, 1.f};
     if (gate != nullptr) {
       const int s0 = gate_rows > 0 ? m0 / gate_rows : 0;
       const int s1 = gate_rows > 0 ? min(M - 1, m0 + BM - 1) / gate_rows : 0;
-      const float* ga = gate + (size_t)s0 * N + my_nc;
-      const float* gb = gate + (size_t)s1 * N + my_nc;
-      gA0 = *reinterpret_cast<const f32x4*>(ga);
-      gA1 = *reinterpret_cast<const f32x4*>(ga + 4);
-      gB0 = *reinterpret_cast<const f32x4*>(gb);
-      gB1 = *reinterpret_cast<const f32x4*>(gb + 4);
+      const float* ga = gate + (size_t)s0 * N + colc;
+      const float* gb = gate + (size_t)s1 * N + colc;
+      gA[0] = *reinterpret_cast<const f32x4*>(ga);
+      gA[1] = *reinterpret_cast<const f32x4*>(ga + 4);
+      gB[0] = *reinterpret_cast<const f32x4*>(gb);
+      gB[1] = *reinterpret_cast<const f32x4*>(gb + 4);
       if (s1 != s0) g_switch = s1 * gate_rows;
     }
+#pragma unroll
+    for (int f = 0; f < RA; ++f) res_load(f, rv[f % (RA + 1)]);
   }
 #pragma unroll
-  for (int p = 0; p < 6; ++p) {
-    if (EPI == EPI_GATE_RES && prefetch && (p == 0 || p == 3)) {  // the residual chunks of three passes at a time (96 registers)
+  for (int f = 0; f < 12; ++f) {
+    if (EPI == EPI_GATE_RES && f + RA < 12) res_load(f + RA, rv[(f + RA) % (RA + 1)]);
+    f32x4 av[8];  // the eight accumulators of this fragment row, whole
 #pragma unroll
-      for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-          const int rl = (tid + 256 * tt) >> 5;
-          const int m = min(m0 + (rl >> 5) * 192 + (p + pp) * 32 + (rl & 31), M - 1);
-          rv[pp][tt] = *reinterpret_cast<const u32x4*>(res + (size_t)m * ldres + my_nc);
-        }
+    for (int g = 0; g < 8; ++g) {
+      if (f < 8) asm volatile("" : "+a"(acc[f][g])); else asm volatile("" : "+v"(acc[f][g]));  // (pins the read-out of fragment row f here)
+      av[g] = acc[f][g];
     }
-    if (p > 0) __syncthreads();
+    f32x4 brow4 = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_BIAS_ROW) brow4 = *reinterpret_cast<const f32x4*>(bias + min(row_base + f * 16, M - 4));  // (M % 4 == 0: the launcher checks)
 #pragma unroll
-    for (int ff = 0; ff < 2; ++ff) {
-      const int f = 2 * p + ff;
-      float brow = 0.f;
-      if (EPI == EPI_BIAS_ROW) brow = bias[min(m0 + wm * 192 + f * 16 + fr, M - 1)];
-      const int rl = wm * 32 + ff * 16 + fr;
+    for (int jj = 0; jj < 4; ++jj) {
+      const int m = row_base + f * 16 + jj;
+      u32x4 y;  // bf16(acc + bias), 8 columns
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int cl = wn * 128 + g * 16 + fg * 4;
-        f32x4 bv = bcol[g];
-        if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow;
-        const f32x4 v = acc[f][g];
-        const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
-        *reinterpret_cast<u32x2*>(smem + rl * CROW + cl * 2) = pk;
+      for (int q = 0; q < 4; ++q) {
+        const int h = q >> 1, e = 2 * (q & 1);
+        const float b0 = EPI == EPI_BIAS_ROW ? brow4[jj] : bvv[h][e], b1 = EPI == EPI_BIAS_ROW ? brow4[jj] : bvv[h][e + 1];
+        y[q] = pack_bf16(av[2 * q][jj] + b0, av[2 * q + 1][jj] + b1);
       }
-    }
-    __syncthreads();
-    if (EPI == EPI_GATE_RES && prefetch) {
+      u32x4 o = y;
+      if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-      for (int tt = 0; tt < 8; ++tt) {
-        const int rl = (tid + 256 * tt) >> 5;
-        const int m = m0 + (rl >> 5) * 192 + p * 32 + (rl & 31);
-        const u32x4 y = *reinterpret_cast<const u32x4*>(smem + rl * CROW + (tid & 31) * 16);
+        for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_tanh(bf16lo(y[q])), gelu_tanh(bf16hi(y[q])));
+      } else if (EPI == EPI_BIAS_GELU_ERF) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = pack_bf16(gelu_erf(bf16lo(y[q])), gelu_erf(bf16hi(y[q])));
+      } else if (EPI == EPI_GATE_RES) {
+        const u32x4 r = rv[f % (RA + 1)][jj];
         const bool second = m >= g_switch;
-        const f32x4 g0 = second ? gB0 : gA0, g1 = second ? gB1 : gA1;
-        const u32x4 r = rv[p % 3][tt];
-        u32x4 o;
+        const f32x4 g0 = second ? gB[0] : gA[0], g1 = second ? gB[1] : gA[1];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float ga = q < 2 ? g0[2 * q] : g1[2 * q - 4], gb = q < 2 ? g0[2 * q + 1] : g1[2 * q - 3];
+          // x.float() + y * gate with both fp32 roundings of the reference (transformer_chronoedit.py:281,293): no fma contraction
           o[q] = pack_bf16(mul_then_add(bf16lo(y[q]), ga, bf16lo(r[q])), mul_then_add(bf16hi(y[q]), gb, bf16hi(r[q])));
         }
-        const uint32_t coff = (m < M && my_n < N) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)my_n * 2u : 0xffffffffu;
-        __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
       }
-    } else if (EPI != EPI_GATE_RES) {
-      epi_chunks<EPI, 8>(smem, CROW,
-                         [&](int tt, int& rl, int& cc, int& mr) {
-                           const int c = tid + 256 * tt;
-                           rl = c >> 5;
-                           cc = c & 31;
-                           mr = (rl >> 5) * 192 + p * 32 + (rl & 31);
-                         },
-                         m0, n0, C, gate, res, M, N, ldc, ldres, gate_rows);
+      const uint32_t coff = (m < M && col_ok) ? (uint32_t)m * (uint32_t)(ldc * 2) + (uint32_t)col0 * 2u : 0xffffffffu;
+      __builtin_amdgcn_raw_buffer_store_b128(o, c_rsrc, coff, 0, 0);
     }
   }
 }
@@ -453,7 +382,8 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
 extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
-  if (epilogue == EPI_GATE_RES && ((gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32)))
+  if ((epilogue == EPI_GATE_RES && gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32) ||
+      (epilogue == EPI_BIAS_ROW && (M & 3)))  // (the register-direct epilogue stores through 32-bit buffer offsets and reads four row biases at once)
     return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
                              w_seg_stride, stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;

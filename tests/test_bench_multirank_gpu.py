@@ -100,6 +100,18 @@ def test_sharded_line_verifies_itself(world):
         assert ex["k|v"]["bytes_sent_off_rank"] == 2 * ex["q"]["bytes_sent_off_rank"] == 2 * ex["output"]["bytes_sent_off_rank"]
 
 
+def test_fp8_flags_under_sharding_say_what_ran():
+    """`bench.py --gpus N --fp8` - the fp8 GEMMs shard with the rows, the MXFP8 self-attention does not exist for the sharded path
+    (the exchange carries bf16 q / k / v: transformer.attention_path()), so the line's `dtype` must say bf16 attention, not claim fp8 attention;
+    and the model's prediction block carries the expected wall time of the default command (6a)."""
+    lines = _run(4, extra=("--fp8", "--no-secondary", "--no-cpu-baseline", "--no-encoders", "--no-reasoning-edit"))
+    o = lines[-1]
+    assert o["n_gpus"] == 4 and o["finite"] is True and o["value"] > 0
+    assert o["dtype"].startswith("fp8 e4m3 GEMMs") and "bf16 attention" in o["dtype"] and "MXFP8" not in o["dtype"], o["dtype"]
+    assert o["config"]["parallelism"].startswith("ulysses sp4")
+    assert o["sharded_vs_single_rel_l2"] is None or o["sharded_vs_single_rel_l2"] < 5e-2  # (fp8 GEMMs on both sides; --no-secondary: no comparison)
+
+
 @pytest.mark.parametrize("who", ["1", "all"])
 def test_sharded_failure_still_prints_the_replica_line(who):
     # (one rank failing alone leaves its peers inside a collective: they run into the data group's timeout, shortened here, and the

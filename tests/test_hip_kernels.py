@@ -278,8 +278,9 @@ def vt_body(request):
     ops.set_attention_waves(old)
 
 
-@pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (7200, 7200, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2), (3000, 200, 40, 2)])
-@pytest.mark.parametrize("slope", [0.0, 0.5, 10.0])
+# (round 6: the one-wave-per-SIMD body is a closed alternative of round 4, selectable in the diagnostic library only - four shapes x two slopes)
+@pytest.mark.parametrize("Nq,Nkv,H,B", [(300, 257, 2, 1), (7200, 7200, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2)])
+@pytest.mark.parametrize("slope", [0.0, 10.0])
 def test_attention_vt_one_wave_per_simd_body_is_bit_identical_to_the_eight_wave_body(Nq, Nkv, H, B, slope):
     """attn_fwd_w4_kernel (4 waves x 64 query rows, Q and O^T in the accumulator file, every matrix instruction an asm statement) computes
     the SAME products in the SAME order with the same rounding points as attn_fwd_sp_kernel<false, true>: outputs are equal bit for bit -
@@ -313,9 +314,9 @@ def test_attention_vt_one_wave_per_simd_body_is_bit_identical_to_the_eight_wave_
         assert rel_l2(outs[128][b * Nq:(b + 1) * Nq], ref) < (1e-2 if slope == 0 else 1.5e-2)
 
 
-@pytest.mark.parametrize("Nq,Nkv,H,B", [(64, 64, 2, 1), (300, 257, 2, 1), (1000, 1000, 8, 1), (7200, 7200, 8, 2), (290, 64, 5, 3), (31, 704, 16, 2),
-                                         (2000, 200, 40, 3), (1090, 1090, 8, 2)])  # the last: sample offsets not 16-byte aligned -> the default body runs
-@pytest.mark.parametrize("slope", [0.0, 10.0])
+# (round 6: a measured-and-closed experiment that lives in the DIAGNOSTIC library only - three shapes keep it honest: ragged, the step's key
+# count, and unaligned sample offsets where the default body must take over)
+@pytest.mark.parametrize("Nq,Nkv,H,B,slope", [(300, 257, 2, 1, 0.0), (7200, 7200, 8, 2, 10.0), (1090, 1090, 8, 2, 0.0)])
 def test_attention_vt_16x16x32_body(Nq, Nkv, H, B, slope):
     """attn_fwd_x16_kernel (csrc/ce_attn16.hip, round 5; ce_set_attention_waves(16)): the V^T self-attention on v_mfma_f32_16x16x32_bf16 - K rows
     permuted inside the tile so that a lane's P operand meets one 16-byte read of natural-order V^T, online softmax with a lazily moved offset -

@@ -360,3 +360,18 @@ def test_scaling_model_prediction_block():
         assert max(sps.values()) > p["one_gpu_steps_per_s"]
     assert m.predict(2)["choice"].startswith("cfg-parallel")       # one xGMI link between two ranks: split the guidance pair instead
     assert m.predict(8)["choice"] == "ulysses 8, B=2, eager"
+
+
+def test_scaling_model_states_the_expected_wall_time_of_the_default_multi_gpu_line():
+    """`rccl.model_prediction` (bench.py --gpus N at full size) carries the expected end-to-end wall time of the driver's
+    default command, leg by leg, so that a first multi-GPU run that takes much longer reads as a hang and not as a slow run."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import scaling_model
+    for W in (2, 4, 8):
+        p = scaling_model.predict(W)
+        w = p["expected_driver_wall_s"]
+        assert 100 < w["total"] < 600 and abs(sum(w["legs"].values()) - w["total"]) < 1.0, w
+        assert p["choice"] in p["steps_per_s"]
+    assert scaling_model.predict(8)["expected_driver_wall_s"]["total"] < scaling_model.predict(2)["expected_driver_wall_s"]["total"]
+

@@ -24,16 +24,17 @@ def main():
     libs = [bind(p) for p in sys.argv[1:]]
     names = [p.split("/")[-1].replace("lib", "").replace(".so", "") for p in sys.argv[1:]]
     dev = torch.device("cuda:0")
-    ws = torch.empty(256 * 1024 * 1024, dtype=torch.uint8, device=dev)
+    ws = torch.empty(96 * 1024 * 1024, dtype=torch.uint8, device=dev)  # the engine's scratch size (ops.GEMM_WS_BYTES)
     for lib, _ in libs:
         lib.ce_set_gemm_workspace(ws.data_ptr(), ws.numel())
     g = torch.Generator().manual_seed(0)
     st = torch.cuda.current_stream().cuda_stream
-    for (M, N, K, epi) in [(14400, 15360, 5120, 0), (14400, 13824, 5120, 1), (14400, 5120, 13824, 2), (14400, 5120, 5120, 2), (14400, 5120, 5120, 0), (5120, 14400, 5120, 6),
-                           (7200, 5120, 5120, 0)]:
+    for (M, N, K, epi) in [(14400, 10240, 5120, 0), (14400, 13824, 5120, 1), (14400, 5120, 13824, 2), (14400, 5120, 5120, 2), (14400, 5120, 5120, 0), (5120, 14400, 5120, 6),
+                           (7200, 10240, 5120, 0), (7200, 13824, 5120, 1), (7200, 5120, 13824, 2), (7200, 5120, 5120, 2), (7200, 5120, 5120, 0), (5120, 7200, 5120, 6),
+                           (26136, 13824, 5120, 1), (28800, 5120, 5120, 2)]:
         a = torch.randn(M, K, generator=g).to(BF).to(dev)
         w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
-        b = torch.randn(N, generator=g).to(dev)
+        b = torch.randn(max(M, N), generator=g).to(dev)
         gate = torch.randn(N, generator=g).to(dev)
         res = torch.randn(M, N, generator=g).to(BF).to(dev)
         outs = [torch.empty(M, N, dtype=BF, device=dev) for _ in libs]
