@@ -346,7 +346,7 @@ def _pmc_traffic(kernel_label: str):
     """HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
     are collected in their own runs, tools/gpu_pmc.sh; they cannot be read live from inside this process).  None when the
     shape of this run has no committed measurement."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:

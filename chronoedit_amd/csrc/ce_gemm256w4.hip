@@ -61,7 +61,7 @@ struct FragSet {
 // accumulators, shuffles every result back through VGPRs (hundreds of v_accvgpr_* per K-tile).  Hazards: the operands come from
 // ds_reads the compiler waits for; consecutive MFMAs never share an accumulator; the first reader of the accumulators after the
 // loop sits behind explicit wait states.
-// REGEPI (round 6; the 256 x 256 tile with plain / singly segmented operands): the A fragment is the FIRST operand instead - the accumulator
+// REGEPI (round 6; the 256 x 256 tile, NG == 8): the A fragment is the FIRST operand instead - the accumulator
 // holds C (lane (fr, fg): rows 16 F + 4 fg + [0,4), the output column of W fragment row fr) and, with the W rows permuted on the DMA's source
 // side, a lane's eight G accumulators of a row are eight consecutive columns: the register-direct epilogue below.  Same products, same sums.
 #define W4_MMA(F, G, S)                                                                                                      \
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra, uint32_t a_seg2_magic, uint32_t a_seg2_extra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BN = 32 * NG;          // tile width
-  constexpr bool REGEPI = NG == 8 && !SEG2;  // register-direct epilogue (round 6): see W4_MMA and the epilogue
+  constexpr bool REGEPI = NG == 8;      // register-direct epilogue (round 6; the 256 x 256 tile, plain or segmented operands - the wide VAE convs too): see W4_MMA
   constexpr int NW = NG;               // W pieces (32 rows each) per K-tile and wave
   constexpr int WTILE = BN * BK * 2;   // one W K-tile stage
   constexpr int CROW = BN * 2 + 16;    // padded epilogue staging row
@@ -532,7 +532,7 @@ static int w4_launch(const void* A, const void* W, void* C, const float* bias, i
     return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
                              w_seg_stride, stream);
   // (the register-direct epilogue of the plain 256 x 256 tile stores through 32-bit buffer offsets and reads four row biases at once)
-  if (ng == 8 && !seg2 && ((long long)M * ldc * 2 >= (1ll << 32) || (epilogue == EPI_BIAS_ROW && (M & 3))))
+  if (ng == 8 && ((long long)M * ldc * 2 >= (1ll << 32) || (epilogue == EPI_BIAS_ROW && (M & 3))))
     return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
                              w_seg_stride, stream);
   const int bn = 32 * ng;

@@ -145,7 +145,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int q = 0; q < 3; ++q) dma(q, STAGE, a1, w1);  // (pieces 3..19 of tile 1 follow in groups 0..13 of tile 0, as in steady state)
   }
+#ifndef G384_ABLATE_PROLOGUE  // (diagnostic builds only, tools/gemm_ab.py: what a tile costs without waiting for its first K-tile - garbage results -
+                             //  = what overlapping the next tile's prologue with this tile's epilogue could buy at most)
   asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
   X_BAR();
   bf16x8 ring[4], bx[8], by[8];
 #pragma unroll

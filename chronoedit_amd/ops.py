@@ -638,8 +638,10 @@ def conv3d_head(in_frames, weight: torch.Tensor, bias: Optional[torch.Tensor], o
 def rms_silu(x: torch.Tensor, gamma: torch.Tensor, out: torch.Tensor, T: int, C: int, H: int, W: int, in_border: int,
              out_border: int, silu: bool = True):
     _dev(x, torch.bfloat16, "x"), _dev(out, torch.bfloat16, "out"), _dev(gamma, torch.float32, "gamma")
+    st = _prof_begin()
     _check(lib().ce_rms_silu_bf16(_ptr(x), _ptr(out), _ptr(gamma), T * H * W, C, H, W, in_border, out_border, int(silu), _stream()),
            "ce_rms_silu_bf16")
+    _prof_end(st, f"rms_silu_{C}ch_{T}x{H}x{W}", 4.0 * T * H * W * C)  # (work: bytes read + written, bf16)
     return out
 
 
@@ -647,13 +649,17 @@ def zero_border(frames: torch.Tensor, T: int, H: int, W: int, C: int):
     """Zero the one-pixel border of T bordered channels-last frames [T, H+2, W+2, ld] (channels [0, C))."""
     _dev(frames, torch.bfloat16, "frames")
     assert frames.is_contiguous() and tuple(frames.shape[:3]) == (T, H + 2, W + 2)
+    st = _prof_begin()
     _check(lib().ce_zero_border_bf16(_ptr(frames), T, H, W, C, frames.shape[3], _stream()), "ce_zero_border_bf16")
+    _prof_end(st, f"zero_border_{C}ch_{T}x{H}x{W}", 2.0 * T * (2 * (W + 2) + 2 * H) * C)
     return frames
 
 
 def upsample2x(x: torch.Tensor, out: torch.Tensor, T: int, C: int, H: int, W: int):
     _dev(x, torch.bfloat16, "x"), _dev(out, torch.bfloat16, "out")
+    st = _prof_begin()
     _check(lib().ce_upsample2x_bf16(_ptr(x), _ptr(out), T, C, H, W, _stream()), "ce_upsample2x_bf16")
+    _prof_end(st, f"upsample2x_{C}ch_{T}x{H}x{W}", 2.0 * T * H * W * C * 5)  # (read once, written four times)
     return out
 
 

@@ -1,4 +1,4 @@
-"""profiles/r05_pmc_*.txt (the summaries the round-5 GPU sessions write: one counter set per rocprofv3 pass) -> profiles/r05_pmc_traffic.json, the
+"""profiles/r06_pmc_*.txt / r05_pmc_*.txt (the summaries the GPU sessions write: one counter set per rocprofv3 pass) -> profiles/r06_pmc_traffic.json, the
 file bench.py::_pmc_traffic reads `roofline.traffic` from.  FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at
 64 bytes (MI355X_MICROARCH.md, HBM section): fetch_bytes = FETCH_SIZE x 1024 x 2.  Effective clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA busy =
 SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).    python tools/pmc_to_json.py"""
@@ -13,17 +13,17 @@ P = os.path.join(ROOT, "profiles")
 SPECS = [
     ("r05_pmc_attention_vt_7200_b2.txt", "attn_fwd_sp_kernel", ["attention_7200x7200+0_h40_b2"], 589824000,
      "attn_fwd_sp_kernel<false, VT = true> (ce_attention_vt_bf16: K and V^T by LDS-DMA), 7200 keys x 40 heads x 2 samples", "tools/one_kernel.py attnvt 7200 40 2"),
-    ("r05_pmc_gemm_outproj.txt", "gemm_bf16_384ILi2E", ["gemm_14400x5120x5120_epi2"], 494796800,
+    ("r06_pmc_gemm_outproj.txt", "gemm_bf16_384ILi2E", ["gemm_14400x5120x5120_epi2"], 494796800,
      "gemm_bf16_384<EPI_GATE_RES> (384 x 256 macro tile, one wave per SIMD) 14400 x 5120 x 5120", "tools/one_kernel.py gemm 14400 5120 5120 2 -1"),
-    ("r05_pmc_gemm_ffnup.txt", "gemm_bf16_w4ILi1E", ["gemm_14400x13824x5120_epi1"], 687144960,
+    ("r06_pmc_gemm_ffnup.txt", "gemm_bf16_w4ILi1E", ["gemm_14400x13824x5120_epi1"], 687144960,
      "gemm_bf16_w4<EPI_BIAS_GELU> (256 x 256 tile, one wave per SIMD; its split-K reduce launch not included) 14400 x 13824 x 5120", "tools/one_kernel.py gemm 14400 13824 5120 1 -1"),
     ("r05_pmc_attn8_7200_b2.txt", "attn_fwd_mxfp8_sp_kernel", ["attention_mxfp8_7200x7200_h40_b2", "attention_mxfp8_7200x7200_h40_b2_mxq"],
      2 * 7200 * 5120 * (1 + 1 + 1 + 2) + 3 * 2 * 7200 * 5120 // 32,
      "attn_fwd_mxfp8_sp_kernel, 7200 keys x 40 heads x 2 samples (q8 + k8 + v8t e4m3, bf16 output, E8M0 scales)", "tools/one_kernel.py attn8 7200 40 2"),
-    ("r05_pmc_gemm8_outproj_sched1.txt", "gemm_fp8_w4ILi2E", ["gemm_mxfp8_14400x5120x5120_epi2"],
+    ("r06_pmc_gemm8_outproj.txt", "gemm_fp8_w4ILi2E", ["gemm_mxfp8_14400x5120x5120_epi2"],
      14400 * 5120 + 5120 * 5120 + 2 * 2 * 14400 * 5120 + (14400 + 5120) * 5120 // 32,
      "gemm_fp8_w4<EPI_GATE_RES, MX> 14400 x 5120 x 5120 (e4m3 operands, bf16 residual in, bf16 out)", "tools/one_kernel.py gemm8 14400 5120 5120 2"),
-    ("r05_pmc_gemm8_ffnup_sched1.txt", "gemm_fp8_w4ILi7E", ["gemm_mxfp8_14400x13824x5120_gelu_quant"],
+    ("r06_pmc_gemm8_ffnup.txt", "gemm_fp8_w4ILi7E", ["gemm_mxfp8_14400x13824x5120_gelu_quant"],
      14400 * 5120 + 13824 * 5120 + 14400 * 13824 + (14400 * 5120 + 13824 * 5120 + 14400 * 13824) // 32,
      "gemm_fp8_w4<EPI_BIAS_GELU_Q, MX> 14400 x 13824 x 5120 (e4m3 operands, e4m3 + E8M0 output)", "tools/one_kernel.py gemm8 14400 13824 5120 7"),
 ]
@@ -50,10 +50,10 @@ def parse(path, frag):
 
 
 def main():
-    out = {"_comment": "HBM-side traffic per launch of the dominant bf16 and fp8 kernels from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only; round-5 sessions "
-                       "tools/sessions_r05/gpu_r5_*.sh; raw summaries: the r05_pmc_*.txt files next to this one).  fetch_bytes = FETCH_SIZE x 1024 x 2 (gfx950 tallies "
+    out = {"_comment": "HBM-side traffic per launch of the dominant bf16 and fp8 kernels from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only; GEMMs: round 6 - the register-direct "
+                       "epilogues - tools/sessions_r06/gpu_r6_i.sh, r06_pmc_*.txt; attention kernels: unchanged since round 5, r05_pmc_*.txt).  fetch_bytes = FETCH_SIZE x 1024 x 2 (gfx950 tallies "
                        "128-byte requests at 64), write_bytes = WRITE_SIZE x 1024; Infinity-Cache hits are included: traffic past the L2, an upper bound on HBM bytes.  "
-                       "Shapes not listed fall back to r04_pmc_traffic.json / r02_pmc_traffic.json (bench.py::_pmc_traffic)."}
+                       "Shapes not listed fall back to r05 / r04 / r02_pmc_traffic.json (bench.py::_pmc_traffic)."}
     for fn, frag, labels, alg, kernel, cmd in SPECS:
         path = os.path.join(P, fn)
         if not os.path.exists(path):
@@ -71,7 +71,7 @@ def main():
                "note": f"{cmd}; raw: {fn}; traffic / algorithmic = {(v['FETCH_SIZE'] * 2048 + v['WRITE_SIZE'] * 1024) / alg:.2f} x"}
         for lb in labels:
             out[lb] = rec
-    json.dump(out, open(os.path.join(P, "r05_pmc_traffic.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(P, "r06_pmc_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
 
