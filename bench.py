@@ -752,9 +752,14 @@ def main():
             g_["labels"].append((d["total_ms"], k))
         dom_sym = max(groups, key=lambda k_: groups[k_]["ms"])
         G = groups[dom_sym]
-        dom = max(G["labels"])[1]  # its largest shape: the one the committed PMC traffic figure is looked up for
+        dom = max(G["labels"])[1]  # its largest shape
         ach = G["fl"] / (G["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = _pmc_traffic(dom)
+        traffic = traffic_src = None
+        for _, lb in sorted(G["labels"], reverse=True):  # the committed PMC traffic figure of the symbol's largest shape that has one (`traffic_of`)
+            traffic, traffic_src = _pmc_traffic(lb)
+            if traffic is not None:
+                dom = lb
+                break
         peak = PEAK_FP8_TFLOPS if ("fp8" in dom) else PEAK_BF16_TFLOPS  # attention_mxfp8_* / gemm_fp8_* run the fp8 MFMA
         roofline = {"kernel": dom_sym, "rule": "largest kernel SYMBOL of the profiled step by summed HIP-event time (launches of one symbol grouped over shapes / call sites)",
                     "labels": [k_ for _, k_ in sorted(G["labels"], reverse=True)], "share_of_step": round(G["ms"] / tot, 4),

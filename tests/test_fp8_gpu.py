@@ -213,8 +213,11 @@ def test_edit_end_to_end_fp8_mode_vs_fp8_contract_oracle(mx):
     vid = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=4, guidance_scale=5.0, latents=lat0.cuda())
     print(f"fp8 edit: latents vs fp8-contract oracle {rel_l2(lat, lat8):.3e}, video {rel_l2(vid, vid8):.3e}; "
           f"contract vs exact edit (latents) {rel_l2(lat8, lat_x):.3e}")
-    assert rel_l2(lat, lat8) < 8e-2 and rel_l2(vid, vid8) < 1e-1
-    assert rel_l2(lat, lat_x) < 0.2
+    # measured on MI355X (round 6): 1.6e-2 / 2.2e-2 against the contract oracle, the contract itself 1.85e-2 from the exact edit at this toy width;
+    # the statement of what fp8 costs where it matters - the full width, both policies - is tests/test_width_depth_gpu.py (the 0.2 that
+    # stood here said nothing)
+    assert rel_l2(lat, lat8) < 4e-2 and rel_l2(vid, vid8) < 5e-2
+    assert rel_l2(lat, lat_x) < 6e-2
 
 
 # ---------------------------------------------------------------------------------------------------------------------

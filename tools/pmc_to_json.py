@@ -15,6 +15,11 @@ SPECS = [
      "attn_fwd_sp_kernel<false, VT = true> (ce_attention_vt_bf16: K and V^T by LDS-DMA), 7200 keys x 40 heads x 2 samples", "tools/one_kernel.py attnvt 7200 40 2"),
     ("r06_pmc_gemm_outproj.txt", "gemm_bf16_384ILi2E", ["gemm_14400x5120x5120_epi2"], 494796800,
      "gemm_bf16_384<EPI_GATE_RES> (384 x 256 macro tile, one wave per SIMD) 14400 x 5120 x 5120", "tools/one_kernel.py gemm 14400 5120 5120 2 -1"),
+    ("r06_pmc_gemm_ffndown.txt", "gemm_bf16_384ILi2E", ["gemm_14400x5120x13824_epi2"], 2 * (14400 * 13824 + 5120 * 13824 + 2 * 14400 * 5120),
+     "gemm_bf16_384<EPI_GATE_RES> 14400 x 5120 x 13824 (FFN-down: bf16 operands, bf16 residual in, bf16 out)", "tools/one_kernel.py gemm 14400 5120 13824 2 -1"),
+    ("r06_pmc_gemm8_ffndown.txt", "gemm_fp8_w4ILi2E", ["gemm_mxfp8_14400x5120x13824_epi2"],
+     14400 * 13824 + 5120 * 13824 + 2 * 2 * 14400 * 5120 + (14400 + 5120) * 13824 // 32,
+     "gemm_fp8_w4<EPI_GATE_RES, MX> 14400 x 5120 x 13824 (FFN-down: e4m3 operands, bf16 residual in, bf16 out)", "tools/one_kernel.py gemm8 14400 5120 13824 2"),
     ("r06_pmc_gemm_ffnup.txt", "gemm_bf16_w4ILi1E", ["gemm_14400x13824x5120_epi1"], 687144960,
      "gemm_bf16_w4<EPI_BIAS_GELU> (256 x 256 tile, one wave per SIMD; its split-K reduce launch not included) 14400 x 13824 x 5120", "tools/one_kernel.py gemm 14400 13824 5120 1 -1"),
     ("r05_pmc_attn8_7200_b2.txt", "attn_fwd_mxfp8_sp_kernel", ["attention_mxfp8_7200x7200_h40_b2", "attention_mxfp8_7200x7200_h40_b2_mxq"],
