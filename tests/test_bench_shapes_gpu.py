@@ -158,6 +158,17 @@ def test_full_width_block_bf16_and_fp8_modes_vs_fp32_oracle(h, w, tag):
     out_fp8 = model(*args, return_dict=False)[0].float().cpu()
     model.enable_fp8_gemms(policy="accurate")                 # round 6: the ungated cross-attention out-projection back on the bf16 GEMM
     out_acc = model(*args, return_dict=False)[0].float().cpu()
+    singles = {}
+    if h == 90:  # the per-Linear sensitivity table (tools/fp8_sensitivity.py runs this test with -s): ONE Linear in fp8 at a time,
+        # attention in bf16; then only the MXFP8 self-attention
+        for name in model.FP8_LINEARS:
+            model.enable_fp8_gemms(linears=(name,)).enable_fp8_attention(False)
+            singles[name] = model(*args, return_dict=False)[0].float().cpu()
+        model.enable_fp8_gemms(False).enable_fp8_attention(True)
+        singles["self-attention MXFP8"] = model(*args, return_dict=False)[0].float().cpu()
+        model.enable_fp8_gemms(policy="fast").enable_fp8_attention(False)
+        singles["all six, attention bf16"] = model(*args, return_dict=False)[0].float().cpu()
+        model.enable_fp8_attention(True)
     model.enable_fp8_gemms(mx=False)                          # the round-1..3 contract: one scale per 5120- / 13824-long row
     out_row = model(*args, return_dict=False)[0].float().cpu()
     del model
@@ -168,6 +179,17 @@ def test_full_width_block_bf16_and_fp8_modes_vs_fp32_oracle(h, w, tag):
     print(f"full-width block, {tag}: bf16 path vs fp32 {e_bf16:.3e} | fp8 mode (MX block scales) vs fp32 {e_fp8:.3e} ({e_fp8 / e_bf16:.2f} x) | "
           f"per-row scales {e_row:.3e} ({e_row / e_bf16:.2f} x) | policy 'accurate' {e_acc:.3e} ({e_acc / e_bf16:.2f} x)")
     assert torch.isfinite(out_acc).all() and e_acc <= 5 * e_bf16, (e_acc, e_bf16)  # <= 5 x bf16 per block (measured 4.0 x)
+    if singles:
+        add = {}
+        for name, o in singles.items():
+            e = rel_l2(o, ref)
+            add[name] = max(e * e - e_bf16 * e_bf16, 0.0) ** 0.5  # what this configuration ADDS, in quadrature, to the bf16 path's error
+            print(f"   fp8 sensitivity, only {name:26s}: rel-L2 vs fp32 {e:.3e} = {e / e_bf16:5.2f} x bf16 | adds {add[name]:.3e}")
+        six = sum(add[n] ** 2 for n in ("qkv", "o1", "q2", "o2", "f1", "f2")) ** 0.5
+        print(f"   quadrature sum of the six single-Linear additions {six:.3e}; all six measured {add['all six, attention bf16']:.3e}")
+        assert abs(six / add["all six, attention bf16"] - 1.0) < 0.1            # the contributions are independent: they add in quadrature
+        assert add["o2"] ** 2 >= 0.6 * add["all six, attention bf16"] ** 2       # the ungated cross-attention out-projection dominates (measured 78 %)
+        assert add["self-attention MXFP8"] <= 0.5 * e_bf16                      # the MXFP8 attention is not an error source at block level (1.0e-3)
     assert torch.isfinite(out_bf16).all() and torch.isfinite(out_fp8).all() and torch.isfinite(out_row).all()
     assert e_bf16 < 1e-2
     assert e_row <= 10 * e_bf16 and e_row < 5e-2, (e_row, e_bf16)
