@@ -575,143 +575,263 @@ CE_API int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int
 // ---- mid-block attention of the Wan VAE as ONE flash-style kernel (wan2pt1.py:223-259: a single head over the h*w positions of a
 // frame, head dim = C = 384 at the shipped width) -----------------------------------------------------------------------------------
 // No [HW, HW] score matrix in memory (0.83 GB fp32 per frame at 720p, 2.7 GB at 1584x1056): scores, online softmax and P.V stay in
-// registers.  4 waves x 16 query rows per workgroup, 64-key tiles staged through LDS (K rows and V^T rows), v_mfma_f32_16x16x32_bf16:
-//   S^T block = K.Q^T   (first operand K: lane (fr, fg) then owns query fr and the four keys 16 kb + 4 fg + j of key block kb)
-//   O^T block = V^T.P^T (first operand V^T rows = output channels; the P operand is taken straight from the S registers: MFMA k-slot
-//                        8 fg + j <-> key 32 h + 4 fg + j, slot 8 fg + 4 + j <-> key 32 h + 16 + 4 fg + j, and V^T is read with the
-//                        same slot -> key map, two 8-byte LDS reads per fragment)
-// so a lane keeps one query's statistics (running maximum, partial row sum) and rescales its own 96 accumulator values.
-// Bound: LDS reads (every wave streams the whole K and V^T tile per 96 MFMAs); the product is ~1.3 TFLOP per 720p edit.
+// registers, v_mfma_f32_16x16x32_bf16:
+//   S^T block = K.Q^T   (first operand K: lane (fr, fg) then owns query fr and the four K-image rows 16 kb + 4 fg + r of row block kb)
+//   O^T block = V^T.P^T (first operand V^T rows = output channels; the P operand is taken straight from the S registers)
+// so a lane keeps one query's statistics (running maximum, partial row sum) and rescales its own accumulator values.
+// Round 6 (rounds 3-5: 64-row workgroups, register-staged 64-key tiles, 0.13 of the matrix peak - every workgroup pulled the whole K and
+// V^T through its CU for 64 query rows, ~10 B / cycle / CU of L2 -> LDS traffic was the bound, not the LDS reads the round-5 notes blamed):
+//   * a wave owns RB = 2 blocks of 16 query rows (128 per workgroup: half the bytes per flop); their Q fragments live in registers
+//     (2 x C / 32 x 4 = 96 at C = 384; one wave per SIMD owns 512) and every K / V^T fragment read feeds two MFMAs;
+//   * K and V^T tiles of 32 keys arrive by LDS-DMA (buffer_load ... lds, 1 KiB per wave instruction) into a ring of three (K, V^T) slots,
+//     TWO tiles ahead of the products, one barrier per tile; no staging registers, no ds_write.  Bank conflicts are taken out on the DMA's
+//     SOURCE side:
+//       K image  [C / 128 column groups][32 rows][16 chunks of 16 B]: position p of image row rho holds chunk p ^ (rho & 15) - a
+//                ds_read_b128 of 16 rows at one chunk index hits 16 distinct bank quads in each of the instruction's four lane groups;
+//                image row rho holds key 8 (rho >> 2 & 3) + 4 (rho >> 4) + (rho & 3) of the tile, so that the eight P values a lane
+//                owns after S^T (rows 4 fg + r and 16 + 4 fg + r) are the keys 8 fg .. 8 fg + 7 = one MFMA k-slot group in natural order;
+//       V^T image [C rows][4 chunks]: keys in natural order, position p of row d holds chunk p ^ (3 (d >> 3 & 1)): ONE ds_read_b128 per
+//                fragment, conflict-free in the same four lane groups;
+//   * the running maximum moves only when a tile's maximum exceeds it by more than 8 (in the exp2 domain: P <= 256, exact after the
+//     normalisation): the 192 accumulators are rescaled in the first tile and practically never again;
+//   * 128-row workgroups are only 113 at 14 400 positions, so the KEY axis is split over gridDim.y workgroups (2 at 720p: 226 workgroups
+//     on 256 CUs): each writes its un-normalised fp32 O and its (maximum, row sum) to the caller's workspace and
+//     attn_1head_merge_kernel combines them - O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m); one split writes bf16 O directly.
 namespace {
 
+typedef __attribute__((address_space(3))) void lds_void_c;
+
 template <int C>
-__global__ __launch_bounds__(256) void attn_1head_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt,
-                                                         bf16* __restrict__ O, int Nq, int Nk, int ldq, int ldk, int ldvt, int ldo, float sl2) {
-  constexpr int KS = C / 32;          // k-steps of the score product
-  constexpr int DB = C / 16;          // 16-channel blocks of the output
-  constexpr int KROW = C * 2 + 16;    // padded K row (bytes)
-  constexpr int VROW = 128 + 16;      // padded V^T row: 64 keys
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sK = smem;
-  unsigned char* sV = smem + 64 * KROW;
-  unsigned char* sQ = sV + C * VROW;  // the workgroup's 64 query rows (fragments are re-read per tile: 48 registers the staging needs)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_1head_kernel(
+    const bf16* __restrict__ Q, const bf16* __restrict__ K, const bf16* __restrict__ Vt, bf16* __restrict__ O, int Nq, int Nk, int ldq, int ldk,
+    int ldvt, int ldo, float sl2, float* __restrict__ wsO, float* __restrict__ wsML, int tiles_per_split) {
+  constexpr int KS = C / 32;            // k-steps of the score product
+  constexpr int DB = C / 16;            // 16-channel blocks of the output
+  constexpr int CG = C / 128;           // 128-channel column groups of the K image
+  constexpr int RB = 2;                 // 16-row query blocks per wave
+  constexpr int KT = 32;                // keys per tile
+  constexpr int K_TILE = KT * C * 2;    // 24 KiB at C = 384
+  constexpr int V_TILE = C * KT * 2;
+  constexpr int SLOT = K_TILE + V_TILE;
+  constexpr int NVD = C / 64;           // V^T DMA pieces per wave and tile (the K image: 2 CG - the same number)
+  constexpr int NDMA = 2 * CG + NVD;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int q0 = blockIdx.x * 64 + wave * 16;
-  for (int c = tid; c < 64 * (C / 8); c += 256) {
-    const int r = c / (C / 8), cc = c - r * (C / 8);
-    *reinterpret_cast<u32x4*>(sQ + r * KROW + cc * 16) = *reinterpret_cast<const u32x4*>(Q + (size_t)min(blockIdx.x * 64 + r, Nq - 1) * ldq + cc * 8);
-  }
-  f32x4 o[DB];
-#pragma unroll
-  for (int d = 0; d < DB; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -3.0e38f, l_run = 0.f;
-  const int ntiles = (Nk + 63) / 64;
-  // Tiles are register-staged ONE AHEAD: the global loads of tile t + 1 are issued before tile t's products and written to LDS after
-  // them (a lone wave per SIMD owns 512 registers: 2 x C / 32 staging vectors are free), so the only exposed memory round trip is the
-  // first tile's.  (Round 3 loaded each tile between two barriers with nothing in flight: 2.25 ms per 14 400-position frame.)
-  // Chunk -> thread maps that keep ONE per-thread offset per operand (everything else is a wave-uniform or immediate term; with 24
-  // per-chunk 64-bit pointers hipcc parked 190 values in the accumulator file and moved 550 of them per tile):
-  //   K tile:   rows (tid >> 4) + 16 j, 16-byte chunks (tid & 15) + 16 m   (j < 4, m < C / 128)
-  //   V^T tile: rows (tid >> 3) + 32 j, chunk tid & 7                       (j < C / 32)
-  // as buffer loads: rows past Nk read as zero (their scores are masked below; V^T columns past Nk are zero by contract).
-  constexpr int NKM = C / 128, NVJ = C / 32;
-  u32x4 stK[4][NKM], stV[NVJ];
+  const int q0 = blockIdx.x * (64 * RB) + wave * (16 * RB);
+  const int ntiles = (Nk + KT - 1) / KT;
+  const int t_begin = blockIdx.y * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
+  const int nt = max(t_end - t_begin, 0);
+
+  // LDS-DMA: rows past Nk read as zero (their scores are masked below; V^T columns past Nk are zero by contract)
   const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (uint32_t)(Nk - 1) * (uint32_t)(ldk * 2) + C * 2u, 0x00020000);
-  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, (uint32_t)(C - 1) * (uint32_t)(ldvt * 2) + (uint32_t)ntiles * 128u, 0x00020000);
-  const int k_voff = (tid >> 4) * ldk * 2 + (tid & 15) * 16, v_voff = (tid >> 3) * ldvt * 2 + (tid & 7) * 16;
-  unsigned char* const k_dst = sK + (tid >> 4) * KROW + (tid & 15) * 16;
-  unsigned char* const v_dst = sV + (tid >> 3) * VROW + (tid & 7) * 16;
-  auto gload = [&](int t) {
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vt, 0, (uint32_t)(C - 1) * (uint32_t)(ldvt * 2) + (uint32_t)ntiles * (KT * 2u), 0x00020000);
+  // K piece (cg, j) of wave w = image rows 4 (w + 4 j) + fg of column group cg, position fr <- chunk fr ^ (4 w + fg) of key 8 w + 4 j + fg
+  const int k_voff = (8 * wave + fg) * ldk * 2 + ((fr ^ (4 * wave + fg)) << 4), k_step = 4 * ldk * 2, k_tile_step = KT * ldk * 2;
+  // V^T piece j of wave w = rows 16 (w + 4 j) + (lane >> 2), position lane & 3 <- chunk (lane & 3) ^ (3 (row >> 3 & 1))
+  const int v_voff = (16 * wave + (lane >> 2)) * ldvt * 2 + (((lane & 3) ^ (3 * ((lane >> 5) & 1))) << 4), v_step = 64 * ldvt * 2;
+  auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+    unsigned char* const sb = smem + slot * SLOT;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
-      for (int m = 0; m < NKM; ++m) stK[j][m] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, k_voff + m * 256, (t * 64 + j * 16) * ldk * 2, 0);
+      for (int j = 0; j < 2; ++j)
+        // (the whole key offset in the VGPR operand: the range check that zeroes the rows past Nk covers the VGPR offset)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void_c*)(sb + cg * 8192 + (wave + 4 * j) * 1024), 16,
+                                                 k_voff + t * k_tile_step + j * k_step + cg * 256, 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < NVJ; ++j) stV[j] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, v_voff, j * 32 * ldvt * 2 + t * 128, 0);
+    for (int j = 0; j < NVD; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void_c*)(sb + K_TILE + (wave + 4 * j) * 1024), 16, v_voff, t * (KT * 2) + j * v_step, 0, 0);
   };
-  auto lstore = [&]() {
+  // Q fragments of this wave's 2 x 16 rows, read once (rows past Nq: clamped copies, never stored); then tiles 0 and 1 of this split
+  bf16x8 qf[RB][KS];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int m = 0; m < NKM; ++m) *reinterpret_cast<u32x4*>(k_dst + j * 16 * KROW + m * 256) = stK[j][m];
+    for (int ks = 0; ks < KS; ++ks)
+      qf[rb][ks] = *reinterpret_cast<const bf16x8*>(Q + (size_t)min(q0 + 16 * rb + fr, Nq - 1) * ldq + 32 * ks + 8 * fg);
 #pragma unroll
-    for (int j = 0; j < NVJ; ++j) *reinterpret_cast<u32x4*>(v_dst + j * 32 * VROW) = stV[j];
-  };
-  gload(0);
-  lstore();
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();  // tile t is in LDS
-    gload(min(t + 1, ntiles - 1));  // (the last iteration re-loads the last tile: harmless, and the loop stays branch-free)
-    __builtin_amdgcn_sched_barrier(0);  // (in flight across the whole tile: hipcc must not sink them towards the LDS stores)
-    f32x4 s[4];
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(sQ + (wave * 16 + fr) * KROW + (32 * ks + 8 * fg) * 2);
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (kb * 16 + fr) * KROW + (32 * ks + 8 * fg) * 2);
-        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, s[kb], 0, 0, 0);
-      }
+    for (int ks = 0; ks < KS; ++ks) {  // (retires the Q loads: the DMA queue below is counted)
+      if (rb == 0) asm volatile("" : "+a"(qf[rb][ks]));  // the first block's fragments beside the 192 accumulators (240 of 256), ...
+      else asm volatile("" : "+v"(qf[rb][ks]));          // ... the second block's in the vector file
     }
-    // online softmax in the exp2 domain; keys past Nk are masked (their K rows were clamped copies)
-    float mt = -3.0e38f;
+  __builtin_amdgcn_sched_barrier(0);
+  dma(min(t_begin, ntiles - 1), 0);
+  __builtin_amdgcn_sched_barrier(0);
+  dma(min(t_begin + 1, ntiles - 1), 1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // fragment read offsets inside a slot: K (kb, ks) at koff[ks & 3] + (ks >> 2) 8192 + kb 4096; V^T (db) at voff + db 1024
+  int koff[4];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+  for (int i = 0; i < 4; ++i) koff[i] = fr * 256 + (((4 * i + fg) ^ fr) << 4);
+  const int voff = K_TILE + fr * 64 + ((fg ^ (3 * ((fr >> 3) & 1))) << 4);
+
+  f32x4 o[RB][DB];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = t * 64 + kb * 16 + 4 * fg + j;
-        s[kb][j] = key < Nk ? s[kb][j] * sl2 : -3.0e38f;
-        mt = fmaxf(mt, s[kb][j]);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s[kb][j] = __builtin_amdgcn_exp2f(s[kb][j] - m_new);
-        psum += s[kb][j];
-      }
-    l_run = l_run * alpha + psum;
-    if (__any(alpha != 1.0f)) {  // the running maxima settle after a few tiles: most tiles rescale nothing
-#pragma unroll
-      for (int d = 0; d < DB; ++d) o[d] *= alpha;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      u32x4 pw = {pack_bf16(s[2 * h][0], s[2 * h][1]), pack_bf16(s[2 * h][2], s[2 * h][3]), pack_bf16(s[2 * h + 1][0], s[2 * h + 1][1]),
-                  pack_bf16(s[2 * h + 1][2], s[2 * h + 1][3])};
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        const unsigned char* vr = sV + (d * 16 + fr) * VROW + (32 * h + 4 * fg) * 2;
-        const u32x2 lo = *reinterpret_cast<const u32x2*>(vr), hi = *reinterpret_cast<const u32x2*>(vr + 32);
-        const u32x4 vw = {lo[0], lo[1], hi[0], hi[1]};
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vw), pf, o[d], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // every wave is done with tile t
-    lstore();
-  }
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_run;
-  if (q0 + fr < Nq) {
-    bf16* orow = O + (size_t)(q0 + fr) * ldo + 4 * fg;
+  for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
-      const u32x2 pk = {pack_bf16(o[d][0] * inv, o[d][1] * inv), pack_bf16(o[d][2] * inv, o[d][3] * inv)};
-      *reinterpret_cast<u32x2*>(orow + d * 16) = pk;
+      o[rb][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+a"(o[rb][d]));
+    }
+  float m_run[RB], l_run[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) m_run[rb] = -3.0e38f, l_run[rb] = 0.f;
+
+  int slot = 0;
+  for (int i = 0; i < nt; ++i) {
+    const int t = t_begin + i;
+    // this wave's pieces of tile i have landed (the NDMA of tile i + 1 may fly); behind the barrier everybody's have, and everybody is
+    // done with tile i - 1, whose slot takes tile i + 2
+    if constexpr (NDMA == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    static_assert(NDMA == 12 || NDMA == 4, "vmcnt immediates above");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    dma(min(t + 2, ntiles - 1), slot == 0 ? 2 : slot - 1);  // (past the end: the last tile again - harmless, and the loop stays branch-free)
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* const sb = smem + slot * SLOT;
+    // The matrix instructions are inline asm with their register files spelled out - accumulators of O ("+a") and the first query block's
+    // fragments ("a") in the accumulator file, the second block's, the scores and the streamed fragments in the vector file: left to hipcc
+    // (builtins) 192 + 96 long-lived registers ended with seven Q fragments in scratch, re-read every tile behind a vmcnt(0) each (which
+    // also drains the DMA queue).  hipcc moves no load across a volatile asm, so the fragment reads are pipelined by hand: a ring of PRE
+    // fragments runs ahead of the products (an LDS read returns in ~100-130 cycles = 3-4 steps of two 16-cycle MFMAs).
+    constexpr int PRE = 4;
+    auto read_k = [&](int n) __attribute__((always_inline)) {  // step n = (ks, kb) = (n >> 1, n & 1)
+      return *reinterpret_cast<const bf16x8*>(sb + koff[(n >> 1) & 3] + (n >> 3) * 8192 + (n & 1) * 4096);
+    };
+    auto read_v = [&](int d) __attribute__((always_inline)) { return *reinterpret_cast<const bf16x8*>(sb + voff + d * 1024); };
+    bf16x8 fr_[PRE];
+#pragma unroll
+    for (int n = 0; n < PRE; ++n) fr_[n] = read_k(n);
+    f32x4 s[RB][2];
+#pragma unroll
+    for (int n = 0; n < 2 * KS; ++n) {
+      const int ks = n >> 1, kb = n & 1;
+      const bf16x8 kf = fr_[n % PRE];
+      if (ks == 0) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[0][kb]) : "v"(kf), "a"(qf[0][ks]));
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(s[1][kb]) : "v"(kf), "v"(qf[1][ks]));
+      } else {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[0][kb]) : "v"(kf), "a"(qf[0][ks]));
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[1][kb]) : "v"(kf), "v"(qf[1][ks]));
+      }
+      if (n + PRE < 2 * KS) fr_[n % PRE] = read_k(n + PRE);
+      else fr_[n % PRE] = read_v(n + PRE - 2 * KS);  // the first V^T fragments fly under the softmax
+    }
+    asm volatile("s_nop 7" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));  // 4-pass results -> the vector ALU: 7 wait states
+    // online softmax in the exp2 domain, per query block; s[rb][kb][r] belongs to key 32 t + 8 fg + 4 kb + r
+    if (t == ntiles - 1 && (Nk & (KT - 1))) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (t * KT + 8 * fg + 4 * kb + r >= Nk) s[rb][kb][r] = -3.0e38f;
+    }
+    bf16x8 pf[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      float mt = fmaxf(fmaxf(fmaxf(s[rb][0][0], s[rb][0][1]), fmaxf(s[rb][0][2], s[rb][0][3])),
+                       fmaxf(fmaxf(s[rb][1][0], s[rb][1][1]), fmaxf(s[rb][1][2], s[rb][1][3])));
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      mt *= sl2;  // (sl2 > 0)
+      const bool move = mt > m_run[rb] + 8.0f;  // the same answer in the four lanes of a query
+      if (__any(move)) {
+        const float m_new = move ? mt : m_run[rb];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+        m_run[rb] = m_new;
+        l_run[rb] *= alpha;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {  // out of the accumulator file, scaled, put back - ONE accumulator at a time (the asm pins order
+          asm volatile("" : "+a"(o[rb][d]));  // the reads: 96 values in flight at once cost the vector file the second block's Q)
+          f32x4 x = o[rb][d];
+          x *= alpha;
+          o[rb][d] = x;
+          asm volatile("" : "+a"(o[rb][d]));
+        }
+      }
+      const float nm = -m_run[rb];
+      float psum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[rb][kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rb][kb][r], sl2, nm));
+          psum += s[rb][kb][r];
+        }
+      l_run[rb] += psum;
+      const u32x4 pw = {pack_bf16(s[rb][0][0], s[rb][0][1]), pack_bf16(s[rb][0][2], s[rb][0][3]), pack_bf16(s[rb][1][0], s[rb][1][1]),
+                        pack_bf16(s[rb][1][2], s[rb][1][3])};
+      pf[rb] = __builtin_bit_cast(bf16x8, pw);
+    }
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      const bf16x8 vf = fr_[(d + 2 * KS) % PRE];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[rb][d]) : "v"(vf), "v"(pf[rb]));
+      if (d + PRE < DB) fr_[(d + 2 * KS) % PRE] = read_v(d + PRE);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" ::: "memory");  // (the run-ahead pieces past this split's end; the last products -> v_accvgpr_read)
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int d = 0; d < DB; ++d) asm volatile("" : "+a"(o[rb][d]));
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    float l = l_run[rb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int q = q0 + rb * 16 + fr;
+    if (q >= Nq) continue;
+    if (wsO == nullptr) {  // one split: normalised bf16 output
+      const float inv = 1.0f / l;
+      bf16* orow = O + (size_t)q * ldo + 4 * fg;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) {
+        const u32x2 pk = {pack_bf16(o[rb][d][0] * inv, o[rb][d][1] * inv), pack_bf16(o[rb][d][2] * inv, o[rb][d][3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + d * 16) = pk;
+      }
+    } else {  // a key split: un-normalised fp32 O [split][Nq][C] and (m, l) [split][Nq][2] for attn_1head_merge_kernel
+      float* orow = wsO + ((size_t)blockIdx.y * Nq + q) * C + 4 * fg;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) *reinterpret_cast<f32x4*>(orow + d * 16) = o[rb][d];
+      if (fg == 0) {
+        wsML[((size_t)blockIdx.y * Nq + q) * 2 + 0] = m_run[rb];
+        wsML[((size_t)blockIdx.y * Nq + q) * 2 + 1] = l;
+      }
     }
   }
+}
+
+// O[q][c] = sum_s O_s[q][c] 2^(m_s - m) / sum_s l_s 2^(m_s - m), m = max_s m_s: one thread per (query, 4 channels)
+__global__ __launch_bounds__(256) void attn_1head_merge_kernel(const float* __restrict__ wsO, const float* __restrict__ wsML, bf16* __restrict__ O, int Nq,
+                                                              int C, int ldo, int nsplit) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = C / 4;
+  if (idx >= (long long)Nq * c4) return;
+  const int q = (int)(idx / c4), c = (int)(idx - (long long)q * c4) * 4;
+  float m = -3.0e38f;
+  for (int s_ = 0; s_ < nsplit; ++s_) m = fmaxf(m, wsML[((size_t)s_ * Nq + q) * 2]);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int s_ = 0; s_ < nsplit; ++s_) {
+    const float w = __builtin_amdgcn_exp2f(wsML[((size_t)s_ * Nq + q) * 2] - m);
+    l += wsML[((size_t)s_ * Nq + q) * 2 + 1] * w;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(wsO + ((size_t)s_ * Nq + q) * C + c);
+    acc += v * w;
+  }
+  const float inv = 1.0f / l;
+  const u32x2 pk = {pack_bf16(acc[0] * inv, acc[1] * inv), pack_bf16(acc[2] * inv, acc[3] * inv)};
+  *reinterpret_cast<u32x2*>(O + (size_t)q * ldo + c) = pk;
 }
 
 }  // namespace
@@ -720,14 +840,28 @@ __global__ __launch_bounds__(256) void attn_1head_kernel(const bf16* __restrict_
 // V transposed (keys contiguous; columns [Nk, 64 ceil(Nk / 64)) must be finite - zero them).  Replaces the q.k^T / softmax / .v of the
 // VAE's AttentionBlock (chronoedit/_src/tokenizers/wan2pt1.py:247-255, F.scaled_dot_product_attention on [b t, 1, h w, c]).
 CE_API int ce_attention_1head_bf16(const void* Q, const void* K, const void* Vt, void* O, int Nq, int Nk, int C, int ldq, int ldk, int ldvt,
-                                       int ldo, float softmax_scale, hipStream_t stream) {
+                                       int ldo, float softmax_scale, void* ws, long long ws_bytes, hipStream_t stream) {
   if (!Q || !K || !Vt || !O || Nq <= 0 || Nk <= 0) return CE_ERR_ARG;
   if ((C != 128 && C != 384) || (ldq & 7) || (ldk & 7) || (ldvt & 7) || (ldo & 3) || ldvt < (Nk + 63) / 64 * 64) return CE_ERR_SHAPE;
   const float sl2 = softmax_scale * 1.4426950408889634f;
-  const dim3 grid((Nq + 63) / 64), block(256);
+  const int blocks = (Nq + 127) / 128, ntiles = (Nk + 31) / 32;  // 32-key tiles
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  // key split: as many splits (<= 4, >= 16 key tiles each) as fill the chip, if the caller's workspace holds the fp32 partial results
+  int nsplit = 1;
+  if (ws != nullptr && blocks * 4 < cus * 3)
+    for (int sp = 4; sp >= 2; --sp)
+      if (blocks * sp <= cus + cus / 8 && ntiles >= 16 * sp && (long long)sp * Nq * (C + 2) * 4 <= ws_bytes) {
+        nsplit = sp;
+        break;
+      }
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  float* wsO = nsplit > 1 ? (float*)ws : nullptr;
+  float* wsML = nsplit > 1 ? wsO + (size_t)nsplit * Nq * C : nullptr;
+  const dim3 grid(blocks, nsplit), block(256);
   static bool done_[CE_MAX_DEVICES] = {};
   bool& done = done_[ce_device_slot()];
-  const int smem384 = 128 * (384 * 2 + 16) + 384 * 144, smem128 = 128 * (128 * 2 + 16) + 128 * 144;  // K tile + Q rows + V^T tile
+  const int smem384 = 3 * 2 * 32 * 384 * 2, smem128 = 3 * 2 * 32 * 128 * 2;  // ring of three (K, V^T) slots of 32 keys
   if (!done) {
     (void)hipFuncSetAttribute((const void*)attn_1head_kernel<384>, hipFuncAttributeMaxDynamicSharedMemorySize, smem384);
     (void)hipFuncSetAttribute((const void*)attn_1head_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem128);
@@ -735,9 +869,13 @@ CE_API int ce_attention_1head_bf16(const void* Q, const void* K, const void* Vt,
   }
   if (C == 384)
     hipLaunchKernelGGL(attn_1head_kernel<384>, grid, block, smem384, stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, Nq, Nk, ldq,
-                       ldk, ldvt, ldo, sl2);
+                       ldk, ldvt, ldo, sl2, wsO, wsML, per);
   else
     hipLaunchKernelGGL(attn_1head_kernel<128>, grid, block, smem128, stream, (const bf16*)Q, (const bf16*)K, (const bf16*)Vt, (bf16*)O, Nq, Nk, ldq,
-                       ldk, ldvt, ldo, sl2);
+                       ldk, ldvt, ldo, sl2, wsO, wsML, per);
+  if (nsplit > 1) {
+    const long long n = (long long)Nq * (C / 4);
+    hipLaunchKernelGGL(attn_1head_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, wsO, wsML, (bf16*)O, Nq, C, ldo, nsplit);
+  }
   return (int)hipGetLastError();
 }

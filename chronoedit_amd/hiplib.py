@@ -88,7 +88,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_rms_silu_bf16": [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _P],
     "ce_upsample2x_bf16": [_P, _P, _I, _I, _I, _I, _P],
     "ce_softmax_rows_f32_bf16": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
-    "ce_attention_1head_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "ce_attention_1head_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _c.c_longlong, _P],
     "ce_cfg_unipc_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _c.c_longlong, _I, _P],
     "ce_build_info": [],
 }

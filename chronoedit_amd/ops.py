@@ -672,9 +672,15 @@ def softmax_rows(scores: torch.Tensor, probs: torch.Tensor, n: int, scale: float
     return probs
 
 
-def attention_1head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None):
+_attn1_ws = {}  # device index -> fp32 scratch of the key split of attention_1head (one per device, grown on demand, never under capture)
+
+
+def attention_1head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None,
+                    split_keys: bool = True):
     """softmax(q k^T * scale) v for one head of dimension C in {128, 384} (the Wan VAE mid-block): q [Nq, C], k [Nk, C] row views,
-    vt [C, >= 64 ceil(Nk / 64)] = v transposed with zero padding columns; flash-style, nothing of size Nq x Nk is materialised."""
+    vt [C, >= 64 ceil(Nk / 64)] = v transposed with zero padding columns; flash-style, nothing of size Nq x Nk is materialised.
+    split_keys: hand the library a scratch (4 Nq (C + 2) floats per device, allocated once) so that it may split the key axis over
+    several workgroups per query block when the query blocks alone do not fill the chip (ce_attention_1head_bf16)."""
     _dev(q, torch.bfloat16, "q"), _dev(k, torch.bfloat16, "k"), _dev(vt, torch.bfloat16, "vt")
     Nq, C, ldq = _rows(q, "q")
     Nk, C2, ldk = _rows(k, "k")
@@ -684,9 +690,18 @@ def attention_1head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: f
         out = torch.empty((Nq, C), dtype=torch.bfloat16, device=q.device)
     _dev(out, torch.bfloat16, "out")
     _, _, ldo = _rows(out, "out")
+    ws = None
+    if split_keys:
+        dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
+        need = 4 * Nq * (C + 2)
+        ws = _attn1_ws.get(dev)
+        if (ws is None or ws.numel() < need) and not torch.cuda.is_current_stream_capturing():
+            ws = _attn1_ws[dev] = torch.empty(need, dtype=torch.float32, device=q.device)
+        if ws is not None and ws.numel() < need:
+            ws = None  # (under capture with a scratch too small for this shape: one workgroup per query block walks all keys)
     st = _prof_begin()
-    _check(lib().ce_attention_1head_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), Nq, Nk, C, ldq, ldk, ldvt, ldo, float(scale), _stream()),
-           "ce_attention_1head_bf16")
+    _check(lib().ce_attention_1head_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), Nq, Nk, C, ldq, ldk, ldvt, ldo, float(scale), _ptr(ws),
+                                         0 if ws is None else ws.numel() * 4, _stream()), "ce_attention_1head_bf16")
     _prof_end(st, f"attention_1head_{Nq}x{Nk}x{C}", 4.0 * Nq * Nk * C)
     return out
 

@@ -276,9 +276,12 @@ int ce_upsample2x_bf16(const void* x, void* y, int T, int C, int H, int W, hipSt
 /* O [Nq][ldo] = softmax(Q K^T * softmax_scale) V for ONE attention head of dimension C (128 or 384) as a single flash-style kernel
  * (no [Nq, Nk] score matrix in memory): Q [Nq][ldq], K [Nk][ldk] bf16 rows; Vt [C][ldvt] = V transposed, keys contiguous, ldvt >=
  * 64 ceil(Nk / 64) with the padding columns finite (zero).  Replaces the scaled_dot_product_attention of the Wan VAE's mid-block
- * AttentionBlock (chronoedit/_src/tokenizers/wan2pt1.py:247-255: one head over the h*w positions of a frame). */
+ * AttentionBlock (chronoedit/_src/tokenizers/wan2pt1.py:247-255: one head over the h*w positions of a frame).
+ * ws / ws_bytes (round 6; may be NULL / 0): caller-owned scratch for a split of the KEY axis - when the 128-row query blocks alone leave most
+ * CUs idle (113 blocks at the 14 400 positions of a 720p frame) up to four workgroups share a query block's keys, write un-normalised fp32
+ * partial results (nsplit * Nq * (C + 2) * 4 bytes) and a second launch merges them; without a workspace one workgroup walks all keys. */
 int ce_attention_1head_bf16(const void* Q, const void* K, const void* Vt, void* O, int Nq, int Nk, int C, int ldq, int ldk, int ldvt,
-                            int ldo, float softmax_scale, hipStream_t stream);
+                            int ldo, float softmax_scale, void* ws, long long ws_bytes, hipStream_t stream);
 
 /* probs[m][0:npad] = bf16(softmax(scale * scores[m][0:n])) (zeros beyond n); scores fp32.  Mid-block attention
  * (wan2pt1.py:247-252) runs as GEMM (CE_EPI_F32) -> this -> GEMM. */

@@ -139,9 +139,9 @@ def test_mxfp8_attention_kernels_have_no_spills_and_their_matrix_work_per_tile()
 def test_vae_head_conv_and_mid_block_attention_kernels_keep_their_shape():
     """ce_conv.hip, round 4.  conv_head_kernel: 90 MFMAs per kt (10 input rows x 9 fragments) in three workgroups' worth of registers, its
     input fragments by BUFFER loads issued a row ahead (a frame pointer read back from LDS made hipcc emit flat loads with a full wait
-    behind every one: 10 x slower) - no flat load, no load waited for where it is issued beyond the weight staging.  attn_1head_kernel:
-    no scratch, the staging registers do not push O into spill copies (the accumulators live in the AGPRs as the MFMAs' own operand:
-    per tile only the conditional rescale block moves them)."""
+    behind every one: 10 x slower) - no flat load, no load waited for where it is issued beyond the weight staging.  attn_1head_kernel
+    (round 6 form: LDS-DMA ring, two query blocks per wave): no scratch, per 32-key tile 96 MFMAs on 48 fragment reads and 12 DMA pieces behind
+    one barrier; the accumulators live in the AGPRs as the MFMAs' own operand: per tile only the conditional rescale blocks move them."""
     import subprocess
     import tempfile
     rows = _rows("ce_conv.hip")
@@ -162,5 +162,13 @@ def test_vae_head_conv_and_mid_block_attention_kernels_keep_their_shape():
     hb = body("conv_head_kernel")
     assert "flat_load" not in hb and hb.count("buffer_load_dwordx4") >= 90, (hb.count("flat_load"), hb.count("buffer_load_dwordx4"))
     ab = body("attn_1head_kernelILi384E")
-    assert "flat_load" not in ab and ab.count("buffer_load_dwordx4") == 48  # 2 x 24 staging loads (prologue tile + the in-loop prefetch)
-    assert ab.count("v_accvgpr") <= 560, ab.count("v_accvgpr")  # (init, one conditional rescale block, the final normalisation)
+    assert "flat_load" not in ab and "ds_write" not in ab and "scratch_" not in ab
+    # round 6: K / V^T tiles by LDS-DMA (no staging registers): 2 prologue tiles + the in-loop run-ahead tile, 12 pieces each; Q by 24 plain loads
+    assert ab.count("buffer_load_dwordx4") == 3 * 12 and ab.count(" lds") == 3 * 12 and ab.count("global_load_dwordx4") == 24, ab.count(" lds")
+    (loop,) = isa_lint.inner_loops(os.path.join(CSRC, "ce_conv.hip"), "attn_1head_kernelILi384E")
+    c = loop[1]  # per 32-key tile: 2 query blocks x (24 score + 24 P.V) products on 48 fragment reads, 12 DMA pieces, ONE barrier
+    assert c.get("v_mfma_f32_16x16x32_bf16", 0) == 96 and c.get("ds_read_b128", 0) == 48 and c.get("buffer_load_dwordx4", 0) == 12, c
+    assert c.get("s_barrier", 0) == 1 and not any(op.startswith("scratch") or op.startswith("ds_write") for op in c), c
+    # the accumulators and the first block's Q live in the accumulator file as the MFMAs' own operands: only the two conditional rescale
+    # blocks (2 x 96 registers out and back) move them inside the loop
+    assert c.get("v_accvgpr_read_b32", 0) <= 192 + 8 and c.get("v_accvgpr_write_b32", 0) <= 192 + 8, c

@@ -115,10 +115,13 @@ def test_head_conv_kernel_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cout, 
                         out_border=1, out_cstride=8)
 
 
-@pytest.mark.parametrize("N,C", [(384, 384), (1000, 384), (100, 128), (3600, 384), (14400, 384)])
-def test_single_head_attention_kernel_vs_fp32(N, C):
+@pytest.mark.parametrize("N,C,split", [(384, 384, True), (1000, 384, True), (1000, 384, False), (100, 128, True), (3600, 384, True), (3600, 128, True),
+                                       (1111, 128, True), (14400, 384, True), (14400, 384, False)])
+def test_single_head_attention_kernel_vs_fp32(N, C, split):
     """ce_attention_1head_bf16 (the VAE mid-block attention as one flash-style kernel, head dim 384 / 128) vs fp32 softmax(q k^T) v;
-    14 400 = the 90 x 160 positions of a 720p frame (the score matrix this kernel never materialises is 0.83 GB in fp32)."""
+    14 400 = the 90 x 160 positions of a 720p frame (the score matrix this kernel never materialises is 0.83 GB in fp32).  split: the caller
+    hands over the scratch for the key split (2 workgroups per query block at 14 400 positions, 4 at 3 600, none below 32 key tiles per split);
+    ragged N: the last 32-key tile is partly past the end (rows zeroed by the DMA's range check, scores masked)."""
     from chronoedit_amd import ops
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(17)
@@ -129,7 +132,7 @@ def test_single_head_attention_kernel_vs_fp32(N, C):
     hwp = (N + 63) // 64 * 64
     vt = torch.zeros((C, hwp), dtype=torch.bfloat16, device=dev)
     vt[:, :N] = v.t()
-    out = ops.attention_1head(q, k, vt, C ** -0.5)
+    out = ops.attention_1head(q, k, vt, C ** -0.5, split_keys=split)
     worst = 0.0
     for r0 in range(0, N, 2048):
         s = torch.softmax(q[r0:r0 + 2048].float() @ k.float().t() * C ** -0.5, dim=-1)
