@@ -22,7 +22,7 @@ class UniPCOracle:
         self.lower_order_final = lower_order_final
         self.disable_corrector = list(disable_corrector)
         alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
-        sigmas = torch.from_numpy(1.0 - alphas).to(torch.float32)
+        sigmas = torch.tensor(1.0 - alphas).to(torch.float32)
         sigmas = shift * sigmas / (1 + (shift - 1) * sigmas)  # :124-127
         self.sigma_min, self.sigma_max = sigmas[-1].item(), sigmas[0].item()
         self.init_shift = shift
@@ -35,8 +35,8 @@ class UniPCOracle:
         if shift is None:
             shift = self.init_shift
         sig = shift * sig / (1 + (shift - 1) * sig)
-        self.timesteps = torch.from_numpy(sig * self.T).to(torch.int64)
-        self.sigmas = torch.from_numpy(np.concatenate([sig, [0]]).astype(np.float32))
+        self.timesteps = torch.tensor(sig * self.T).to(torch.int64)
+        self.sigmas = torch.tensor(np.concatenate([sig, [0]]).astype(np.float32))
         self.model_outputs = [None] * self.solver_order
         self.lower_order_nums = 0
         self.last_sample = None

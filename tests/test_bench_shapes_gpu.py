@@ -12,6 +12,7 @@ References: fp32 torch SDPA on the device for the attention kernels (the operand
 import pytest
 import torch
 
+from oracle import device as OD
 from oracle import dit_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -172,9 +173,9 @@ def test_full_width_block_bf16_and_fp8_modes_vs_fp32_oracle(h, w, tag):
     model.enable_fp8_gemms(mx=False)                          # the round-1..3 contract: one scale per 5120- / 13824-long row
     out_row = model(*args, return_dict=False)[0].float().cpu()
     del model
-    p32 = {k: v.float() for k, v in p_bf.items()}
-    with torch.no_grad():
-        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([800]), text.float(), image.float())
+    with torch.no_grad(), OD.on() as dev:  # the fp32 oracle, evaluated where oracle/device.py says (CE_ORACLE_DEVICE=cpu: the host cores)
+        ref = O.dit_forward(OD.to(p_bf, dev, torch.float32), cfg, OD.to(lat, dev, torch.float32), torch.tensor([800]), OD.to(text, dev, torch.float32),
+                            OD.to(image, dev, torch.float32)).cpu()
     e_bf16, e_fp8, e_row, e_acc = rel_l2(out_bf16, ref), rel_l2(out_fp8, ref), rel_l2(out_row, ref), rel_l2(out_acc, ref)
     print(f"full-width block, {tag}: bf16 path vs fp32 {e_bf16:.3e} | fp8 mode (MX block scales) vs fp32 {e_fp8:.3e} ({e_fp8 / e_bf16:.2f} x) | "
           f"per-row scales {e_row:.3e} ({e_row / e_bf16:.2f} x) | policy 'accurate' {e_acc:.3e} ({e_acc / e_bf16:.2f} x)")

@@ -10,6 +10,7 @@ import os
 import pytest
 import torch
 
+from oracle import device as OD
 from oracle import dit_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -116,9 +117,9 @@ def test_full_width_block_at_720p_vs_fp32_reference():
     model = _build(cfg, p_bf)
     ts = torch.tensor([800], device="cuda:0")
     out = model(lat.cuda(), ts, text.cuda(), image.cuda(), return_dict=False)[0]
-    p32 = {k: v.float() for k, v in p_bf.items()}
-    with torch.no_grad():
-        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([800]), text.float(), image.float())
+    with torch.no_grad(), OD.on() as dev:  # the fp32 oracle, evaluated where oracle/device.py says (CE_ORACLE_DEVICE=cpu: the host cores, ~20 s)
+        ref = O.dit_forward(OD.to(p_bf, dev, torch.float32), cfg, OD.to(lat, dev, torch.float32), torch.tensor([800]), OD.to(text, dev, torch.float32),
+                            OD.to(image, dev, torch.float32)).cpu()
     e = rel_l2(out, ref)
     print(f"full-width block @N=7200: rel-L2 vs fp32 {e:.3e}")
     assert out.shape == (1, 16, 2, 90, 160) and torch.isfinite(out.float()).all()

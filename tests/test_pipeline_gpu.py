@@ -4,6 +4,7 @@ steps x 2 forwards x 2 blocks in bf16, decoded video <= 8e-2; also checked: batc
 import pytest
 import torch
 
+from oracle import device as OD
 from oracle import dit_oracle as D
 from oracle import pipeline_oracle as P
 from oracle import vae_oracle as V
@@ -124,11 +125,11 @@ def test_temporal_reasoning_edit_vs_oracle():
     img_emb = torch.randn(1, 257, 64, generator=g)
     lat0 = torch.randn(1, 16, 8, H // 8, W // 8, generator=g)
     bf = torch.bfloat16
-    dp32 = {k: v.float() for k, v in dp.items()}
     kw = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=2)
-    with torch.no_grad():
-        lat_ref, vid_ref = P.edit(dp32, dcfg, vp, vcfg, image.to(bf).float(), prompt.to(bf).float(), negative.to(bf).float(),
-                                  img_emb.to(bf).float(), lat0.clone(), num_frames=F, steps=4, **kw)
+    with torch.no_grad(), OD.on() as dev:  # the fp32 oracle (29-frame VAE included) where oracle/device.py says; CE_ORACLE_DEVICE=cpu: the host cores
+        dp32, vp32 = OD.to(dp, dev, torch.float32), OD.to(vp, dev)
+        oargs = tuple(OD.to(x.to(bf).float(), dev) for x in (image, prompt, negative, img_emb))
+        lat_ref, vid_ref = (x.cpu() for x in P.edit(dp32, dcfg, vp32, vcfg, *oargs, lat0.clone().to(dev), num_frames=F, steps=4, **kw))
     assert lat_ref.shape[2] == 2 and vid_ref.shape[2] == 5
     m = ChronoEditTransformer3DModel(num_attention_heads=2, in_channels=36, ffn_dim=512, num_layers=2, text_dim=128, image_dim=64,
                                      added_kv_proj_dim=256, device="cuda:0")
@@ -144,9 +145,8 @@ def test_temporal_reasoning_edit_vs_oracle():
     assert e_lat < 6e-2 and e_vid < 8e-2
     # never truncated (k >= steps): 8 latent frames to the end, reasoning video (all but the last latent frame) + edited frame
     kw2 = dict(enable_temporal_reasoning=True, num_temporal_reasoning_steps=50)
-    with torch.no_grad():
-        lat_ref2, vid_ref2 = P.edit(dp32, dcfg, vp, vcfg, image.to(bf).float(), prompt.to(bf).float(), negative.to(bf).float(),
-                                    img_emb.to(bf).float(), lat0.clone(), num_frames=F, steps=3, **kw2)
+    with torch.no_grad(), OD.on() as dev:
+        lat_ref2, vid_ref2 = (x.cpu() for x in P.edit(dp32, dcfg, vp32, vcfg, *oargs, lat0.clone().to(dev), num_frames=F, steps=3, **kw2))
     vid2 = pipe.edit_tensors(*args, num_frames=F, num_inference_steps=3, guidance_scale=5.0, latents=lat0.cuda(), **kw2)
     print(f"reasoning (no truncation): video rel-L2 {rel_l2(vid2, vid_ref2):.3e}  shape {tuple(vid2.shape)}")
     assert vid2.shape == vid_ref2.shape and rel_l2(vid2, vid_ref2) < 8e-2

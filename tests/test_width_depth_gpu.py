@@ -15,6 +15,7 @@ import time
 import pytest
 import torch
 
+from oracle import device as OD
 from oracle import dit_oracle as O
 from oracle import pipeline_oracle as P
 from oracle import vae_oracle as V
@@ -52,18 +53,19 @@ def test_full_width_eight_blocks_at_the_configs0_shape_vs_fp32_oracle():
     del model
     torch.cuda.empty_cache()
     t0 = time.perf_counter()
-    with torch.no_grad():
-        eager = O.dit_forward(p_bf, cfg, lat, torch.tensor([637]), text, image).float()  # the reference's run mode: bf16 eager
-    t_bf = time.perf_counter() - t0
-    p32 = {k: v.float() for k, v in p_bf.items()}
-    del p_bf
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ref = O.dit_forward(p32, cfg, lat.float(), torch.tensor([637]), text.float(), image.float())
-    t_32 = time.perf_counter() - t0
+    with torch.no_grad(), OD.on() as dev:  # both oracle runs where oracle/device.py says (CE_ORACLE_DEVICE=cpu: the host cores, ~25 s)
+        eager = O.dit_forward(OD.to(p_bf, dev), cfg, lat.to(dev), torch.tensor([637]), text.to(dev), image.to(dev)).float().cpu()  # the reference's run mode: bf16 eager
+        torch.cuda.synchronize()
+        t_bf = time.perf_counter() - t0
+        p32 = OD.to(p_bf, dev, torch.float32)
+        del p_bf
+        t0 = time.perf_counter()
+        ref = O.dit_forward(p32, cfg, lat.float().to(dev), torch.tensor([637]), text.float().to(dev), image.float().to(dev)).cpu()
+        t_32 = time.perf_counter() - t0
+        del p32
     e_hip, e_eager = rel_l2(out_hip, ref), rel_l2(eager, ref)
     print(f"D = 5120 x L = 8 at N = 512: HIP vs fp32 oracle {e_hip:.3e} | bf16 eager oracle vs fp32 {e_eager:.3e} ({e_hip / e_eager:.2f} x) "
-          f"| host: fp32 {t_32:.1f} s, bf16 {t_bf:.1f} s")
+          f"| oracle on {OD.oracle_device().type}: fp32 {t_32:.1f} s, bf16 {t_bf:.1f} s")
     assert torch.isfinite(out_hip).all()
     assert e_hip < 2e-2, e_hip  # measured 7.9e-3 = 1.00 x the bf16 eager oracle's 7.9e-3
     assert e_hip <= 3 * e_eager, (e_hip, e_eager)
@@ -103,16 +105,18 @@ def test_configs0_edit_full_width_reduced_depth_vs_fp32_pipeline_oracle():
     del model, vae, pipe
     torch.cuda.empty_cache()
 
-    dp32 = {k: v.float() for k, v in dp.items()}
-    del dp
     t0 = time.perf_counter()
-    with torch.no_grad():
-        lat_ref, vid_ref = P.edit(dp32, dcfg, vp, vcfg, image.float(), text.float(), negative.float(), img_emb.float(), lat0.clone(),
-                                  num_frames=F, steps=4, guidance=5.0, shift=5.0)
+    with torch.no_grad(), OD.on() as dev:  # the fp32 pipeline oracle where oracle/device.py says (CE_ORACLE_DEVICE=cpu: the host cores, ~50 s)
+        dp32 = OD.to(dp, dev, torch.float32)
+        del dp
+        lat_ref, vid_ref = P.edit(dp32, dcfg, OD.to(vp, dev), vcfg, image.float().to(dev), text.float().to(dev), negative.float().to(dev),
+                                  img_emb.float().to(dev), lat0.clone().to(dev), num_frames=F, steps=4, guidance=5.0, shift=5.0)
+        lat_ref, vid_ref = lat_ref.cpu(), vid_ref.cpu()
+        del dp32
     t_ref = time.perf_counter() - t0
     e_lat, e_vid = rel_l2(lat, lat_ref), rel_l2(vid, vid_ref)
     print(f"configs[0] (256x256, 2 latent frames, 4 steps, guidance 5) at D = 5120 x L = 4: final latents {e_lat:.3e}, video {e_vid:.3e} "
-          f"| fp32 CPU oracle edit {t_ref:.1f} s")
+          f"| fp32 oracle edit {t_ref:.1f} s on {OD.oracle_device().type}")
     assert vid.shape == (1, 3, F, H, W) and torch.isfinite(vid).all()
     assert e_lat < 3e-2, e_lat   # measured 1.6e-2
     assert e_vid < 4e-2, e_vid   # measured 2.3e-2
