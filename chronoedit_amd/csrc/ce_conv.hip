@@ -33,6 +33,7 @@ struct ConvParams {
 };
 
 __device__ __forceinline__ int cswz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+typedef __attribute__((address_space(3))) void lds_void_c;  // LDS-DMA destinations
 
 template <int BN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
@@ -473,6 +474,201 @@ __global__ __launch_bounds__(256) void zero_border_kernel(bf16* __restrict__ y, 
 }
 }  // namespace
 
+// ---- 3 x 3 (x 3) stride-1 convolutions onto 96 output channels: the full-resolution layers of the VAE (round 6) ----------------------
+// The same linear view as above (GEMM row r <-> bordered position r + Wp + 1, tap (kt, kh, kw) = input position r + kt Hp Wp + kh Wp + kw),
+// but the A operand is NOT staged as GEMM tiles.  On the 256 x 96 macro tile of the large-tile GEMM these layers ran at 0.9 PFLOP/s because
+// of bytes, not flops: a workgroup pulled 44 KB through its LDS per 3.1 MFLOP (70 flop / byte, ~21 B / cycle / CU at that rate - the
+// L2 -> LDS ceiling), and two thirds of the A bytes were the SAME input pixels fetched once per kw: row r of the (kt, kh) run is the 3 Cin
+// channels starting at position r, row r + 1 the same run one pixel on.  Here the LDS holds the input SLAB itself:
+//   * a workgroup owns 512 consecutive positions x 96 output channels (four waves x (8 position blocks x 6 channel blocks) = 192 accumulators
+//     per lane, one wave per SIMD); the K walk is (kt, kh, 32-channel chunk c): 3 KT Cin / 32 sub-stages of A image [528 positions][32 ch] (33 KB; 514
+//     are read) + W image [3 kw][96 cout][32 ch] (18 KB), and the three kw taps read the A image at position offsets 0 / 1 / 2:
+//     51 KB per 9.4 MFLOP = 181 flop / byte;
+//   * both images arrive by LDS-DMA into a ring of three slots, two sub-stages ahead, one barrier per sub-stage (144 MFMAs per wave); rows
+//     are 64 B, and position p of row r holds 16-byte chunk p ^ (2 (r >> 2 & 1)): a ds_read_b128 of 16 consecutive rows is conflict-free in
+//     the instruction's four lane groups at ANY row offset (searched exhaustively), so the kw-shifted reads cost nothing;
+//   * weights are read straight from the GEMM layout of ce_conv3d_gemm_bf16 (column ((kt 3 + kh) S + kw Cin + ci)): same entry point, same
+//     operands, same result up to the summation order.
+// Epilogue: bias, bf16 rounding, bf16(res + .), 8-byte stores (a lane owns 4 consecutive channels of a position); border positions are
+// zeroed afterwards by zero_border_kernel, as for the GEMM route.
+namespace {
+
+constexpr int CR_TM = 510;  // positions per workgroup: with the two positions the kw taps reach past them the A image is 512 rows = 32 pieces
+constexpr int CR_A_PIECES = 32, CR_A_BYTES = CR_A_PIECES * 1024;
+constexpr int CR_B_PIECES = 18, CR_B_BYTES = CR_B_PIECES * 1024;
+constexpr int CR_SLOT = CR_A_BYTES + CR_B_BYTES;  // 51 200
+constexpr int CR_SMEM = 3 * CR_SLOT;              // 153 600 of 163 840
+
+// NC = Cin / 32; NW waves: 4 (one per SIMD, 128 positions x 96 channels = 192 accumulators each) or 8 (two per SIMD, 64 positions = 96
+// accumulators each: while one wave of a SIMD sits in the issue of an LDS-DMA piece - ~60-100 cycles each, 13 per sub-stage and wave with
+// four waves - the other one feeds the matrix pipe)
+template <int NC, int NW>
+__device__ __forceinline__ void conv3x3_c96_body(const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw,
+                                                 const float* __restrict__ bias, bf16* __restrict__ out, const bf16* __restrict__ res, int rows, int KT,
+                                                 int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame) {
+  constexpr int Cin = 32 * NC;
+  constexpr int MF = 32 / NW;                           // 16-position blocks per wave (8 or 4)
+  constexpr int NA = CR_A_PIECES / NW;                  // A pieces per wave and sub-stage (8 or 4)
+  constexpr int NB = (CR_B_PIECES + NW - 1) / NW;       // W issue slots per wave (5 or 3; the surplus ones repeat the last piece)
+  constexpr int NSTEP = 3 * MF;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  // Tile order.  Workgroup b runs on XCD b % 8 (observed dispatch order; a speed matter only) and the eight L2s share nothing, while the
+  // input rows a tile reads are read again by the tiles one image row up and down (kh) and by the same tile of the neighbouring output
+  // frames (kt): dealt round-robin, tiles 8 apart (3.2 image rows at 720p) meet in no L2.  So an XCD takes a CONTIGUOUS run of the virtual
+  // tile list, and the list walks the frames innermost: (position chunk, output frame) - the 32 CUs of an XCD then work on neighbouring
+  // rows of all output frames at once (+ 9 % on the 4 x 720 x 1280 layer).
+  const int per_xcd = gridDim.x >> 3;  // (the grid is a multiple of 8)
+  const int v = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (v >= tiles_per_frame * T_out) return;
+  const int t_out = v % T_out, chunk = v / T_out;
+  const long long r0 = (long long)t_out * FS + (long long)chunk * CR_TM;
+  const long long r_end = min((long long)rows, (long long)(t_out + 1) * FS);  // (the next frame's positions belong to its own tiles)
+  const int nss = KT * 3 * NC;
+
+  // LDS-DMA sources.  A: the input stack from this workgroup's first position on (positions past the stack read as zero: the range check
+  // covers the VGPR offset, which carries the whole address here); W: always inside the matrix.
+  const long long a_left = in_bytes - r0 * (Cin * 2);
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(in + r0 * Cin), 0, (uint32_t)(a_left > 0xffffffffll ? 0xffffffffll : a_left), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wgt, 0, (uint32_t)(96 * ldw * 2), 0x00020000);
+  const int sw = 2 * ((lane >> 4) & 1);  // rows 16 P + (lane >> 2): (row >> 2) & 1 = (lane >> 4) & 1
+  const int a_lane = (lane >> 2) * (Cin * 2) + (((lane & 3) ^ sw) << 4);
+  int b_lane[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int P = min(wave + NW * j, CR_B_PIECES - 1);
+    const int rho = 16 * P + (lane >> 2), kw = rho / 96, co = rho - 96 * kw;
+    b_lane[j] = co * (ldw * 2) + kw * (Cin * 2) + (((lane & 3) ^ sw) << 4);
+  }
+  auto dma = [&](int i, int slot) __attribute__((always_inline)) {  // sub-stage i = ((kt 3 + kh) NC + c)
+    const int c = i % NC, g = i / NC, kh = g % 3, kt = g / 3;
+    const int a_off = (kt * FS + kh * Wp) * (Cin * 2) + c * 64, b_off = (g * S + 32 * c) * 2;
+    unsigned char* const sb = smem + slot * CR_SLOT;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int P = wave + NW * j;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void_c*)(sb + P * 1024), 16, a_lane + (P * 16 * (Cin * 2) + a_off), 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int P = min(wave + NW * j, CR_B_PIECES - 1);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void_c*)(sb + CR_A_BYTES + P * 1024), 16, b_lane[j], b_off, 0, 0);
+    }
+  };
+  dma(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  dma(min(1, nss - 1), 1);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // fragment read offsets inside a slot: A (kw, mf) at a_rd[kw] + mf 1024; W (kw, n) at b_rd + (kw 96 + 16 n) 64
+  int a_rd[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) a_rd[kw] = (16 * MF * wave + fr + kw) * 64 + ((fg ^ (2 * (((fr + kw) >> 2) & 1))) << 4);
+  const int b_rd = CR_A_BYTES + fr * 64 + ((fg ^ (2 * ((fr >> 2) & 1))) << 4);
+
+  f32x4 acc[MF][6];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      acc[mf][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("" : "+a"(acc[mf][n]));
+    }
+
+  int slot = 0;
+  for (int i = 0; i < nss; ++i) {
+    // this wave's pieces of sub-stage i have landed (those of i + 1 may fly); behind the barrier everybody's have, and everybody is done with
+    // sub-stage i - 1, whose slot is refilled
+    if constexpr (NA + NB == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    static_assert(NA + NB == 13 || NA + NB == 7, "vmcnt immediates above");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    dma(min(i + 2, nss - 1), slot == 0 ? 2 : slot - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* const sb = smem + slot * CR_SLOT;
+    // NSTEP steps (kw, mf) of six MFMAs; hipcc moves no load across a volatile asm, so the reads are pipelined by hand: the A fragment runs
+    // three steps ahead, the six W fragments of the next kw are read during the current kw's steps
+    auto read_a = [&](int s_) __attribute__((always_inline)) { return *reinterpret_cast<const bf16x8*>(sb + a_rd[s_ / MF] + (s_ % MF) * 1024); };
+    auto read_w = [&](int kw, int n) __attribute__((always_inline)) { return *reinterpret_cast<const bf16x8*>(sb + b_rd + (kw * 96 + 16 * n) * 64); };
+    bf16x8 wf[2][6], af[3];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) wf[0][n] = read_w(0, n);
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) af[s_] = read_a(s_);
+#pragma unroll
+    for (int s_ = 0; s_ < NSTEP; ++s_) {
+      const int kw = s_ / MF, mf = s_ % MF;
+      const bf16x8 a = af[s_ % 3];
+#pragma unroll
+      for (int n = 0; n < 6; ++n) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[mf][n]) : "v"(wf[kw & 1][n]), "v"(a));
+      if (s_ + 3 < NSTEP) af[s_ % 3] = read_a(s_ + 3);
+      if (kw < 2) {
+        if constexpr (MF == 8) {
+          if (mf >= 2) wf[(kw + 1) & 1][mf - 2] = read_w(kw + 1, mf - 2);
+        } else {  // four steps per kw: two W fragments per step during the first three
+          if (mf < 3) {
+            wf[(kw + 1) & 1][2 * mf] = read_w(kw + 1, 2 * mf);
+            wf[(kw + 1) & 1][2 * mf + 1] = read_w(kw + 1, 2 * mf + 1);
+          }
+        }
+      }
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7" ::: "memory");  // (the repeated pieces of the last sub-stage; the last products -> v_accvgpr_read)
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int n = 0; n < 6; ++n) asm volatile("" : "+a"(acc[mf][n]));
+
+  // epilogue: lane (fr, fg) owns tile position 16 MF wave + 16 mf + fr, channels 16 n + 4 fg .. + 3
+  f32x4 bv[6];
+#pragma unroll
+  for (int n = 0; n < 6; ++n) bv[n] = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * n + 4 * fg) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const size_t shift = (size_t)Wp + 1;
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    const int pt = 16 * MF * wave + 16 * mf + fr;
+    const long long r = r0 + pt;
+    if (pt >= CR_TM || r >= r_end) continue;
+    bf16* const orow = out + ((size_t)r + shift) * ocs + 4 * fg;
+    const bf16* const rrow = res ? res + ((size_t)r + shift) * ocs + 4 * fg : nullptr;
+    u32x2 rr[6];
+    if (rrow) {  // (the six loads of a position issued together)
+#pragma unroll
+      for (int n = 0; n < 6; ++n) rr[n] = *reinterpret_cast<const u32x2*>(rrow + 16 * n);
+    }
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      const f32x4 v4 = acc[mf][n] + bv[n];
+      u32x2 pk = {pack_bf16(v4[0], v4[1]), pack_bf16(v4[2], v4[3])};
+      if (rrow)  // bf16(res + bf16(acc + bias)): the rounding of the GEMM route's residual epilogue
+        pk = u32x2{pack_bf16(bf16lo(pk[0]) + bf16lo(rr[n][0]), bf16hi(pk[0]) + bf16hi(rr[n][0])),
+                   pack_bf16(bf16lo(pk[1]) + bf16lo(rr[n][1]), bf16hi(pk[1]) + bf16hi(rr[n][1]))};
+      *reinterpret_cast<u32x2*>(orow + 16 * n) = pk;
+    }
+  }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_c96_kernel(
+    const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw, const float* __restrict__ bias, bf16* __restrict__ out,
+    const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame) {
+  conv3x3_c96_body<NC, 4>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame);
+}
+
+template <int NC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c96_w8_kernel(
+    const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw, const float* __restrict__ bias, bf16* __restrict__ out,
+    const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame) {
+  conv3x3_c96_body<NC, 8>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame);
+}
+
+}  // namespace
+
 extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const void* res, int M, int N,
                                         int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
                                         long long a_seg2_stride, int n_tile, hipStream_t stream);
@@ -480,7 +676,7 @@ extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, c
 CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
                                    int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream) {
   if (!in_stack || !weight || !out_stack) return CE_ERR_ARG;
-  if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3) || (n_tile != 0 && n_tile != 96 && n_tile != 128 && n_tile != 256)) return CE_ERR_SHAPE;
+  if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3) || (n_tile != 0 && n_tile != 1 && n_tile != 2 && n_tile != 96 && n_tile != 128 && n_tile != 256)) return CE_ERR_SHAPE;
   if ((Cin % 32) || (Cout & 7) || (out_cstride & 7) || out_cstride < Cout) return CE_ERR_SHAPE;
   const int Hp = H + 2, Wp = W + 2;
   // one (kt, kh) run of the K axis = the 3 Cin channels of three neighbouring pixels, rounded up to whole 64-wide K-tiles (Cin = 96: 288
@@ -490,6 +686,37 @@ CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw
   if (ldw < kpad || (ldw & 7)) return CE_ERR_SHAPE;
   const long long rows = (long long)T_out * Hp * Wp - 2ll * (Wp + 1);
   if (rows <= 0 || rows * Cin * 2 >= (1ll << 32) || rows * out_cstride * 2 >= (1ll << 32)) return CE_ERR_SHAPE;
+  if ((n_tile == 1 || n_tile == 2) && !(Cout == 96 && (Cin == 96 || Cin == 192))) return CE_ERR_SHAPE;
+  if ((n_tile == 0 || n_tile == 1 || n_tile == 2) && Cout == 96 && (Cin == 96 || Cin == 192) && 2ll * Hp * Wp * Cin * 2 + 3ll * Wp * Cin * 2 < (1ll << 31)) {
+    // the 96-channel full-resolution layers: the input slab itself in the LDS, 512 positions x 96 channels per workgroup (conv3x3_c96_kernel)
+    static bool done_[CE_MAX_DEVICES] = {};
+    bool& done = done_[ce_device_slot()];
+    if (!done) {
+      (void)hipFuncSetAttribute((const void*)conv3x3_c96_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
+      (void)hipFuncSetAttribute((const void*)conv3x3_c96_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
+      (void)hipFuncSetAttribute((const void*)conv3x3_c96_w8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
+      (void)hipFuncSetAttribute((const void*)conv3x3_c96_w8_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
+      done = true;
+    }
+    const long long in_bytes = (long long)(T_out + KT) * Hp * Wp * Cin * 2;  // T_out + KT - 1 frames and the slack frame
+    const int tiles_per_frame = (Hp * Wp + CR_TM - 1) / CR_TM;
+    const dim3 grid((unsigned)(((long long)tiles_per_frame * T_out + 7) / 8 * 8));
+#define CE_C96(KERNEL, THREADS)                                                                                                               \
+  hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), CR_SMEM, stream, (const bf16*)in_stack, in_bytes, (const bf16*)weight, ldw, bias, (bf16*)out_stack, \
+                     (const bf16*)res_stack, (int)rows, KT, Wp, Hp * Wp, seg, out_cstride, T_out, tiles_per_frame)
+    if (n_tile == 2) {  // (A/B partner: one wave per SIMD)
+      if (Cin == 96) CE_C96(conv3x3_c96_kernel<3>, 256);
+      else CE_C96(conv3x3_c96_kernel<6>, 256);
+    } else {
+      if (Cin == 96) CE_C96(conv3x3_c96_w8_kernel<3>, 512);
+      else CE_C96(conv3x3_c96_w8_kernel<6>, 512);
+    }
+#undef CE_C96
+    const long long nb = (long long)T_out * (2 * Wp + 2 * (Hp - 2)) * (Cout / 8);
+    hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, (bf16*)out_stack, T_out, Hp, Wp, Cout / 8,
+                       out_cstride / 8);
+    return (int)hipGetLastError();
+  }
   if (n_tile == 0) {
     // Priced per macro tile from the A/B of the 720p decode shapes (profiles/r05_conv_gemm_tile96_ab.txt): a 256 x 96 / 256 x 128 / 256 x 256 tile
     // costs 0.82 : 1 : 1.6 (the narrower ones read more LDS bytes per MFMA); a grid of a few rounds of 256 CUs pays whole rounds.  96 output
@@ -598,8 +825,6 @@ CE_API int ce_softmax_rows_f32_bf16(const float* scores, void* probs, int M, int
 //     on 256 CUs): each writes its un-normalised fp32 O and its (maximum, row sum) to the caller's workspace and
 //     attn_1head_merge_kernel combines them - O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m); one split writes bf16 O directly.
 namespace {
-
-typedef __attribute__((address_space(3))) void lds_void_c;
 
 template <int C>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_1head_kernel(

@@ -41,12 +41,16 @@ def test_conv_igemm_matches_conv3d():
 @pytest.mark.parametrize("KT,Cin,Cout,T,H,W,with_res,n_tile", [(3, 192, 192, 2, 24, 40, False, 0), (3, 384, 384, 1, 22, 30, True, 256),
                                                                (1, 384, 192, 3, 16, 24, False, 256), (3, 192, 384, 4, 45, 80, True, 128),
                                                                (3, 96, 96, 2, 40, 64, True, 0), (1, 192, 96, 3, 30, 44, False, 0),
-                                                               (3, 96, 192, 1, 20, 28, False, 128), (3, 384, 384, 2, 30, 50, True, 0)])
+                                                               (3, 96, 192, 1, 20, 28, False, 128), (3, 384, 384, 2, 30, 50, True, 0),
+                                                               (3, 96, 96, 2, 40, 64, True, 96), (3, 96, 96, 1, 3, 5, True, 1), (1, 96, 96, 2, 9, 7, False, 1),
+                                                               (3, 192, 96, 3, 33, 47, True, 1), (3, 96, 96, 4, 90, 160, False, 1), (3, 96, 96, 2, 40, 64, True, 2),
+                                                               (1, 192, 96, 3, 30, 44, False, 2)])
 def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, T, H, W, with_res, n_tile):
     """ce_conv3d_gemm_bf16 (stride-1 3x3 / 3x3x3 convs as one large-tile GEMM over a contiguous stack of bordered frames) vs fp32
     conv3d with causal front frames, and vs ce_conv_igemm_bf16 on the same operands; borders come back zero; odd and even K-tile
     counts, both macro tiles (256 x 256, 256 x 128), one to three N tiles, several M tiles, and Cin = 96 (a (kt, kh) run of 4.5 K-tiles
-    rounded up to 5 against zero weights)."""
+    rounded up to 5 against zero weights).  n_tile 1 (and 0 when Cout = 96 with 96 / 192 input channels): the slab kernel of the full-resolution
+    layers (conv3x3_c96_kernel, round 6) - frames smaller than one 512-position tile, ragged last tiles, KT 1 and 3, with and without residual."""
     from chronoedit_amd import ops
     from chronoedit_amd.vae import Frames, _ConvPack
     dev = torch.device("cuda:0")

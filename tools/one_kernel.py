@@ -2,7 +2,9 @@
    one_kernel.py gemm M N K epi variant [iters]  |  one_kernel.py attn Nq Nkv H [iters]  |  one_kernel.py attn8 N H B [iters]
    |  one_kernel.py attnvt N H B [iters]   (the V^T / LDS-DMA form of the bf16 self-attention, B samples per launch)
    |  one_kernel.py gemm8 M N K epi [iters]   (MX fp8 GEMM, ce_gemm_mxfp8: operands quantised once outside the counted launches; epi 7 = the
-      FFN-up form with the GELU + MX quantiser in the epilogue, ce_gemm_mxfp8_gelu_quant)"""
+      FFN-up form with the GELU + MX quantiser in the epilogue, ce_gemm_mxfp8_gelu_quant)
+   |  one_kernel.py conv KT Cin Cout T H W n_tile [iters]   (ce_conv3d_gemm_bf16; n_tile 1 = the slab kernel of the 96-channel layers)
+   |  one_kernel.py attn1 N C [iters]   (the VAE mid-block attention, ce_attention_1head_bf16)"""
 import os
 import sys
 
@@ -44,6 +46,25 @@ elif kind == "gemm8":
         out = torch.zeros(M, N, dtype=BF, device=dev)
         for _ in range(iters):
             ops.gemm_mxfp8(aq, sa, wq, sw, b, out=out, epilogue=epi, gate=gate if epi == 2 else None, res=out if epi == 2 else None)
+elif kind == "conv":
+    from chronoedit_amd.vae import Frames, _ConvPack
+    KT, Cin, Cout, T, H, W, n_tile = map(int, sys.argv[2:9])
+    iters = int(sys.argv[9]) if len(sys.argv) > 9 else 5
+    n_in = T + KT - 1
+    f = Frames(T, H, W, Cin, dev, front=KT - 1)
+    f.stack[:n_in, 1:-1, 1:-1] = torch.randn(n_in, H, W, Cin, generator=g).to(BF).to(dev)
+    pk = _ConvPack((torch.randn(Cout, Cin, KT, 3, 3, generator=g) / (9 * KT * Cin) ** 0.5).to(BF).to(dev), torch.randn(Cout, generator=g).to(dev))
+    out = Frames(T, H, W, Cout, dev)
+    for _ in range(iters):
+        ops.conv3d_gemm(f.stack, pk.gemm_weight(), pk.b, out.data, None, T_out=T, H=H, W=W, Cin=Cin, Cout=Cout, KT=KT, n_tile=n_tile)
+elif kind == "attn1":
+    N, C = map(int, sys.argv[2:4])
+    iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+    qkv = torch.randn(N, 3 * C, generator=g).to(BF).to(dev)
+    vt = torch.zeros((C, (N + 63) // 64 * 64), dtype=BF, device=dev)
+    vt[:, :N] = qkv[:, 2 * C:].t()
+    for _ in range(iters):
+        ops.attention_1head(qkv[:, :C], qkv[:, C:2 * C], vt, C ** -0.5)
 elif kind == "attnvt":
     N, H, B = map(int, sys.argv[2:5])
     iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
