@@ -686,8 +686,8 @@ CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw
   if (ldw < kpad || (ldw & 7)) return CE_ERR_SHAPE;
   const long long rows = (long long)T_out * Hp * Wp - 2ll * (Wp + 1);
   if (rows <= 0 || rows * Cin * 2 >= (1ll << 32) || rows * out_cstride * 2 >= (1ll << 32)) return CE_ERR_SHAPE;
-  if ((n_tile == 1 || n_tile == 2) && !(Cout == 96 && (Cin == 96 || Cin == 192))) return CE_ERR_SHAPE;
-  if ((n_tile == 0 || n_tile == 1 || n_tile == 2) && Cout == 96 && (Cin == 96 || Cin == 192) && 2ll * Hp * Wp * Cin * 2 + 3ll * Wp * Cin * 2 < (1ll << 31)) {
+  if ((n_tile == 1 || n_tile == 2) && !(Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192))) return CE_ERR_SHAPE;
+  if ((n_tile == 0 || n_tile == 1 || n_tile == 2) && Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192) && 2ll * Hp * Wp * Cin * 2 + 3ll * Wp * Cin * 2 < (1ll << 31)) {
     // the 96-channel full-resolution layers: the input slab itself in the LDS, 512 positions x 96 channels per workgroup (conv3x3_c96_kernel)
     static bool done_[CE_MAX_DEVICES] = {};
     bool& done = done_[ce_device_slot()];
@@ -696,6 +696,8 @@ CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw
       (void)hipFuncSetAttribute((const void*)conv3x3_c96_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
       (void)hipFuncSetAttribute((const void*)conv3x3_c96_w8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
       (void)hipFuncSetAttribute((const void*)conv3x3_c96_w8_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
+      (void)hipFuncSetAttribute((const void*)conv3x3_c96_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
+      (void)hipFuncSetAttribute((const void*)conv3x3_c96_w8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, CR_SMEM);
       done = true;
     }
     const long long in_bytes = (long long)(T_out + KT) * Hp * Wp * Cin * 2;  // T_out + KT - 1 frames and the slack frame
@@ -706,10 +708,12 @@ CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw
                      (const bf16*)res_stack, (int)rows, KT, Wp, Hp * Wp, seg, out_cstride, T_out, tiles_per_frame)
     if (n_tile == 2) {  // (A/B partner: one wave per SIMD)
       if (Cin == 96) CE_C96(conv3x3_c96_kernel<3>, 256);
-      else CE_C96(conv3x3_c96_kernel<6>, 256);
+      else if (Cin == 192) CE_C96(conv3x3_c96_kernel<6>, 256);
+      else CE_C96(conv3x3_c96_kernel<1>, 256);
     } else {
       if (Cin == 96) CE_C96(conv3x3_c96_w8_kernel<3>, 512);
-      else CE_C96(conv3x3_c96_w8_kernel<6>, 512);
+      else if (Cin == 192) CE_C96(conv3x3_c96_w8_kernel<6>, 512);
+      else CE_C96(conv3x3_c96_w8_kernel<1>, 512);  // (the encoder's 3 -> 96 stem on its 32-channel padded frames: 27 k-steps where 3 would do, still 2 x the implicit GEMM)
     }
 #undef CE_C96
     const long long nb = (long long)T_out * (2 * Wp + 2 * (Hp - 2)) * (Cout / 8);

@@ -195,8 +195,8 @@ class WanVAEEngine:
         """Does conv `name` run on the large-tile GEMM (ce_conv3d_gemm_bf16)?  Stride-1 3x3(x3), at least 96 channels in and out.
         (The strided resample convs share the kernel size: the stride is part of the question.)"""
         pk = self.packs[name]
-        return (self.use_gemm_conv and st == 1 and ss == 1 and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and C_in >= 96
-                and pk.Cout_p >= 96)
+        return (self.use_gemm_conv and st == 1 and ss == 1 and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and pk.Cout_p >= 96
+                and (C_in >= 96 or (C_in == 32 and pk.Cout_p == 96)))  # (32 -> 96: the encoder's stem, on the slab kernel of the 96-channel layers)
 
     def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None) -> Frames:
         pk = self.packs[name]
@@ -378,10 +378,11 @@ class WanVAEEngine:
                 x = self._up(kind, l[1], x, caches)
         return x
 
-    def _to_frames(self, x: torch.Tensor, C_pad: int) -> Frames:
-        """[C, T, H, W] (any float dtype) -> bordered channels-last bf16 frames with channels zero-padded to C_pad."""
+    def _to_frames(self, x: torch.Tensor, C_pad: int, front=None) -> Frames:
+        """[C, T, H, W] (any float dtype) -> bordered channels-last bf16 frames with channels zero-padded to C_pad (front: room for the
+        consumer's cache frames, see Frames)."""
         C, T, H, W = x.shape
-        f = Frames(T, H, W, C_pad, self.dev)
+        f = Frames(T, H, W, C_pad, self.dev, front=front)
         f.data[:, 1 : H + 1, 1 : W + 1, :C] = x.permute(1, 2, 3, 0).to(torch.bfloat16)
         return f
 
@@ -401,8 +402,9 @@ class WanVAEEngine:
         outs = []
         for ch in chunks:
             caches["i"] = 0
-            f = self._to_frames(ch, 32)
-            f = self._cached_conv("encoder.conv1", f, caches)
+            g1 = self._gemm_ok("encoder.conv1", 32)
+            f = self._to_frames(ch, 32, front=2 if g1 else None)
+            f = self._cached_conv("encoder.conv1", f, caches, gemm=g1)
             f = self._run(self.enc, f, caches)
             f = self._rms_silu(f, "encoder.head.0.gamma")
             f = self._cached_conv("encoder.head.2", f, caches)  # 2*z channels

@@ -255,7 +255,7 @@ int ce_conv3d_head_bf16(const void* const* in_frames, int n_in_frames, const voi
  *             between when Cin = 96), zero from KT*3*S up to ldw >= the K-tile count rounded up to even x 64
  *   out_stack [T_out][H+2][W+2][out_cstride] (channels [0, Cout) written, borders zeroed); res_stack: same geometry, added, or NULL
  *   n_tile    256, 128 or 96: width of the macro tile (256 x 256 with 128 x 128 wave tiles | 256 x 128 with 128 x 64 | 256 x 96 with
- *             128 x 48); 1 (round 6; Cout == 96 and Cin 96 or 192 only): not a GEMM tile - 512 positions x 96 channels per workgroup with
+ *             128 x 48); 1 (round 6; Cout == 96 and Cin 32, 96 or 192 only): not a GEMM tile - 512 positions x 96 channels per workgroup with
  *             the input slab itself in the LDS, the kw taps as position offsets (the same weight matrix, the same result up to the
  *             summation order); 0 = 1 where it applies (the full-resolution layers of the VAE), else whichever tile wastes less of Cout
  * Cin % 32 == 0, Cout % 8 == 0. */

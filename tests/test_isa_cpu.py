@@ -172,3 +172,21 @@ def test_vae_head_conv_and_mid_block_attention_kernels_keep_their_shape():
     # the accumulators and the first block's Q live in the accumulator file as the MFMAs' own operands: only the two conditional rescale
     # blocks (2 x 96 registers out and back) move them inside the loop
     assert c.get("v_accvgpr_read_b32", 0) <= 192 + 8 and c.get("v_accvgpr_write_b32", 0) <= 192 + 8, c
+
+
+def test_vae_slab_conv_kernels_keep_their_shape():
+    """ce_conv.hip, round 6: conv3x3_c96 (the 96-channel full-resolution convs with the input slab in the LDS).  Per sub-stage (one (kt, kh)
+    row of 32 input channels) a wave of the two-waves-per-SIMD form issues 72 MFMAs on 12 A + 18 W fragment reads and 7 LDS-DMA pieces behind ONE
+    barrier (one wave per SIMD: 144 / 24 + 18 / 13); accumulators tied in the AGPRs, no scratch, no ds_write, no accumulator moves in the loop."""
+    rows = _rows("ce_conv.hip")
+    for r in _pick(rows, "conv3x3_c96_w8_kernel"):
+        assert r[3] == 0 and r[2] <= 256, r   # two waves per SIMD
+    for r in _pick(rows, "conv3x3_c96_kernel"):
+        assert r[3] == 0 and r[2] <= 512, r
+    for sub, mfma, reads, pieces in (("conv3x3_c96_w8_kernelILi3E", 72, 30, 7), ("conv3x3_c96_w8_kernelILi6E", 72, 30, 7), ("conv3x3_c96_kernelILi3E", 144, 42, 13)):
+        (loop,) = isa_lint.inner_loops(os.path.join(CSRC, "ce_conv.hip"), sub)
+        c = loop[1]
+        assert c.get("v_mfma_f32_16x16x32_bf16", 0) == mfma and c.get("ds_read_b128", 0) == reads and c.get("buffer_load_dwordx4", 0) == pieces, (sub, c)
+        assert c.get("s_barrier", 0) == 1, (sub, c)
+        assert not any(op.startswith("scratch") or op.startswith("ds_write") or op.startswith("v_accvgpr") for op in c), (sub, c)
+

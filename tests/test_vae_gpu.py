@@ -44,7 +44,7 @@ def test_conv_igemm_matches_conv3d():
                                                                (3, 96, 192, 1, 20, 28, False, 128), (3, 384, 384, 2, 30, 50, True, 0),
                                                                (3, 96, 96, 2, 40, 64, True, 96), (3, 96, 96, 1, 3, 5, True, 1), (1, 96, 96, 2, 9, 7, False, 1),
                                                                (3, 192, 96, 3, 33, 47, True, 1), (3, 96, 96, 4, 90, 160, False, 1), (3, 96, 96, 2, 40, 64, True, 2),
-                                                               (1, 192, 96, 3, 30, 44, False, 2)])
+                                                               (1, 192, 96, 3, 30, 44, False, 2), (3, 32, 96, 4, 24, 40, False, 0), (3, 32, 96, 1, 20, 36, False, 2)])
 def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, T, H, W, with_res, n_tile):
     """ce_conv3d_gemm_bf16 (stride-1 3x3 / 3x3x3 convs as one large-tile GEMM over a contiguous stack of bordered frames) vs fp32
     conv3d with causal front frames, and vs ce_conv_igemm_bf16 on the same operands; borders come back zero; odd and even K-tile
