@@ -505,7 +505,8 @@ constexpr int CR_SMEM = 3 * CR_SLOT;              // 153 600 of 163 840
 template <int NC, int NW>
 __device__ __forceinline__ void conv3x3_c96_body(const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw,
                                                  const float* __restrict__ bias, bf16* __restrict__ out, const bf16* __restrict__ res, int rows, int KT,
-                                                 int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame) {
+                                                 int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame, const float* __restrict__ gamma,
+                                                 int apply_silu) {
   constexpr int Cin = 32 * NC;
   constexpr int MF = 32 / NW;                           // 16-position blocks per wave (8 or 4)
   constexpr int NA = CR_A_PIECES / NW;                  // A pieces per wave and sub-stage (8 or 4)
@@ -629,6 +630,41 @@ __device__ __forceinline__ void conv3x3_c96_body(const bf16* __restrict__ in, lo
 #pragma unroll
   for (int n = 0; n < 6; ++n) bv[n] = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * n + 4 * fg) : f32x4{0.f, 0.f, 0.f, 0.f};
   const size_t shift = (size_t)Wp + 1;
+  if (gamma != nullptr) {
+    // the next layer's RMS_norm (+ SiLU) applied to the bf16-rounded result before it is stored (ce_conv3d_gemm_rms_silu_bf16: the first conv
+    // of a ResidualBlock feeds nothing but the block's second norm, wan2pt1.py:195-200): the four lanes fg of a position hold its 96
+    // channels - sum of squares in registers, two lane exchanges; the formula of rms_silu_kernel on the values it would have read
+    f32x4 gv[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) gv[n] = *reinterpret_cast<const f32x4*>(gamma + 16 * n + 4 * fg);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int pt = 16 * MF * wave + 16 * mf + fr;
+      const long long r = r0 + pt;
+      u32x2 pk[6];
+      float ss = 0.f;
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        const f32x4 v4 = acc[mf][n] + bv[n];
+        pk[n] = u32x2{pack_bf16(v4[0], v4[1]), pack_bf16(v4[2], v4[3])};
+        ss += bf16lo(pk[n][0]) * bf16lo(pk[n][0]) + bf16hi(pk[n][0]) * bf16hi(pk[n][0]) + bf16lo(pk[n][1]) * bf16lo(pk[n][1]) +
+              bf16hi(pk[n][1]) * bf16hi(pk[n][1]);
+      }
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      if (pt >= CR_TM || r >= r_end) continue;
+      const float scale = sqrtf(96.0f) / fmaxf(sqrtf(ss), 1e-12f);
+      bf16* const orow = out + ((size_t)r + shift) * ocs + 4 * fg;
+#pragma unroll
+      for (int n = 0; n < 6; ++n) {
+        float y0 = bf16lo(pk[n][0]) * scale * gv[n][0], y1 = bf16hi(pk[n][0]) * scale * gv[n][1];
+        float y2 = bf16lo(pk[n][1]) * scale * gv[n][2], y3 = bf16hi(pk[n][1]) * scale * gv[n][3];
+        if (apply_silu) y0 = silu_fast(y0), y1 = silu_fast(y1), y2 = silu_fast(y2), y3 = silu_fast(y3);
+        *reinterpret_cast<u32x2*>(orow + 16 * n) = u32x2{pack_bf16(y0, y1), pack_bf16(y2, y3)};
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int pt = 16 * MF * wave + 16 * mf + fr;
@@ -656,15 +692,17 @@ __device__ __forceinline__ void conv3x3_c96_body(const bf16* __restrict__ in, lo
 template <int NC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_c96_kernel(
     const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw, const float* __restrict__ bias, bf16* __restrict__ out,
-    const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame) {
-  conv3x3_c96_body<NC, 4>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame);
+    const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame, const float* __restrict__ gamma,
+    int apply_silu) {
+  conv3x3_c96_body<NC, 4>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame, gamma, apply_silu);
 }
 
 template <int NC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c96_w8_kernel(
     const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw, const float* __restrict__ bias, bf16* __restrict__ out,
-    const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame) {
-  conv3x3_c96_body<NC, 8>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame);
+    const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame, const float* __restrict__ gamma,
+    int apply_silu) {
+  conv3x3_c96_body<NC, 8>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame, gamma, apply_silu);
 }
 
 }  // namespace
@@ -673,8 +711,9 @@ extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, c
                                         int K, int lda, int ldw, int ldc, int ldres, int a_seg_k, long long a_seg_stride, int a_seg2_k,
                                         long long a_seg2_stride, int n_tile, hipStream_t stream);
 
-CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
-                                   int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream) {
+static int conv3d_gemm_launch(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
+                              int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, const float* gamma, int apply_silu,
+                              hipStream_t stream) {
   if (!in_stack || !weight || !out_stack) return CE_ERR_ARG;
   if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3) || (n_tile != 0 && n_tile != 1 && n_tile != 2 && n_tile != 96 && n_tile != 128 && n_tile != 256)) return CE_ERR_SHAPE;
   if ((Cin % 32) || (Cout & 7) || (out_cstride & 7) || out_cstride < Cout) return CE_ERR_SHAPE;
@@ -687,6 +726,8 @@ CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw
   const long long rows = (long long)T_out * Hp * Wp - 2ll * (Wp + 1);
   if (rows <= 0 || rows * Cin * 2 >= (1ll << 32) || rows * out_cstride * 2 >= (1ll << 32)) return CE_ERR_SHAPE;
   if ((n_tile == 1 || n_tile == 2) && !(Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192))) return CE_ERR_SHAPE;
+  const bool slab_shape = Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192) && 2ll * Hp * Wp * Cin * 2 + 3ll * Wp * Cin * 2 < (1ll << 31);
+  if (gamma != nullptr && (!slab_shape || res_stack != nullptr || (n_tile != 0 && n_tile != 1 && n_tile != 2))) return CE_ERR_SHAPE;  // (the fused norm exists on the slab kernel only)
   if ((n_tile == 0 || n_tile == 1 || n_tile == 2) && Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192) && 2ll * Hp * Wp * Cin * 2 + 3ll * Wp * Cin * 2 < (1ll << 31)) {
     // the 96-channel full-resolution layers: the input slab itself in the LDS, 512 positions x 96 channels per workgroup (conv3x3_c96_kernel)
     static bool done_[CE_MAX_DEVICES] = {};
@@ -705,7 +746,7 @@ CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw
     const dim3 grid((unsigned)(((long long)tiles_per_frame * T_out + 7) / 8 * 8));
 #define CE_C96(KERNEL, THREADS)                                                                                                               \
   hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), CR_SMEM, stream, (const bf16*)in_stack, in_bytes, (const bf16*)weight, ldw, bias, (bf16*)out_stack, \
-                     (const bf16*)res_stack, (int)rows, KT, Wp, Hp * Wp, seg, out_cstride, T_out, tiles_per_frame)
+                     (const bf16*)res_stack, (int)rows, KT, Wp, Hp * Wp, seg, out_cstride, T_out, tiles_per_frame, gamma, apply_silu)
     if (n_tile == 2) {  // (A/B partner: one wave per SIMD)
       if (Cin == 96) CE_C96(conv3x3_c96_kernel<3>, 256);
       else if (Cin == 192) CE_C96(conv3x3_c96_kernel<6>, 256);
@@ -751,6 +792,20 @@ CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw
   hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (bf16*)out_stack, T_out, Hp, Wp, Cout / 8,
                      out_cstride / 8);
   return (int)hipGetLastError();
+}
+
+CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
+                                   int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream) {
+  return conv3d_gemm_launch(in_stack, weight, ldw, bias, out_stack, res_stack, T_out, H, W, Cin, Cout, KT, out_cstride, n_tile, nullptr, 0, stream);
+}
+
+// out = [silu](RMS_norm(bf16(conv(in) + bias)) * gamma): the convolution of ce_conv3d_gemm_bf16 with the NEXT layer's RMS_norm (+ SiLU) in its
+// epilogue (ce_rms_silu_bf16's formula on the bf16-rounded conv result) - Cout == 96 and Cin 32 / 96 / 192 only (the slab kernel, whose lanes
+// hold all 96 channels of a position).  Replaces CausalConv3d -> RMS_norm -> SiLU inside a ResidualBlock (wan2pt1.py:195-200).
+CE_API int ce_conv3d_gemm_rms_silu_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, int T_out, int H,
+                                            int W, int Cin, int Cout, int KT, int out_cstride, const float* gamma, int apply_silu, hipStream_t stream) {
+  if (!gamma) return CE_ERR_ARG;
+  return conv3d_gemm_launch(in_stack, weight, ldw, bias, out_stack, nullptr, T_out, H, W, Cin, Cout, KT, out_cstride, 0, gamma, apply_silu, stream);
 }
 
 CE_API int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,

@@ -596,6 +596,23 @@ def conv3d_gemm(in_stack: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     _prof_end(st_ev, f"conv_{KT}x3x3_{Cin}->{Cout}_{T_out}x{H}x{W}", 2.0 * T_out * H * W * Cout * Cin * KT * 9)
 
 
+def conv3d_gemm_rms_silu(in_stack: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out_stack: torch.Tensor, gamma: torch.Tensor, *,
+                         T_out: int, H: int, W: int, Cin: int, Cout: int, KT: int, silu: bool = True):
+    """conv3d_gemm with the next layer's RMS_norm (+ SiLU) in its epilogue: out = silu(rms_norm(bf16(conv + bias)) * gamma).  96 output
+    channels only (ce_conv3d_gemm_rms_silu_bf16)."""
+    _dev(in_stack, torch.bfloat16, "in_stack")
+    _dev(out_stack, torch.bfloat16, "out_stack")
+    _dev(weight, torch.bfloat16, "weight")
+    _dev(gamma, torch.float32, "gamma")
+    assert in_stack.is_contiguous() and out_stack.is_contiguous() and weight.is_contiguous() and weight.dim() == 2 and gamma.numel() == Cout
+    assert in_stack.shape[0] >= T_out + KT and tuple(in_stack.shape[1:]) == (H + 2, W + 2, Cin), in_stack.shape
+    assert out_stack.shape[0] >= T_out and tuple(out_stack.shape[1:3]) == (H + 2, W + 2), out_stack.shape
+    st_ev = _prof_begin()
+    _check(lib().ce_conv3d_gemm_rms_silu_bf16(_ptr(in_stack), _ptr(weight), weight.shape[1], _ptr(bias), _ptr(out_stack), T_out, H, W, Cin, Cout, KT,
+                                              out_stack.shape[3], _ptr(gamma), int(bool(silu)), _stream()), "ce_conv3d_gemm_rms_silu_bf16")
+    _prof_end(st_ev, f"conv_{KT}x3x3_{Cin}->{Cout}_{T_out}x{H}x{W}+norm", 2.0 * T_out * H * W * Cout * Cin * KT * 9)
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):

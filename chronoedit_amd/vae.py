@@ -117,6 +117,7 @@ class WanVAEEngine:
         self._attn_ws: Dict[tuple, tuple] = {}
         self.use_gemm_conv = True  # wide stride-1 3x3(x3) convs on the large-tile GEMM (False: every conv on the implicit-GEMM kernel)
         self.use_head_conv = True  # the decoder's 96 -> 3 head conv on its own bandwidth kernel (False: implicit GEMM with N = 8)
+        self.fuse_norm = True      # 96-channel ResidualBlocks: the second RMS_norm + SiLU in the first conv's epilogue (False: its own pass)
         self._layers()
 
     # -- architecture (wan2pt1.py:283-305, 384-415) ------------------------------------------------
@@ -198,7 +199,9 @@ class WanVAEEngine:
         return (self.use_gemm_conv and st == 1 and ss == 1 and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and pk.Cout_p >= 96
                 and (C_in >= 96 or (C_in == 32 and pk.Cout_p == 96)))  # (32 -> 96: the encoder's stem, on the slab kernel of the 96-channel layers)
 
-    def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None) -> Frames:
+    def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None, norm=None) -> Frames:
+        """norm = (gamma name, front): the NEXT layer's RMS_norm + SiLU in this conv's epilogue (ce_conv3d_gemm_rms_silu_bf16; the output is
+        what _rms_silu(conv output, gamma, front=front) would have produced, and the un-normalised activation is never written)."""
         pk = self.packs[name]
         KT = pk.k[0]
         need = KT - 1
@@ -212,12 +215,23 @@ class WanVAEEngine:
                 x.stack[j].zero_()
             else:
                 x.stack[j].copy_(f)
+        if norm is not None:
+            assert res is None and out_C is None and self._norm_fusable(name)
+            out = Frames(x.T, x.H, x.W, pk.Cout_p, self.dev, front=norm[1], zero=False)
+            ops.conv3d_gemm_rms_silu(x.stack, pk.gemm_weight(), pk.b, out.data, self.gammas[norm[0]], T_out=x.T, H=x.H, W=x.W, Cin=pk.Cin_p,
+                                     Cout=pk.Cout_p, KT=KT)
+            return out
         out = Frames(x.T, x.H, x.W, out_C or pk.Cout_p, self.dev, zero=(out_C or pk.Cout_p) != pk.Cout_p)  # (the kernel zeroes the border)
         ops.conv3d_gemm(x.stack, pk.gemm_weight(), pk.b, out.data, res.data if res is not None else None, T_out=x.T, H=x.H, W=x.W,
                         Cin=pk.Cin_p, Cout=pk.Cout_p, KT=KT)
         return out
 
-    def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None, gemm: Optional[bool] = None) -> Frames:
+    def _norm_fusable(self, name) -> bool:
+        """Can conv `name` take the next RMS_norm + SiLU into its epilogue?  The slab kernel of the 96-channel layers only."""
+        pk = self.packs[name]
+        return self.fuse_norm and pk.Cout_p == 96 and pk.Cin_p in (32, 96, 192) and pk.k in ((3, 3, 3), (1, 3, 3))
+
+    def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None, gemm: Optional[bool] = None, norm=None) -> Frames:
         """3x3x3 causal conv with the chunk-to-chunk frame cache (wan2pt1.py:200-210): two frames in front of the chunk.
         gemm: the routing decision when the caller already took it (the producer sized x's stack by it); None: decide here."""
         i = caches["i"]
@@ -239,8 +253,9 @@ class WanVAEEngine:
         if gemm is None:
             gemm = self._gemm_ok(name, x.C)
         if gemm:
-            out = self._conv_gemm(name, x, front, res, out_C)
+            out = self._conv_gemm(name, x, front, res, out_C, norm=norm)
         else:
+            assert norm is None
             out = self._conv(name, front + x.frame_list(), x.T, x.H, x.W, x.W, res=res, out_C=out_C)
         caches["slots"][i] = keep
         return out
@@ -261,9 +276,13 @@ class WanVAEEngine:
             h = self._conv(name + ".shortcut", x.frame_list(), x.T, x.H, x.W, x.W, in_off=1)
         g2 = self._gemm_ok(name + ".residual.2", x.C)  # one routing decision per layer: it sizes the producer's stack AND picks the conv
         y = self._rms_silu(x, name + ".residual.0.gamma", front=2 if g2 else None)
-        y = self._cached_conv(name + ".residual.2", y, caches, gemm=g2)
-        g6 = self._gemm_ok(name + ".residual.6", y.C)
-        y = self._rms_silu(y, name + ".residual.3.gamma", front=2 if g6 else None)
+        g6 = self._gemm_ok(name + ".residual.6", self.packs[name + ".residual.2"].Cout_p)
+        if g2 and self._norm_fusable(name + ".residual.2"):
+            # the first conv's output feeds nothing but the second norm (wan2pt1.py:195-200): norm + SiLU ride in the conv's epilogue
+            y = self._cached_conv(name + ".residual.2", y, caches, gemm=True, norm=(name + ".residual.3.gamma", 2 if g6 else None))
+        else:
+            y = self._cached_conv(name + ".residual.2", y, caches, gemm=g2)
+            y = self._rms_silu(y, name + ".residual.3.gamma", front=2 if g6 else None)
         return self._cached_conv(name + ".residual.6", y, caches, res=h, gemm=g6)
 
     def _attn(self, name, x: Frames) -> Frames:

@@ -85,6 +85,47 @@ def test_conv3d_gemm_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cin, Cout, 
     assert rel_l2(out.data, old.data) < 3e-3, rel_l2(out.data, old.data)  # same products, another summation order, one bf16 rounding
 
 
+@pytest.mark.parametrize("KT,Cin,T,H,W,silu", [(3, 96, 2, 40, 64, True), (3, 96, 1, 5, 7, True), (1, 192, 3, 30, 44, False), (3, 32, 4, 24, 40, True)])
+def test_conv3d_gemm_with_the_next_norm_in_its_epilogue(KT, Cin, T, H, W, silu):
+    """ce_conv3d_gemm_rms_silu_bf16 (96 output channels: conv -> RMS_norm -> SiLU as ONE launch, the activation in between never written) vs
+    the two launches it replaces on the same operands (ce_conv3d_gemm_bf16, then ce_rms_silu_bf16 on its bf16 output: same formula on the same
+    rounded values, another order of the 96-term sum of squares) and vs fp32 conv3d + the norm's definition; borders come back zero."""
+    from chronoedit_amd import ops
+    from chronoedit_amd.vae import Frames, _ConvPack
+    dev = torch.device("cuda:0")
+    Cout = 96
+    g = torch.Generator().manual_seed(KT * 100 + Cin + T)
+    n_in = T + KT - 1
+    x = torch.randn(Cin, n_in, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn((Cout, Cin, KT, 3, 3), generator=g) / (9 * KT * Cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(Cout, generator=g)
+    gamma = (1.0 + 0.2 * torch.randn(Cout, generator=g)).float()
+    conv = torch.nn.functional.conv3d(torch.nn.functional.pad(x.float()[None], (1, 1, 1, 1, 0, 0)), w.float(), b)[0]  # [Cout, T, H, W]
+    ref = torch.nn.functional.normalize(conv, dim=0) * Cout ** 0.5 * gamma[:, None, None, None]
+    if silu:
+        ref = torch.nn.functional.silu(ref)
+    f = Frames(T, H, W, Cin, dev, front=KT - 1)
+    f.stack[:n_in, 1:-1, 1:-1] = x.permute(1, 2, 3, 0).to(dev)
+    pk = _ConvPack(w.to(dev), b.to(dev))
+    fused = Frames(T, H, W, Cout, dev, front=2)
+    fused.stack.fill_(7.0)
+    ops.conv3d_gemm_rms_silu(f.stack, pk.gemm_weight(), pk.b, fused.data, gamma.to(dev), T_out=T, H=H, W=W, Cin=Cin, Cout=Cout, KT=KT, silu=silu)
+    mid = Frames(T, H, W, Cout, dev)
+    ops.conv3d_gemm(f.stack, pk.gemm_weight(), pk.b, mid.data, None, T_out=T, H=H, W=W, Cin=Cin, Cout=Cout, KT=KT)
+    two = Frames(T, H, W, Cout, dev)
+    ops.rms_silu(mid.data, gamma.to(dev), two.data, T, Cout, H, W, 1, 1, silu)
+    got = fused.data[:, 1:-1, 1:-1].permute(3, 0, 1, 2)
+    assert rel_l2(got, ref) < 8e-3, rel_l2(got, ref)
+    assert rel_l2(got, two.data[:, 1:-1, 1:-1].permute(3, 0, 1, 2)) < 2e-3
+    for border in (fused.data[:, 0], fused.data[:, -1], fused.data[:, :, 0], fused.data[:, :, -1]):
+        assert float(border.abs().max()) == 0.0
+    assert float((fused.stack[:2] - 7.0).abs().max()) == 0.0  # the front frames are the consumer's
+    with pytest.raises(ops.HipKernelError):  # only the 96-channel layers have it
+        bad = _ConvPack(torch.randn(192, Cin, KT, 3, 3).to(torch.bfloat16).to(dev), torch.zeros(192).to(dev))
+        ops.conv3d_gemm_rms_silu(f.stack, bad.gemm_weight(), bad.b, Frames(T, H, W, 192, dev).data, torch.ones(192, device=dev), T_out=T, H=H, W=W,
+                                 Cin=Cin, Cout=192, KT=KT)
+
+
 @pytest.mark.parametrize("KT,Cout,T,H,W", [(3, 3, 4, 40, 128), (3, 3, 1, 13, 70), (1, 3, 2, 8, 64), (3, 4, 2, 17, 129), (3, 1, 1, 3, 5)])
 def test_head_conv_kernel_matches_conv3d_and_the_implicit_gemm_kernel(KT, Cout, T, H, W):
     """ce_conv3d_head_bf16 (the decoder's 96 -> 3 head conv with the three kernel rows in the matrix instruction's output rows) vs fp32

@@ -14,6 +14,8 @@ H, W, T = (int(a) for a in (sys.argv[1:4] if len(sys.argv) > 3 else (720, 1280, 
 vae = AutoencoderKLWan.random_init(torch.device("cuda:0"), seed=4321)
 if os.environ.get("CE_VAE_GEMM_CONV") == "0":  # A/B: every conv on the implicit-GEMM kernel (the wide 3x3(x3) ones not on the large-tile GEMM)
     vae.engine().use_gemm_conv = False
+if os.environ.get("CE_VAE_FUSE_NORM") == "0":  # A/B: the second norm of the 96-channel ResidualBlocks as its own pass
+    vae.engine().fuse_norm = False
 if os.environ.get("CE_VAE_HEAD_CONV") == "0":  # A/B: the decoder's 96 -> 3 head conv on the implicit-GEMM kernel
     vae.engine().use_head_conv = False
 x = (torch.rand(1, 3, T, H, W, device="cuda") * 2 - 1).to(torch.bfloat16)
@@ -44,7 +46,7 @@ if os.environ.get("CE_VAE_GRAPH", "1") != "0":  # the same calls as replays of c
         out = fn()
         torch.cuda.synchronize()
         res[name + "_graph_s"] = time.perf_counter() - t0
-        print(name, "as a hipGraph replay", f"{res[name + '_graph_s']:.3f} s", flush=True)
+        print(name, "as a hipGraph replay", f"{res[name + '_graph_s'] * 1e3:.2f} ms", flush=True)
     vae.use_graph = False
 with ops.profile() as prof:
     dec()
