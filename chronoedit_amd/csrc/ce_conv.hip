@@ -506,7 +506,7 @@ template <int NC, int NW>
 __device__ __forceinline__ void conv3x3_c96_body(const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw,
                                                  const float* __restrict__ bias, bf16* __restrict__ out, const bf16* __restrict__ res, int rows, int KT,
                                                  int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame, const float* __restrict__ gamma,
-                                                 int apply_silu) {
+                                                 int apply_silu, bf16* __restrict__ out2) {
   constexpr int Cin = 32 * NC;
   constexpr int MF = 32 / NW;                           // 16-position blocks per wave (8 or 4)
   constexpr int NA = CR_A_PIECES / NW;                  // A pieces per wave and sub-stage (8 or 4)
@@ -630,61 +630,59 @@ __device__ __forceinline__ void conv3x3_c96_body(const bf16* __restrict__ in, lo
 #pragma unroll
   for (int n = 0; n < 6; ++n) bv[n] = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * n + 4 * fg) : f32x4{0.f, 0.f, 0.f, 0.f};
   const size_t shift = (size_t)Wp + 1;
+  // gamma != nullptr: the NEXT layer's RMS_norm (+ SiLU) applied to the bf16-rounded result (ce_conv3d_gemm_rms_silu_bf16).  The four lanes fg
+  // of a position hold its 96 channels - sum of squares in registers, two lane exchanges; the formula of rms_silu_kernel on the values it
+  // would have read.  out2 == nullptr: only the normalised activation is stored (the first conv of a ResidualBlock feeds nothing but the
+  // block's second norm, wan2pt1.py:195-200); out2 != nullptr: the result itself to `out` (the next block's shortcut) AND its normalised
+  // form to `out2` (the next block's first norm) - the pass that would have re-read it is gone.
+  f32x4 gv[6];
   if (gamma != nullptr) {
-    // the next layer's RMS_norm (+ SiLU) applied to the bf16-rounded result before it is stored (ce_conv3d_gemm_rms_silu_bf16: the first conv
-    // of a ResidualBlock feeds nothing but the block's second norm, wan2pt1.py:195-200): the four lanes fg of a position hold its 96
-    // channels - sum of squares in registers, two lane exchanges; the formula of rms_silu_kernel on the values it would have read
-    f32x4 gv[6];
 #pragma unroll
     for (int n = 0; n < 6; ++n) gv[n] = *reinterpret_cast<const f32x4*>(gamma + 16 * n + 4 * fg);
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-      const int pt = 16 * MF * wave + 16 * mf + fr;
-      const long long r = r0 + pt;
-      u32x2 pk[6];
-      float ss = 0.f;
-#pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        const f32x4 v4 = acc[mf][n] + bv[n];
-        pk[n] = u32x2{pack_bf16(v4[0], v4[1]), pack_bf16(v4[2], v4[3])};
-        ss += bf16lo(pk[n][0]) * bf16lo(pk[n][0]) + bf16hi(pk[n][0]) * bf16hi(pk[n][0]) + bf16lo(pk[n][1]) * bf16lo(pk[n][1]) +
-              bf16hi(pk[n][1]) * bf16hi(pk[n][1]);
-      }
-      ss += __shfl_xor(ss, 16, 64);
-      ss += __shfl_xor(ss, 32, 64);
-      if (pt >= CR_TM || r >= r_end) continue;
-      const float scale = sqrtf(96.0f) / fmaxf(sqrtf(ss), 1e-12f);
-      bf16* const orow = out + ((size_t)r + shift) * ocs + 4 * fg;
-#pragma unroll
-      for (int n = 0; n < 6; ++n) {
-        float y0 = bf16lo(pk[n][0]) * scale * gv[n][0], y1 = bf16hi(pk[n][0]) * scale * gv[n][1];
-        float y2 = bf16lo(pk[n][1]) * scale * gv[n][2], y3 = bf16hi(pk[n][1]) * scale * gv[n][3];
-        if (apply_silu) y0 = silu_fast(y0), y1 = silu_fast(y1), y2 = silu_fast(y2), y3 = silu_fast(y3);
-        *reinterpret_cast<u32x2*>(orow + 16 * n) = u32x2{pack_bf16(y0, y1), pack_bf16(y2, y3)};
-      }
-    }
-    return;
   }
 #pragma unroll
   for (int mf = 0; mf < MF; ++mf) {
     const int pt = 16 * MF * wave + 16 * mf + fr;
     const long long r = r0 + pt;
-    if (pt >= CR_TM || r >= r_end) continue;
-    bf16* const orow = out + ((size_t)r + shift) * ocs + 4 * fg;
-    const bf16* const rrow = res ? res + ((size_t)r + shift) * ocs + 4 * fg : nullptr;
+    const bool valid = pt < CR_TM && r < r_end;
+    const size_t off = ((size_t)(valid ? r : r0) + shift) * ocs + 4 * fg;  // (invalid lanes: a clamped, in-range address; never stored)
     u32x2 rr[6];
-    if (rrow) {  // (the six loads of a position issued together)
+    if (res) {  // (the six loads of a position issued together)
 #pragma unroll
-      for (int n = 0; n < 6; ++n) rr[n] = *reinterpret_cast<const u32x2*>(rrow + 16 * n);
+      for (int n = 0; n < 6; ++n) rr[n] = *reinterpret_cast<const u32x2*>(res + off + 16 * n);
     }
+    u32x2 pk[6];
+    float ss = 0.f;
 #pragma unroll
     for (int n = 0; n < 6; ++n) {
       const f32x4 v4 = acc[mf][n] + bv[n];
-      u32x2 pk = {pack_bf16(v4[0], v4[1]), pack_bf16(v4[2], v4[3])};
-      if (rrow)  // bf16(res + bf16(acc + bias)): the rounding of the GEMM route's residual epilogue
-        pk = u32x2{pack_bf16(bf16lo(pk[0]) + bf16lo(rr[n][0]), bf16hi(pk[0]) + bf16hi(rr[n][0])),
-                   pack_bf16(bf16lo(pk[1]) + bf16lo(rr[n][1]), bf16hi(pk[1]) + bf16hi(rr[n][1]))};
-      *reinterpret_cast<u32x2*>(orow + 16 * n) = pk;
+      pk[n] = u32x2{pack_bf16(v4[0], v4[1]), pack_bf16(v4[2], v4[3])};
+      if (res)  // bf16(res + bf16(acc + bias)): the rounding of the GEMM route's residual epilogue
+        pk[n] = u32x2{pack_bf16(bf16lo(pk[n][0]) + bf16lo(rr[n][0]), bf16hi(pk[n][0]) + bf16hi(rr[n][0])),
+                      pack_bf16(bf16lo(pk[n][1]) + bf16lo(rr[n][1]), bf16hi(pk[n][1]) + bf16hi(rr[n][1]))};
+      ss += bf16lo(pk[n][0]) * bf16lo(pk[n][0]) + bf16hi(pk[n][0]) * bf16hi(pk[n][0]) + bf16lo(pk[n][1]) * bf16lo(pk[n][1]) +
+            bf16hi(pk[n][1]) * bf16hi(pk[n][1]);
+    }
+    if (gamma == nullptr || out2 != nullptr) {
+      if (valid) {
+#pragma unroll
+        for (int n = 0; n < 6; ++n) *reinterpret_cast<u32x2*>(out + off + 16 * n) = pk[n];
+      }
+    }
+    if (gamma != nullptr) {  // (wave-uniform)
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      const float scale = sqrtf(96.0f) / fmaxf(sqrtf(ss), 1e-12f);
+      bf16* const nrow = (out2 != nullptr ? out2 : out) + off;
+      if (valid) {
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+          float y0 = bf16lo(pk[n][0]) * scale * gv[n][0], y1 = bf16hi(pk[n][0]) * scale * gv[n][1];
+          float y2 = bf16lo(pk[n][1]) * scale * gv[n][2], y3 = bf16hi(pk[n][1]) * scale * gv[n][3];
+          if (apply_silu) y0 = silu_fast(y0), y1 = silu_fast(y1), y2 = silu_fast(y2), y3 = silu_fast(y3);
+          *reinterpret_cast<u32x2*>(nrow + 16 * n) = u32x2{pack_bf16(y0, y1), pack_bf16(y2, y3)};
+        }
+      }
     }
   }
 }
@@ -693,16 +691,16 @@ template <int NC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_c96_kernel(
     const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw, const float* __restrict__ bias, bf16* __restrict__ out,
     const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame, const float* __restrict__ gamma,
-    int apply_silu) {
-  conv3x3_c96_body<NC, 4>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame, gamma, apply_silu);
+    int apply_silu, bf16* __restrict__ out2) {
+  conv3x3_c96_body<NC, 4>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame, gamma, apply_silu, out2);
 }
 
 template <int NC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c96_w8_kernel(
     const bf16* __restrict__ in, long long in_bytes, const bf16* __restrict__ wgt, int ldw, const float* __restrict__ bias, bf16* __restrict__ out,
     const bf16* __restrict__ res, int rows, int KT, int Wp, int FS, int S, int ocs, int T_out, int tiles_per_frame, const float* __restrict__ gamma,
-    int apply_silu) {
-  conv3x3_c96_body<NC, 8>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame, gamma, apply_silu);
+    int apply_silu, bf16* __restrict__ out2) {
+  conv3x3_c96_body<NC, 8>(in, in_bytes, wgt, ldw, bias, out, res, rows, KT, Wp, FS, S, ocs, T_out, tiles_per_frame, gamma, apply_silu, out2);
 }
 
 }  // namespace
@@ -713,7 +711,7 @@ extern "C" int ce_gemm256w4_seg2_launch(const void* A, const void* W, void* C, c
 
 static int conv3d_gemm_launch(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
                               int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, const float* gamma, int apply_silu,
-                              hipStream_t stream) {
+                              void* normed_stack, hipStream_t stream) {
   if (!in_stack || !weight || !out_stack) return CE_ERR_ARG;
   if (T_out <= 0 || H <= 0 || W <= 0 || (KT != 1 && KT != 3) || (n_tile != 0 && n_tile != 1 && n_tile != 2 && n_tile != 96 && n_tile != 128 && n_tile != 256)) return CE_ERR_SHAPE;
   if ((Cin % 32) || (Cout & 7) || (out_cstride & 7) || out_cstride < Cout) return CE_ERR_SHAPE;
@@ -727,7 +725,7 @@ static int conv3d_gemm_launch(const void* in_stack, const void* weight, int ldw,
   if (rows <= 0 || rows * Cin * 2 >= (1ll << 32) || rows * out_cstride * 2 >= (1ll << 32)) return CE_ERR_SHAPE;
   if ((n_tile == 1 || n_tile == 2) && !(Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192))) return CE_ERR_SHAPE;
   const bool slab_shape = Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192) && 2ll * Hp * Wp * Cin * 2 + 3ll * Wp * Cin * 2 < (1ll << 31);
-  if (gamma != nullptr && (!slab_shape || res_stack != nullptr || (n_tile != 0 && n_tile != 1 && n_tile != 2))) return CE_ERR_SHAPE;  // (the fused norm exists on the slab kernel only)
+  if (gamma != nullptr && (!slab_shape || (n_tile != 0 && n_tile != 1 && n_tile != 2))) return CE_ERR_SHAPE;  // (the fused norm exists on the slab kernel only)
   if ((n_tile == 0 || n_tile == 1 || n_tile == 2) && Cout == 96 && (Cin == 32 || Cin == 96 || Cin == 192) && 2ll * Hp * Wp * Cin * 2 + 3ll * Wp * Cin * 2 < (1ll << 31)) {
     // the 96-channel full-resolution layers: the input slab itself in the LDS, 512 positions x 96 channels per workgroup (conv3x3_c96_kernel)
     static bool done_[CE_MAX_DEVICES] = {};
@@ -746,7 +744,7 @@ static int conv3d_gemm_launch(const void* in_stack, const void* weight, int ldw,
     const dim3 grid((unsigned)(((long long)tiles_per_frame * T_out + 7) / 8 * 8));
 #define CE_C96(KERNEL, THREADS)                                                                                                               \
   hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), CR_SMEM, stream, (const bf16*)in_stack, in_bytes, (const bf16*)weight, ldw, bias, (bf16*)out_stack, \
-                     (const bf16*)res_stack, (int)rows, KT, Wp, Hp * Wp, seg, out_cstride, T_out, tiles_per_frame, gamma, apply_silu)
+                     (const bf16*)res_stack, (int)rows, KT, Wp, Hp * Wp, seg, out_cstride, T_out, tiles_per_frame, gamma, apply_silu, (bf16*)normed_stack)
     if (n_tile == 2) {  // (A/B partner: one wave per SIMD)
       if (Cin == 96) CE_C96(conv3x3_c96_kernel<3>, 256);
       else if (Cin == 192) CE_C96(conv3x3_c96_kernel<6>, 256);
@@ -760,6 +758,9 @@ static int conv3d_gemm_launch(const void* in_stack, const void* weight, int ldw,
     const long long nb = (long long)T_out * (2 * Wp + 2 * (Hp - 2)) * (Cout / 8);
     hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, (bf16*)out_stack, T_out, Hp, Wp, Cout / 8,
                        out_cstride / 8);
+    if (normed_stack != nullptr)
+      hipLaunchKernelGGL(zero_border_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream, (bf16*)normed_stack, T_out, Hp, Wp, Cout / 8,
+                         out_cstride / 8);
     return (int)hipGetLastError();
   }
   if (n_tile == 0) {
@@ -796,16 +797,24 @@ static int conv3d_gemm_launch(const void* in_stack, const void* weight, int ldw,
 
 CE_API int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
                                    int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream) {
-  return conv3d_gemm_launch(in_stack, weight, ldw, bias, out_stack, res_stack, T_out, H, W, Cin, Cout, KT, out_cstride, n_tile, nullptr, 0, stream);
+  return conv3d_gemm_launch(in_stack, weight, ldw, bias, out_stack, res_stack, T_out, H, W, Cin, Cout, KT, out_cstride, n_tile, nullptr, 0, nullptr, stream);
 }
 
-// out = [silu](RMS_norm(bf16(conv(in) + bias)) * gamma): the convolution of ce_conv3d_gemm_bf16 with the NEXT layer's RMS_norm (+ SiLU) in its
-// epilogue (ce_rms_silu_bf16's formula on the bf16-rounded conv result) - Cout == 96 and Cin 32 / 96 / 192 only (the slab kernel, whose lanes
-// hold all 96 channels of a position).  Replaces CausalConv3d -> RMS_norm -> SiLU inside a ResidualBlock (wan2pt1.py:195-200).
-CE_API int ce_conv3d_gemm_rms_silu_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, int T_out, int H,
-                                            int W, int Cin, int Cout, int KT, int out_cstride, const float* gamma, int apply_silu, hipStream_t stream) {
-  if (!gamma) return CE_ERR_ARG;
-  return conv3d_gemm_launch(in_stack, weight, ldw, bias, out_stack, nullptr, T_out, H, W, Cin, Cout, KT, out_cstride, 0, gamma, apply_silu, stream);
+// The convolution of ce_conv3d_gemm_bf16 with the NEXT layer's RMS_norm (+ SiLU) in its epilogue (ce_rms_silu_bf16's formula on the bf16-rounded
+// result y = bf16(conv(in) + bias) [then bf16(res + y)]) - Cout == 96 and Cin 32 / 96 / 192 only (the slab kernel, whose lanes hold all 96
+// channels of a position):
+//   out_stack == NULL: normed_stack = [silu](RMS_norm(y) gamma) and y itself is never written (no residual) - CausalConv3d -> RMS_norm -> SiLU
+//                      INSIDE a ResidualBlock (wan2pt1.py:195-200);
+//   out_stack != NULL: y to out_stack (the next block's shortcut operand) and its normalised form to normed_stack (the next block's first norm,
+//                      or the head's): the pass that would have re-read y is gone.
+CE_API int ce_conv3d_gemm_rms_silu_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
+                                            void* normed_stack, int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, const float* gamma,
+                                            int apply_silu, hipStream_t stream) {
+  if (!gamma || !normed_stack || (!out_stack && res_stack)) return CE_ERR_ARG;
+  if (out_stack == nullptr)  // (the kernel's single-output form writes the normalised activation through its `out`)
+    return conv3d_gemm_launch(in_stack, weight, ldw, bias, normed_stack, nullptr, T_out, H, W, Cin, Cout, KT, out_cstride, 0, gamma, apply_silu, nullptr, stream);
+  return conv3d_gemm_launch(in_stack, weight, ldw, bias, out_stack, res_stack, T_out, H, W, Cin, Cout, KT, out_cstride, 0, gamma, apply_silu, normed_stack,
+                            stream);
 }
 
 CE_API int ce_rms_silu_bf16(const void* x, void* y, const float* gamma, long long npix, int C, int H, int W, int in_border,

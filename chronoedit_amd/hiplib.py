@@ -85,7 +85,7 @@ SIGNATURES: Dict[str, List] = {
     "ce_gemm_bf16_tile_rows": [_I, _I, _I, _I, _c.c_longlong],
     "ce_zero_border_bf16": [_P, _I, _I, _I, _I, _I, _P],
     "ce_conv3d_gemm_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "ce_conv3d_gemm_rms_silu_bf16": [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "ce_conv3d_gemm_rms_silu_bf16": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "ce_rms_silu_bf16": [_P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _I, _I, _P],
     "ce_upsample2x_bf16": [_P, _P, _I, _I, _I, _I, _P],
     "ce_softmax_rows_f32_bf16": [_P, _P, _I, _I, _I, _I, _I, _F, _P],

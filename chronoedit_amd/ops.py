@@ -596,20 +596,28 @@ def conv3d_gemm(in_stack: torch.Tensor, weight: torch.Tensor, bias: Optional[tor
     _prof_end(st_ev, f"conv_{KT}x3x3_{Cin}->{Cout}_{T_out}x{H}x{W}", 2.0 * T_out * H * W * Cout * Cin * KT * 9)
 
 
-def conv3d_gemm_rms_silu(in_stack: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out_stack: torch.Tensor, gamma: torch.Tensor, *,
-                         T_out: int, H: int, W: int, Cin: int, Cout: int, KT: int, silu: bool = True):
-    """conv3d_gemm with the next layer's RMS_norm (+ SiLU) in its epilogue: out = silu(rms_norm(bf16(conv + bias)) * gamma).  96 output
+def conv3d_gemm_rms_silu(in_stack: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], normed_stack: torch.Tensor, gamma: torch.Tensor, *,
+                         T_out: int, H: int, W: int, Cin: int, Cout: int, KT: int, silu: bool = True, out_stack: Optional[torch.Tensor] = None,
+                         res_stack: Optional[torch.Tensor] = None):
+    """conv3d_gemm with the next layer's RMS_norm (+ SiLU) in its epilogue: normed_stack = silu(rms_norm(y) * gamma), y = bf16(conv + bias)
+    [bf16(res + .)]; y itself goes to out_stack when one is given (the next block's shortcut operand), else it is never written.  96 output
     channels only (ce_conv3d_gemm_rms_silu_bf16)."""
     _dev(in_stack, torch.bfloat16, "in_stack")
-    _dev(out_stack, torch.bfloat16, "out_stack")
+    _dev(normed_stack, torch.bfloat16, "normed_stack")
     _dev(weight, torch.bfloat16, "weight")
     _dev(gamma, torch.float32, "gamma")
-    assert in_stack.is_contiguous() and out_stack.is_contiguous() and weight.is_contiguous() and weight.dim() == 2 and gamma.numel() == Cout
+    assert in_stack.is_contiguous() and normed_stack.is_contiguous() and weight.is_contiguous() and weight.dim() == 2 and gamma.numel() == Cout
     assert in_stack.shape[0] >= T_out + KT and tuple(in_stack.shape[1:]) == (H + 2, W + 2, Cin), in_stack.shape
-    assert out_stack.shape[0] >= T_out and tuple(out_stack.shape[1:3]) == (H + 2, W + 2), out_stack.shape
+    assert normed_stack.shape[0] >= T_out and tuple(normed_stack.shape[1:3]) == (H + 2, W + 2), normed_stack.shape
+    for t, nm in ((out_stack, "out_stack"), (res_stack, "res_stack")):
+        if t is not None:
+            _dev(t, torch.bfloat16, nm)
+            assert t.is_contiguous() and t.shape[1:] == normed_stack.shape[1:] and t.shape[0] >= T_out, (nm, t.shape)
+    assert res_stack is None or out_stack is not None
     st_ev = _prof_begin()
-    _check(lib().ce_conv3d_gemm_rms_silu_bf16(_ptr(in_stack), _ptr(weight), weight.shape[1], _ptr(bias), _ptr(out_stack), T_out, H, W, Cin, Cout, KT,
-                                              out_stack.shape[3], _ptr(gamma), int(bool(silu)), _stream()), "ce_conv3d_gemm_rms_silu_bf16")
+    _check(lib().ce_conv3d_gemm_rms_silu_bf16(_ptr(in_stack), _ptr(weight), weight.shape[1], _ptr(bias), _ptr(out_stack), _ptr(res_stack), _ptr(normed_stack),
+                                              T_out, H, W, Cin, Cout, KT, normed_stack.shape[3], _ptr(gamma), int(bool(silu)), _stream()),
+           "ce_conv3d_gemm_rms_silu_bf16")
     _prof_end(st_ev, f"conv_{KT}x3x3_{Cin}->{Cout}_{T_out}x{H}x{W}+norm", 2.0 * T_out * H * W * Cout * Cin * KT * 9)
 
 
@@ -689,14 +697,15 @@ def softmax_rows(scores: torch.Tensor, probs: torch.Tensor, n: int, scale: float
     return probs
 
 
-_attn1_ws = {}  # device index -> fp32 scratch of the key split of attention_1head (one per device, grown on demand, never under capture)
+_attn1_ws = {}  # (device index, floats) -> fp32 scratch of the key split of attention_1head: one per shape, allocated outside capture and NEVER
+                # freed or replaced (a captured graph of an earlier shape keeps writing through its pointer)
 
 
 def attention_1head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None,
                     split_keys: bool = True):
     """softmax(q k^T * scale) v for one head of dimension C in {128, 384} (the Wan VAE mid-block): q [Nq, C], k [Nk, C] row views,
     vt [C, >= 64 ceil(Nk / 64)] = v transposed with zero padding columns; flash-style, nothing of size Nq x Nk is materialised.
-    split_keys: hand the library a scratch (4 Nq (C + 2) floats per device, allocated once) so that it may split the key axis over
+    split_keys: hand the library a scratch (4 Nq (C + 2) floats per device and shape, allocated once, shared by the launches of ONE stream) so that it may split the key axis over
     several workgroups per query block when the query blocks alone do not fill the chip (ce_attention_1head_bf16)."""
     _dev(q, torch.bfloat16, "q"), _dev(k, torch.bfloat16, "k"), _dev(vt, torch.bfloat16, "vt")
     Nq, C, ldq = _rows(q, "q")
@@ -711,11 +720,10 @@ def attention_1head(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, scale: f
     if split_keys:
         dev = q.device.index if q.device.index is not None else torch.cuda.current_device()
         need = 4 * Nq * (C + 2)
-        ws = _attn1_ws.get(dev)
-        if (ws is None or ws.numel() < need) and not torch.cuda.is_current_stream_capturing():
-            ws = _attn1_ws[dev] = torch.empty(need, dtype=torch.float32, device=q.device)
-        if ws is not None and ws.numel() < need:
-            ws = None  # (under capture with a scratch too small for this shape: one workgroup per query block walks all keys)
+        ws = _attn1_ws.get((dev, need))
+        if ws is None and not torch.cuda.is_current_stream_capturing():
+            ws = _attn1_ws[(dev, need)] = torch.empty(need, dtype=torch.float32, device=q.device)
+        # (first seen under capture: no scratch - one workgroup per query block walks all keys)
     st = _prof_begin()
     _check(lib().ce_attention_1head_bf16(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), Nq, Nk, C, ldq, ldk, ldvt, ldo, float(scale), _ptr(ws),
                                          0 if ws is None else ws.numel() * 4, _stream()), "ce_attention_1head_bf16")

@@ -262,12 +262,16 @@ int ce_conv3d_head_bf16(const void* const* in_frames, int n_in_frames, const voi
 int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
                         int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream);
 
-/* out = [silu]( RMS_norm( bf16(conv(in) + bias) ) * gamma ): ce_conv3d_gemm_bf16 (same in_stack / weight / out_stack operands, no residual)
- * with the NEXT layer's RMS_norm (+ SiLU) applied in the epilogue - ce_rms_silu_bf16's formula on the bf16-rounded convolution result, so the
- * activation between the two is never written.  Cout == 96 and Cin 32 / 96 / 192 only (the kernel whose lanes hold all 96 channels of a
- * position); gamma fp32 [96].  Replaces CausalConv3d -> RMS_norm -> SiLU inside a ResidualBlock (wan2pt1.py:195-200). */
-int ce_conv3d_gemm_rms_silu_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, int T_out, int H, int W,
-                                 int Cin, int Cout, int KT, int out_cstride, const float* gamma, int apply_silu, hipStream_t stream);
+/* ce_conv3d_gemm_bf16 (same in_stack / weight / out_stack / res_stack operands and geometry) with the NEXT layer's RMS_norm (+ SiLU) applied in
+ * the epilogue: with y = bf16(conv(in) + bias) [then bf16(res + y)], normed_stack = [silu]( RMS_norm(y) * gamma ) - ce_rms_silu_bf16's formula on
+ * the rounded values it would have read.  Cout == 96 and Cin 32 / 96 / 192 only (the kernel whose lanes hold all 96 channels of a position);
+ * gamma fp32 [96]; normed_stack has out_stack's geometry (borders zeroed).
+ *   out_stack == NULL (then res_stack == NULL): y is never written - CausalConv3d -> RMS_norm -> SiLU inside a ResidualBlock (wan2pt1.py:195-200);
+ *   out_stack != NULL: y to out_stack AND its normalised form to normed_stack (the next block's shortcut and first norm, :186-220, or the
+ *                      head's norm, :401-403): the pass that would have re-read y is gone. */
+int ce_conv3d_gemm_rms_silu_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
+                                 void* normed_stack, int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, const float* gamma,
+                                 int apply_silu, hipStream_t stream);
 
 /* y = [silu]( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ) per pixel over C channels; x, y are stacks of npix/(H*W) frames
  * with in_border / out_border zero borders (the interiors are written, never the border).  C % 8 == 0, C <= 512.
