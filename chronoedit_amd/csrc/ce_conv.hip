@@ -645,7 +645,7 @@ __device__ __forceinline__ void conv3x3_c96_body(const bf16* __restrict__ in, lo
     const int pt = 16 * MF * wave + 16 * mf + fr;
     const long long r = r0 + pt;
     const bool valid = pt < CR_TM && r < r_end;
-    const size_t off = ((size_t)(valid ? r : r0) + shift) * ocs + 4 * fg;  // (invalid lanes: a clamped, in-range address; never stored)
+    const size_t off = ((size_t)(valid ? r : 0) + shift) * ocs + 4 * fg;  // (invalid lanes: position 0 - in range for the residual loads; never stored)
     u32x2 rr[6];
     if (res) {  // (the six loads of a position issued together)
 #pragma unroll

@@ -44,6 +44,7 @@ class Frames:
         consumer's to fill (cache frames or zeros)."""
         self.T, self.H, self.W, self.C = T, H, W, C
         self.stack, self.front = None, 0
+        self.normed = None  # (gamma name, Frames): this activation after the NEXT layer's RMS_norm + SiLU, written by the conv that produced it
         alloc = torch.zeros if zero else torch.empty
         if front is not None:
             self.stack = alloc((front + T + 1, H + 2, W + 2, C), dtype=torch.bfloat16, device=device)
@@ -199,9 +200,10 @@ class WanVAEEngine:
         return (self.use_gemm_conv and st == 1 and ss == 1 and pk.k in ((3, 3, 3), (1, 3, 3)) and pk.Cin_p == C_in and pk.Cout_p >= 96
                 and (C_in >= 96 or (C_in == 32 and pk.Cout_p == 96)))  # (32 -> 96: the encoder's stem, on the slab kernel of the 96-channel layers)
 
-    def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None, norm=None) -> Frames:
+    def _conv_gemm(self, name, x: Frames, front_frames, res: Optional[Frames], out_C=None, norm=None, also_norm=None) -> Frames:
         """norm = (gamma name, front): the NEXT layer's RMS_norm + SiLU in this conv's epilogue (ce_conv3d_gemm_rms_silu_bf16; the output is
-        what _rms_silu(conv output, gamma, front=front) would have produced, and the un-normalised activation is never written)."""
+        what _rms_silu(conv output, gamma, front=front) would have produced, and the un-normalised activation is never written).
+        also_norm = (gamma name, front): the conv's result as usual, plus that normalised form as `result.normed` (taken when the kernel can)."""
         pk = self.packs[name]
         KT = pk.k[0]
         need = KT - 1
@@ -221,6 +223,14 @@ class WanVAEEngine:
             ops.conv3d_gemm_rms_silu(x.stack, pk.gemm_weight(), pk.b, out.data, self.gammas[norm[0]], T_out=x.T, H=x.H, W=x.W, Cin=pk.Cin_p,
                                      Cout=pk.Cout_p, KT=KT)
             return out
+        if also_norm is not None and out_C is None and self._norm_fusable(name):
+            # the result AND its normalised form (the next layer's first norm): two outputs of one launch, the re-reading pass is gone
+            out = Frames(x.T, x.H, x.W, pk.Cout_p, self.dev, zero=False)
+            nrm = Frames(x.T, x.H, x.W, pk.Cout_p, self.dev, front=also_norm[1], zero=False)
+            ops.conv3d_gemm_rms_silu(x.stack, pk.gemm_weight(), pk.b, nrm.data, self.gammas[also_norm[0]], T_out=x.T, H=x.H, W=x.W, Cin=pk.Cin_p,
+                                     Cout=pk.Cout_p, KT=KT, out_stack=out.data, res_stack=res.data if res is not None else None)
+            out.normed = (also_norm[0], nrm)
+            return out
         out = Frames(x.T, x.H, x.W, out_C or pk.Cout_p, self.dev, zero=(out_C or pk.Cout_p) != pk.Cout_p)  # (the kernel zeroes the border)
         ops.conv3d_gemm(x.stack, pk.gemm_weight(), pk.b, out.data, res.data if res is not None else None, T_out=x.T, H=x.H, W=x.W,
                         Cin=pk.Cin_p, Cout=pk.Cout_p, KT=KT)
@@ -231,7 +241,7 @@ class WanVAEEngine:
         pk = self.packs[name]
         return self.fuse_norm and pk.Cout_p == 96 and pk.Cin_p in (32, 96, 192) and pk.k in ((3, 3, 3), (1, 3, 3))
 
-    def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None, gemm: Optional[bool] = None, norm=None) -> Frames:
+    def _cached_conv(self, name, x: Frames, caches, res=None, out_C=None, gemm: Optional[bool] = None, norm=None, also_norm=None) -> Frames:
         """3x3x3 causal conv with the chunk-to-chunk frame cache (wan2pt1.py:200-210): two frames in front of the chunk.
         gemm: the routing decision when the caller already took it (the producer sized x's stack by it); None: decide here."""
         i = caches["i"]
@@ -253,7 +263,7 @@ class WanVAEEngine:
         if gemm is None:
             gemm = self._gemm_ok(name, x.C)
         if gemm:
-            out = self._conv_gemm(name, x, front, res, out_C, norm=norm)
+            out = self._conv_gemm(name, x, front, res, out_C, norm=norm, also_norm=also_norm)
         else:
             assert norm is None
             out = self._conv(name, front + x.frame_list(), x.T, x.H, x.W, x.W, res=res, out_C=out_C)
@@ -270,12 +280,20 @@ class WanVAEEngine:
         ops.rms_silu(x.data, self.gammas[gname], rows, x.T, x.C, x.H, x.W, 1, 0, silu)
         return rows
 
-    def _res(self, name, x: Frames, cin, cout, caches) -> Frames:
+    def _first_norm(self, x: Frames, gname, front) -> Frames:
+        """RMS_norm + SiLU of x - already there when the conv that produced x wrote it as a second output (Frames.normed)."""
+        if x.normed is not None and x.normed[0] == gname and (x.normed[1].front if x.normed[1].stack is not None else None) == front:
+            return x.normed[1]
+        return self._rms_silu(x, gname, front=front)
+
+    def _res(self, name, x: Frames, cin, cout, caches, next_norm=None) -> Frames:
+        """next_norm = (gamma name, front) of the layer that consumes this block's output through an RMS_norm + SiLU first (the next
+        ResidualBlock or the head): handed to the block's last conv, which writes that normalised form beside its result when it can."""
         h = x
         if (name + ".shortcut") in self.packs:
             h = self._conv(name + ".shortcut", x.frame_list(), x.T, x.H, x.W, x.W, in_off=1)
         g2 = self._gemm_ok(name + ".residual.2", x.C)  # one routing decision per layer: it sizes the producer's stack AND picks the conv
-        y = self._rms_silu(x, name + ".residual.0.gamma", front=2 if g2 else None)
+        y = self._first_norm(x, name + ".residual.0.gamma", 2 if g2 else None)
         g6 = self._gemm_ok(name + ".residual.6", self.packs[name + ".residual.2"].Cout_p)
         if g2 and self._norm_fusable(name + ".residual.2"):
             # the first conv's output feeds nothing but the second norm (wan2pt1.py:195-200): norm + SiLU ride in the conv's epilogue
@@ -283,7 +301,7 @@ class WanVAEEngine:
         else:
             y = self._cached_conv(name + ".residual.2", y, caches, gemm=g2)
             y = self._rms_silu(y, name + ".residual.3.gamma", front=2 if g6 else None)
-        return self._cached_conv(name + ".residual.6", y, caches, res=h, gemm=g6)
+        return self._cached_conv(name + ".residual.6", y, caches, res=h, gemm=g6, also_norm=next_norm if (g6 and self.fuse_norm) else None)
 
     def _attn(self, name, x: Frames) -> Frames:
         """Per-frame single-head attention over h*w (wan2pt1.py:240-259): 1x1 qkv conv -> one flash-style attention kernel
@@ -384,11 +402,19 @@ class WanVAEEngine:
             return self._conv_gemm(name + ".resample.1", u, [], None)
         return self._conv(name + ".resample.1", u.frame_list(), u.T, u.H, u.W, u.W)
 
-    def _run(self, layers, x, caches):
-        for l in layers:
+    def _run(self, layers, x, caches, tail_norm=None):
+        """tail_norm: the gamma of the RMS_norm + SiLU that follows the last layer (the head's)."""
+        for i, l in enumerate(layers):
             kind = l[0]
             if kind == "res":
-                x = self._res(l[1], x, l[2], l[3], caches)
+                nxt = layers[i + 1] if i + 1 < len(layers) else None
+                if nxt is not None and nxt[0] == "res":  # the next block's first norm; its conv's routing decides the stack the norm leaves room in
+                    nn_ = (nxt[1] + ".residual.0.gamma", 2 if self._gemm_ok(nxt[1] + ".residual.2", self.packs[l[1] + ".residual.6"].Cout_p) else None)
+                elif nxt is None and tail_norm is not None:
+                    nn_ = tail_norm
+                else:
+                    nn_ = None
+                x = self._res(l[1], x, l[2], l[3], caches, next_norm=nn_)
             elif kind == "attn":
                 x = self._attn(l[1], x)
             elif kind in ("down2d", "down3d"):
@@ -423,10 +449,15 @@ class WanVAEEngine:
             caches["i"] = 0
             g1 = self._gemm_ok("encoder.conv1", 32)
             f = self._to_frames(ch, 32, front=2 if g1 else None)
-            f = self._cached_conv("encoder.conv1", f, caches, gemm=g1)
-            f = self._run(self.enc, f, caches)
-            f = self._rms_silu(f, "encoder.head.0.gamma")
-            f = self._cached_conv("encoder.head.2", f, caches)  # 2*z channels
+            first = self.enc[0]  # the stem feeds the first ResidualBlock's shortcut and, through its first norm, its first conv
+            an = None
+            if g1 and self.fuse_norm and first[0] == "res":
+                an = (first[1] + ".residual.0.gamma", 2 if self._gemm_ok(first[1] + ".residual.2", self.packs["encoder.conv1"].Cout_p) else None)
+            f = self._cached_conv("encoder.conv1", f, caches, gemm=g1, also_norm=an)
+            gh = self._gemm_ok("encoder.head.2", self.packs["encoder.head.2"].Cin_p)
+            f = self._run(self.enc, f, caches, tail_norm=("encoder.head.0.gamma", 2 if gh else None))
+            f = self._first_norm(f, "encoder.head.0.gamma", 2 if gh else None)
+            f = self._cached_conv("encoder.head.2", f, caches, gemm=gh)  # 2*z channels
             f = self._conv("conv1", f.frame_list(), f.T, f.H, f.W, f.W, in_off=1)
             outs.append(f.data[:, 1:-1, 1:-1, : c.z_dim])
         mu = torch.cat(outs, 0)  # [T', h, w, z]
@@ -444,8 +475,8 @@ class WanVAEEngine:
             caches["i"] = 0
             f = Frames(1, x.H, x.W, x.C, self.dev, data=x.data[i : i + 1])
             f = self._cached_conv("decoder.conv1", f, caches)
-            f = self._run(self.dec, f, caches)
-            f = self._rms_silu(f, "decoder.head.0.gamma")
+            f = self._run(self.dec, f, caches, tail_norm=("decoder.head.0.gamma", None))
+            f = self._first_norm(f, "decoder.head.0.gamma", None)
             f = self._cached_conv("decoder.head.2", f, caches)  # 3 (+5 pad) channels
             outs.append(f.data[:, 1:-1, 1:-1, :3])
         v = torch.cat(outs, 0)  # [T, H, W, 3]

@@ -120,6 +120,20 @@ def test_conv3d_gemm_with_the_next_norm_in_its_epilogue(KT, Cin, T, H, W, silu):
     for border in (fused.data[:, 0], fused.data[:, -1], fused.data[:, :, 0], fused.data[:, :, -1]):
         assert float(border.abs().max()) == 0.0
     assert float((fused.stack[:2] - 7.0).abs().max()) == 0.0  # the front frames are the consumer's
+    # both outputs of one launch: the result itself (+ residual) and its normalised form == conv3d_gemm with the residual, then rms_silu
+    r = torch.randn(T, H, W, Cout, generator=g).to(torch.bfloat16)
+    res = Frames(T, H, W, Cout, dev)
+    res.data[:, 1:-1, 1:-1] = r.to(dev)
+    raw, nrm = Frames(T, H, W, Cout, dev), Frames(T, H, W, Cout, dev, front=2)
+    raw.data.fill_(5.0), nrm.stack.fill_(7.0)
+    ops.conv3d_gemm_rms_silu(f.stack, pk.gemm_weight(), pk.b, nrm.data, gamma.to(dev), T_out=T, H=H, W=W, Cin=Cin, Cout=Cout, KT=KT, silu=silu,
+                             out_stack=raw.data, res_stack=res.data)
+    ops.conv3d_gemm(f.stack, pk.gemm_weight(), pk.b, mid.data, res.data, T_out=T, H=H, W=W, Cin=Cin, Cout=Cout, KT=KT)
+    assert torch.equal(raw.data, mid.data)  # the same kernel, the same epilogue arithmetic
+    ops.rms_silu(mid.data, gamma.to(dev), two.data, T, Cout, H, W, 1, 1, silu)
+    assert rel_l2(nrm.data, two.data) < 2e-3
+    for border in (nrm.data[:, 0], nrm.data[:, -1], nrm.data[:, :, 0], nrm.data[:, :, -1]):
+        assert float(border.abs().max()) == 0.0
     with pytest.raises(ops.HipKernelError):  # only the 96-channel layers have it
         bad = _ConvPack(torch.randn(192, Cin, KT, 3, 3).to(torch.bfloat16).to(dev), torch.zeros(192).to(dev))
         ops.conv3d_gemm_rms_silu(f.stack, bad.gemm_weight(), bad.b, Frames(T, H, W, 192, dev).data, torch.ones(192, device=dev), T_out=T, H=H, W=W,
