@@ -365,8 +365,8 @@ class WanVAEEngine:
                 y = y2
         return y
 
-    def _up(self, kind, name, x: Frames, caches) -> Frames:
-        """Resample upsample2d/3d (wan2pt1.py:99-104,118-139)."""
+    def _up(self, kind, name, x: Frames, caches, next_norm=None) -> Frames:
+        """Resample upsample2d/3d (wan2pt1.py:99-104,118-139).  next_norm: see _res (the upsample's conv is the producer here)."""
         C = x.C
         if kind == "up3d":
             i = caches["i"]
@@ -399,28 +399,29 @@ class WanVAEEngine:
         ops.upsample2x(x.data, u.data, x.T, C, x.H, x.W)
         ops.zero_border(u.data, u.T, u.H, u.W, C)
         if gemm:
-            return self._conv_gemm(name + ".resample.1", u, [], None)
+            return self._conv_gemm(name + ".resample.1", u, [], None, also_norm=next_norm if self.fuse_norm else None)
         return self._conv(name + ".resample.1", u.frame_list(), u.T, u.H, u.W, u.W)
 
     def _run(self, layers, x, caches, tail_norm=None):
         """tail_norm: the gamma of the RMS_norm + SiLU that follows the last layer (the head's)."""
         for i, l in enumerate(layers):
             kind = l[0]
-            if kind == "res":
-                nxt = layers[i + 1] if i + 1 < len(layers) else None
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            nn_ = None
+            if kind in ("res", "up2d", "up3d"):
+                last = l[1] + (".residual.6" if kind == "res" else ".resample.1")  # the conv whose epilogue would carry the next norm
                 if nxt is not None and nxt[0] == "res":  # the next block's first norm; its conv's routing decides the stack the norm leaves room in
-                    nn_ = (nxt[1] + ".residual.0.gamma", 2 if self._gemm_ok(nxt[1] + ".residual.2", self.packs[l[1] + ".residual.6"].Cout_p) else None)
+                    nn_ = (nxt[1] + ".residual.0.gamma", 2 if self._gemm_ok(nxt[1] + ".residual.2", self.packs[last].Cout_p) else None)
                 elif nxt is None and tail_norm is not None:
                     nn_ = tail_norm
-                else:
-                    nn_ = None
+            if kind == "res":
                 x = self._res(l[1], x, l[2], l[3], caches, next_norm=nn_)
             elif kind == "attn":
                 x = self._attn(l[1], x)
             elif kind in ("down2d", "down3d"):
                 x = self._down(kind, l[1], x, caches)
             else:
-                x = self._up(kind, l[1], x, caches)
+                x = self._up(kind, l[1], x, caches, next_norm=nn_)
         return x
 
     def _to_frames(self, x: torch.Tensor, C_pad: int, front=None) -> Frames:
