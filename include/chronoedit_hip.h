@@ -257,7 +257,8 @@ int ce_conv3d_head_bf16(const void* const* in_frames, int n_in_frames, const voi
  *   n_tile    256, 128 or 96: width of the macro tile (256 x 256 with 128 x 128 wave tiles | 256 x 128 with 128 x 64 | 256 x 96 with
  *             128 x 48); 1 (round 6; Cout == 96 and Cin 32, 96 or 192 only): not a GEMM tile - 512 positions x 96 channels per workgroup with
  *             the input slab itself in the LDS, the kw taps as position offsets (the same weight matrix, the same result up to the
- *             summation order); 0 = 1 where it applies (the full-resolution layers of the VAE), else whichever tile wastes less of Cout
+ *             summation order), two waves per SIMD; 2: the same with one wave per SIMD (its A/B partner); 0 = 1 where it applies (the
+ *             full-resolution layers of the VAE), else whichever tile wastes less of Cout
  * Cin % 32 == 0, Cout % 8 == 0. */
 int ce_conv3d_gemm_bf16(const void* in_stack, const void* weight, int ldw, const float* bias, void* out_stack, const void* res_stack,
                         int T_out, int H, int W, int Cin, int Cout, int KT, int out_cstride, int n_tile, hipStream_t stream);
