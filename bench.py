@@ -369,7 +369,8 @@ def _kernel_symbol(label: str, work: float):
         if e in (4, 5) or M * N < 256 * 256 * 128 or K % 128:
             return f"gemm_bf16_128<{e}>"
         rows = ops.lib().ce_gemm_bf16_tile_rows(M, N, K, 256, ops.GEMM_WS_BYTES)
-        return f"gemm_bf16_384<{e}>" if rows == 384 else f"gemm_bf16_w4<{e}>"
+        # (384 rows: gemm_bf16_384<EPI, 12>, written <EPI> as in rounds 4-6's profiles; 288 rows: the NF = 9 instantiation of the same kernel)
+        return f"gemm_bf16_384<{e}>" if rows == 384 else f"gemm_bf16_384<{e}, NF=9 (288 rows)>" if rows == 288 else f"gemm_bf16_w4<{e}>"
     m = re.match(r"^gemm_mxfp8_\d+x\d+x\d+_(epi(\d+)|gelu_quant)$", label)
     if m:
         return f"gemm_fp8_w4<{m.group(2) if m.group(2) is not None else 7}, MX>"
@@ -782,7 +783,7 @@ def main():
             fam_ms = sum(d["total_ms"] for d in big.values())
             fam_fl = sum(d["work"] * d["n"] for d in big.values())
             fam = fam_fl / (fam_ms * 1e-3) / 1e12
-            roofline_family = {"kernel": "gemm_bf16_w4 + gemm_bf16_384 (every launch of the large-tile LDS-DMA GEMM in the step - one wave per SIMD, 256x256 or 384x256 macro tile chosen per shape, all epilogues, split-K reduces included)", "bound": "mfma",
+            roofline_family = {"kernel": "gemm_bf16_w4 + gemm_bf16_384 (every launch of the large-tile LDS-DMA GEMM in the step - one wave per SIMD, 256x256, 288x256 or 384x256 macro tile chosen per shape, all epilogues, split-K reduces included)", "bound": "mfma",
                                "achieved": round(fam, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fam / PEAK_BF16_TFLOPS, 4),
                                "launches": sum(d["n"] for d in big.values()), "total_ms": round(fam_ms, 3), "share_of_step": round(fam_ms / tot, 4)}
 

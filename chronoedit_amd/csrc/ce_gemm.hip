@@ -232,15 +232,18 @@ extern "C" void ce_gemm256_set_staggered(int on);
 extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
+extern "C" int ce_gemm288_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
 extern "C" int ce_gemm256w4_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
                                    const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                    int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, int nsa, hipStream_t stream);
 
 // kernel selection: -1 = automatic (for large shapes the one-wave-per-SIMD LDS-DMA kernels, macro tile 384 x 256 or 256 x 256 by
-// the round count of the shape: prefer_tile384), 0 = always the
+// the round count of the shape: ce_gemm_bf16_tile_rows), 0 = always the
 // 128-tile kernel; whenever the shape allows the 256-tile kernel: 1 = its 8-wave / 8-phase main loop, 2 = the same staggered (two
 // wave groups one barrier apart), 3 / 4 = the one-wave-per-SIMD main loop of ce_gemm256w4.hip with an A ring of 3 / 2 stages, 5 = 3 stages and one barrier per K-tile,
-// 6 = the 384 x 256 macro tile of ce_gemm384.hip (4 waves, 192 x 128 wave tiles, one barrier per K-tile)
+// 6 = the 384 x 256 macro tile of ce_gemm384.hip (4 waves, 192 x 128 wave tiles, one barrier per K-tile), 7 = its 288 x 256 form (144 x 128 wave tiles)
 CE_KNOB g_gemm_variant = -1;
 #ifdef CE_DIAGNOSTICS
 CE_API int ce_set_gemm_variant(int v) {
@@ -282,7 +285,9 @@ CE_API int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_byt
     const long long nwg = (long long)((M + bm - 1) / bm) * ((N + 255) / 256);
     const long long full = nwg / cus;
     const int tail = (int)(nwg % cus);
-    const double c = bm == 256 ? 1.40 : 1.40 * 1.5 * 0.96 * ((double)M * K * 2.0 > 128.0 * 1048576.0 ? 1.04 : 1.0);
+    // (288 x 256, round 6: 1.125 x the area of the 256-row tile, a twentieth fewer operand bytes per flop; priced between the other two)
+    const double llc = (double)M * K * 2.0 > 128.0 * 1048576.0 ? 1.04 : 1.0;
+    const double c = bm == 256 ? 1.40 : bm == 288 ? 1.40 * 1.125 * 0.985 * llc : 1.40 * 1.5 * 0.96 * llc;
     double t = (double)full * kt * c;
     if (tail > 0) {
       int split = 1;
@@ -296,15 +301,28 @@ CE_API int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_byt
     }
     return t;
   };
-  return cost(384) <= cost(256) ? 384 : 256;
+  const double c384 = cost(384), c256 = cost(256);
+  // The 288-row form of the 384-row kernel (round 6) only where all three timings of profiles/r06_gemm_tile_choice_3tiles.txt agree it wins:
+  // M a whole number of 288-row tiles and a last round that is full enough to run whole (no slabs) - M = 7 200 at N = K = 5120 (the
+  // out-projections and the cross-attention's q of the distilled B = 1 step): 500 workgroups = 1.95 rounds against 380 = 1.48 rounds whose tail
+  // goes through 97 MB of fp32 slabs: 0.267 against 0.314 ms.  Elsewhere its main loop is 2-6 % behind the larger tile's.
+  if (M % 288 == 0) {
+    const long long nwg = (long long)(M / 288) * ((N + 255) / 256);
+    const int tail = (int)(nwg % cus);
+    if (tail == 0 || tail * 10 >= cus * 9) {
+      const double c288 = cost(288);
+      if (c288 < 0.97 * (c384 < c256 ? c384 : c256)) return 288;
+    }
+  }
+  return c384 <= c256 ? 384 : 256;
 }
 
-static bool prefer_tile384(int M, int N, int K, hipStream_t stream) {
+static int auto_tile_rows(int M, int N, int K, hipStream_t stream) {
   float* ws = nullptr;
   size_t ws_bytes = 0;
   int cus = 256;
   ce_gemm256_workspace(stream, &ws, &ws_bytes, &cus);
-  return ce_gemm_bf16_tile_rows(M, N, K, cus, ws != nullptr ? (long long)ws_bytes : 0) == 384;
+  return ce_gemm_bf16_tile_rows(M, N, K, cus, ws != nullptr ? (long long)ws_bytes : 0);
 }
 
 CE_API int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
@@ -325,8 +343,12 @@ CE_API int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* 
     if ((want || w_seg_k) && ce_gemm256_supported(M, N, K, lda, ldw)) {
       // the 256-tile kernel has two main loops: one wave per SIMD (ce_gemm256w4.hip; the default: +3...5 % on the step's shapes,
       // profiles/r03_gemm_variants_ab.txt) and the 8-wave / 8-phase loop of ce_gemm256.hip (variants 1, 2)
-      if (g_gemm_variant == 6 || (g_gemm_variant == -1 && prefer_tile384(M, N, K, stream)))  // the 384 x 256 macro tile (ce_gemm384.hip)
+      const int rows_auto = g_gemm_variant == -1 ? auto_tile_rows(M, N, K, stream) : 0;
+      if (g_gemm_variant == 6 || rows_auto == 384)  // the 384 x 256 macro tile (ce_gemm384.hip)
         return ce_gemm384_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
+                                 w_seg_k, w_seg_stride, stream);
+      if (g_gemm_variant == 7 || rows_auto == 288)  // the 288 x 256 macro tile (the same kernel, 144 x 128 wave tiles)
+        return ce_gemm288_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,
                                  w_seg_k, w_seg_stride, stream);
       if (g_gemm_variant == 1 || g_gemm_variant == 2)
         return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride,

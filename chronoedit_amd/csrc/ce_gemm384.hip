@@ -24,10 +24,18 @@
 
 namespace {
 
-constexpr int BM = 384, BN = 256, BK = 64;
-constexpr int A_TILE = BM * BK * 2;       // 48 KiB
+// NF = 16-row fragments of a wave's tile: 12 (384 x 256 macro tile, 192 x 128 wave tiles) or - round 6 - 9 (288 x 256, 144 x 128: M = 7 200, the
+// distilled B = 1 step, is 25 tiles of 288 rows exactly where it is 18.75 of 384: at N = 5120 that is 500 workgroups = 1.95 rounds of 256 CUs
+// instead of 380 = 1.48 rounds whose tail is cut along K through fp32 slabs; same main loop, 18 groups per K-tile instead of 24)
+constexpr int BN = 256, BK = 64;
 constexpr int W_TILE = BN * BK * 2;       // 32 KiB
-constexpr int STAGE = A_TILE + W_TILE;    // 80 KiB
+template <int NF> struct T384 {
+  static constexpr int BM = 32 * NF;                // 384 | 288
+  static constexpr int A_TILE = BM * BK * 2;        // 48 | 36 KiB
+  static constexpr int STAGE = A_TILE + W_TILE;     // 80 | 68 KiB
+  static constexpr int NG = 2 * NF;                 // groups of 8 MFMAs per K-tile
+  static constexpr int NP = NF + 8;                 // LDS-DMA pieces per wave and K-tile (NF of A, 8 of W)
+};
 constexpr int CROW = BN * 2 + 16;         // padded epilogue staging row (528 B)
 constexpr int QROW = 128 * 2 + 16;        // padded staging row of a quadrant (split-K reduce)
 
@@ -36,6 +44,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 #define X_BAR() __builtin_amdgcn_s_barrier()
 #define X_PIN() __builtin_amdgcn_sched_barrier(0)
 
+template <int BM>
 __device__ __forceinline__ void tile_origin_384(int wg, int tiles_m, int tiles_n, int& m0, int& n0) {
   constexpr int GROUP = 4;
   const int group_sz = GROUP * tiles_n;
@@ -57,12 +66,14 @@ __device__ __forceinline__ void mma1(f32x4& acc, const bf16x8& b, const bf16x8& 
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
-template <int EPI>
+template <int EPI, int NF = 12>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_bf16_384(
     const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C, const float* __restrict__ bias,
     const float* __restrict__ gate, const bf16* __restrict__ res, int M, int N, int K, int lda, int ldw, int ldc, int ldres,
     int gate_rows, int tiles_m, int tiles_n, int t_full, int split, float* __restrict__ ws, uint32_t a_seg_magic,
     uint32_t a_seg_extra, uint32_t w_seg_magic, uint32_t w_seg_extra) {
+  constexpr int BM = T384<NF>::BM, A_TILE = T384<NF>::A_TILE, STAGE = T384<NF>::STAGE, NG = T384<NF>::NG, NP = T384<NF>::NP;
+  static_assert(NF >= 9 && NF <= 12, "the W fragments of the second k-step are read in groups 1..8 of the first; rows 8.. of the accumulator live in 128 VGPRs");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     kt0 = (tb % split) * ktn;
   }
   int m0, n0;
-  tile_origin_384(wg, tiles_m, tiles_n, m0, n0);
+  tile_origin_384<BM>(wg, tiles_m, tiles_n, m0, n0);
   const int kt_last = ktn - 1;
 
   // LDS-DMA sources.  Piece p of this wave = rows 8 (wave + 4 p) .. + 8 of the operand tile (lane l: row + (l >> 3), slot l & 7 <- chunk
@@ -109,14 +120,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int ta = kt0 + min(t, kt_last);
     return ta * (BK * 2) + (int)((((uint32_t)ta * magic) >> 16) * extra);
   };
-  // piece q of a tile's 20 per wave: 0..11 = A pieces, 12..19 = W pieces
+  // piece q of a tile's NP per wave: 0..NF-1 = A pieces, NF..NP-1 = W pieces
   auto dma = [&](int q, int stage_bytes, int a_soff, int w_soff) __attribute__((always_inline)) {
-    if (q < 12) {
+    if (q < NF) {
       const uint32_t v = min(a_off0 + (uint32_t)q * a_pstride, a_lim);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_void*)(smem + stage_bytes + (wave + 4 * q) * 1024), 16, v, a_soff, 0, 0);
     } else {
-      const uint32_t v = min(w_off0 + (uint32_t)(128 * ((q - 12) >> 2) + 2 * ((q - 12) & 3)) * w_rowb, w_lim);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + stage_bytes + A_TILE + (wave + 4 * (q - 12)) * 1024), 16, v, w_soff, 0, 0);
+      const uint32_t v = min(w_off0 + (uint32_t)(128 * ((q - NF) >> 2) + 2 * ((q - NF) & 3)) * w_rowb, w_lim);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + stage_bytes + A_TILE + (wave + 4 * (q - NF)) * 1024), 16, v, w_soff, 0, 0);
     }
   };
 
@@ -126,13 +137,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int par = 0; par < 2; ++par)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      a_rd[par][ks] = par * STAGE + (wm * 192 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
+      a_rd[par][ks] = par * STAGE + (wm * (16 * NF) + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
       w_rd[par][ks] = par * STAGE + A_TILE + (wn * 128 + fr) * 128 + (((fg + 4 * ks) ^ (fr >> 1)) << 4);
     }
 
-  f32x4 acc[12][8];
+  f32x4 acc[NF][8];
 #pragma unroll
-  for (int f = 0; f < 12; ++f)
+  for (int f = 0; f < NF; ++f)
 #pragma unroll
     for (int g = 0; g < 8; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -141,7 +152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int a0 = koff(0, a_seg_magic, a_seg_extra), w0 = koff(0, w_seg_magic, w_seg_extra);
     const int a1 = koff(1, a_seg_magic, a_seg_extra), w1 = koff(1, w_seg_magic, w_seg_extra);
 #pragma unroll
-    for (int q = 0; q < 20; ++q) dma(q, 0, a0, w0);
+    for (int q = 0; q < NP; ++q) dma(q, 0, a0, w0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) dma(q, STAGE, a1, w1);  // (pieces 3..19 of tile 1 follow in groups 0..13 of tile 0, as in steady state)
   }
@@ -158,48 +169,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   X_PIN();
 
-  // group G (0..23) of the tile in stage PAR; T = index of that tile (runtime); fillers between the MFMAs, one scheduling region each
+  // ring slot of group g of a tile in stage par: the ring runs on across tiles, so the slot follows the group count of the PAIR of tiles
+  // (NG = 24: the same slots in both stages; NG = 18: the odd stage is two slots on)
+#define RS_(g, par) (((g) + (par) * NG) % 4)
+  // group G (0..NG-1) of the tile in stage PAR; T = index of that tile (runtime); fillers between the MFMAs, one scheduling region each
 #define X_GROUP(G, PAR, T)                                                                                                       \
   {                                                                                                                              \
-    constexpr int ks_ = (G) / 12, f_ = (G) % 12;                                                                                 \
+    constexpr int ks_ = (G) / NF, f_ = (G) % NF;                                                                                 \
     constexpr int gn_ = (G) + 3;                          /* the group whose A fragment is fetched now */                        \
-    constexpr bool nxt_ = gn_ >= 24;                      /* ... in the next tile (other stage; legal: G >= 21 is behind the barrier) */ \
-    constexpr int ksn_ = (nxt_ ? gn_ - 24 : gn_) / 12, fn_ = (nxt_ ? gn_ - 24 : gn_) % 12;                                       \
-    if ((G) == 21) {                                                                                                             \
+    constexpr bool nxt_ = gn_ >= NG;                      /* ... in the next tile (other stage; legal: G >= NG - 3 is behind the barrier) */ \
+    constexpr int ksn_ = (nxt_ ? gn_ - NG : gn_) / NF, fn_ = (nxt_ ? gn_ - NG : gn_) % NF;                                       \
+    if ((G) == NG - 3) {                                                                                                         \
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
       X_BAR();                                                                                                                   \
       X_PIN();                                                                                                                   \
     }                                                                                                                            \
     bf16x8(&bb_)[8] = ks_ ? by : bx;                                                                                             \
-    mma1<f_>(acc[f_][0], bb_[0], ring[(G) % 4]);                                                                                 \
-    ring[gn_ % 4] = *reinterpret_cast<const bf16x8*>(smem + a_rd[nxt_ ? 1 - (PAR) : (PAR)][ksn_] + fn_ * 2048);                  \
+    mma1<f_>(acc[f_][0], bb_[0], ring[RS_(G, PAR)]);                                                                                 \
+    ring[RS_(gn_, PAR)] = *reinterpret_cast<const bf16x8*>(smem + a_rd[nxt_ ? 1 - (PAR) : (PAR)][ksn_] + fn_ * 2048);            \
     X_PIN();                                                                                                                     \
-    mma1<f_>(acc[f_][1], bb_[1], ring[(G) % 4]);                                                                                 \
+    mma1<f_>(acc[f_][1], bb_[1], ring[RS_(G, PAR)]);                                                                                 \
     if ((G) >= 1 && (G) <= 8) by[((G) >= 1 && (G) <= 8) ? (G) - 1 : 0] = *reinterpret_cast<const bf16x8*>(smem + w_rd[(PAR)][1] + ((G) - 1) * 2048);          \
-    if ((G) == 21) { bx[0] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 0 * 2048);                              \
+    if ((G) == NG - 3) { bx[0] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 0 * 2048);                          \
                      bx[1] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 1 * 2048);                              \
                      bx[2] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 2 * 2048); }                            \
-    if ((G) == 22) { bx[3] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 3 * 2048);                              \
+    if ((G) == NG - 2) { bx[3] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 3 * 2048);                          \
                      bx[4] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 4 * 2048);                              \
                      bx[5] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 5 * 2048); }                            \
     X_PIN();                                                                                                                     \
-    mma1<f_>(acc[f_][2], bb_[2], ring[(G) % 4]);                                                                                 \
-    if ((G) == 23) { bx[6] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 6 * 2048);                              \
+    mma1<f_>(acc[f_][2], bb_[2], ring[RS_(G, PAR)]);                                                                                 \
+    if ((G) == NG - 1) { bx[6] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 6 * 2048);                          \
                      bx[7] = *reinterpret_cast<const bf16x8*>(smem + w_rd[1 - (PAR)][0] + 7 * 2048); }                            \
     X_PIN();                                                                                                                     \
-    mma1<f_>(acc[f_][3], bb_[3], ring[(G) % 4]);                                                                                 \
+    mma1<f_>(acc[f_][3], bb_[3], ring[RS_(G, PAR)]);                                                                                 \
     /* LDS-DMA of the tile two ahead of the one whose stage is being overwritten: pieces 0..2 in groups 21..23 (into THIS tile's   \
        stage, free behind the barrier), pieces 3..19 in groups 0..13 of the next tile (= into the other stage, seen from there) */ \
-    if ((G) >= 21) dma((G) - 21, (PAR) * STAGE, a_soff_next, w_soff_next);                                                       \
+    if ((G) >= NG - 3) dma((G) - (NG - 3), (PAR) * STAGE, a_soff_next, w_soff_next);                                             \
     if ((G) <= 2) { dma(3 + 2 * (G), (1 - (PAR)) * STAGE, a_soff_prev, w_soff_prev); }                                            \
-    if ((G) >= 3 && (G) <= 13) dma(6 + (G), (1 - (PAR)) * STAGE, a_soff_prev, w_soff_prev);                                        \
+    if ((G) >= 3 && (G) <= NP - 7) dma(6 + (G), (1 - (PAR)) * STAGE, a_soff_prev, w_soff_prev);                                    \
     X_PIN();                                                                                                                     \
-    mma1<f_>(acc[f_][4], bb_[4], ring[(G) % 4]);                                                                                 \
+    mma1<f_>(acc[f_][4], bb_[4], ring[RS_(G, PAR)]);                                                                                 \
     if ((G) <= 2) { dma(4 + 2 * (G), (1 - (PAR)) * STAGE, a_soff_prev, w_soff_prev); }                                            \
     X_PIN();                                                                                                                     \
-    mma1<f_>(acc[f_][5], bb_[5], ring[(G) % 4]);                                                                                 \
-    mma1<f_>(acc[f_][6], bb_[6], ring[(G) % 4]);                                                                                 \
-    mma1<f_>(acc[f_][7], bb_[7], ring[(G) % 4]);                                                                                 \
+    mma1<f_>(acc[f_][5], bb_[5], ring[RS_(G, PAR)]);                                                                                 \
+    mma1<f_>(acc[f_][6], bb_[6], ring[RS_(G, PAR)]);                                                                                 \
+    mma1<f_>(acc[f_][7], bb_[7], ring[RS_(G, PAR)]);                                                                                 \
     X_PIN();                                                                                                                     \
   }
   // pieces of groups 0..13: 3,4 | 5,6 | 7,8 | 9 .. 19  (two per group in groups 0..2, one per group in 3..13: 6 + 11 = 17)
@@ -212,7 +226,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     X_GROUP(0, PAR, T) X_GROUP(1, PAR, T) X_GROUP(2, PAR, T) X_GROUP(3, PAR, T) X_GROUP(4, PAR, T) X_GROUP(5, PAR, T)             \
     X_GROUP(6, PAR, T) X_GROUP(7, PAR, T) X_GROUP(8, PAR, T) X_GROUP(9, PAR, T) X_GROUP(10, PAR, T) X_GROUP(11, PAR, T)           \
     X_GROUP(12, PAR, T) X_GROUP(13, PAR, T) X_GROUP(14, PAR, T) X_GROUP(15, PAR, T) X_GROUP(16, PAR, T) X_GROUP(17, PAR, T)       \
-    X_GROUP(18, PAR, T) X_GROUP(19, PAR, T) X_GROUP(20, PAR, T) X_GROUP(21, PAR, T) X_GROUP(22, PAR, T) X_GROUP(23, PAR, T)       \
+    if constexpr (NG > 18) {                                                                                                     \
+      X_GROUP(18, PAR, T) X_GROUP(19, PAR, T) X_GROUP(20, PAR, T) X_GROUP(21, PAR, T) X_GROUP(22, PAR, T) X_GROUP(23, PAR, T)     \
+    }                                                                                                                            \
   }
 
   const int npairs = ktn >> 1;
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 #undef X_TILE
 #undef X_GROUP
+#undef RS_
   asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 
   // ---- epilogue, REGISTER-DIRECT (round 6; the fp8 GEMM's, csrc/ce_gemm_fp8w4.hip).  The accumulator holds C: lane (fr, fg) of acc[f][g] owns rows
@@ -234,14 +251,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int col0 = n0 + wn * 128 + fr * 8;  // this lane's 8 output columns
   const bool col_ok = col0 < N;
   const int colc = min(col0, N - 8);
-  const int row_base = m0 + wm * 192 + fg * 4;  // + f*16 + jj
+  const int row_base = m0 + wm * (16 * NF) + fg * 4;  // + f*16 + jj
   if (partial) {
     // split-K tail piece: fp32 slab in the [wave][f][g][lane'] order gemm384_reduce reads (the C^T accumulator order of the staged form: lane'
     // (fr', fg') of [f][g] = row f*16 + fr', columns g*16 + fg'*4 + [0,4)): this lane's (f, jj, g = 4 h .. 4 h + 3) is row f*16 + fg*4 + jj,
     // columns fr*8 + 4 h + [0,4) -> fr' = fg*4 + jj, g' = fr >> 1, fg' = 2 (fr & 1) + h
     float* slab = ws + (size_t)(blockIdx.x - t_full) * (BM * BN);
 #pragma unroll
-    for (int f = 0; f < 12; ++f) {
+    for (int f = 0; f < NF; ++f) {
       f32x4 av[8];
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int h = 0; h < 2; ++h) {
           const f32x4 o = {av[4 * h + 0][jj], av[4 * h + 1][jj], av[4 * h + 2][jj], av[4 * h + 3][jj]};
           const int lane_o = fg * 4 + jj + 16 * (2 * (fr & 1) + h);
-          *reinterpret_cast<f32x4*>(slab + (((wave * 96 + f * 8 + (fr >> 1)) * 64) + lane_o) * 4) = o;
+          *reinterpret_cast<f32x4*>(slab + (((wave * (8 * NF) + f * 8 + (fr >> 1)) * 64) + lane_o) * 4) = o;
         }
     }
     return;
@@ -293,8 +310,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int f = 0; f < RA; ++f) res_load(f, rv[f % (RA + 1)]);
   }
 #pragma unroll
-  for (int f = 0; f < 12; ++f) {
-    if (EPI == EPI_GATE_RES && f + RA < 12) res_load(f + RA, rv[(f + RA) % (RA + 1)]);
+  for (int f = 0; f < NF; ++f) {
+    if (EPI == EPI_GATE_RES && f + RA < NF) res_load(f + RA, rv[(f + RA) % (RA + 1)]);
     f32x4 av[8];  // the eight accumulators of this fragment row, whole
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
@@ -339,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // Sums the `split` fp32 slabs of one wave quadrant (192 x 128 accumulators) of a tail tile and applies the epilogue.
 // grid = 4 x the number of tail tiles, 256 threads: thread (w, lane) takes accumulator rows f = 3w .. 3w + 2 of the quadrant.
-template <int EPI>
+template <int EPI, int NF = 12>
 __global__ __launch_bounds__(256) void gemm384_reduce(bf16* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ gate,
                                                       const bf16* __restrict__ res, int M, int N, int ldc, int ldres, int gate_rows,
                                                       int tiles_m, int tiles_n, int t_full, int split, const float* __restrict__ ws) {
@@ -347,14 +364,16 @@ __global__ __launch_bounds__(256) void gemm384_reduce(bf16* __restrict__ C, cons
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;  // q = producer wave = (wm, wn)
+  constexpr int BM = T384<NF>::BM;
   int m0, n0;
-  tile_origin_384(t_full + tile, tiles_m, tiles_n, m0, n0);
-  m0 += (q >> 1) * 192;
+  tile_origin_384<BM>(t_full + tile, tiles_m, tiles_n, m0, n0);
+  m0 += (q >> 1) * (16 * NF);
   n0 += (q & 1) * 128;
   const float* slab = ws + (size_t)tile * split * (BM * BN);
 #pragma unroll
   for (int ff = 0; ff < 3; ++ff) {
-    const int f = 3 * w + ff;
+    const int f = 3 * w + ff;  // (NF = 9: the fourth wave has no rows)
+    if (f >= NF) break;
     const int rl = f * 16 + fr;
     float brow = 0.f;
     if (EPI == EPI_BIAS_ROW) brow = bias[min(m0 + rl, M - 1)];
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(256) void gemm384_reduce(bf16* __restrict__ C, cons
       const int cl = g * 16 + fg * 4;
       f32x4 bv = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + min(n0 + cl, N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
       if (EPI == EPI_BIAS_ROW) bv[0] = bv[1] = bv[2] = bv[3] = brow;
-      const int e = (((q * 96 + f * 8 + g) * 64) + lane) * 4;
+      const int e = (((q * (8 * NF) + f * 8 + g) * 64) + lane) * 4;
       f32x4 v = *reinterpret_cast<const f32x4*>(slab + e);
       for (int sidx = 1; sidx < split; ++sidx) v += *reinterpret_cast<const f32x4*>(slab + (size_t)sidx * (BM * BN) + e);
       const u32x2 pk = {pack_bf16(v[0] + bv[0], v[1] + bv[1]), pack_bf16(v[2] + bv[2], v[3] + bv[3])};
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(256) void gemm384_reduce(bf16* __restrict__ C, cons
     }
   }
   __syncthreads();
-  epi_chunks<EPI, 12>(smem, QROW, [&](int tt, int& rl, int& cc, int& mr) { const int c = tid + 256 * tt; rl = mr = c >> 4; cc = c & 15; }, m0, n0,
+  epi_chunks<EPI, NF>(smem, QROW, [&](int tt, int& rl, int& cc, int& mr) { const int c = tid + 256 * tt; rl = mr = c >> 4; cc = c & 15; }, m0, n0,
                       C, gate, res, M, N, ldc, ldres, gate_rows);
 }
 
@@ -382,9 +401,11 @@ extern "C" int ce_gemm256_launch(const void* A, const void* W, void* C, const fl
                                  const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                  int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream);
 
-extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
-                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
-                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
+template <int NF>
+static int gemm384_launch_impl(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate, const void* res, int M, int N,
+                               int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride, int w_seg_k,
+                               long long w_seg_stride, hipStream_t stream) {
+  constexpr int BM = T384<NF>::BM, STAGE = T384<NF>::STAGE;
   if ((epilogue == EPI_GATE_RES && gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32) ||
       (epilogue == EPI_BIAS_ROW && (M & 3)))  // (the register-direct epilogue stores through 32-bit buffer offsets and reads four row biases at once)
     return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
@@ -427,15 +448,15 @@ extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const fl
 #define CE_LAUNCH(E)                                                                                                       \
   do {                                                                                                                     \
     if (!attr_done[E]) {                                                                                                   \
-      if (hipFuncSetAttribute((const void*)gemm_bf16_384<E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
-      (void)hipFuncSetAttribute((const void*)gemm384_reduce<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 192 * QROW);   \
+      if (hipFuncSetAttribute((const void*)gemm_bf16_384<E, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG; \
+      (void)hipFuncSetAttribute((const void*)gemm384_reduce<E, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * NF * QROW); \
       attr_done[E] = true;                                                                                                 \
     }                                                                                                                      \
-    hipLaunchKernelGGL((gemm_bf16_384<E>), grid, block, lds, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
+    hipLaunchKernelGGL((gemm_bf16_384<E, NF>), grid, block, lds, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, \
                        (const bf16*)res, M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, \
                        a_seg_magic, a_seg_extra, w_seg_magic, w_seg_extra);                                                \
     if (tail)                                                                                                              \
-      hipLaunchKernelGGL((gemm384_reduce<E>), dim3(4 * tail), block, 192 * QROW, stream, (bf16*)C, bias, gate,             \
+      hipLaunchKernelGGL((gemm384_reduce<E, NF>), dim3(4 * tail), block, 16 * NF * QROW, stream, (bf16*)C, bias, gate,     \
                          (const bf16*)res, M, N, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws);           \
   } while (0)
   switch (epilogue) {
@@ -448,4 +469,19 @@ extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const fl
   }
 #undef CE_LAUNCH
   return (int)hipGetLastError();
+}
+
+extern "C" int ce_gemm384_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
+  return gemm384_launch_impl<12>(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
+                                 w_seg_stride, stream);
+}
+
+// the 288 x 256 macro tile (NF = 9): same kernel, 144 x 128 wave tiles
+extern "C" int ce_gemm288_launch(const void* A, const void* W, void* C, const float* bias, int epilogue, const float* gate,
+                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
+                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
+  return gemm384_launch_impl<9>(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
+                                w_seg_stride, stream);
 }

@@ -84,7 +84,7 @@ int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* bias, i
  * (include/chronoedit_hip_diag.h, -DCE_DIAGNOSTICS), which tools/ and tests/ load beside this one. ---- */
 
 
-/* Which macro tile ce_gemm_bf16 runs a LARGE product on when the choice is automatic: 384 (x 256, ce_gemm384.hip) or 256 (x 256,
+/* Which macro tile ce_gemm_bf16 runs a LARGE product on when the choice is automatic: 384 or 288 (x 256, ce_gemm384.hip) or 256 (x 256,
  * ce_gemm256w4.hip) rows - the one whose tile count falls better on `cus` compute units (full rounds + the last round, which is cut
  * along K when the split-K workspace of `ws_bytes` bytes allows it).  A pure function: no device is touched.  0: invalid arguments. */
 int ce_gemm_bf16_tile_rows(int M, int N, int K, int cus, long long ws_bytes);

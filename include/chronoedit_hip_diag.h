@@ -18,7 +18,7 @@ extern "C" {
  * LDS-DMA kernels, macro tile per ce_gemm_bf16_tile_rows), 0 force the 128x128 register-staged kernel; wherever the shape allows the
  * large-tile kernels: 1 the 8-wave 256x256 main loop (csrc/ce_gemm256.hip), 2 the same staggered, 3 / 4 / 5 the one-wave-per-SIMD
  * 256x256 main loop (csrc/ce_gemm256w4.hip; A ring of 3 stages / 2 stages / 3 stages and one barrier per K-tile), 6 the 384x256 macro
- * tile (csrc/ce_gemm384.hip).  Host-side test/bench knob. */
+ * tile (csrc/ce_gemm384.hip), 7 its 288x256 form.  Host-side test/bench knob. */
 int ce_set_gemm_variant(int variant);
 
 /* Loop body behind ce_attention_bf16 / ce_attention_batched_bf16 (returns the previous value; all are tested against the

@@ -80,7 +80,7 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6], ids=["tile128", "tile256w8", "tile256w8stag", "tile256w4_3stage", "tile256w4", "tile256w4_1barrier", "tile384x256"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5, 6, 7], ids=["tile128", "tile256w8", "tile256w8stag", "tile256w4_3stage", "tile256w4", "tile256w4_1barrier", "tile384x256", "tile288x256"])
 def gemm_variant(request):
     from chronoedit_amd import ops
     old = ops.set_gemm_variant(request.param)
@@ -151,7 +151,7 @@ def test_gemm_epilogues(gemm_variant):
     assert rel_l2(x, ref) < 5e-3
 
 
-@pytest.mark.parametrize("variant", [1, 4, 6], ids=["tile256w8", "tile256w4", "tile384x256"])
+@pytest.mark.parametrize("variant", [1, 4, 6, 7], ids=["tile256w8", "tile256w4", "tile384x256", "tile288x256"])
 @pytest.mark.parametrize("M,N,K,epi", [(4352, 4096, 1024, "bias"), (7200, 5120, 5120, "gate"), (1538, 10240, 5120, "gelu"),
                                        (600, 512, 1024, "bias")])
 def test_gemm_split_k_tail(M, N, K, epi, variant):

@@ -198,7 +198,7 @@ def test_conv3d_gemm_address_map_reproduces_the_convolution(KT, T_out, H, W, Cin
 
 
 def test_macro_tile_choice_of_the_step_shapes():
-    """ce_gemm_bf16_tile_rows: the automatic 384 x 256 / 256 x 256 macro-tile choice is a pure function of the shape, the CU count and
+    """ce_gemm_bf16_tile_rows: the automatic 384 x 256 / 288 x 256 / 256 x 256 macro-tile choice is a pure function of the shape, the CU count and
     the split-K workspace - pinned here for the five large GEMMs of a block at BOTH row counts of the 720p step (M = 14 400: guidance pair
     batched, BASELINE configs[1]; M = 7 200: the distilled B = 1 step, configs[2]) on 256 CUs with the engine's 96 MiB workspace: what the
     same-box A/B measured as the faster tile for each (profiles/r06_gemm_tile_choice.txt; round 6 refit)."""
@@ -214,14 +214,20 @@ def test_macro_tile_choice_of_the_step_shapes():
     assert pick(14400, 5120, 13824) == 384   # FFN-down: 384 by 3.6 %
     assert pick(7200, 10240, 5120) == 384    # q | k: 384 by 11.5 %
     assert pick(5120, 7200, 5120) == 256     # V^T: 256 by 4.5 %
-    assert pick(7200, 5120, 5120) == 384     # out-projections: 384 by 1.2 %
+    assert pick(7200, 5120, 5120) == 288     # out-projections, q of the cross-attention: the 288-row form (25 whole row tiles, 1.95 rounds, no slabs) by 17 %
     assert pick(7200, 13824, 5120) == 384    # FFN-up: 384 by 3.0 % (the round-3 model said 256)
     assert pick(7200, 5120, 13824) == 384    # FFN-down: 384 by 2.8 % - needs the 96 MiB scratch: 124 tail tiles x 2 slabs of 384 rows
+    # the 288-row form nowhere else on the engine's shapes (its loop is 2-6 % behind the 384-row one; measured slower wherever its tail needs slabs)
+    for M in (14400, 13068, 26136, 28800, 57600, 3648, 7296):
+        for N, K in ((10240, 5120), (5120, 5120), (13824, 5120), (5120, 13824)):
+            assert pick(M, N, K) != 288, (M, N, K)
+        assert pick(5120, (M + 63) // 64 * 64, 5120) != 288
+    assert pick(5120, 7232, 5120) == 256
     assert pick(0, 5120, 5120) == 0 and pick(256, 256, 32) == 0
     # without a workspace a partial last round cannot be cut along K
     assert lib.ce_gemm_bf16_tile_rows(14400, 5120, 5120, 256, 0) == 384
     assert lib.ce_gemm_bf16_tile_rows(14400, 13824, 5120, 256, 0) == 256
-    assert lib.ce_gemm_bf16_tile_rows(7200, 5120, 13824, 256, 64 << 20) == 256  # the 64 MiB scratch of rounds 1-5: 384 cannot cut its tail (-13 %)
+    assert lib.ce_gemm_bf16_tile_rows(7200, 5120, 13824, 256, 64 << 20) != 384  # the 64 MiB scratch of rounds 1-5: 384 cannot cut its tail (-13 %)
 
 
 def test_mx_scale_layout_helpers_agree_with_the_kernels_offset_formula():

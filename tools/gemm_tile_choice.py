@@ -1,4 +1,4 @@
-"""The automatic macro-tile choice of ce_gemm_bf16 (ce_gemm_bf16_tile_rows: 384 x 256 or 256 x 256) against a measurement of BOTH tiles, for the
+"""The automatic macro-tile choice of ce_gemm_bf16 (ce_gemm_bf16_tile_rows: 384 x 256, 288 x 256 or 256 x 256) against a measurement of ALL THREE tiles, for the
 large GEMMs of a block at every row count the engine runs them on: M = 7 200 (BASELINE configs[2], B = 1), 14 400 (configs[1], pair batched),
 13 068 / 26 136 (configs[4]), 28 800 / 57 600 (configs[3] on one GPU), 3 648 / 7 296 (a rank of the 8-GPU Ulysses split, B = 1 / 2).
 Interleaved rounds, best of each; "loss" = what the model's pick costs against the measured winner.
@@ -45,18 +45,23 @@ def main():
                 torch.cuda.synchronize()
                 return e0.elapsed_time(e1) / iters
 
-            t = {4: 1e9, 6: 1e9}
+            t = {4: 1e9, 6: 1e9, 7: 1e9}
+            outs = {}
             for _ in range(rounds):
-                for v in (4, 6):
+                for v in (4, 6, 7):
                     t[v] = min(t[v], timeit(v))
+                    outs[v] = out.clone()
+            same = bool(torch.equal(outs[7], outs[6]))  # the 288-row form of the 384-row kernel: the same k order per accumulator
             ops.set_gemm_variant(-1)
             pick = lib.ce_gemm_bf16_tile_rows(M, N, K, 256, ops.GEMM_WS_BYTES)
-            t_pick, t_best = t[6 if pick == 384 else 4], min(t.values())
+            t_pick, t_best = t[{384: 6, 288: 7, 256: 4}[pick]], min(t.values())
             tot_auto += t_pick
             tot_best += t_best
             fl = 2.0 * M * N * K
-            print(f"{tag:9s} {M:6d}x{N:5d}x{K:5d}: 256-row {t[4]:.3f} ms {fl/t[4]/1e9:5.0f} TF | 384-row {t[6]:.3f} ms {fl/t[6]/1e9:5.0f} TF | measured "
-                  f"{'384' if t[6] < t[4] else '256'} by {abs(t[4]/t[6]-1)*100:4.1f} % | model picks {pick}" + ("" if t_pick == t_best else f"  <-- loses {(t_pick/t_best-1)*100:.1f} %"), flush=True)
+            best_v = min(t, key=t.get)
+            print(f"{tag:9s} {M:6d}x{N:5d}x{K:5d}: 256-row {t[4]:.3f} ms {fl/t[4]/1e9:5.0f} TF | 288-row {t[7]:.3f} ms {fl/t[7]/1e9:5.0f} TF (== 384-row result: {same}) | "
+                  f"384-row {t[6]:.3f} ms {fl/t[6]/1e9:5.0f} TF | measured {({4: 256, 6: 384, 7: 288})[best_v]} | model picks {pick}" +
+                  ("" if t_pick == t_best else f"  <-- loses {(t_pick/t_best-1)*100:.1f} %"), flush=True)
             del a, w, out, kw
     print(f"sum over all shapes: automatic choice {tot_auto:.3f} ms, per-shape best {tot_best:.3f} ms ({(tot_auto/tot_best-1)*100:.2f} % lost to wrong picks)")
 
