@@ -29,6 +29,7 @@
 #define EPI_BIAS_GELU_ERF 3
 #define EPI_F32 4  // C is float*: raw fp32 accumulators (attention scores of the VAE mid block)
 #define EPI_BIAS_ROW 6  // C = bf16(acc + bias[m]): bias along the rows of C - a product with swapped operand roles (V^T = W_v.X^T)
+#define EPI_BIAS_T 7    // the transpose of the product is stored (C is [N][ldc]): ce_gemm_epi.h / ce_gemm384.hip
 #define EPI_MUL 5  // C = bf16(bf16(acc + bias) * res): the gated activation of the UMT5 feed-forward (wi_1(x) * gelu(wi_0(x)))
 
 namespace {
@@ -329,6 +330,31 @@ CE_API int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* 
                                 const void* res, int M, int N, int K, int lda, int ldw, int ldc, int ldres, int gate_rows,
                                 int a_seg_k, long long a_seg_stride, int w_seg_k, long long w_seg_stride, hipStream_t stream) {
   if (!A || !W || !C) return CE_ERR_ARG;
+  if (epilogue == EPI_BIAS_T) {
+    // C^T is stored (C is [N][ldc]).  Mathematically the EPI_BIAS_ROW product with the operands swapped; run as written - M the token count -
+    // on the 384- / 288-row kernel when that is what the dispatcher would give (M, N, K) anyway and its last round runs whole (the transposed
+    // store has no split-K reduce), as the swapped EPI_BIAS_ROW product otherwise: the same sums either way (same products, same k order).
+    if (!bias || M <= 0 || N <= 0 || K <= 0 || (K % BK)) return CE_ERR_ARG;
+    if ((lda & 7) || (ldw & 7) || (ldc & 7)) return CE_ERR_ALIGN;
+    const bool plain = (a_seg_k <= 0 || a_seg_k >= K) && (w_seg_k <= 0 || w_seg_k >= K);
+    if (plain && (M & 3) == 0 && (N & 7) == 0 && (long long)M * N >= 256ll * 256 * 128 && (long long)N * ldc * 2 < (1ll << 32) &&
+        ce_gemm256_supported(M, N, K, lda, ldw) && (g_gemm_variant == -1 || g_gemm_variant == 6 || g_gemm_variant == 7)) {
+      float* ws = nullptr;
+      size_t ws_bytes = 0;
+      int cus = 256;
+      ce_gemm256_workspace(stream, &ws, &ws_bytes, &cus);
+      const int rows = g_gemm_variant == 6 ? 384 : g_gemm_variant == 7 ? 288 : ce_gemm_bf16_tile_rows(M, N, K, cus, ws != nullptr ? (long long)ws_bytes : 0);
+      if (rows == 384 || rows == 288) {
+        const long long nwg = (long long)((M + rows - 1) / rows) * ((N + 255) / 256);
+        const int tail = (int)(nwg % cus);
+        if (g_gemm_variant != -1 || tail == 0 || tail * 10 >= cus * 9)
+          return (rows == 384 ? ce_gemm384_launch : ce_gemm288_launch)(A, W, C, bias, EPI_BIAS_T, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, 0, 0, 0, 0,
+                                                                      stream);
+      }
+    }
+    if (!plain) return CE_ERR_SHAPE;
+    return ce_gemm_seg_bf16(W, A, C, bias, EPI_BIAS_ROW, nullptr, nullptr, N, M, K, ldw, lda, ldc, 0, 0, 0, 0, 0, 0, stream);
+  }
   if (w_seg_k < 0 || (w_seg_k > 0 && w_seg_k < K && ((w_seg_k % BK) || (K % w_seg_k) || (w_seg_stride & 7)))) return CE_ERR_SHAPE;
   if (w_seg_k >= K) w_seg_k = 0;
   if (a_seg_k < 0 || (a_seg_k > 0 && a_seg_k < K && ((a_seg_k % BK) || (K % a_seg_k) || (a_seg_stride & 7)))) return CE_ERR_SHAPE;

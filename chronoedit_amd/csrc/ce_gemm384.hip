@@ -283,6 +283,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int h = 0; h < 2; ++h)
     bvv[h] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + colc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == EPI_BIAS_T) {
+    // The TRANSPOSE of the tile is stored (C is [N][ldc]): for output column col0 + g the lane owns rows row_base + f*16 + [0,4) - four consecutive
+    // elements of row col0 + g of C^T, one 8-byte store; the four fg lanes of a quad-row cover 32 contiguous bytes, the twelve (nine) row
+    // fragments 384 (288) contiguous bytes of that row.  (M % 4 == 0: the launcher checks; never a split-K tail piece.)
+    const auto t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(N - 1) * (uint32_t)(ldc * 2) + (uint32_t)M * 2u, 0x00020000);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      f32x4 av[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (f < 8) asm volatile("" : "+a"(acc[f][g])); else asm volatile("" : "+v"(acc[f][g]));  // (pins the read-out of fragment row f here)
+        av[g] = acc[f][g];
+      }
+      const int m = row_base + f * 16;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float b = bvv[g >> 2][g & 3];
+        const u32x2 y = {pack_bf16(av[g][0] + b, av[g][1] + b), pack_bf16(av[g][2] + b, av[g][3] + b)};
+        const uint32_t toff = (m < M && col_ok) ? (uint32_t)(col0 + g) * (uint32_t)(ldc * 2) + (uint32_t)m * 2u : 0xffffffffu;
+        __builtin_amdgcn_raw_buffer_store_b64(y, t_rsrc, toff, 0, 0);
+      }
+    }
+    return;
+  }
   // (the launcher sends C beyond 32-bit byte offsets, and gate rows shorter than a tile, to the 8-wave kernel)
   const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(M - 1) * (uint32_t)(ldc * 2) + (uint32_t)N * 2u, 0x00020000);
   f32x4 gA[2], gB[2];
@@ -406,6 +430,9 @@ static int gemm384_launch_impl(const void* A, const void* W, void* C, const floa
                                int K, int lda, int ldw, int ldc, int ldres, int gate_rows, int a_seg_k, long long a_seg_stride, int w_seg_k,
                                long long w_seg_stride, hipStream_t stream) {
   constexpr int BM = T384<NF>::BM, STAGE = T384<NF>::STAGE;
+  if (epilogue == EPI_BIAS_T) {  // (C is [N][ldc]; no other kernel stores the transpose: the dispatcher only comes here with a shape this one takes)
+    if ((M & 3) || (long long)N * ldc * 2 >= (1ll << 32) || !bias) return CE_ERR_SHAPE;
+  } else
   if ((epilogue == EPI_GATE_RES && gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32) ||
       (epilogue == EPI_BIAS_ROW && (M & 3)))  // (the register-direct epilogue stores through 32-bit buffer offsets and reads four row biases at once)
     return ce_gemm256_launch(A, W, C, bias, epilogue, gate, res, M, N, K, lda, ldw, ldc, ldres, gate_rows, a_seg_k, a_seg_stride, w_seg_k,
@@ -432,7 +459,7 @@ static int gemm384_launch_impl(const void* A, const void* W, void* C, const floa
   int g_cus = 256;
   ce_gemm256_workspace(stream, &g_ws, &g_ws_bytes, &g_cus);
   int tail = nwg % g_cus, split = 1;
-  if (tail > 0 && g_ws != nullptr) {
+  if (tail > 0 && g_ws != nullptr && epilogue != EPI_BIAS_T) {  // (the transposed store has no reduce form: its last round runs whole)
     for (int s = std::min(g_cus / tail, 8); s >= 2; --s)
       if (kt % (2 * s) == 0 && (size_t)tail * s * BM * BN * sizeof(float) <= g_ws_bytes) {
         split = s;
@@ -465,6 +492,18 @@ static int gemm384_launch_impl(const void* A, const void* W, void* C, const floa
     case EPI_GATE_RES: CE_LAUNCH(EPI_GATE_RES); break;
     case EPI_BIAS_GELU_ERF: CE_LAUNCH(EPI_BIAS_GELU_ERF); break;
     case EPI_BIAS_ROW: CE_LAUNCH(EPI_BIAS_ROW); break;
+    case EPI_BIAS_T: {
+      static bool t_done_[CE_MAX_DEVICES] = {};
+      bool& t_done = t_done_[ce_device_slot()];
+      if (!t_done) {
+        if (hipFuncSetAttribute((const void*)gemm_bf16_384<EPI_BIAS_T, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return CE_ERR_ARG;
+        t_done = true;
+      }
+      hipLaunchKernelGGL((gemm_bf16_384<EPI_BIAS_T, NF>), grid, block, lds, stream, (const bf16*)A, (const bf16*)W, (bf16*)C, bias, gate, (const bf16*)res,
+                         M, N, K, lda, ldw, ldc, ldres, gate_rows, tiles_m, tiles_n, t_full2, split, g_ws, a_seg_magic, a_seg_extra, w_seg_magic,
+                         w_seg_extra);
+      break;
+    }
     default: return CE_ERR_ARG;
   }
 #undef CE_LAUNCH

@@ -11,6 +11,9 @@
 #ifndef EPI_BIAS_ROW
 #define EPI_BIAS_ROW 6  // C = bf16(acc + bias[m]): the bias runs along the ROWS of C (operand roles swapped: C = W.X^T)
 #endif
+#ifndef EPI_BIAS_T
+#define EPI_BIAS_T 7    // C^T is stored: the caller's matrix is [N][ldc], element (n, m) = bf16(acc[m][n] + bias[n]) - the same V^T = W_v.X^T
+#endif                  // WITHOUT swapping the operand roles: M stays the token count, whose tile count falls better on the chip (ce_gemm384.hip)
 
 namespace {
 

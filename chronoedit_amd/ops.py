@@ -14,7 +14,7 @@ import torch
 from . import hiplib
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_GATE_RES, EPI_BIAS_GELU_ERF = 0, 1, 2, 3
-EPI_F32, EPI_MUL, EPI_BIAS_ROW = 4, 5, 6
+EPI_F32, EPI_MUL, EPI_BIAS_ROW, EPI_BIAS_T = 4, 5, 6, 7
 
 _lib = None      # the library launches go through: the product library unless a diagnostic selector is away from its default
 _product = None
@@ -192,7 +192,8 @@ def rmsnorm_rope_(x: torch.Tensor, w: torch.Tensor, cos_sin: Optional[torch.Tens
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
          epilogue: int = EPI_BIAS, gate: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, gate_rows: int = 0):
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T + bias).  gate [N] or, with gate_rows > 0, [M/gate_rows, N] (one per sample).
-    a may be a 3-D [S, M, K/S] tensor (contiguous): the K-segmented operand an all-to-all leaves behind (ce_gemm_aseg_bf16)."""
+    a may be a 3-D [S, M, K/S] tensor (contiguous): the K-segmented operand an all-to-all leaves behind (ce_gemm_aseg_bf16).
+    epilogue EPI_BIAS_T: out is [N, M] and receives the TRANSPOSE of a @ w^T + bias[n] (CE_EPI_BIAS_T)."""
     _dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w")
     a_seg_k, a_seg_stride = 0, 0
     if a.dim() == 3:
@@ -208,11 +209,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: Op
     if bias is not None:
         _dev(bias, torch.float32, "bias")
         assert bias.numel() == (M if epilogue == EPI_BIAS_ROW else N) and bias.is_contiguous()
+    oshape = (N, M) if epilogue == EPI_BIAS_T else (M, N)
     if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        out = torch.empty(oshape, dtype=torch.bfloat16, device=a.device)
     _dev(out, torch.bfloat16, "out")
     Mo, No, ldc = _rows(out, "out")
-    assert (Mo, No) == (M, N), ((Mo, No), (M, N))
+    assert (Mo, No) == oshape, ((Mo, No), oshape)
     ldres = 0
     if epilogue in (EPI_GATE_RES, EPI_MUL):
         if res is None:

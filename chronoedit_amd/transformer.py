@@ -26,6 +26,9 @@ from . import ops, weights
 from .weights import LoraMixin
 
 
+_VT_GEMM_SWAPPED = __import__("os").environ.get("CE_VT_GEMM") == "row"  # (tools: the rounds-2-5 form of the V^T product, see forward)
+
+
 @dataclass
 class Transformer2DModelOutput:
     sample: torch.Tensor
@@ -927,13 +930,17 @@ class DiTEngine:
                     ops.attention_mxfp8(ws.q8, ws.sq, ws.k8, ws.sk, ws.v8t, ws.sv, H, out=ws.att, batch=B)
                 att = ws.att
             elif sp is None and self.v_transposed and "qkv" not in self.fp8_set and (B * Nl) % 8 == 0 and (B == 1 or Nl % 2 == 0):
-                # q | k as one GEMM, V^T = W_v.h^T as the same GEMM with the operand roles swapped (bias along rows): the attention
-                # kernel's V^T operand [D][keys of all samples] without a transpose pass; K and V^T tiles both go by LDS-DMA
+                # q | k as one GEMM, V^T = (h.W_v^T)^T by a GEMM whose epilogue stores the transpose (round 6; rounds 2-5: the operand roles
+                # swapped, bias along rows - what shapes outside the large tile still run): the attention kernel's V^T operand [D][keys of all
+                # samples] without a transpose pass; K and V^T tiles both go by LDS-DMA
                 if getattr(ws, "vt", None) is None:
                     ws.vt = torch.zeros((D, ops.vt_columns(B * Nl)), dtype=torch.bfloat16, device=self.dev)  # padding columns stay zero
                 ops.ln_affine(x, mod[li, 0, 1], mod[li, 0, 0], eps, out=ws.h, ab_rows=Nl, ab_stride=6 * D)
                 ops.gemm(ws.h, p.w_qkv[: 2 * D], p.b_qkv[: 2 * D], out=ws.qkv[:, : 2 * D])
-                ops.gemm(p.w_qkv[2 * D :], ws.h, p.b_qkv[2 * D :], out=ws.vt[:, : B * Nl], epilogue=ops.EPI_BIAS_ROW)
+                if _VT_GEMM_SWAPPED:  # (A/B knob of tools: CE_VT_GEMM=row - the rounds-2-5 form of the same product)
+                    ops.gemm(p.w_qkv[2 * D :], ws.h, p.b_qkv[2 * D :], out=ws.vt[:, : B * Nl], epilogue=ops.EPI_BIAS_ROW)
+                else:
+                    ops.gemm(ws.h, p.w_qkv[2 * D :], p.b_qkv[2 * D :], out=ws.vt[:, : B * Nl], epilogue=ops.EPI_BIAS_T)  # (stores the transpose: V^T)
                 ops.rmsnorm_rope_(ws.qkv[:, :D], p.nq1, cs, hd, eps, x2=ws.qkv[:, D : 2 * D], w2=p.nk1)
                 ops.attention_vt(ws.qkv[:, :D], ws.qkv[:, D : 2 * D], ws.vt, H, out=ws.att, batch=B)
                 att = ws.att

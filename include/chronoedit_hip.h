@@ -37,6 +37,10 @@ typedef struct ihipStream_t* hipStream_t;
 #define CE_EPI_BIAS_GELU_ERF 3 /* exact-erf GELU: diffusers FeedForward("gelu") of the image embedder */
 #define CE_EPI_BIAS_ROW 6      /* C = bf16(A.W^T + bias[m]): bias along the ROWS of C - a product taken with the operand roles swapped
                                 * (V^T = W_v.X^T: the attention kernel's V^T operand straight out of the projection, no transpose pass) */
+#define CE_EPI_BIAS_T 7        /* C is [N][ldc] and holds the TRANSPOSE: C[n][m] = bf16(A.W^T[m][n] + bias[n]) - the same V^T as CE_EPI_BIAS_ROW
+                                * gives with the operands swapped, but M stays the token count (round 6: 760 tiles of 384 rows = 2.97 rounds of
+                                * 256 CUs where the swapped product is 1140 tiles of 256 = 4.45 rounds with a split-K tail); shapes the large-tile
+                                * kernel does not take run as that swapped product: the same sums either way.  M % 8 == 0, N % 8 == 0 */
 #define CE_EPI_F32 4           /* C is float* (ldc in floats): raw fp32 A.W^T, no bias (VAE mid-block attention scores) */
 
 /* y = LayerNorm_fp32(x, eps) * a[d] + b[d] -> bf16.   One wave64 per row; D % 8 == 0, D <= 5120.

@@ -82,7 +82,7 @@ def test_tile384_gemm_keeps_its_384_accumulators_in_place():
         assert r[2] <= 512 and r[4] == 32 * nf, r
         assert r[3] <= (128 if "ILi2E" in r[0] else 0), f"{r[0]}: scratch"
     loops = isa_lint.inner_loops(src, "gemm_bf16_384")
-    assert len(loops) == 10
+    assert len(loops) == 12  # five epilogues + the transposed store (EPI_BIAS_T), two tile heights each
     for name, c in loops:
         nf = 9 if "ELi9EEE" in name else 12
         assert c.get("v_mfma_f32_16x16x32_bf16", 0) == 32 * nf, (name, c)
