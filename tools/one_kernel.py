@@ -23,7 +23,7 @@ if kind == "gemm":
     a = torch.randn(M, K, generator=g).to(BF).to(dev)
     w = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(dev)
     b = torch.zeros(N, device=dev)
-    out = torch.zeros(M, N, dtype=BF, device=dev)
+    out = torch.zeros((N, M) if epi == 7 else (M, N), dtype=BF, device=dev)  # (epi 7 = CE_EPI_BIAS_T: the transpose is stored)
     gate = torch.ones(N, device=dev)
     ops.set_gemm_variant(var)
     for _ in range(iters):
