@@ -337,7 +337,7 @@ CE_API int ce_gemm_seg_bf16(const void* A, const void* W, void* C, const float* 
     if (!bias || M <= 0 || N <= 0 || K <= 0 || (K % BK)) return CE_ERR_ARG;
     if ((lda & 7) || (ldw & 7) || (ldc & 7)) return CE_ERR_ALIGN;
     const bool plain = (a_seg_k <= 0 || a_seg_k >= K) && (w_seg_k <= 0 || w_seg_k >= K);
-    if (plain && (M & 3) == 0 && (N & 7) == 0 && (long long)M * N >= 256ll * 256 * 128 && (long long)N * ldc * 2 < (1ll << 32) &&
+    if (plain && (M & 7) == 0 && (N & 7) == 0 && (long long)M * N >= 256ll * 256 * 128 && (long long)N * ldc * 2 < (1ll << 32) &&
         ce_gemm256_supported(M, N, K, lda, ldw) && (g_gemm_variant == -1 || g_gemm_variant == 6 || g_gemm_variant == 7)) {
       float* ws = nullptr;
       size_t ws_bytes = 0;

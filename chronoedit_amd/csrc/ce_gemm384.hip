@@ -284,10 +284,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int h = 0; h < 2; ++h)
     bvv[h] = (EPI != EPI_BIAS_ROW && bias != nullptr) ? *reinterpret_cast<const f32x4*>(bias + colc + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (EPI == EPI_BIAS_T) {
-    // The TRANSPOSE of the tile is stored (C is [N][ldc]): for output column col0 + g the lane owns rows row_base + f*16 + [0,4) - four consecutive
-    // elements of row col0 + g of C^T, one 8-byte store; the four fg lanes of a quad-row cover 32 contiguous bytes, the twelve (nine) row
-    // fragments 384 (288) contiguous bytes of that row.  (M % 4 == 0: the launcher checks; never a split-K tail piece.)
+    // The TRANSPOSE of the tile is stored (C is [N][ldc]): for output column col0 + g a lane owns rows row_base + f*16 + [0,4) - four consecutive
+    // elements of row col0 + g of C^T.  (M % 4 == 0: the launcher checks; never a split-K tail piece.)
     const auto t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, (uint32_t)(N - 1) * (uint32_t)(ldc * 2) + (uint32_t)M * 2u, 0x00020000);
+    if constexpr (NF == 12) {
+      // Stored straight from the registers (8 bytes per lane: sixteen C^T rows x 32 bytes per instruction) the launch wrote 233 MB for a 147 MB
+      // result - quarter lines leave the L2 before their neighbours arrive (PMC WRITE_SIZE, profiles/r06_pmc_vt_store.txt) - and the better tile
+      // fit bought 4 % where 10 % were on the table.  So each wave turns its 128 x 192 sub-tile through a private LDS region in three passes of
+      // four row fragments: 64 consecutive rows of the tile = exactly one aligned 128-byte line of every C^T row (a wave's first row is a
+      // multiple of 192), and a store instruction writes eight WHOLE lines.  One workgroup barrier first: slower waves still read the stages.
+      constexpr int TROW = 128 + 16;  // padded LDS row: 64 elements
+      X_BAR();
+      unsigned char* const tb = smem + wave * (128 * TROW);
+      const int n_base = n0 + wn * 128, m_base = m0 + wm * 192;
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+        for (int ff = 0; ff < 4; ++ff) {
+          const int f = 4 * pass + ff;
+          f32x4 av[8];
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            if (f < 8) asm volatile("" : "+a"(acc[f][g])); else asm volatile("" : "+v"(acc[f][g]));  // (pins the read-out of fragment row f here)
+            av[g] = acc[f][g];
+          }
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const float b = bvv[g >> 2][g & 3];
+            const u32x2 y = {pack_bf16(av[g][0] + b, av[g][1] + b), pack_bf16(av[g][2] + b, av[g][3] + b)};
+            *reinterpret_cast<u32x2*>(tb + (fr * 8 + g) * TROW + (ff * 16 + fg * 4) * 2) = y;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private region: no barrier)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // 128 rows x 8 chunks of 16 bytes: lane -> (row 8 i + (lane >> 3), chunk lane & 7)
+          const int r = 8 * i + (lane >> 3), c = lane & 7;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(tb + r * TROW + c * 16);
+          const int n = n_base + r, m = m_base + pass * 64 + c * 8;
+          const uint32_t toff = (n < N && m < M) ? (uint32_t)n * (uint32_t)(ldc * 2) + (uint32_t)m * 2u : 0xffffffffu;
+          __builtin_amdgcn_raw_buffer_store_b128(v, t_rsrc, toff, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the reads are done before the next pass overwrites the region)
+      }
+      return;
+    }
+    // (NF = 9: a wave's 144 rows are 288 bytes of a C^T row - no whole number of lines whatever the split; the direct form)
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       f32x4 av[8];
@@ -431,7 +472,7 @@ static int gemm384_launch_impl(const void* A, const void* W, void* C, const floa
                                long long w_seg_stride, hipStream_t stream) {
   constexpr int BM = T384<NF>::BM, STAGE = T384<NF>::STAGE;
   if (epilogue == EPI_BIAS_T) {  // (C is [N][ldc]; no other kernel stores the transpose: the dispatcher only comes here with a shape this one takes)
-    if ((M & 3) || (long long)N * ldc * 2 >= (1ll << 32) || !bias) return CE_ERR_SHAPE;
+    if ((M & 7) || (long long)N * ldc * 2 >= (1ll << 32) || !bias) return CE_ERR_SHAPE;
   } else
   if ((epilogue == EPI_GATE_RES && gate != nullptr && gate_rows > 0 && gate_rows < BM) || (long long)M * ldc * 2 >= (1ll << 32) ||
       (epilogue == EPI_BIAS_ROW && (M & 3)))  // (the register-direct epilogue stores through 32-bit buffer offsets and reads four row biases at once)
