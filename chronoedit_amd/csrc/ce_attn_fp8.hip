@@ -71,21 +71,41 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_mxfp8_kernel(const bf16* __r
   const int half = head_dim >> 1;
   unsigned char* qr = q8 + (size_t)row * ldq;
   unsigned char* sr = sc + (size_t)row * (D >> 5);
+  // The weight and cos / sin vectors of a chunk are fetched ONE CHUNK AHEAD of its arithmetic (round 6: written as loads at their point of use,
+  // hipcc waited for each chunk's four loads before anything else - ten serial L2 round trips per row: 3.3 TB/s where the bf16 kernel, whose
+  // loop has no cross-lane step, runs 4.9), and the four scale bytes of 16 lanes leave as ONE dword store.
+  // (a lane's chunks are 64 chunks = 512 channels apart: whenever 512 is a multiple of head_dim - 128 here - they all sit at the SAME place of
+  //  their head and share one cos / sin entry: two loads per row instead of twenty - the row's 512-byte table was read forty times over)
+  const bool cs_once = cs != nullptr && (512 % head_dim) == 0;
+  f32x4 wv0[2], wv1[2], cv0[2], cv1[2];
+  if (cs_once) {
+    const float* p = cs + ((size_t)cs_row * half + (((lane * 8) % head_dim) >> 1)) * 2;
+    cv0[0] = cv0[1] = *reinterpret_cast<const f32x4*>(p);
+    cv1[0] = cv1[1] = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  auto fetch = [&](int i, int slot) __attribute__((always_inline)) {
+    const int c = lane + 64 * i;
+    if (FULL || c < nch) {
+      wv0[slot] = *reinterpret_cast<const f32x4*>(w + c * 8);
+      wv1[slot] = *reinterpret_cast<const f32x4*>(w + c * 8 + 4);
+      if (cs != nullptr && !cs_once) {
+        const int pair0 = ((c * 8) % head_dim) >> 1;
+        const float* p = cs + ((size_t)cs_row * half + pair0) * 2;
+        cv0[slot] = *reinterpret_cast<const f32x4*>(p);
+        cv1[slot] = *reinterpret_cast<const f32x4*>(p + 4);
+      }
+    }
+  };
+  fetch(0, 0);
 #pragma unroll
   for (int i = 0; i < ROW_MAXC; ++i) {
     const int c = lane + 64 * i;
     const bool on = FULL || c < nch;
+    if (i + 1 < ROW_MAXC) fetch(i + 1, (i + 1) & 1);
     float v[8];
     float amax = 0.f;
     if (on) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c * 8), w1 = *reinterpret_cast<const f32x4*>(w + c * 8 + 4);
-      f32x4 cs0, cs1;
-      if (cs != nullptr) {
-        const int pair0 = ((c * 8) % head_dim) >> 1;
-        const float* p = cs + ((size_t)cs_row * half + pair0) * 2;
-        cs0 = *reinterpret_cast<const f32x4*>(p);
-        cs1 = *reinterpret_cast<const f32x4*>(p + 4);
-      }
+      const f32x4 w0 = wv0[i & 1], w1 = wv1[i & 1], cs0 = cv0[i & 1], cs1 = cv1[i & 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float ww0 = j < 2 ? w0[2 * j] : w1[2 * j - 4], ww1 = j < 2 ? w0[2 * j + 1] : w1[2 * j - 3];
@@ -107,8 +127,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_mxfp8_kernel(const bf16* __r
     // a 32-element block = 4 consecutive chunks = lanes 4a .. 4a+3
     amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
     amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    const int byte = on ? mx_scale_byte(amax) : 0;
+    // the scale bytes of four consecutive blocks (lanes 16 a, + 4, + 8, + 12) as one dword from lane 16 a
+    int packed = byte | (__shfl_down(byte, 4, 64) << 8) | (__shfl_down(byte, 8, 64) << 16) | (__shfl_down(byte, 12, 64) << 24);
     if (on) {
-      const int byte = mx_scale_byte(amax);
       const float inv = mx_inv_scale(byte);
       int w0 = 0, w1 = 0;
       w0 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[0] * inv), clamp448(v[1] * inv), w0, false);
@@ -117,7 +139,11 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_mxfp8_kernel(const bf16* __r
       w1 = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v[6] * inv), clamp448(v[7] * inv), w1, true);
       const u32x2 o = {(uint32_t)w0, (uint32_t)w1};
       *reinterpret_cast<u32x2*>(qr + c * 8) = o;
-      if ((lane & 3) == 0) sr[c >> 2] = (unsigned char)byte;
+      if ((lane & 15) == 0) {
+        if (FULL || c + 12 < nch) *reinterpret_cast<int*>(sr + (c >> 2)) = packed;  // (D % 128 == 0 whenever FULL; else byte by byte below)
+        else
+          for (int k = 0; k < 4 && c + 4 * k < nch; ++k) sr[(c >> 2) + k] = (unsigned char)(packed >> (8 * k));
+      }
     }
   }
 }

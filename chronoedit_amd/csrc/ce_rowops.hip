@@ -189,14 +189,23 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(bf16* __restrict__ x0
   }
   const float rstd = 1.0f / sqrtf(wave_sum(s) / (float)D + eps);
   const int half = head_dim >> 1;
+  // (round 6) a lane's chunks are 64 chunks = 512 channels apart: whenever 512 is a multiple of head_dim (128 here) they all sit at the same
+  // place of their head and share ONE cos / sin entry - two loads per row instead of twenty (the row's 512-byte table was read forty times over)
+  const bool cs_once = cs != nullptr && (512 % head_dim) == 0;
+  f32x4 csa = {0.f, 0.f, 0.f, 0.f}, csb = {0.f, 0.f, 0.f, 0.f};
+  if (cs_once) {
+    const float* p = cs + ((size_t)cs_row * half + (((lane * 8) % head_dim) >> 1)) * 2;
+    csa = *reinterpret_cast<const f32x4*>(p);
+    csb = *reinterpret_cast<const f32x4*>(p + 4);
+  }
 #pragma unroll
   for (int i = 0; i < ROW_MAXC; ++i) {
     const int c = lane + 64 * i;
     if (FULL || c < nch) {
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c * 8), w1 = *reinterpret_cast<const f32x4*>(w + c * 8 + 4);
       u32x4 o;
-      f32x4 cs0, cs1;
-      if (cs != nullptr) {
+      f32x4 cs0 = csa, cs1 = csb;
+      if (cs != nullptr && !cs_once) {
         const int pair0 = ((c * 8) % head_dim) >> 1;  // first of the 4 (even,odd) pairs of this chunk
         const float* p = cs + ((size_t)cs_row * half + pair0) * 2;
         cs0 = *reinterpret_cast<const f32x4*>(p);
